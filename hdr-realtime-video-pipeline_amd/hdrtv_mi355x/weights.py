@@ -1,0 +1,158 @@
+"""Weight pack (``.hdrw``) writer/reader and the seeded HG weight generator.
+
+The C-ABI library (``include/hdrtv_mi355x.h``: ``hdrtv_create``) takes one flat
+blob; this module turns a reference ``state_dict`` (name -> array) into that blob
+and back.  Layout (little endian):
+
+    0   char[8]  magic "HDRW1\\0\\0\\0"
+    8   u32      n_entries
+    12  u32      reserved
+    16  n_entries x { char name[96]; u32 dtype(0=f32 1=f16 2=i8 3=i64);
+                      u32 ndim; u32 dims[4]; u64 offset; u64 nbytes }   (136 B each)
+    ..  data, every tensor 64-byte aligned; offsets are from the blob start
+
+HG weights are not shipped with the reference: timing and
+parity use ``seeded_hg_state`` below, a numpy-only generator both the golden
+script (feeding the reference's own ``Hallucination_Generator``) and the GPU box
+can reproduce bit for bit.
+"""
+from __future__ import annotations
+
+import struct
+from collections import OrderedDict
+
+import numpy as np
+
+from . import arch
+
+MAGIC = b"HDRW1\0\0\0"
+_ENTRY = struct.Struct("<96sII4IQQ")
+_DT_CODE = {np.dtype(np.float32): 0, np.dtype(np.float16): 1, np.dtype(np.int8): 2,
+            np.dtype(np.int64): 3}
+_DT_FROM = {v: k for k, v in _DT_CODE.items()}
+
+
+def pack_state(state) -> bytes:
+    """name -> ndarray (or torch tensor)  ->  .hdrw blob."""
+    items = []
+    for name, value in state.items():
+        if hasattr(value, "detach"):
+            value = value.detach().cpu().numpy()
+        a = np.ascontiguousarray(value)
+        if a.dtype == np.float64:
+            a = a.astype(np.float32)
+        if a.dtype not in _DT_CODE:
+            raise ValueError(f"unsupported dtype {a.dtype} for {name}")
+        if a.ndim > 4:
+            raise ValueError(f"rank > 4 for {name}")
+        if len(name.encode()) >= 96:
+            raise ValueError(f"name too long: {name}")
+        items.append((name, a))
+    head = 16 + _ENTRY.size * len(items)
+    off = (head + 63) & ~63
+    table, blobs = [], []
+    for name, a in items:
+        dims = list(a.shape) + [1] * (4 - a.ndim)
+        nbytes = a.nbytes
+        table.append(_ENTRY.pack(name.encode(), _DT_CODE[a.dtype], a.ndim, *dims, off, nbytes))
+        blobs.append((off, a.tobytes()))
+        off = (off + nbytes + 63) & ~63
+    out = bytearray(off)
+    out[0:8] = MAGIC
+    struct.pack_into("<II", out, 8, len(items), 0)
+    pos = 16
+    for t in table:
+        out[pos:pos + _ENTRY.size] = t
+        pos += _ENTRY.size
+    for o, b in blobs:
+        out[o:o + len(b)] = b
+    return bytes(out)
+
+
+def unpack_state(blob: bytes) -> "OrderedDict[str, np.ndarray]":
+    if blob[:8] != MAGIC:
+        raise ValueError("not an HDRW1 weight pack")
+    n, _ = struct.unpack_from("<II", blob, 8)
+    out = OrderedDict()
+    pos = 16
+    for _ in range(n):
+        name, dt, ndim, d0, d1, d2, d3, off, nbytes = _ENTRY.unpack_from(blob, pos)
+        pos += _ENTRY.size
+        name = name.rstrip(b"\0").decode()
+        shape = (d0, d1, d2, d3)[:ndim]
+        out[name] = np.frombuffer(blob, dtype=_DT_FROM[dt], count=nbytes // _DT_FROM[dt].itemsize,
+                                  offset=off).reshape(shape)
+    return out
+
+
+def load_pack(path) -> "OrderedDict[str, np.ndarray]":
+    with open(path, "rb") as f:
+        return unpack_state(f.read())
+
+
+def save_pack(path, state) -> None:
+    with open(path, "wb") as f:
+        f.write(pack_state(state))
+
+
+def check_hr_state(state) -> None:
+    """Raise ValueError unless ``state`` has exactly the HR (AGCM+LE) tensors."""
+    want = dict(arch.hr_params())
+    missing = [k for k in want if k not in state]
+    if missing:
+        raise ValueError(f"checkpoint is missing {len(missing)} tensors, e.g. {missing[0]}")
+    for k, shp in want.items():
+        if tuple(state[k].shape) != tuple(shp):
+            raise ValueError(f"bad shape for {k}: {tuple(state[k].shape)} != {shp}")
+
+
+def seeded_hg_state(seed: int = 1234) -> "OrderedDict[str, np.ndarray]":
+    """Deterministic stand-in for the absent HG.pt (keys as Hallucination_Generator's).
+
+    Conv weights: N(0, 2/fan_in) (the reference's own kaiming fan-in init,
+    Hallucination_arch.py:13-21), biases N(0, 0.02); BatchNorm gamma N(1, 0.02),
+    beta N(0, 0.02), running_mean N(0, 0.1), running_var U(0.5, 1.5) so that BN
+    folding is exercised with non-trivial statistics.  The 1x1 fuse convs and
+    conv_last are scaled down so the seeded head stays O(1) in fp16.
+    """
+    rng = np.random.default_rng(seed)
+    out = OrderedDict()
+    for name, shape in arch.hg_params(with_counters=True):
+        if name.endswith("num_batches_tracked"):
+            out[name] = np.array(1, dtype=np.int64)
+        elif name.endswith("running_mean"):
+            out[name] = (0.1 * rng.standard_normal(shape)).astype(np.float32)
+        elif name.endswith("running_var"):
+            out[name] = rng.uniform(0.5, 1.5, shape).astype(np.float32)
+        elif ".1.weight" in name:
+            out[name] = (1.0 + 0.02 * rng.standard_normal(shape)).astype(np.float32)
+        elif len(shape) == 4:
+            fan_in = shape[1] * shape[2] * shape[3]
+            std = np.sqrt(2.0 / fan_in)
+            if shape[2] == 1:          # 1x1 fuse convs see un-normalised concat inputs
+                std *= 0.5
+            out[name] = (std * rng.standard_normal(shape)).astype(np.float32)
+        else:
+            out[name] = (0.02 * rng.standard_normal(shape)).astype(np.float32)
+    return out
+
+
+def synthetic_frame(h: int, w: int, seed: int = 1234, kind: str = "noise") -> np.ndarray:
+    """u8 BGR HWC test frame.  ``noise``: BASELINE.md section 3 protocol
+    (``default_rng(seed).integers(0,256)``); ``gradient``: smooth ramps plus a few
+    bright blobs so the HG highlight mask is a 0/1 mixture."""
+    rng = np.random.default_rng(seed)
+    if kind == "noise":
+        return rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    if kind != "gradient":
+        raise ValueError(kind)
+    yy, xx = np.meshgrid(np.linspace(0, 1, h, dtype=np.float32),
+                         np.linspace(0, 1, w, dtype=np.float32), indexing="ij")
+    img = np.stack([0.15 + 0.5 * xx, 0.1 + 0.45 * yy, 0.2 + 0.3 * (1 - xx) * yy], axis=2)
+    for _ in range(6):
+        cy, cx = rng.uniform(0.1, 0.9, 2)
+        r = rng.uniform(0.04, 0.15)
+        d2 = ((yy - cy) ** 2 + (xx - cx) ** 2) / (r * r)
+        img += (0.9 * np.exp(-d2))[:, :, None] * rng.uniform(0.7, 1.0, 3).astype(np.float32)
+    img += rng.normal(0, 0.01, img.shape).astype(np.float32)
+    return np.clip(img * 255.0 + 0.5, 0, 255).astype(np.uint8)
