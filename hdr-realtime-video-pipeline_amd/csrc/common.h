@@ -1,0 +1,69 @@
+// common.h -- shared device/host declarations for libhdrtv_mi355x (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 f16;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define HDRTV_WAVE 64
+
+// Epilogue activation codes
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU01 = 2 };
+// Conv store modes
+enum { ST_NHWC = 0, ST_PS = 1, ST_POOL = 2, ST_PLANAR3 = 3 };
+
+__device__ __forceinline__ float act_apply(float v, int act)
+{
+    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == ACT_LRELU01) return v >= 0.f ? v : v * 0.1f;
+    return v;
+}
+
+// K-dimension permutation that lets a 32x32 MFMA accumulator tile be re-used, packed to f16,
+// as the B operand of the next MFMA (cdna_hip_programming.md section 3, "An accumulator tile as
+// the next MFMA's operand"): operand slot p (0..15) of a 16-wide k-step holds logical k
+// perm16[p].  Weight packers apply it to the K (input-channel) axis of chained layers.
+__host__ __device__ __forceinline__ int acc_kperm16(int p)
+{
+    return ((p >> 3) << 2) | (((p >> 2) & 1) << 3) | (p & 3);
+}
+
+// ------------------------------------------------------------------------------------------
+// Parameter block of the implicit-GEMM convolution (conv_igemm.hip).
+struct ConvParams {
+    const f16 *src0;   // NHWC, c0 channels
+    const f16 *src1;   // NHWC, c1 channels (channel concat after src0) or nullptr
+    int c0, c1;        // multiples of the kernel's CIN_T
+    int Hi, Wi;        // input spatial size
+    int Ho, Wo;        // conv output spatial size
+    const f16 *wpk;    // [KS*KS][Cin/CIN_T][CoutPad][CIN_T]
+    const float *scale;  // [CoutPad] per-channel multiplier (folded BatchNorm, else 1)
+    const float *shift;  // [CoutPad] per-channel offset (bias, folded)
+    int CoutPad;       // multiple of BN
+    int Cout;          // real output channels (<= CoutPad)
+    int act;
+    int mode;
+    f16 *dst;          // NHWC [Hd][Wd][dstC]           (ST_NHWC, ST_PS, ST_POOL)
+    f16 *dst_full;     // ST_POOL only: optional un-pooled NHWC copy [Ho][Wo][Cout]
+    int dstC;
+    int Hd, Wd;        // dst spatial size (crop bound for ST_PS; Ho/2,Wo/2 for ST_POOL)
+    const f16 *res1;   // optional residuals, same layout/shape as dst
+    const f16 *res2;
+    f16 *dst_planar;       // ST_PLANAR3: f16 [3][Hd][Wd]
+    const f16 *res_planar; // ST_PLANAR3: residual planes
+    int tiles_x, tiles_y;
+};
+
+struct SftParams {
+    const f16 *x;      // NHWC 32
+    const f16 *cond;   // NHWC 16
+    f16 *y;            // NHWC 32
+    const f16 *wfrag;  // 3 A-fragments [3][64 lanes][8] (hidden stack, scale, shift), f16
+    const float *bias; // [32 hidden (scale16|shift16)] [32 scale-out] [32 shift-out]
+    int npix;
+};

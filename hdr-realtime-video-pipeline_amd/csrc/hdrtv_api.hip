@@ -1,0 +1,968 @@
+// hdrtv_api.hip -- C ABI of libhdrtv_mi355x.so (see include/hdrtv_mi355x.h).
+// Host side only: weight-pack parsing, repacking into MFMA operand layouts, workspace
+// management and the per-frame launch sequence.  No kernel lives in this file.
+#include "../../include/hdrtv_mi355x.h"
+
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "launchers.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------ weight pack
+struct PackEntry {
+    int dtype;  // 0 f32, 1 f16, 2 i8, 3 i64
+    int ndim;
+    int dims[4];
+    const unsigned char *data;
+    size_t nbytes;
+    size_t numel() const
+    {
+        size_t n = 1;
+        for (int i = 0; i < ndim; ++i) n *= (size_t)dims[i];
+        return n;
+    }
+};
+
+struct Pack {
+    std::map<std::string, PackEntry> e;
+    bool parse(const void *blob, size_t bytes, std::string &err)
+    {
+        const unsigned char *b = (const unsigned char *)blob;
+        if (bytes < 16 || memcmp(b, "HDRW1\0\0\0", 8) != 0) { err = "not an HDRW1 weight pack"; return false; }
+        uint32_t n;
+        memcpy(&n, b + 8, 4);
+        if (16 + (size_t)n * 136 > bytes) { err = "weight pack truncated (table)"; return false; }
+        for (uint32_t i = 0; i < n; ++i) {
+            const unsigned char *r = b + 16 + (size_t)i * 136;
+            char name[97];
+            memcpy(name, r, 96);
+            name[96] = 0;
+            PackEntry pe;
+            uint32_t dt, nd, d[4];
+            uint64_t off, nb;
+            memcpy(&dt, r + 96, 4); memcpy(&nd, r + 100, 4); memcpy(d, r + 104, 16);
+            memcpy(&off, r + 120, 8); memcpy(&nb, r + 128, 8);
+            if (off + nb > bytes || nd > 4) { err = std::string("weight pack truncated: ") + name; return false; }
+            pe.dtype = (int)dt; pe.ndim = (int)nd;
+            for (int k = 0; k < 4; ++k) pe.dims[k] = (int)d[k];
+            pe.data = b + off; pe.nbytes = nb;
+            e[name] = pe;
+        }
+        return true;
+    }
+    // fetch as fp32 vector with an expected element count
+    bool get(const std::string &name, size_t numel, std::vector<float> &out, std::string &err) const
+    {
+        auto it = e.find(name);
+        if (it == e.end()) { err = "tensor missing from weight pack: " + name; return false; }
+        const PackEntry &pe = it->second;
+        if (pe.numel() != numel) { err = "bad shape for " + name; return false; }
+        out.resize(numel);
+        if (pe.dtype == 0) memcpy(out.data(), pe.data, numel * 4);
+        else if (pe.dtype == 1) { const f16 *s = (const f16 *)pe.data; for (size_t i = 0; i < numel; ++i) out[i] = (float)s[i]; }
+        else { err = "unsupported dtype for " + name; return false; }
+        return true;
+    }
+};
+
+// --------------------------------------------------------------------------- device arenas
+struct Arena {
+    std::vector<unsigned char> host;   // staging (weights) -- empty for workspace arenas
+    unsigned char *dev = nullptr;
+    size_t size = 0;
+    size_t reserve(size_t bytes)
+    {
+        const size_t off = (size + 255) & ~(size_t)255;
+        size = off + bytes;
+        return off;
+    }
+    size_t put(const void *src, size_t bytes)
+    {
+        const size_t off = reserve(bytes);
+        if (host.size() < size) host.resize(size);
+        memcpy(host.data() + off, src, bytes);
+        return off;
+    }
+};
+
+struct ConvLayer {
+    size_t wpk = 0, scale = 0, shift = 0;   // weight-arena offsets
+    int cin = 0, cout = 0, coutPad = 0, ks = 0, stride = 1, cin_t = 0, bn = 0;
+};
+struct C3Layer { size_t wfrag = 0, scale = 0, shift = 0; int cout = 0; };
+struct SftLayer { size_t wfrag = 0, bias = 0; };
+
+struct Tensor {
+    size_t off = 0;
+    int C = 0, H = 0, W = 0, layout = 0;   // 0 NHWC f16, 1 planar f16, 2 planar f32, 3 f32 vector, 4 u8 plane
+    size_t bytes() const
+    {
+        const size_t n = (size_t)C * H * W;
+        return layout == 2 || layout == 3 ? n * 4 : (layout == 4 ? n : n * 2);
+    }
+};
+
+struct RingSlot {
+    uint16_t *host = nullptr, *dev = nullptr;
+    hipEvent_t ev = nullptr;
+    int state = 0;   // 0 free, 1 acquired, 2 committed
+};
+
+}  // namespace
+
+struct hdrtv_ctx {
+    int device = 0;
+    bool has_hg = false;
+    std::string err;
+    Arena wts;
+    std::map<std::string, ConvLayer> conv;
+    std::map<std::string, C3Layer> c3;
+    std::map<std::string, SftLayer> sft;
+    std::map<std::string, size_t> f32v;   // raw fp32 vectors/matrices in the weight arena
+    // workspace
+    int H = 0, W = 0;
+    Arena ws;
+    std::map<std::string, Tensor> t;
+    int launches = 0;
+    double macs = 0.0;
+    // ring
+    std::vector<RingSlot> ring;
+    int ring_next = 0, ring_H = 0, ring_W = 0;
+    std::mutex ring_mu;
+    std::condition_variable ring_cv;
+};
+
+namespace {
+
+int fail(hdrtv_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return fail(c, HDRTV_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// ------------------------------------------------------------------------- weight repacking
+// Implicit-GEMM conv: [Co][Ci][K][K] f32 -> wpk [K*K][Ci/CT][CoPad][CT] f16, per-channel scale/shift.
+// ps_cps > 0: output channels are re-ordered for a fused PixelShuffle(2): packed row
+// n' = sub*cps + c holds original channel 4*c + sub.
+bool pack_conv(hdrtv_ctx *c, const Pack &pk, const std::string &key, const std::string &wname, int co, int ci, int ks,
+               int stride, const std::string &bn_name, int ps_cps)
+{
+    std::vector<float> w, b;
+    if (!pk.get(wname + ".weight", (size_t)co * ci * ks * ks, w, c->err)) return false;
+    if (!pk.get(wname + ".bias", (size_t)co, b, c->err)) return false;
+    ConvLayer L;
+    L.cin = ci; L.cout = co; L.ks = ks; L.stride = stride;
+    L.coutPad = (co + 31) / 32 * 32;
+    L.cin_t = (stride == 2 || ci == 32) ? 32 : 64;
+    L.bn = L.coutPad >= 128 ? 128 : L.coutPad;
+    if (ci % L.cin_t != 0 || L.coutPad % L.bn != 0) { c->err = "unsupported conv shape: " + wname; return false; }
+    std::vector<float> scale(L.coutPad, 1.f), shift(L.coutPad, 0.f);
+    std::vector<float> g, be, mu, var;
+    const bool has_bn = !bn_name.empty();
+    if (has_bn) {
+        if (!pk.get(bn_name + ".weight", co, g, c->err) || !pk.get(bn_name + ".bias", co, be, c->err) ||
+            !pk.get(bn_name + ".running_mean", co, mu, c->err) || !pk.get(bn_name + ".running_var", co, var, c->err))
+            return false;
+    }
+    const int nch = ci / L.cin_t, ct = L.cin_t;
+    std::vector<f16> wp((size_t)ks * ks * nch * L.coutPad * ct, (f16)0.f);
+    for (int np = 0; np < co; ++np) {
+        const int n = ps_cps > 0 ? 4 * (np % ps_cps) + np / ps_cps : np;
+        if (has_bn) {
+            const float s = g[n] / std::sqrt(var[n] + 1e-5f);
+            scale[np] = s;
+            shift[np] = (b[n] - mu[n]) * s + be[n];
+        } else {
+            shift[np] = b[n];
+        }
+        for (int k = 0; k < ci; ++k)
+            for (int tap = 0; tap < ks * ks; ++tap)
+                wp[(((size_t)tap * nch + k / ct) * L.coutPad + np) * ct + k % ct] = (f16)w[((size_t)n * ci + k) * ks * ks + tap];
+    }
+    L.wpk = c->wts.put(wp.data(), wp.size() * sizeof(f16));
+    L.scale = c->wts.put(scale.data(), scale.size() * 4);
+    L.shift = c->wts.put(shift.data(), shift.size() * 4);
+    c->conv[key] = L;
+    return true;
+}
+
+// 3x3 conv from 3 planar channels: A fragments [MT][2][64 lanes][8], k = (ky*3+kx)*3 + c (27 of 32 used)
+bool pack_c3(hdrtv_ctx *c, const Pack &pk, const std::string &key, const std::string &wname, int co, const std::string &bn_name)
+{
+    std::vector<float> w, b;
+    if (!pk.get(wname + ".weight", (size_t)co * 27, w, c->err) || !pk.get(wname + ".bias", co, b, c->err)) return false;
+    std::vector<float> scale(co, 1.f), shift(co, 0.f), g, be, mu, var;
+    if (!bn_name.empty()) {
+        if (!pk.get(bn_name + ".weight", co, g, c->err) || !pk.get(bn_name + ".bias", co, be, c->err) ||
+            !pk.get(bn_name + ".running_mean", co, mu, c->err) || !pk.get(bn_name + ".running_var", co, var, c->err))
+            return false;
+    }
+    for (int n = 0; n < co; ++n) {
+        if (!bn_name.empty()) {
+            const float s = g[n] / std::sqrt(var[n] + 1e-5f);
+            scale[n] = s;
+            shift[n] = (b[n] - mu[n]) * s + be[n];
+        } else shift[n] = b[n];
+    }
+    const int mt = co / 32;
+    std::vector<f16> fr((size_t)mt * 2 * 64 * 8, (f16)0.f);
+    for (int i = 0; i < mt; ++i)
+        for (int ks = 0; ks < 2; ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int m = i * 32 + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
+                    if (k < 27) {
+                        const int tap = k / 3, ch = k % 3;
+                        fr[(((size_t)i * 2 + ks) * 64 + lane) * 8 + j] = (f16)w[((size_t)m * 3 + ch) * 9 + tap];
+                    }
+                }
+    C3Layer L;
+    L.cout = co;
+    L.wfrag = c->wts.put(fr.data(), fr.size() * sizeof(f16));
+    L.scale = c->wts.put(scale.data(), co * 4);
+    L.shift = c->wts.put(shift.data(), co * 4);
+    c->c3[key] = L;
+    return true;
+}
+
+// SFTLayer: three A fragments (hidden stack natural-k; scale/shift heads k-permuted) + 96 biases
+bool pack_sft(hdrtv_ctx *c, const Pack &pk, const std::string &key, const std::string &name)
+{
+    std::vector<float> w0s, b0s, w1s, b1s, w0t, b0t, w1t, b1t;
+    if (!pk.get(name + ".SFT_scale_conv0.weight", 256, w0s, c->err) || !pk.get(name + ".SFT_scale_conv0.bias", 16, b0s, c->err) ||
+        !pk.get(name + ".SFT_scale_conv1.weight", 512, w1s, c->err) || !pk.get(name + ".SFT_scale_conv1.bias", 32, b1s, c->err) ||
+        !pk.get(name + ".SFT_shift_conv0.weight", 256, w0t, c->err) || !pk.get(name + ".SFT_shift_conv0.bias", 16, b0t, c->err) ||
+        !pk.get(name + ".SFT_shift_conv1.weight", 512, w1t, c->err) || !pk.get(name + ".SFT_shift_conv1.bias", 32, b1t, c->err))
+        return false;
+    std::vector<f16> fr(3 * 64 * 8);
+    std::vector<float> bias(96);
+    for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+            const int m = lane & 31, p = 8 * (lane >> 5) + j;
+            fr[(0 * 64 + lane) * 8 + j] = (f16)(m < 16 ? w0s[m * 16 + p] : w0t[(m - 16) * 16 + p]);
+            fr[(1 * 64 + lane) * 8 + j] = (f16)w1s[m * 16 + acc_kperm16(p)];
+            fr[(2 * 64 + lane) * 8 + j] = (f16)w1t[m * 16 + acc_kperm16(p)];
+        }
+    for (int i = 0; i < 16; ++i) { bias[i] = b0s[i]; bias[16 + i] = b0t[i]; }
+    for (int i = 0; i < 32; ++i) { bias[32 + i] = b1s[i]; bias[64 + i] = b1t[i]; }
+    SftLayer L;
+    L.wfrag = c->wts.put(fr.data(), fr.size() * sizeof(f16));
+    L.bias = c->wts.put(bias.data(), bias.size() * 4);
+    c->sft[key] = L;
+    return true;
+}
+
+bool put_f32(hdrtv_ctx *c, const Pack &pk, const std::string &key, const std::string &name, size_t numel)
+{
+    std::vector<float> v;
+    if (!pk.get(name, numel, v, c->err)) return false;
+    c->f32v[key] = c->wts.put(v.data(), v.size() * 4);
+    return true;
+}
+
+bool build_weights(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
+{
+    // ---- AGCM (fp32 on device: tiny)
+    const int cls_ci[5] = {3, 16, 32, 64, 128}, cls_co[5] = {16, 32, 64, 128, 128}, cls_idx[5] = {0, 4, 8, 12, 16};
+    char nm[160], key[64];
+    for (int i = 0; i < 5; ++i) {
+        snprintf(nm, sizeof nm, "AGCM.classifier.model.%d", cls_idx[i]);
+        snprintf(key, sizeof key, "cls%d.w", i);
+        if (!put_f32(c, hr, key, std::string(nm) + ".weight", (size_t)cls_co[i] * cls_ci[i])) return false;
+        snprintf(key, sizeof key, "cls%d.b", i);
+        if (!put_f32(c, hr, key, std::string(nm) + ".bias", cls_co[i])) return false;
+        if (i < 4) {
+            snprintf(nm, sizeof nm, "AGCM.classifier.model.%d", cls_idx[i] + 3);
+            snprintf(key, sizeof key, "cls%d.g", i);
+            if (!put_f32(c, hr, key, std::string(nm) + ".weight", cls_co[i])) return false;
+            snprintf(key, sizeof key, "cls%d.be", i);
+            if (!put_f32(c, hr, key, std::string(nm) + ".bias", cls_co[i])) return false;
+        }
+    }
+    if (!put_f32(c, hr, "cls20.w", "AGCM.classifier.model.20.weight", 6 * 128) ||
+        !put_f32(c, hr, "cls20.b", "AGCM.classifier.model.20.bias", 6))
+        return false;
+    const char *stage[3] = {"first", "HR", "last"};
+    const int stage_n[3] = {64, 64, 3};
+    for (int s = 0; s < 3; ++s) {
+        for (int kind = 0; kind < 2; ++kind) {
+            snprintf(nm, sizeof nm, "AGCM.cond_%s_%s", kind ? "shift" : "scale", stage[s]);
+            snprintf(key, sizeof key, "gfm.%c%d.w", kind ? 't' : 's', s);
+            if (!put_f32(c, hr, key, std::string(nm) + ".weight", (size_t)stage_n[s] * 6)) return false;
+            snprintf(key, sizeof key, "gfm.%c%d.b", kind ? 't' : 's', s);
+            if (!put_f32(c, hr, key, std::string(nm) + ".bias", stage_n[s])) return false;
+        }
+    }
+    if (!put_f32(c, hr, "agcm.w1", "AGCM.conv_first.weight", 192) || !put_f32(c, hr, "agcm.b1", "AGCM.conv_first.bias", 64) ||
+        !put_f32(c, hr, "agcm.w2", "AGCM.HRconv.weight", 4096) || !put_f32(c, hr, "agcm.b2", "AGCM.HRconv.bias", 64) ||
+        !put_f32(c, hr, "agcm.w3", "AGCM.conv_last.weight", 192) || !put_f32(c, hr, "agcm.b3", "AGCM.conv_last.bias", 3))
+        return false;
+
+    // ---- LE
+    if (!pack_c3(c, hr, "le.cond_first.0", "LE.cond_first.0", 64, "") || !pack_c3(c, hr, "le.conv_first", "LE.conv_first", 32, ""))
+        return false;
+    struct Spec { const char *name; int co, ci, ks, stride, ps; };
+    const Spec le_convs[] = {
+        {"LE.cond_first.2", 64, 64, 1, 1, 0}, {"LE.cond_first.4", 64, 64, 1, 1, 0},
+        {"LE.CondNet1.0", 64, 64, 1, 1, 0}, {"LE.CondNet1.2", 64, 64, 1, 1, 0}, {"LE.CondNet1.4", 16, 64, 1, 1, 0},
+        {"LE.CondNet2.0", 64, 64, 3, 2, 0}, {"LE.CondNet2.2", 64, 64, 1, 1, 0}, {"LE.CondNet2.4", 16, 64, 1, 1, 0},
+        {"LE.CondNet3.0", 64, 64, 3, 2, 0}, {"LE.CondNet3.2", 64, 64, 3, 2, 0}, {"LE.CondNet3.4", 16, 64, 1, 1, 0},
+        {"LE.CondNet4.0", 64, 64, 3, 2, 0}, {"LE.CondNet4.2", 64, 64, 3, 2, 0}, {"LE.CondNet4.4", 16, 64, 3, 2, 0},
+        {"LE.HR_conv1", 32, 32, 3, 1, 0}, {"LE.HR_conv2", 32, 32, 3, 1, 0}, {"LE.conv_last", 3, 32, 3, 1, 0},
+        {"LE.down_conv1", 32, 32, 3, 2, 0}, {"LE.down_conv2", 32, 32, 3, 2, 0}, {"LE.down_conv3", 32, 32, 3, 2, 0},
+        {"LE.up_conv1.0", 128, 32, 3, 1, 32}, {"LE.up_conv2.0", 128, 32, 3, 1, 32}, {"LE.up_conv3.0", 128, 32, 3, 1, 32},
+    };
+    for (const Spec &s : le_convs)
+        if (!pack_conv(c, hr, s.name, s.name, s.co, s.ci, s.ks, s.stride, "", s.ps)) return false;
+    const char *trunks[5] = {"recon_trunk1", "recon_trunk2", "recon_trunk3", "recon_trunk4", "recon_trunk5"};
+    const int trunk_n[5] = {1, 1, 4, 1, 1};
+    for (int t = 0; t < 5; ++t)
+        for (int b = 0; b < trunk_n[t]; ++b) {
+            snprintf(nm, sizeof nm, "LE.%s.%d", trunks[t], b);
+            const std::string base = nm;
+            if (!pack_conv(c, hr, base + ".conv1", base + ".conv1", 32, 32, 3, 1, "", 0) ||
+                !pack_conv(c, hr, base + ".conv2", base + ".conv2", 32, 32, 3, 1, "", 0) ||
+                !pack_sft(c, hr, base + ".sft1", base + ".sft1") || !pack_sft(c, hr, base + ".sft2", base + ".sft2"))
+                return false;
+        }
+    if (!pack_sft(c, hr, "LE.SFT_layer1", "LE.SFT_layer1") || !pack_sft(c, hr, "LE.SFT_layer2", "LE.SFT_layer2")) return false;
+
+    // ---- HG
+    if (hg) {
+        if (!pack_c3(c, *hg, "hg.conv1", "conv1.0", 64, "conv1.1")) return false;
+        const Spec blocks[] = {{"conv2", 128, 64, 3, 1, 0}, {"conv3_1", 256, 128, 3, 1, 0}, {"conv3_2", 256, 256, 3, 1, 0},
+                               {"conv4_1", 512, 256, 3, 1, 0}, {"conv4_2", 512, 512, 3, 1, 0}, {"conv5_1", 512, 512, 3, 1, 0},
+                               {"conv5_2", 512, 512, 3, 1, 0}, {"conv_code1", 512, 512, 3, 1, 0}, {"conv_code2", 512, 512, 3, 1, 0}};
+        for (const Spec &s : blocks)
+            if (!pack_conv(c, *hg, std::string("hg.") + s.name, std::string(s.name) + ".0", s.co, s.ci, 3, 1,
+                           std::string(s.name) + ".1", 0))
+                return false;
+        const Spec ups[] = {{"Up_conv1", 2048, 512, 3, 1, 512}, {"Up_conv2", 2048, 512, 3, 1, 512}, {"Up_conv3", 1024, 256, 3, 1, 256},
+                            {"Up_conv4", 512, 128, 3, 1, 128}, {"Up_conv5", 256, 64, 3, 1, 64}};
+        for (const Spec &s : ups)
+            if (!pack_conv(c, *hg, std::string("hg.") + s.name, std::string(s.name) + ".0", s.co, s.ci, 3, 1, "", s.ps)) return false;
+        const Spec fuses[] = {{"conv6", 512, 1024, 1, 1, 0}, {"conv7", 256, 1024, 1, 1, 0}, {"conv8", 128, 512, 1, 1, 0},
+                              {"conv9", 64, 256, 1, 1, 0}};
+        for (const Spec &s : fuses)
+            if (!pack_conv(c, *hg, std::string("hg.") + s.name, s.name, s.co, s.ci, 1, 1, "", 0)) return false;
+        if (!put_f32(c, *hg, "hg.w10", "conv10.weight", 3 * 128) || !put_f32(c, *hg, "hg.b10", "conv10.bias", 3) ||
+            !put_f32(c, *hg, "hg.wl", "conv_last.weight", 18) || !put_f32(c, *hg, "hg.bl", "conv_last.bias", 3))
+            return false;
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------- workspace
+inline int half_up(int n) { return (n - 1) / 2 + 1; }
+
+Tensor &ws_add(hdrtv_ctx *c, const std::string &name, int C, int H, int W, int layout)
+{
+    Tensor t;
+    t.C = C; t.H = H; t.W = W; t.layout = layout;
+    t.off = c->ws.reserve(t.bytes() + 256);
+    c->t[name] = t;
+    return c->t[name];
+}
+
+template <typename T>
+T *wsp(hdrtv_ctx *c, const std::string &name)
+{
+    auto it = c->t.find(name);
+    if (it == c->t.end()) { fprintf(stderr, "hdrtv: internal error, no workspace tensor %s\n", name.c_str()); abort(); }
+    return reinterpret_cast<T *>(c->ws.dev + it->second.off);
+}
+template <typename T>
+const T *wtp(hdrtv_ctx *c, size_t off) { return reinterpret_cast<const T *>(c->wts.dev + off); }
+
+// ATen _upsample_bicubic2d_aa tap table for scale 4 (see oracle/hdrtv_oracle.c aa_weights)
+float cubic_aa(float x)
+{
+    const float a = -0.5f;
+    x = std::fabs(x);
+    if (x < 1.0f) return ((a + 2.0f) * x - (a + 3.0f)) * x * x + 1.0f;
+    if (x < 2.0f) return (((x - 5.0f) * x + 8.0f) * x - 4.0f) * a;
+    return 0.0f;
+}
+void aa_table(int in, int out, std::vector<float> &w, std::vector<int> &mn, std::vector<int> &ns)
+{
+    const float scale = 4.0f, support = 8.0f;
+    w.assign((size_t)out * 17, 0.f);
+    mn.resize(out);
+    ns.resize(out);
+    for (int i = 0; i < out; ++i) {
+        const float center = scale * ((float)i + 0.5f);
+        int xmin = (int)(center - support + 0.5f);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5f);
+        if (xmax > in) xmax = in;
+        const int xs = xmax - xmin;
+        float total = 0.f;
+        for (int j = 0; j < xs; ++j) {
+            w[(size_t)i * 17 + j] = cubic_aa(((float)(j + xmin) - center + 0.5f) / scale);
+            total += w[(size_t)i * 17 + j];
+        }
+        for (int j = 0; j < xs; ++j) w[(size_t)i * 17 + j] /= total;
+        mn[i] = xmin;
+        ns[i] = xs;
+    }
+}
+
+struct Shapes {
+    int H, W, h4, w4;
+    int ch[6], cw[6];        // classifier spatial sizes: [0]=cond, [i]=after block i
+    int H1, W1, H2, W2, H3, W3;
+    int Hp, Wp;
+};
+Shapes shapes_for(int H, int W)
+{
+    Shapes s;
+    s.H = H; s.W = W;
+    s.h4 = H / 4 > 0 ? H / 4 : 1; s.w4 = W / 4 > 0 ? W / 4 : 1;
+    s.ch[0] = s.h4; s.cw[0] = s.w4;
+    for (int i = 1; i <= 5; ++i) { s.ch[i] = half_up(s.ch[i - 1]); s.cw[i] = half_up(s.cw[i - 1]); }
+    s.H1 = half_up(H); s.W1 = half_up(W);
+    s.H2 = half_up(s.H1); s.W2 = half_up(s.W1);
+    s.H3 = half_up(s.H2); s.W3 = half_up(s.W2);
+    s.Hp = (H + 31) / 32 * 32; s.Wp = (W + 31) / 32 * 32;
+    return s;
+}
+
+int do_reserve(hdrtv_ctx *c, int H, int W)
+{
+    if (c->H == H && c->W == W && c->ws.dev) return HDRTV_OK;
+    if (H < 8 || W < 8 || H > 16384 || W > 16384) return fail(c, HDRTV_EINVAL, "unsupported frame size %dx%d", W, H);
+    const Shapes s = shapes_for(H, W);
+    // InstanceNorm2d needs more than one spatial element at the 4th classifier block (the reference raises
+    // ValueError there too: torch/nn/functional.py _verify_spatial_size)
+    if (s.ch[4] * s.cw[4] < 2) return fail(c, HDRTV_EINVAL, "frame %dx%d too small for the AGCM classifier", W, H);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    if (c->ws.dev) { (void)hipFree(c->ws.dev); c->ws.dev = nullptr; }
+    c->ws = Arena();
+    c->t.clear();
+    // resize tables
+    std::vector<float> wx, wy;
+    std::vector<int> xmn, xns, ymn, yns;
+    aa_table(W, s.w4, wx, xmn, xns);
+    aa_table(H, s.h4, wy, ymn, yns);
+    ws_add(c, "aa.wx", (int)wx.size(), 1, 1, 3); ws_add(c, "aa.wy", (int)wy.size(), 1, 1, 3);
+    ws_add(c, "aa.xmn", s.w4, 1, 1, 3); ws_add(c, "aa.xns", s.w4, 1, 1, 3);
+    ws_add(c, "aa.ymn", s.h4, 1, 1, 3); ws_add(c, "aa.yns", s.h4, 1, 1, 3);
+    // AGCM
+    const int cls_co[5] = {16, 32, 64, 128, 128};
+    char nm[64];
+    for (int i = 0; i < 5; ++i) {
+        snprintf(nm, sizeof nm, "agcm.u%d", i + 1);
+        ws_add(c, nm, cls_co[i], s.ch[i + 1], s.cw[i + 1], 2);
+        snprintf(nm, sizeof nm, "agcm.mean%d", i + 1);
+        ws_add(c, nm, cls_co[i], 1, 1, 3);
+        snprintf(nm, sizeof nm, "agcm.rstd%d", i + 1);
+        ws_add(c, nm, cls_co[i], 1, 1, 3);
+    }
+    ws_add(c, "agcm.frags", 14 * 64 * 8 / 2, 1, 1, 3);   // f16 elements stored in an f32-sized slot
+    ws_add(c, "agcm.bias", 168, 1, 1, 3);
+    ws_add(c, "agcm.out", 3, H, W, 1);
+    // LE
+    ws_add(c, "le.t64a", 64, H, W, 0); ws_add(c, "le.t64b", 64, H, W, 0); ws_add(c, "le.cond", 64, H, W, 0);
+    ws_add(c, "le.cond1", 16, H, W, 0);
+    ws_add(c, "le.h1a", 64, s.H1, s.W1, 0); ws_add(c, "le.h1b", 64, s.H1, s.W1, 0);
+    ws_add(c, "le.h2a", 64, s.H2, s.W2, 0);
+    ws_add(c, "le.cond2", 16, s.H1, s.W1, 0); ws_add(c, "le.cond3", 16, s.H2, s.W2, 0); ws_add(c, "le.cond4", 16, s.H3, s.W3, 0);
+    ws_add(c, "le.f0a", 32, H, W, 0); ws_add(c, "le.f0b", 32, H, W, 0); ws_add(c, "le.fea0", 32, H, W, 0);
+    ws_add(c, "le.up3", 32, H, W, 0);
+    ws_add(c, "le.fea1a", 32, s.H1, s.W1, 0); ws_add(c, "le.fea1", 32, s.H1, s.W1, 0);
+    ws_add(c, "le.l1a", 32, s.H1, s.W1, 0); ws_add(c, "le.l1b", 32, s.H1, s.W1, 0); ws_add(c, "le.l1c", 32, s.H1, s.W1, 0);
+    ws_add(c, "le.up2", 32, s.H1, s.W1, 0); ws_add(c, "le.t5", 32, s.H1, s.W1, 0);
+    ws_add(c, "le.fea2a", 32, s.H2, s.W2, 0); ws_add(c, "le.fea2", 32, s.H2, s.W2, 0);
+    ws_add(c, "le.l2a", 32, s.H2, s.W2, 0); ws_add(c, "le.l2b", 32, s.H2, s.W2, 0); ws_add(c, "le.l2c", 32, s.H2, s.W2, 0);
+    ws_add(c, "le.up1", 32, s.H2, s.W2, 0); ws_add(c, "le.t4", 32, s.H2, s.W2, 0);
+    ws_add(c, "le.fea3", 32, s.H3, s.W3, 0);
+    ws_add(c, "le.l3a", 32, s.H3, s.W3, 0); ws_add(c, "le.l3b", 32, s.H3, s.W3, 0); ws_add(c, "le.l3c", 32, s.H3, s.W3, 0);
+    ws_add(c, "le.t3x", 32, s.H3, s.W3, 0); ws_add(c, "le.t3y", 32, s.H3, s.W3, 0);
+    ws_add(c, "le.out", 3, H, W, 1);
+    if (c->has_hg) {
+        const int Hp = s.Hp, Wp = s.Wp;
+        ws_add(c, "hg.img", 3, Hp, Wp, 1); ws_add(c, "hg.mask", 1, Hp, Wp, 4);
+        ws_add(c, "hg.conv1", 64, Hp, Wp, 0); ws_add(c, "hg.p1", 64, Hp / 2, Wp / 2, 0);
+        ws_add(c, "hg.conv2", 128, Hp / 2, Wp / 2, 0);
+        ws_add(c, "hg.p3", 256, Hp / 4, Wp / 4, 0); ws_add(c, "hg.conv3_2", 256, Hp / 4, Wp / 4, 0);
+        ws_add(c, "hg.p4", 512, Hp / 8, Wp / 8, 0); ws_add(c, "hg.conv4_2", 512, Hp / 8, Wp / 8, 0);
+        ws_add(c, "hg.p5", 512, Hp / 16, Wp / 16, 0); ws_add(c, "hg.conv5_2", 512, Hp / 16, Wp / 16, 0);
+        ws_add(c, "hg.pc", 512, Hp / 32, Wp / 32, 0); ws_add(c, "hg.conv_code2", 512, Hp / 32, Wp / 32, 0);
+        ws_add(c, "hg.up1", 512, Hp / 16, Wp / 16, 0); ws_add(c, "hg.conv6", 512, Hp / 16, Wp / 16, 0);
+        ws_add(c, "hg.up2", 512, Hp / 8, Wp / 8, 0); ws_add(c, "hg.conv7", 256, Hp / 8, Wp / 8, 0);
+        ws_add(c, "hg.up3", 256, Hp / 4, Wp / 4, 0); ws_add(c, "hg.conv8", 128, Hp / 4, Wp / 4, 0);
+        ws_add(c, "hg.up4", 128, Hp / 2, Wp / 2, 0); ws_add(c, "hg.conv9", 64, Hp / 2, Wp / 2, 0);
+        ws_add(c, "hg.up5", 64, Hp, Wp, 0);
+    }
+    if (hipMalloc((void **)&c->ws.dev, c->ws.size + 4096) != hipSuccess) {
+        c->ws.dev = nullptr;
+        c->H = c->W = 0;
+        return fail(c, HDRTV_ENOMEM, "workspace allocation of %zu bytes failed", c->ws.size);
+    }
+    HIPCHK(c, hipMemset(c->ws.dev, 0, c->ws.size + 4096));
+    HIPCHK(c, hipMemcpy(wsp<float>(c, "aa.wx"), wx.data(), wx.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(wsp<float>(c, "aa.wy"), wy.data(), wy.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(wsp<int>(c, "aa.xmn"), xmn.data(), xmn.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(wsp<int>(c, "aa.xns"), xns.data(), xns.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(wsp<int>(c, "aa.ymn"), ymn.data(), ymn.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(wsp<int>(c, "aa.yns"), yns.data(), yns.size() * 4, hipMemcpyHostToDevice));
+    c->H = H; c->W = W;
+    return HDRTV_OK;
+}
+
+// ----------------------------------------------------------------------- launch sequencing
+struct Seq {
+    hdrtv_ctx *c;
+    hipStream_t s;
+    int rc = HDRTV_OK;
+    bool ok() const { return rc == HDRTV_OK; }
+    void chk(hipError_t e, const char *what)
+    {
+        ++c->launches;
+        if (e != hipSuccess && rc == HDRTV_OK) rc = fail(c, HDRTV_EHIP, "launch %s failed: %s", what, hipGetErrorString(e));
+    }
+    // generic conv: src0 (+src1) -> dst
+    void conv(const std::string &key, const f16 *src0, int c0, const f16 *src1, int c1, int Hi, int Wi, int act, int mode,
+              f16 *dst, int dstC, int Hd, int Wd, const f16 *res1 = nullptr, const f16 *res2 = nullptr, f16 *dst_full = nullptr,
+              f16 *dst_planar = nullptr, const f16 *res_planar = nullptr)
+    {
+        if (!ok()) return;
+        auto it = c->conv.find(key);
+        if (it == c->conv.end()) { rc = fail(c, HDRTV_ESTATE, "no packed conv %s", key.c_str()); return; }
+        const ConvLayer &L = it->second;
+        ConvParams p;
+        memset(&p, 0, sizeof p);
+        p.src0 = src0; p.src1 = src1; p.c0 = c0; p.c1 = c1;
+        p.Hi = Hi; p.Wi = Wi;
+        const int pad = L.ks / 2;
+        p.Ho = (Hi + 2 * pad - L.ks) / L.stride + 1;
+        p.Wo = (Wi + 2 * pad - L.ks) / L.stride + 1;
+        p.wpk = wtp<f16>(c, L.wpk); p.scale = wtp<float>(c, L.scale); p.shift = wtp<float>(c, L.shift);
+        p.CoutPad = L.coutPad; p.Cout = L.cout; p.act = act; p.mode = mode;
+        p.dst = dst; p.dst_full = dst_full; p.dstC = dstC; p.Hd = Hd; p.Wd = Wd;
+        p.res1 = res1; p.res2 = res2; p.dst_planar = dst_planar; p.res_planar = res_planar;
+        if (c0 + c1 != L.cin) { rc = fail(c, HDRTV_ESTATE, "conv %s: channel mismatch", key.c_str()); return; }
+        chk(conv_igemm_launch(p, L.cin_t, L.bn, L.ks, L.stride, s), key.c_str());
+        c->macs += (double)p.Ho * p.Wo * L.cin * L.ks * L.ks * L.cout;
+    }
+    void c3(const std::string &key, const f16 *in, int H, int W, int act, f16 *out, f16 *out_pool)
+    {
+        if (!ok()) return;
+        const C3Layer &L = c->c3.at(key);
+        chk(conv_c3_launch(in, H, W, wtp<f16>(c, L.wfrag), wtp<float>(c, L.scale), wtp<float>(c, L.shift), L.cout, act, out,
+                           out_pool, s), key.c_str());
+        c->macs += (double)H * W * 27 * L.cout;
+    }
+    void sft(const std::string &key, const f16 *x, const f16 *cond, f16 *y, int npix)
+    {
+        if (!ok()) return;
+        const SftLayer &L = c->sft.at(key);
+        SftParams p;
+        p.x = x; p.cond = cond; p.y = y; p.wfrag = wtp<f16>(c, L.wfrag); p.bias = wtp<float>(c, L.bias); p.npix = npix;
+        chk(sft_launch(p, s), key.c_str());
+        c->macs += (double)npix * 2 * (16 * 16 + 16 * 32);
+    }
+    // ResBlock_with_SFT (arch_util.py:89-95): y = x + conv2(sft2(relu(conv1(sft1(x,c))),c))  [+ extra]
+    void resblock(const std::string &base, const f16 *x, const f16 *cond, int H, int W, f16 *ta, f16 *tb, f16 *y,
+                  const f16 *extra = nullptr)
+    {
+        sft(base + ".sft1", x, cond, ta, H * W);
+        conv(base + ".conv1", ta, 32, nullptr, 0, H, W, ACT_RELU, ST_NHWC, tb, 32, H, W);
+        sft(base + ".sft2", tb, cond, ta, H * W);
+        conv(base + ".conv2", ta, 32, nullptr, 0, H, W, ACT_NONE, ST_NHWC, y, 32, H, W, x, extra);
+    }
+};
+
+int run_agcm(hdrtv_ctx *c, Seq &q, const f16 *rgb, const f16 *cond, f16 *agcm_out)
+{
+    const Shapes s = shapes_for(c->H, c->W);
+    const int cls_ci[5] = {3, 16, 32, 64, 128}, cls_co[5] = {16, 32, 64, 128, 128};
+    char a[64], b[64];
+    for (int i = 0; i < 5; ++i) {
+        snprintf(a, sizeof a, "agcm.u%d", i + 1);
+        float *out = wsp<float>(c, a);
+        const void *in = cond;
+        const float *nm = nullptr, *nr = nullptr, *ng = nullptr, *nb = nullptr;
+        if (i > 0) {
+            snprintf(b, sizeof b, "agcm.u%d", i);
+            in = wsp<float>(c, b);
+            snprintf(b, sizeof b, "agcm.mean%d", i); nm = wsp<float>(c, b);
+            snprintf(b, sizeof b, "agcm.rstd%d", i); nr = wsp<float>(c, b);
+            snprintf(b, sizeof b, "cls%d.g", i - 1); ng = wtp<float>(c, c->f32v.at(b));
+            snprintf(b, sizeof b, "cls%d.be", i - 1); nb = wtp<float>(c, c->f32v.at(b));
+        }
+        snprintf(b, sizeof b, "cls%d.w", i);
+        const float *w = wtp<float>(c, c->f32v.at(b));
+        snprintf(b, sizeof b, "cls%d.b", i);
+        const float *bias = wtp<float>(c, c->f32v.at(b));
+        q.chk(cls_block_launch(in, i == 0, cls_ci[i], s.ch[i], s.cw[i], nm, nr, ng, nb, w, bias, cls_co[i], out, s.ch[i + 1],
+                               s.cw[i + 1], q.s), "cls_block");
+        c->macs += (double)s.ch[i] * s.cw[i] * cls_ci[i] * cls_co[i];
+        snprintf(a, sizeof a, "agcm.mean%d", i + 1);
+        snprintf(b, sizeof b, "agcm.rstd%d", i + 1);
+        q.chk(cls_stats_launch(out, cls_co[i], s.ch[i + 1] * s.cw[i + 1], 1e-5f, wsp<float>(c, a), wsp<float>(c, b), q.s),
+              "cls_stats");
+    }
+    AgcmFoldArgs fa;
+    fa.mean5 = wsp<float>(c, "agcm.mean5");
+    fa.w20 = wtp<float>(c, c->f32v.at("cls20.w")); fa.b20 = wtp<float>(c, c->f32v.at("cls20.b"));
+    for (int st = 0; st < 3; ++st) {
+        snprintf(a, sizeof a, "gfm.s%d.w", st); fa.ws[st] = wtp<float>(c, c->f32v.at(a));
+        snprintf(a, sizeof a, "gfm.s%d.b", st); fa.bs[st] = wtp<float>(c, c->f32v.at(a));
+        snprintf(a, sizeof a, "gfm.t%d.w", st); fa.wt[st] = wtp<float>(c, c->f32v.at(a));
+        snprintf(a, sizeof a, "gfm.t%d.b", st); fa.bt[st] = wtp<float>(c, c->f32v.at(a));
+    }
+    fa.w1 = wtp<float>(c, c->f32v.at("agcm.w1")); fa.b1 = wtp<float>(c, c->f32v.at("agcm.b1"));
+    fa.w2 = wtp<float>(c, c->f32v.at("agcm.w2")); fa.b2 = wtp<float>(c, c->f32v.at("agcm.b2"));
+    fa.w3 = wtp<float>(c, c->f32v.at("agcm.w3")); fa.b3 = wtp<float>(c, c->f32v.at("agcm.b3"));
+    q.chk(agcm_fold_launch(fa, wsp<f16>(c, "agcm.frags"), wsp<float>(c, "agcm.bias"), q.s), "agcm_fold");
+    c->macs += 128.0 * 6 + 6.0 * (64 + 64 + 3) * 2;
+    q.chk(agcm_mlp_launch(rgb, agcm_out, (size_t)c->H * c->W, wsp<f16>(c, "agcm.frags"), wsp<float>(c, "agcm.bias"), q.s),
+          "agcm_mlp");
+    c->macs += (double)c->H * c->W * (3 * 64 + 64 * 64 + 64 * 3);
+    return q.rc;
+}
+
+// HDRUNet3T1._forward_safe_aligned (HDRUNet3T1_arch.py:152-206) with x = [agcm_out, agcm_out]
+int run_le(hdrtv_ctx *c, Seq &q, const f16 *img, f16 *out_planar)
+{
+    const Shapes s = shapes_for(c->H, c->W);
+    const int H = s.H, W = s.W;
+    f16 *t64a = wsp<f16>(c, "le.t64a"), *t64b = wsp<f16>(c, "le.t64b"), *cond = wsp<f16>(c, "le.cond");
+    f16 *cond1 = wsp<f16>(c, "le.cond1"), *cond2 = wsp<f16>(c, "le.cond2"), *cond3 = wsp<f16>(c, "le.cond3"),
+        *cond4 = wsp<f16>(c, "le.cond4");
+    f16 *h1a = wsp<f16>(c, "le.h1a"), *h1b = wsp<f16>(c, "le.h1b"), *h2a = wsp<f16>(c, "le.h2a");
+    // condition trunk
+    q.c3("le.cond_first.0", img, H, W, ACT_LRELU01, t64a, nullptr);
+    q.conv("LE.cond_first.2", t64a, 64, nullptr, 0, H, W, ACT_LRELU01, ST_NHWC, t64b, 64, H, W);
+    q.conv("LE.cond_first.4", t64b, 64, nullptr, 0, H, W, ACT_LRELU01, ST_NHWC, cond, 64, H, W);
+    q.conv("LE.CondNet1.0", cond, 64, nullptr, 0, H, W, ACT_LRELU01, ST_NHWC, t64a, 64, H, W);
+    q.conv("LE.CondNet1.2", t64a, 64, nullptr, 0, H, W, ACT_LRELU01, ST_NHWC, t64b, 64, H, W);
+    q.conv("LE.CondNet1.4", t64b, 64, nullptr, 0, H, W, ACT_NONE, ST_NHWC, cond1, 16, H, W);
+    q.conv("LE.CondNet2.0", cond, 64, nullptr, 0, H, W, ACT_LRELU01, ST_NHWC, h1a, 64, s.H1, s.W1);
+    q.conv("LE.CondNet2.2", h1a, 64, nullptr, 0, s.H1, s.W1, ACT_LRELU01, ST_NHWC, h1b, 64, s.H1, s.W1);
+    q.conv("LE.CondNet2.4", h1b, 64, nullptr, 0, s.H1, s.W1, ACT_NONE, ST_NHWC, cond2, 16, s.H1, s.W1);
+    q.conv("LE.CondNet3.0", cond, 64, nullptr, 0, H, W, ACT_LRELU01, ST_NHWC, h1a, 64, s.H1, s.W1);
+    q.conv("LE.CondNet3.2", h1a, 64, nullptr, 0, s.H1, s.W1, ACT_LRELU01, ST_NHWC, h2a, 64, s.H2, s.W2);
+    q.conv("LE.CondNet3.4", h2a, 64, nullptr, 0, s.H2, s.W2, ACT_NONE, ST_NHWC, cond3, 16, s.H2, s.W2);
+    q.conv("LE.CondNet4.0", cond, 64, nullptr, 0, H, W, ACT_LRELU01, ST_NHWC, h1a, 64, s.H1, s.W1);
+    q.conv("LE.CondNet4.2", h1a, 64, nullptr, 0, s.H1, s.W1, ACT_LRELU01, ST_NHWC, h2a, 64, s.H2, s.W2);
+    q.conv("LE.CondNet4.4", h2a, 64, nullptr, 0, s.H2, s.W2, ACT_NONE, ST_NHWC, cond4, 16, s.H3, s.W3);
+    // main branch
+    f16 *f0a = wsp<f16>(c, "le.f0a"), *f0b = wsp<f16>(c, "le.f0b"), *fea0 = wsp<f16>(c, "le.fea0"), *up3 = wsp<f16>(c, "le.up3");
+    q.c3("le.conv_first", img, H, W, ACT_RELU, f0a, nullptr);
+    q.sft("LE.SFT_layer1", f0a, cond1, f0b, H * W);
+    q.conv("LE.HR_conv1", f0b, 32, nullptr, 0, H, W, ACT_RELU, ST_NHWC, fea0, 32, H, W);
+    f16 *fea1a = wsp<f16>(c, "le.fea1a"), *fea1 = wsp<f16>(c, "le.fea1"), *l1a = wsp<f16>(c, "le.l1a"), *l1b = wsp<f16>(c, "le.l1b");
+    q.conv("LE.down_conv1", fea0, 32, nullptr, 0, H, W, ACT_RELU, ST_NHWC, fea1a, 32, s.H1, s.W1);
+    q.resblock("LE.recon_trunk1.0", fea1a, cond2, s.H1, s.W1, l1a, l1b, fea1);
+    f16 *fea2a = wsp<f16>(c, "le.fea2a"), *fea2 = wsp<f16>(c, "le.fea2"), *l2a = wsp<f16>(c, "le.l2a"), *l2b = wsp<f16>(c, "le.l2b");
+    q.conv("LE.down_conv2", fea1, 32, nullptr, 0, s.H1, s.W1, ACT_RELU, ST_NHWC, fea2a, 32, s.H2, s.W2);
+    q.resblock("LE.recon_trunk2.0", fea2a, cond3, s.H2, s.W2, l2a, l2b, fea2);
+    f16 *fea3 = wsp<f16>(c, "le.fea3"), *l3a = wsp<f16>(c, "le.l3a"), *l3b = wsp<f16>(c, "le.l3b"), *t3x = wsp<f16>(c, "le.t3x"),
+        *t3y = wsp<f16>(c, "le.t3y");
+    q.conv("LE.down_conv3", fea2, 32, nullptr, 0, s.H2, s.W2, ACT_RELU, ST_NHWC, fea3, 32, s.H3, s.W3);
+    q.resblock("LE.recon_trunk3.0", fea3, cond4, s.H3, s.W3, l3a, l3b, t3x);
+    q.resblock("LE.recon_trunk3.1", t3x, cond4, s.H3, s.W3, l3a, l3b, t3y);
+    q.resblock("LE.recon_trunk3.2", t3y, cond4, s.H3, s.W3, l3a, l3b, t3x);
+    q.resblock("LE.recon_trunk3.3", t3x, cond4, s.H3, s.W3, l3a, l3b, t3y, fea3);   // "+ fea3" (line 180) fused as 2nd residual
+    // up path: relu(shuffle(conv)) + skip, cropped to the skip's size (_align_to)
+    f16 *up1 = wsp<f16>(c, "le.up1"), *t4 = wsp<f16>(c, "le.t4");
+    q.conv("LE.up_conv1.0", t3y, 32, nullptr, 0, s.H3, s.W3, ACT_RELU, ST_PS, up1, 32, s.H2, s.W2, fea2);
+    q.resblock("LE.recon_trunk4.0", up1, cond3, s.H2, s.W2, l2a, l2b, t4);
+    f16 *up2 = wsp<f16>(c, "le.up2"), *t5 = wsp<f16>(c, "le.t5");
+    q.conv("LE.up_conv2.0", t4, 32, nullptr, 0, s.H2, s.W2, ACT_RELU, ST_PS, up2, 32, s.H1, s.W1, fea1);
+    q.resblock("LE.recon_trunk5.0", up2, cond2, s.H1, s.W1, l1a, l1b, t5);
+    q.conv("LE.up_conv3.0", t5, 32, nullptr, 0, s.H1, s.W1, ACT_RELU, ST_PS, up3, 32, H, W, fea0);
+    q.sft("LE.SFT_layer2", up3, cond1, f0a, H * W);
+    q.conv("LE.HR_conv2", f0a, 32, nullptr, 0, H, W, ACT_RELU, ST_NHWC, f0b, 32, H, W);
+    q.conv("LE.conv_last", f0b, 32, nullptr, 0, H, W, ACT_NONE, ST_PLANAR3, nullptr, 0, H, W, nullptr, nullptr, nullptr,
+           out_planar, img);
+    return q.rc;
+}
+
+// HG_Composite.forward tail + Hallucination_Generator.forward
+int run_hg(hdrtv_ctx *c, Seq &q, const f16 *base, void *out, int out_f32)
+{
+    const Shapes s = shapes_for(c->H, c->W);
+    const int Hp = s.Hp, Wp = s.Wp;
+    f16 *img = wsp<f16>(c, "hg.img");
+    uint8_t *mask = wsp<uint8_t>(c, "hg.mask");
+    q.chk(hg_prep_launch(base, s.H, s.W, Hp, Wp, img, mask, 0.75f, 0.1f, q.s), "hg_prep");
+    f16 *c1 = wsp<f16>(c, "hg.conv1"), *p1 = wsp<f16>(c, "hg.p1"), *c2 = wsp<f16>(c, "hg.conv2"), *p3 = wsp<f16>(c, "hg.p3"),
+        *c3 = wsp<f16>(c, "hg.conv3_2"), *p4 = wsp<f16>(c, "hg.p4"), *c4 = wsp<f16>(c, "hg.conv4_2"), *p5 = wsp<f16>(c, "hg.p5"),
+        *c5 = wsp<f16>(c, "hg.conv5_2"), *pc = wsp<f16>(c, "hg.pc"), *code = wsp<f16>(c, "hg.conv_code2");
+    q.c3("hg.conv1", img, Hp, Wp, ACT_RELU, c1, p1);
+    q.conv("hg.conv2", p1, 64, nullptr, 0, Hp / 2, Wp / 2, ACT_RELU, ST_NHWC, c2, 128, Hp / 2, Wp / 2);
+    q.conv("hg.conv3_1", c2, 128, nullptr, 0, Hp / 2, Wp / 2, ACT_RELU, ST_POOL, p3, 256, Hp / 4, Wp / 4);
+    q.conv("hg.conv3_2", p3, 256, nullptr, 0, Hp / 4, Wp / 4, ACT_RELU, ST_NHWC, c3, 256, Hp / 4, Wp / 4);
+    q.conv("hg.conv4_1", c3, 256, nullptr, 0, Hp / 4, Wp / 4, ACT_RELU, ST_POOL, p4, 512, Hp / 8, Wp / 8);
+    q.conv("hg.conv4_2", p4, 512, nullptr, 0, Hp / 8, Wp / 8, ACT_RELU, ST_NHWC, c4, 512, Hp / 8, Wp / 8);
+    q.conv("hg.conv5_1", c4, 512, nullptr, 0, Hp / 8, Wp / 8, ACT_RELU, ST_POOL, p5, 512, Hp / 16, Wp / 16);
+    q.conv("hg.conv5_2", p5, 512, nullptr, 0, Hp / 16, Wp / 16, ACT_RELU, ST_NHWC, c5, 512, Hp / 16, Wp / 16);
+    q.conv("hg.conv_code1", c5, 512, nullptr, 0, Hp / 16, Wp / 16, ACT_RELU, ST_POOL, pc, 512, Hp / 32, Wp / 32);
+    q.conv("hg.conv_code2", pc, 512, nullptr, 0, Hp / 32, Wp / 32, ACT_RELU, ST_NHWC, code, 512, Hp / 32, Wp / 32);
+    f16 *u1 = wsp<f16>(c, "hg.up1"), *c6 = wsp<f16>(c, "hg.conv6"), *u2 = wsp<f16>(c, "hg.up2"), *c7 = wsp<f16>(c, "hg.conv7"),
+        *u3 = wsp<f16>(c, "hg.up3"), *c8 = wsp<f16>(c, "hg.conv8"), *u4 = wsp<f16>(c, "hg.up4"), *c9 = wsp<f16>(c, "hg.conv9"),
+        *u5 = wsp<f16>(c, "hg.up5");
+    q.conv("hg.Up_conv1", code, 512, nullptr, 0, Hp / 32, Wp / 32, ACT_RELU, ST_PS, u1, 512, Hp / 16, Wp / 16);
+    q.conv("hg.conv6", u1, 512, c5, 512, Hp / 16, Wp / 16, ACT_NONE, ST_NHWC, c6, 512, Hp / 16, Wp / 16);
+    q.conv("hg.Up_conv2", c6, 512, nullptr, 0, Hp / 16, Wp / 16, ACT_RELU, ST_PS, u2, 512, Hp / 8, Wp / 8);
+    q.conv("hg.conv7", u2, 512, c4, 512, Hp / 8, Wp / 8, ACT_NONE, ST_NHWC, c7, 256, Hp / 8, Wp / 8);
+    q.conv("hg.Up_conv3", c7, 256, nullptr, 0, Hp / 8, Wp / 8, ACT_RELU, ST_PS, u3, 256, Hp / 4, Wp / 4);
+    q.conv("hg.conv8", u3, 256, c3, 256, Hp / 4, Wp / 4, ACT_NONE, ST_NHWC, c8, 128, Hp / 4, Wp / 4);
+    q.conv("hg.Up_conv4", c8, 128, nullptr, 0, Hp / 4, Wp / 4, ACT_RELU, ST_PS, u4, 128, Hp / 2, Wp / 2);
+    q.conv("hg.conv9", u4, 128, c2, 128, Hp / 2, Wp / 2, ACT_NONE, ST_NHWC, c9, 64, Hp / 2, Wp / 2);
+    q.conv("hg.Up_conv5", c9, 64, nullptr, 0, Hp / 2, Wp / 2, ACT_RELU, ST_PS, u5, 64, Hp, Wp);
+    if (!q.ok()) return q.rc;
+    HgFinalArgs fa;
+    fa.up5 = u5; fa.c1 = c1; fa.img = img; fa.mask = mask;
+    fa.w10 = wtp<float>(c, c->f32v.at("hg.w10")); fa.b10 = wtp<float>(c, c->f32v.at("hg.b10"));
+    fa.wl = wtp<float>(c, c->f32v.at("hg.wl")); fa.bl = wtp<float>(c, c->f32v.at("hg.bl"));
+    fa.out = out; fa.out_f32 = out_f32; fa.H = s.H; fa.W = s.W; fa.Hp = Hp; fa.Wp = Wp;
+    q.chk(hg_final_launch(fa, q.s), "hg_final");
+    c->macs += (double)Hp * Wp * (128 * 3 + 6 * 3);
+    return q.rc;
+}
+
+}  // namespace
+
+// =========================================================================== exported C ABI
+extern "C" {
+
+const char *hdrtv_version(void) { return "hdrtv_mi355x 0.1 gfx950 (MFMA f16 implicit-GEMM, hand-written HIP)"; }
+
+int hdrtv_create(const void *hr_pack, size_t hr_bytes, const void *hg_pack, size_t hg_bytes, int device_id, hdrtv_ctx **out)
+{
+    if (!out) return HDRTV_EINVAL;
+    *out = nullptr;
+    hdrtv_ctx *c = new hdrtv_ctx();
+    *out = c;   // returned even on failure so hdrtv_last_error() can be read; caller still destroys it
+    c->device = device_id;
+    if (!hr_pack || hr_bytes == 0) return fail(c, HDRTV_EINVAL, "hr_pack is required");
+    Pack hr, hg;
+    if (!hr.parse(hr_pack, hr_bytes, c->err)) return HDRTV_EWEIGHTS;
+    c->has_hg = hg_pack != nullptr && hg_bytes > 0;
+    if (c->has_hg && !hg.parse(hg_pack, hg_bytes, c->err)) return HDRTV_EWEIGHTS;
+    if (!build_weights(c, hr, c->has_hg ? &hg : nullptr)) return HDRTV_EWEIGHTS;
+    int ndev = 0;
+    HIPCHK(c, hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail(c, HDRTV_EINVAL, "device %d not available (%d devices)", device_id, ndev);
+    HIPCHK(c, hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(c, HDRTV_EINVAL, "device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
+    if (hipMalloc((void **)&c->wts.dev, c->wts.size + 256) != hipSuccess) {
+        c->wts.dev = nullptr;
+        return fail(c, HDRTV_ENOMEM, "weight allocation failed");
+    }
+    HIPCHK(c, hipMemcpy(c->wts.dev, c->wts.host.data(), c->wts.host.size(), hipMemcpyHostToDevice));
+    c->wts.host.clear();
+    c->wts.host.shrink_to_fit();
+    return HDRTV_OK;
+}
+
+int hdrtv_destroy(hdrtv_ctx *c)
+{
+    if (!c) return HDRTV_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    hdrtv_ring_destroy(c);
+    if (c->ws.dev) (void)hipFree(c->ws.dev);
+    if (c->wts.dev) (void)hipFree(c->wts.dev);
+    delete c;
+    return HDRTV_OK;
+}
+
+int hdrtv_has_hg(const hdrtv_ctx *c) { return c && c->has_hg ? 1 : 0; }
+
+int hdrtv_reserve(hdrtv_ctx *c, int H, int W)
+{
+    if (!c) return HDRTV_EINVAL;
+    if (!c->wts.dev) return fail(c, HDRTV_ESTATE, "context not initialised");
+    return do_reserve(c, H, W);
+}
+
+int hdrtv_preprocess(hdrtv_ctx *c, void *stream, const uint8_t *bgr, int H, int W, void *rgb, void *cond)
+{
+    if (!c || !bgr || !rgb || !cond) return fail(c, HDRTV_EINVAL, "null argument");
+    if (c->H != H || c->W != W || !c->ws.dev) return fail(c, HDRTV_ESTATE, "call hdrtv_reserve(%d,%d) first", H, W);
+    hipStream_t s = (hipStream_t)stream;
+    Seq q{c, s};
+    q.chk(pre_unpack_launch(bgr, (f16 *)rgb, H, W, s), "pre_unpack");
+    const Shapes sh = shapes_for(H, W);
+    q.chk(cond_resize_launch((const f16 *)rgb, (f16 *)cond, H, W, sh.h4, sh.w4, wsp<float>(c, "aa.wx"), wsp<int>(c, "aa.xmn"),
+                             wsp<int>(c, "aa.xns"), wsp<float>(c, "aa.wy"), wsp<int>(c, "aa.ymn"), wsp<int>(c, "aa.yns"), s),
+          "cond_resize");
+    return q.rc;
+}
+
+int hdrtv_infer(hdrtv_ctx *c, void *stream, const void *rgb, const void *cond, int H, int W, void *out, int out_dtype,
+                void *agcm_out)
+{
+    if (!c || !rgb || !cond || !out) return fail(c, HDRTV_EINVAL, "null argument");
+    if (c->H != H || c->W != W || !c->ws.dev) return fail(c, HDRTV_ESTATE, "call hdrtv_reserve(%d,%d) first", H, W);
+    if (out_dtype != HDRTV_F16 && out_dtype != HDRTV_F32) return fail(c, HDRTV_EINVAL, "bad out_dtype");
+    if (!c->has_hg && out_dtype != HDRTV_F16) return fail(c, HDRTV_EINVAL, "the no-HG model returns f16");
+    Seq q{c, (hipStream_t)stream};
+    c->launches = 0;
+    c->macs = 0.0;
+    f16 *agcm = agcm_out ? (f16 *)agcm_out : wsp<f16>(c, "agcm.out");
+    if (run_agcm(c, q, (const f16 *)rgb, (const f16 *)cond, agcm) != HDRTV_OK) return q.rc;
+    f16 *le_out = c->has_hg ? wsp<f16>(c, "le.out") : (f16 *)out;
+    if (run_le(c, q, agcm, le_out) != HDRTV_OK) return q.rc;
+    if (c->has_hg && run_hg(c, q, le_out, out, out_dtype == HDRTV_F32) != HDRTV_OK) return q.rc;
+    return q.rc;
+}
+
+int hdrtv_post_u8(hdrtv_ctx *c, void *stream, const void *in, int dtype, int H, int W, uint8_t *bgr)
+{
+    if (!c || !in || !bgr || H <= 0 || W <= 0) return fail(c, HDRTV_EINVAL, "bad argument");
+    hipError_t e = post_u8_launch(in, dtype == HDRTV_F32, H, W, bgr, (hipStream_t)stream);
+    return e == hipSuccess ? HDRTV_OK : fail(c, HDRTV_EHIP, "post_u8: %s", hipGetErrorString(e));
+}
+
+int hdrtv_post_rgb48(hdrtv_ctx *c, void *stream, const void *in, int dtype, int H, int W, uint16_t *dst)
+{
+    if (!c || !in || !dst || H <= 0 || W <= 0) return fail(c, HDRTV_EINVAL, "bad argument");
+    hipError_t e = post_rgb48_launch(in, dtype == HDRTV_F32, H, W, dst, 0, 0.f, (hipStream_t)stream);
+    return e == hipSuccess ? HDRTV_OK : fail(c, HDRTV_EHIP, "post_rgb48: %s", hipGetErrorString(e));
+}
+
+int hdrtv_post_pq_rgb48(hdrtv_ctx *c, void *stream, const void *in, int dtype, int H, int W, float peak_nits, uint16_t *dst)
+{
+    if (!c || !in || !dst || H <= 0 || W <= 0 || !(peak_nits > 0.f)) return fail(c, HDRTV_EINVAL, "bad argument");
+    hipError_t e = post_rgb48_launch(in, dtype == HDRTV_F32, H, W, dst, 1, peak_nits, (hipStream_t)stream);
+    return e == hipSuccess ? HDRTV_OK : fail(c, HDRTV_EHIP, "post_pq_rgb48: %s", hipGetErrorString(e));
+}
+
+// ------------------------------------------------------------------------------------ ring
+int hdrtv_ring_create(hdrtv_ctx *c, int slots, int H, int W)
+{
+    if (!c || slots < 2 || slots > 8 || H <= 0 || W <= 0) return fail(c, HDRTV_EINVAL, "ring: slots must be 2..8");
+    hdrtv_ring_destroy(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    std::lock_guard<std::mutex> lk(c->ring_mu);
+    const size_t bytes = (size_t)H * W * 3 * 2;
+    c->ring.resize(slots);
+    for (auto &sl : c->ring) {
+        HIPCHK(c, hipHostMalloc((void **)&sl.host, bytes, hipHostMallocMapped | hipHostMallocPortable));
+        HIPCHK(c, hipHostGetDevicePointer((void **)&sl.dev, sl.host, 0));
+        HIPCHK(c, hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+        sl.state = 0;
+    }
+    c->ring_next = 0; c->ring_H = H; c->ring_W = W;
+    return HDRTV_OK;
+}
+
+int hdrtv_ring_acquire(hdrtv_ctx *c, int timeout_ms, uint16_t **host_ptr, uint16_t **dev_ptr)
+{
+    if (!c || c->ring.empty()) return fail(c, HDRTV_ESTATE, "ring not created");
+    std::unique_lock<std::mutex> lk(c->ring_mu);
+    const int n = (int)c->ring.size();
+    auto pick = [&]() -> int {
+        for (int o = 0; o < n; ++o) {
+            const int i = (c->ring_next + o) % n;
+            if (c->ring[i].state == 0) return i;
+        }
+        return -1;
+    };
+    int i = pick();
+    if (i < 0) {
+        const bool got = c->ring_cv.wait_for(lk, std::chrono::milliseconds(timeout_ms < 0 ? 0 : timeout_ms),
+                                             [&] { return (i = pick()) >= 0; });
+        if (!got) return fail(c, HDRTV_ESTATE, "no free ring slot within %d ms", timeout_ms);
+    }
+    c->ring[i].state = 1;
+    c->ring_next = (i + 1) % n;
+    if (host_ptr) *host_ptr = c->ring[i].host;
+    if (dev_ptr) *dev_ptr = c->ring[i].dev;
+    return i;
+}
+
+int hdrtv_ring_commit(hdrtv_ctx *c, int slot, void *stream)
+{
+    if (!c || slot < 0 || slot >= (int)c->ring.size()) return fail(c, HDRTV_EINVAL, "bad ring slot");
+    HIPCHK(c, hipEventRecord(c->ring[slot].ev, (hipStream_t)stream));
+    std::lock_guard<std::mutex> lk(c->ring_mu);
+    c->ring[slot].state = 2;
+    return HDRTV_OK;
+}
+
+int hdrtv_ring_wait(hdrtv_ctx *c, int slot)
+{
+    if (!c || slot < 0 || slot >= (int)c->ring.size()) return fail(c, HDRTV_EINVAL, "bad ring slot");
+    HIPCHK(c, hipEventSynchronize(c->ring[slot].ev));
+    return HDRTV_OK;
+}
+
+int hdrtv_ring_release(hdrtv_ctx *c, int slot)
+{
+    if (!c || slot < 0 || slot >= (int)c->ring.size()) return fail(c, HDRTV_EINVAL, "bad ring slot");
+    {
+        std::lock_guard<std::mutex> lk(c->ring_mu);
+        c->ring[slot].state = 0;
+    }
+    c->ring_cv.notify_all();
+    return HDRTV_OK;
+}
+
+int hdrtv_ring_destroy(hdrtv_ctx *c)
+{
+    if (!c) return HDRTV_OK;
+    std::lock_guard<std::mutex> lk(c->ring_mu);
+    for (auto &sl : c->ring) {
+        if (sl.ev) (void)hipEventDestroy(sl.ev);
+        if (sl.host) (void)hipHostFree(sl.host);
+    }
+    c->ring.clear();
+    return HDRTV_OK;
+}
+
+int hdrtv_get_tap(hdrtv_ctx *c, const char *name, void **dev_ptr, int *C, int *H, int *W, int *layout)
+{
+    if (!c || !name) return HDRTV_EINVAL;
+    auto it = c->t.find(name);
+    if (it == c->t.end() || !c->ws.dev) return fail(c, HDRTV_EINVAL, "no tap named %s", name);
+    if (dev_ptr) *dev_ptr = c->ws.dev + it->second.off;
+    if (C) *C = it->second.C;
+    if (H) *H = it->second.H;
+    if (W) *W = it->second.W;
+    if (layout) *layout = it->second.layout;
+    return HDRTV_OK;
+}
+
+int hdrtv_infer_stats(hdrtv_ctx *c, int *launches, double *macs)
+{
+    if (!c) return HDRTV_EINVAL;
+    if (launches) *launches = c->launches;
+    if (macs) *macs = c->macs;
+    return HDRTV_OK;
+}
+
+const char *hdrtv_last_error(const hdrtv_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+}  // extern "C"

@@ -1,0 +1,39 @@
+// launchers.h -- host-callable launch wrappers defined in the .hip kernel files.
+#pragma once
+#include "common.h"
+
+hipError_t conv_igemm_launch(ConvParams p, int cin_t, int bn, int ks, int stride, hipStream_t stream);
+
+hipError_t pre_unpack_launch(const uint8_t *bgr, f16 *out, int H, int W, hipStream_t s);
+hipError_t cond_resize_launch(const f16 *in, f16 *out, int H, int W, int Ho, int Wo, const float *wx, const int *xmn,
+                              const int *xns, const float *wy, const int *ymn, const int *yns, hipStream_t s);
+hipError_t post_u8_launch(const void *in, int is_f32, int H, int W, uint8_t *bgr, hipStream_t s);
+hipError_t post_rgb48_launch(const void *in, int is_f32, int H, int W, uint16_t *rgb, int pq, float peak, hipStream_t s);
+
+hipError_t cls_block_launch(const void *in, int in_f16, int Ci, int Hi, int Wi, const float *nmean, const float *nrstd,
+                            const float *ngamma, const float *nbeta, const float *Wt, const float *bias, int Co, float *out,
+                            int Ho, int Wo, hipStream_t s);
+hipError_t cls_stats_launch(const float *x, int C, int n, float eps, float *mean, float *rstd, hipStream_t s);
+struct AgcmFoldArgs {
+    const float *mean5;
+    const float *w20, *b20;
+    const float *ws[3], *bs[3], *wt[3], *bt[3];
+    const float *w1, *b1, *w2, *b2, *w3, *b3;
+};
+hipError_t agcm_fold_launch(const AgcmFoldArgs &a, f16 *frags, float *biasbuf, hipStream_t s);
+hipError_t agcm_mlp_launch(const f16 *in, f16 *out, size_t npix, const f16 *frags, const float *biasbuf, hipStream_t s);
+
+hipError_t conv_c3_launch(const f16 *in, int H, int W, const f16 *wfrag, const float *scale, const float *shift, int cout,
+                          int act, f16 *out, f16 *out_pool, hipStream_t s);
+hipError_t sft_launch(const SftParams &p, hipStream_t s);
+hipError_t hg_prep_launch(const f16 *base, int H, int W, int Hp, int Wp, f16 *img_pad, uint8_t *mask, float r, float thresh,
+                          hipStream_t s);
+struct HgFinalArgs {
+    const f16 *up5, *c1, *img;
+    const uint8_t *mask;
+    const float *w10, *b10, *wl, *bl;
+    void *out;
+    int out_f32, H, W, Hp, Wp;
+};
+hipError_t hg_final_launch(const HgFinalArgs &a, hipStream_t s);
+hipError_t maxpool2_launch(const f16 *in, int H, int W, int C, f16 *out, hipStream_t s);

@@ -1,0 +1,298 @@
+// prepost.hip -- the HBM-bound per-pixel stages either side of the network (gfx950).
+//
+//  pre_unpack      u8 HWC BGR -> f16 planar RGB * (1/255)     hdrtvnet_torch.py:2256-2261
+//  cond_resize     0.25x antialiased bicubic -> f16 planar    hdrtvnet_torch.py:2278-2285
+//  post_u8         planar -> u8 HWC BGR                       hdrtvnet_torch.py:2357-2361
+//  post_rgb48      planar -> u16 HWC RGB (rgb48le)            gui_pipeline_worker_feeders.py:223-227
+//  post_pq_rgb48   BT.709->BT.2020 matrix + ST.2084 PQ + u16  (north-star display variant)
+//
+// All are one pass, 8 pixels per lane, 16-byte planar accesses and 8/16-byte interleaved
+// accesses, so every wave instruction moves whole cache lines.  Quantisers use __fmul_rn /
+// __fadd_rn: the reference rounds the multiply and the add separately.
+#include "launchers.h"
+
+namespace {
+
+__device__ __forceinline__ float clamp01(float v)
+{
+    // torch.clamp semantics incl. NaN propagation
+    return v != v ? v : fminf(fmaxf(v, 0.f), 1.f);
+}
+
+__global__ __launch_bounds__(256) void pre_unpack_kernel(const uint8_t *__restrict__ bgr, f16 *__restrict__ out,
+                                                         size_t npix)
+{
+    const float k = (float)(1.0 / 255.0);
+    const size_t ngrp = npix / 8;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngrp; g += (size_t)gridDim.x * blockDim.x) {
+        const uint2 *src = reinterpret_cast<const uint2 *>(bgr + g * 24);
+        const uint2 a = src[0], b = src[1], c = src[2];
+        const uint32_t w[6] = {a.x, a.y, b.x, b.y, c.x, c.y};
+        f16x8 r, gg, bb;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int o = i * 3;
+            const uint32_t vb = (w[o >> 2] >> ((o & 3) * 8)) & 0xff;
+            const uint32_t vg = (w[(o + 1) >> 2] >> (((o + 1) & 3) * 8)) & 0xff;
+            const uint32_t vr = (w[(o + 2) >> 2] >> (((o + 2) & 3) * 8)) & 0xff;
+            r[i] = (f16)__fmul_rn((float)vr, k);
+            gg[i] = (f16)__fmul_rn((float)vg, k);
+            bb[i] = (f16)__fmul_rn((float)vb, k);
+        }
+        *reinterpret_cast<f16x8 *>(out + g * 8) = r;
+        *reinterpret_cast<f16x8 *>(out + npix + g * 8) = gg;
+        *reinterpret_cast<f16x8 *>(out + 2 * npix + g * 8) = bb;
+    }
+    // tail (< 8 pixels)
+    if (blockIdx.x == 0 && threadIdx.x < (npix & 7)) {
+        const size_t i = ngrp * 8 + threadIdx.x;
+        out[i] = (f16)__fmul_rn((float)bgr[i * 3 + 2], k);
+        out[npix + i] = (f16)__fmul_rn((float)bgr[i * 3 + 1], k);
+        out[2 * npix + i] = (f16)__fmul_rn((float)bgr[i * 3 + 0], k);
+    }
+}
+
+// ---- 0.25x antialiased bicubic.  Tap tables (ATen _upsample_bicubic2d_aa weights, computed on
+// the host in fp32 exactly as ATen does) : wtab[o][0..16], first input index mn[o], count ns[o].
+constexpr int RT_W = 32, RT_H = 8;          // output tile
+constexpr int RT_IW = RT_W * 4 + 12;        // 140 input columns cover 32 outputs
+constexpr int RT_IH = RT_H * 4 + 12;        // 44 input rows cover 8 outputs
+constexpr int AA_TAPS = 17;
+
+__global__ __launch_bounds__(256) void cond_resize_kernel(const f16 *__restrict__ in, f16 *__restrict__ out, int H,
+                                                          int W, int Ho, int Wo, const float *__restrict__ wx,
+                                                          const int *__restrict__ xmn, const int *__restrict__ xns,
+                                                          const float *__restrict__ wy, const int *__restrict__ ymn,
+                                                          const int *__restrict__ yns)
+{
+    __shared__ float s_in[RT_IH][RT_IW + 1];
+    __shared__ float s_h[RT_IH][RT_W + 1];
+    const int c = blockIdx.z;
+    const int ox0 = blockIdx.x * RT_W, oy0 = blockIdx.y * RT_H;
+    const int ix0 = xmn[ox0], iy0 = ymn[oy0];
+    const f16 *src = in + (size_t)c * H * W;
+    for (int e = threadIdx.x; e < RT_IH * RT_IW; e += 256) {
+        const int r = e / RT_IW, q = e % RT_IW;
+        const int iy = iy0 + r, ix = ix0 + q;
+        s_in[r][q] = (iy < H && ix < W) ? (float)src[(size_t)iy * W + ix] : 0.f;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < RT_IH * RT_W; e += 256) {
+        const int r = e / RT_W, o = e % RT_W;
+        const int ox = ox0 + o;
+        float s = 0.f;
+        if (ox < Wo) {
+            const int base = xmn[ox] - ix0, n = xns[ox];
+            const float *w = wx + (size_t)ox * AA_TAPS;
+            for (int j = 0; j < n; ++j) s = __fadd_rn(s, __fmul_rn(w[j], s_in[r][base + j]));
+        }
+        s_h[r][o] = s;
+    }
+    __syncthreads();
+    {
+        const int o = threadIdx.x % RT_W, r = threadIdx.x / RT_W;
+        const int ox = ox0 + o, oy = oy0 + r;
+        if (ox < Wo && oy < Ho) {
+            const int base = ymn[oy] - iy0, n = yns[oy];
+            const float *w = wy + (size_t)oy * AA_TAPS;
+            float s = 0.f;
+            for (int j = 0; j < n; ++j) s = __fadd_rn(s, __fmul_rn(w[j], s_h[base + j][o]));
+            out[((size_t)c * Ho + oy) * Wo + ox] = (f16)s;
+        }
+    }
+}
+
+// ---- post-process quantisers ----------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void load8(const T *p, float (&v)[8]);
+template <>
+__device__ __forceinline__ void load8<f16>(const f16 *p, float (&v)[8])
+{
+    const f16x8 x = *reinterpret_cast<const f16x8 *>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)x[i];
+}
+template <>
+__device__ __forceinline__ void load8<float>(const float *p, float (&v)[8])
+{
+    const float4 a = reinterpret_cast<const float4 *>(p)[0], b = reinterpret_cast<const float4 *>(p)[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+// u8: the reference quantises in the tensor's own dtype (fp16 model: every op rounds to fp16).
+template <typename T>
+__device__ __forceinline__ uint32_t quant_u8(float x)
+{
+    if (sizeof(T) == 2) {
+        const f16 c = (f16)clamp01(x);
+        const f16 m = (f16)__fmul_rn((float)c, 255.f);
+        const f16 a = (f16)__fadd_rn((float)m, 0.5f);
+        return (uint32_t)(int)(float)a & 0xff;
+    }
+    return (uint32_t)(int)__fadd_rn(__fmul_rn(clamp01(x), 255.f), 0.5f) & 0xff;
+}
+
+__device__ __forceinline__ uint32_t quant_u16(float x)
+{
+    return (uint32_t)(int)__fadd_rn(__fmul_rn(clamp01(x), 65535.f), 0.5f) & 0xffff;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void post_u8_kernel(const T *__restrict__ in, uint8_t *__restrict__ bgr, size_t npix)
+{
+    const size_t ngrp = npix / 8;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngrp; g += (size_t)gridDim.x * blockDim.x) {
+        float r[8], gg[8], b[8];
+        load8<T>(in + g * 8, r);
+        load8<T>(in + npix + g * 8, gg);
+        load8<T>(in + 2 * npix + g * 8, b);
+        uint32_t w[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int o = i * 3;
+            w[o >> 2] |= quant_u8<T>(b[i]) << ((o & 3) * 8);
+            w[(o + 1) >> 2] |= quant_u8<T>(gg[i]) << (((o + 1) & 3) * 8);
+            w[(o + 2) >> 2] |= quant_u8<T>(r[i]) << (((o + 2) & 3) * 8);
+        }
+        uint2 *dst = reinterpret_cast<uint2 *>(bgr + g * 24);
+        dst[0] = make_uint2(w[0], w[1]);
+        dst[1] = make_uint2(w[2], w[3]);
+        dst[2] = make_uint2(w[4], w[5]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (npix & 7)) {
+        const size_t i = ngrp * 8 + threadIdx.x;
+        bgr[i * 3 + 0] = (uint8_t)quant_u8<T>((float)in[2 * npix + i]);
+        bgr[i * 3 + 1] = (uint8_t)quant_u8<T>((float)in[npix + i]);
+        bgr[i * 3 + 2] = (uint8_t)quant_u8<T>((float)in[i]);
+    }
+}
+
+// PQ constants: gui_objective_metrics.py:63-67
+#define PQ_M1 0.1593017578125f
+#define PQ_M2 78.84375f
+#define PQ_C1 0.8359375f
+#define PQ_C2 18.8515625f
+#define PQ_C3 18.6875f
+
+__device__ __forceinline__ float pq_oetf(float nits)
+{
+    float y = nits / 10000.f;
+    y = fminf(fmaxf(y, 0.f), 1.f);
+    const float yp = powf(y, PQ_M1);
+    return powf((PQ_C1 + PQ_C2 * yp) / (1.f + PQ_C3 * yp), PQ_M2);
+}
+
+template <typename T, bool PQ>
+__global__ __launch_bounds__(256) void post_rgb48_kernel(const T *__restrict__ in, uint16_t *__restrict__ rgb,
+                                                         size_t npix, float peak)
+{
+    const size_t ngrp = npix / 8;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngrp; g += (size_t)gridDim.x * blockDim.x) {
+        float r[8], gg[8], b[8];
+        load8<T>(in + g * 8, r);
+        load8<T>(in + npix + g * 8, gg);
+        load8<T>(in + 2 * npix + g * 8, b);
+        uint32_t w[12];
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            uint32_t q[6];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float cr = r[i + k], cg = gg[i + k], cb = b[i + k];
+                if (PQ) {
+                    // ITU-R BT.2087 BT.709 -> BT.2020 (linear light)
+                    const float xr = 0.6274f * cr + 0.3293f * cg + 0.0433f * cb;
+                    const float xg = 0.0691f * cr + 0.9195f * cg + 0.0114f * cb;
+                    const float xb = 0.0164f * cr + 0.0880f * cg + 0.8956f * cb;
+                    const float c3[3] = {xr, xg, xb};
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const float lin = fminf(fmaxf(c3[ch], 0.f), 1.f);
+                        float qv = __fadd_rn(__fmul_rn(pq_oetf(lin * peak), 65535.f), 0.5f);
+                        qv = fminf(fmaxf(qv, 0.f), 65535.f);
+                        q[k * 3 + ch] = (uint32_t)(int)qv;
+                    }
+                } else {
+                    q[k * 3 + 0] = quant_u16(cr);
+                    q[k * 3 + 1] = quant_u16(cg);
+                    q[k * 3 + 2] = quant_u16(cb);
+                }
+            }
+            w[(i / 2) * 3 + 0] = q[0] | (q[1] << 16);
+            w[(i / 2) * 3 + 1] = q[2] | (q[3] << 16);
+            w[(i / 2) * 3 + 2] = q[4] | (q[5] << 16);
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(rgb + g * 24);
+        dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        dst[2] = make_uint4(w[8], w[9], w[10], w[11]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (npix & 7)) {
+        const size_t i = ngrp * 8 + threadIdx.x;
+        float c3[3] = {(float)in[i], (float)in[npix + i], (float)in[2 * npix + i]};
+        if (PQ) {
+            const float cr = c3[0], cg = c3[1], cb = c3[2];
+            c3[0] = 0.6274f * cr + 0.3293f * cg + 0.0433f * cb;
+            c3[1] = 0.0691f * cr + 0.9195f * cg + 0.0114f * cb;
+            c3[2] = 0.0164f * cr + 0.0880f * cg + 0.8956f * cb;
+        }
+        for (int ch = 0; ch < 3; ++ch) {
+            if (PQ) {
+                const float lin = fminf(fmaxf(c3[ch], 0.f), 1.f);
+                float qv = __fadd_rn(__fmul_rn(pq_oetf(lin * peak), 65535.f), 0.5f);
+                rgb[i * 3 + ch] = (uint16_t)(int)fminf(fmaxf(qv, 0.f), 65535.f);
+            } else {
+                rgb[i * 3 + ch] = (uint16_t)quant_u16(c3[ch]);
+            }
+        }
+    }
+}
+
+inline int ew_grid(size_t ngrp)
+{
+    size_t g = (ngrp + 255) / 256;
+    if (g > 2048) g = 2048;   // 256 CUs x 8 blocks, grid-stride beyond (guide: Guideline 11)
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+hipError_t pre_unpack_launch(const uint8_t *bgr, f16 *out, int H, int W, hipStream_t s)
+{
+    const size_t npix = (size_t)H * W;
+    hipLaunchKernelGGL(pre_unpack_kernel, dim3(ew_grid(npix / 8)), dim3(256), 0, s, bgr, out, npix);
+    return hipGetLastError();
+}
+
+hipError_t cond_resize_launch(const f16 *in, f16 *out, int H, int W, int Ho, int Wo, const float *wx, const int *xmn,
+                              const int *xns, const float *wy, const int *ymn, const int *yns, hipStream_t s)
+{
+    dim3 grid((Wo + RT_W - 1) / RT_W, (Ho + RT_H - 1) / RT_H, 3);
+    hipLaunchKernelGGL(cond_resize_kernel, grid, dim3(256), 0, s, in, out, H, W, Ho, Wo, wx, xmn, xns, wy, ymn, yns);
+    return hipGetLastError();
+}
+
+hipError_t post_u8_launch(const void *in, int is_f32, int H, int W, uint8_t *bgr, hipStream_t s)
+{
+    const size_t npix = (size_t)H * W;
+    if (is_f32)
+        hipLaunchKernelGGL(post_u8_kernel<float>, dim3(ew_grid(npix / 8)), dim3(256), 0, s, (const float *)in, bgr, npix);
+    else
+        hipLaunchKernelGGL(post_u8_kernel<f16>, dim3(ew_grid(npix / 8)), dim3(256), 0, s, (const f16 *)in, bgr, npix);
+    return hipGetLastError();
+}
+
+hipError_t post_rgb48_launch(const void *in, int is_f32, int H, int W, uint16_t *rgb, int pq, float peak, hipStream_t s)
+{
+    const size_t npix = (size_t)H * W;
+    const dim3 g(ew_grid(npix / 8)), b(256);
+    if (is_f32) {
+        if (pq) hipLaunchKernelGGL((post_rgb48_kernel<float, true>), g, b, 0, s, (const float *)in, rgb, npix, peak);
+        else hipLaunchKernelGGL((post_rgb48_kernel<float, false>), g, b, 0, s, (const float *)in, rgb, npix, peak);
+    } else {
+        if (pq) hipLaunchKernelGGL((post_rgb48_kernel<f16, true>), g, b, 0, s, (const f16 *)in, rgb, npix, peak);
+        else hipLaunchKernelGGL((post_rgb48_kernel<f16, false>), g, b, 0, s, (const f16 *)in, rgb, npix, peak);
+    }
+    return hipGetLastError();
+}

@@ -1,0 +1,71 @@
+"""ctypes binding of libhdrtv_mi355x.so (C ABI: include/hdrtv_mi355x.h).
+
+There is no CPU fallback: if the shared library is missing, or the device is not
+gfx950, construction raises.  Build with ``python -c "import __graft_entry__ as g; g.build()"``
+or ``make -C hdr-realtime-video-pipeline_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_PKG), "lib", "libhdrtv_mi355x.so")
+
+OK, EINVAL, EWEIGHTS, EHIP, ENOMEM, ESTATE = 0, -1, -2, -3, -4, -5
+F16, F32 = 0, 1
+
+# every symbol include/hdrtv_mi355x.h declares: (name, restype, argtypes)
+_VP, _I, _SZ = C.c_void_p, C.c_int, C.c_size_t
+SYMBOLS = [
+    ("hdrtv_version", C.c_char_p, []),
+    ("hdrtv_create", _I, [_VP, _SZ, _VP, _SZ, _I, C.POINTER(_VP)]),
+    ("hdrtv_destroy", _I, [_VP]),
+    ("hdrtv_has_hg", _I, [_VP]),
+    ("hdrtv_reserve", _I, [_VP, _I, _I]),
+    ("hdrtv_preprocess", _I, [_VP, _VP, _VP, _I, _I, _VP, _VP]),
+    ("hdrtv_infer", _I, [_VP, _VP, _VP, _VP, _I, _I, _VP, _I, _VP]),
+    ("hdrtv_post_u8", _I, [_VP, _VP, _VP, _I, _I, _I, _VP]),
+    ("hdrtv_post_rgb48", _I, [_VP, _VP, _VP, _I, _I, _I, _VP]),
+    ("hdrtv_post_pq_rgb48", _I, [_VP, _VP, _VP, _I, _I, _I, C.c_float, _VP]),
+    ("hdrtv_ring_create", _I, [_VP, _I, _I, _I]),
+    ("hdrtv_ring_acquire", _I, [_VP, _I, C.POINTER(_VP), C.POINTER(_VP)]),
+    ("hdrtv_ring_commit", _I, [_VP, _I, _VP]),
+    ("hdrtv_ring_wait", _I, [_VP, _I]),
+    ("hdrtv_ring_release", _I, [_VP, _I]),
+    ("hdrtv_ring_destroy", _I, [_VP]),
+    ("hdrtv_get_tap", _I, [_VP, C.c_char_p, C.POINTER(_VP), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    ("hdrtv_infer_stats", _I, [_VP, C.POINTER(_I), C.POINTER(C.c_double)]),
+    ("hdrtv_last_error", C.c_char_p, [_VP]),
+]
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the MI355X HIP extension is not built and there is no "
+            "fallback path (run __graft_entry__.build())")
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)      # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class HdrtvError(RuntimeError):
+    pass
+
+
+def check(lib, ctx, rc, what):
+    if rc < 0:
+        msg = lib.hdrtv_last_error(ctx)
+        raise HdrtvError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+    return rc

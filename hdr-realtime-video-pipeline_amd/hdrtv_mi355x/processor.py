@@ -1,0 +1,301 @@
+"""HDRTVNetMI355X -- drop-in processor for the reference's ``HDRTVNetTorch``.
+
+Mirrors the call surface of ``src/models/hdrtvnet_torch.py:1513-2472`` (constructor
+arguments, ``preprocess`` / ``infer`` / ``postprocess`` / ``process`` /
+``process_timed`` / ``warmup_compile`` / ``end_profiling`` and the attributes callers
+read: ``gui_pipeline_worker_model.py:52,238,242,274``, ``main.py:68,96,104,487``,
+``compile_kernels.py:332-345``), the same way the reference's own
+``HDRTVNetTensorRT(HDRTVNetTorch)`` is a second backend behind that surface.
+
+All arithmetic runs in ``libhdrtv_mi355x.so`` (hand-written gfx950 HIP kernels) through
+the C ABI in ``include/hdrtv_mi355x.h``.  torch is used for device buffers, pinned host
+buffers and streams only.  There is no CPU path and no eager fallback: a missing
+library, a non-gfx950 device or ``device="cpu"`` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import lib as _L
+from . import weights as _W
+
+
+def _load_state(path_or_state, what):
+    """Accepts a mapping, an ``.hdrw`` pack, or a torch checkpoint (raw state_dict or the
+    reference's ``{"state_dict":..., "architecture":...}`` wrapper, hdrtvnet_torch.py:1491)."""
+    if isinstance(path_or_state, dict):
+        return path_or_state
+    path = str(path_or_state)
+    if not os.path.isfile(path):
+        raise FileNotFoundError(f"{what} not found: {path}")
+    if path.endswith(".hdrw"):
+        return _W.load_pack(path)
+    payload = torch.load(path, map_location="cpu", weights_only=True)
+    if isinstance(payload, dict) and "state_dict" in payload:
+        payload = payload["state_dict"] or {}
+    if not isinstance(payload, dict):
+        raise ValueError(f"{what}: unsupported checkpoint payload in {path}")
+    return {(k[7:] if k.startswith("module.") else k): v for k, v in payload.items()}
+
+
+class HDRTVNetMI355X:
+    """MI355X-native backend with the ``HDRTVNetTorch`` surface.
+
+    ``model_path``: HR checkpoint (``HR.pt``, an ``.hdrw`` pack, or a state mapping).
+    ``hg_weights``: HG checkpoint path / mapping, or ``"seeded:<int>"`` for the deterministic
+    stand-in of the un-shipped ``HG.pt`` (weights.seeded_hg_state).  As in the reference
+    (hdrtvnet_torch.py:2065-2086): an explicit but missing path raises ``FileNotFoundError``;
+    with no path given and ``use_hg=True`` the model silently continues without HG.
+    ``compile_*``, ``use_cuda_graphs``, ``force_channels_last``, ``predequantize`` are accepted
+    and ignored: there is nothing to JIT (kernels are precompiled for gfx950).
+    """
+
+    def __init__(self, model_path, device="auto", precision="auto",
+                 compile_model=True, force_compile=False, compile_mode="auto",
+                 use_cuda_graphs=False, force_channels_last=False,
+                 predequantize="auto", hg_weights=None, use_hg=True,
+                 warmup_passes=3, fast_condition_resize=False):
+        self.model_path = model_path
+        self._warmup_passes = int(warmup_passes)
+        if fast_condition_resize:
+            raise ValueError("fast_condition_resize (bilinear cond) is not implemented by the MI355X backend")
+        self.device = self._resolve_device(device)
+        self.precision = self._resolve_precision(precision)
+        self._use_cuda = True
+        self._dtype = torch.float16
+        self._compiled = False          # nothing is JIT-compiled; warmup_compile() is a no-op
+        self._compile_mode = None
+        self._trt_engine = None
+        self._is_w8_model = False
+        self._memory_format_name = "nhwc-internal"
+        self.engine_path = _L.LIB_PATH
+        self.model = None               # no nn.Module exists; callers treat None as "0 MB"
+        self._lib = _L.load()
+        self._ctx = C.c_void_p()
+
+        hr_state = _load_state(model_path, "model weights")
+        try:
+            _W.check_hr_state(hr_state)
+        except ValueError as exc:
+            raise ValueError(f"Unsupported checkpoint for the MI355X backend: {exc}") from exc
+        hg_state = None
+        self._use_hg = bool(use_hg)
+        if self._use_hg:
+            if isinstance(hg_weights, str) and hg_weights.startswith("seeded:"):
+                hg_state = _W.seeded_hg_state(int(hg_weights.split(":", 1)[1]))
+            elif hg_weights is not None:
+                hg_state = _load_state(hg_weights, "HG weights")     # FileNotFoundError if missing
+            else:
+                print("WARNING: HG weights not given; continuing with no-HG model.")
+                self._use_hg = False
+        self._hg_weights = hg_weights if self._use_hg else None
+        hr_blob = _W.pack_state({k: hr_state[k] for k, _ in _arch_hr()})
+        hg_blob = _W.pack_state({k: v for k, v in hg_state.items()
+                                 if not k.endswith("num_batches_tracked")}) if hg_state is not None else b""
+        rc = self._lib.hdrtv_create(hr_blob, len(hr_blob), hg_blob if hg_blob else None, len(hg_blob),
+                                    self.device.index or 0, C.byref(self._ctx))
+        if rc < 0:
+            msg = self._lib.hdrtv_last_error(self._ctx).decode() if self._ctx else "allocation failed"
+            self._lib.hdrtv_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+            if rc == _L.EWEIGHTS:
+                raise ValueError(f"model backend failed - {msg}")
+            raise RuntimeError(f"model backend failed - {msg}")
+
+        self._buf_hw = None
+        self._gpu_input = self._gpu_cond = self._gpu_raw = None
+        self._pin_input = self._pin_output = None
+        self._gpu_out = self._gpu_agcm = self._gpu_u8 = None
+        print(f"MI355X device : {self.device}")
+        print(f"MI355X precision: {self.precision}  (HG {'on' if self._use_hg else 'off'})")
+        if self._warmup_passes > 0:
+            self._warmup()
+
+    # ------------------------------------------------------------------ helpers
+    def _resolve_device(self, device):
+        mode = str(device).lower()
+        if mode not in ("auto", "cuda", "cpu") and not mode.startswith("cuda:"):
+            raise ValueError("device must be one of: auto, cuda, cpu")
+        if mode == "cpu":
+            raise RuntimeError("the MI355X backend has no CPU path; use the reference's HDRTVNetTorch for device='cpu'")
+        if not torch.cuda.is_available():
+            raise RuntimeError("CUDA/ROCm device not available for the MI355X backend.")
+        if mode.startswith("cuda:"):
+            return torch.device(mode)
+        return torch.device("cuda", torch.cuda.current_device())
+
+    def _resolve_precision(self, precision):
+        p = str(precision).lower()
+        if p not in {"auto", "fp16", "fp32", "int8-full", "int8-mixed"}:
+            raise ValueError("precision must be one of: auto, fp16, fp32, int8-full, int8-mixed")
+        if p in ("auto", "fp16"):
+            return "fp16"
+        raise ValueError(f"precision '{p}' is not implemented by the MI355X backend yet (fp16 only)")
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _chk(self, rc, what):
+        return _L.check(self._lib, self._ctx, rc, what)
+
+    def _warmup(self):
+        h, w = 1080, 1920
+        dummy = np.zeros((h, w, 3), dtype=np.uint8)
+        for _ in range(self._warmup_passes):
+            self.process(dummy)
+        torch.cuda.synchronize(self.device)
+
+    # ------------------------------------------------------------------ buffers
+    def _ensure_buffers(self, h, w):
+        """hdrtvnet_torch.py:2198-2233."""
+        if self._buf_hw == (h, w):
+            return
+        with torch.cuda.device(self.device):
+            self._chk(self._lib.hdrtv_reserve(self._ctx, h, w), "hdrtv_reserve")
+            ch, cw = max(1, h // 4), max(1, w // 4)
+            dev = self.device
+            self._gpu_input = torch.empty((1, 3, h, w), dtype=torch.float16, device=dev)
+            self._gpu_cond = torch.empty((1, 3, ch, cw), dtype=torch.float16, device=dev)
+            self._gpu_raw = torch.empty((h, w, 3), dtype=torch.uint8, device=dev)
+            self._gpu_u8 = torch.empty((h, w, 3), dtype=torch.uint8, device=dev)
+            self._gpu_out = torch.empty((1, 3, h, w), dtype=torch.float32 if self._use_hg else torch.float16, device=dev)
+            self._gpu_agcm = torch.empty((1, 3, h, w), dtype=torch.float16, device=dev)
+            self._pin_input = torch.empty((h, w, 3), dtype=torch.uint8, pin_memory=True)
+            self._pin_output = torch.empty((h, w, 3), dtype=torch.uint8, pin_memory=True)
+        self._buf_hw = (h, w)
+
+    # ------------------------------------------------------------------ API
+    @torch.inference_mode()
+    def preprocess(self, frame_bgr):
+        """hdrtvnet_torch.py:2238-2296.  Returns processor-owned persistent tensors."""
+        if frame_bgr.ndim != 3 or frame_bgr.shape[2] != 3 or frame_bgr.dtype != np.uint8:
+            raise ValueError("frame_bgr must be uint8 [H,W,3]")
+        h, w = frame_bgr.shape[:2]
+        self._ensure_buffers(h, w)
+        self._pin_input.copy_(torch.from_numpy(np.ascontiguousarray(frame_bgr)))
+        self._gpu_raw.copy_(self._pin_input, non_blocking=True)
+        self._chk(self._lib.hdrtv_preprocess(self._ctx, self._stream(), self._gpu_raw.data_ptr(), h, w,
+                                             self._gpu_input.data_ptr(), self._gpu_cond.data_ptr()), "hdrtv_preprocess")
+        return self._gpu_input, self._gpu_cond
+
+    @torch.inference_mode()
+    def infer(self, input_cond):
+        """hdrtvnet_torch.py:2301-2346.  Returns ``(out, agcm_out)`` like the eager model; both are
+        processor-owned and overwritten by the next call (as HDRTVNetTensorRT's output is)."""
+        tensor, cond = input_cond
+        if tensor.dtype != torch.float16 or cond.dtype != torch.float16 or not tensor.is_cuda:
+            raise ValueError("infer expects the fp16 CUDA tensors returned by preprocess()")
+        h, w = int(tensor.shape[2]), int(tensor.shape[3])
+        self._ensure_buffers(h, w)
+        tensor = tensor.contiguous()
+        cond = cond.contiguous()
+        if tuple(cond.shape[2:]) != (max(1, h // 4), max(1, w // 4)):
+            raise ValueError("cond must be [1,3,H//4,W//4]")
+        self._chk(self._lib.hdrtv_infer(self._ctx, self._stream(), tensor.data_ptr(), cond.data_ptr(), h, w,
+                                        self._gpu_out.data_ptr(), _L.F32 if self._use_hg else _L.F16,
+                                        self._gpu_agcm.data_ptr()), "hdrtv_infer")
+        return self._gpu_out, self._gpu_agcm
+
+    @torch.inference_mode()
+    def postprocess(self, output):
+        """hdrtvnet_torch.py:2351-2368.  Returns a zero-copy view of processor-owned pinned memory."""
+        if isinstance(output, (tuple, list)):
+            output = output[0]
+        h, w = int(output.shape[-2]), int(output.shape[-1])
+        self._ensure_buffers(h, w)
+        output = output.contiguous()
+        dt = _L.F32 if output.dtype == torch.float32 else _L.F16
+        if output.dtype not in (torch.float16, torch.float32):
+            raise ValueError("postprocess expects an fp16 or fp32 tensor")
+        self._chk(self._lib.hdrtv_post_u8(self._ctx, self._stream(), output.data_ptr(), dt, h, w,
+                                          self._gpu_u8.data_ptr()), "hdrtv_post_u8")
+        self._pin_output.copy_(self._gpu_u8, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return self._pin_output.numpy()
+
+    @torch.inference_mode()
+    def process(self, frame_bgr):
+        tensor, cond = self.preprocess(frame_bgr)
+        return self.postprocess(self.infer((tensor, cond)))
+
+    @torch.inference_mode()
+    def process_timed(self, frame_bgr):
+        """hdrtvnet_torch.py:2379-2395 -> (output, pre_ms, run_ms, post_ms)."""
+        t0 = time.perf_counter()
+        tensor, cond = self.preprocess(frame_bgr)
+        torch.cuda.synchronize(self.device)
+        t1 = time.perf_counter()
+        out = self.infer((tensor, cond))
+        torch.cuda.synchronize(self.device)
+        t2 = time.perf_counter()
+        output = self.postprocess(out)
+        t3 = time.perf_counter()
+        return output, (t1 - t0) * 1000.0, (t2 - t1) * 1000.0, (t3 - t2) * 1000.0
+
+    def warmup_compile(self, width=1920, height=1080):
+        """hdrtvnet_torch.py:2400-2469: only meaningful when torch.compile is active; never here."""
+        return None
+
+    def end_profiling(self):
+        return None
+
+    # ------------------------------------------------------------------ extras (tests / bench)
+    def tap(self, name):
+        """Internal activation by name (after infer) as a torch tensor copy: NHWC taps come back
+        as [C,H,W] float32 for direct comparison with the oracle."""
+        p, c, h, w, lay = C.c_void_p(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self._chk(self._lib.hdrtv_get_tap(self._ctx, name.encode(), C.byref(p), C.byref(c), C.byref(h), C.byref(w),
+                                          C.byref(lay)), "hdrtv_get_tap")
+        n = c.value * h.value * w.value
+        torch.cuda.synchronize(self.device)
+        if lay.value in (0, 1):
+            buf = torch.empty(n, dtype=torch.float16, device=self.device)
+        elif lay.value == 4:
+            buf = torch.empty(n, dtype=torch.uint8, device=self.device)
+        else:
+            buf = torch.empty(n, dtype=torch.float32, device=self.device)
+        _hip_memcpy_d2d(buf.data_ptr(), p.value, buf.numel() * buf.element_size())
+        torch.cuda.synchronize(self.device)
+        if lay.value == 0:
+            return buf.view(h.value, w.value, c.value).permute(2, 0, 1).float().cpu()
+        return buf.view(c.value, h.value, w.value).float().cpu()
+
+    def infer_stats(self):
+        n, m = C.c_int(), C.c_double()
+        self._lib.hdrtv_infer_stats(self._ctx, C.byref(n), C.byref(m))
+        return n.value, m.value
+
+    def close(self):
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._lib.hdrtv_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _arch_hr():
+    from . import arch
+    return arch.hr_params()
+
+
+_hip = None
+
+
+def _hip_memcpy_d2d(dst, src, nbytes):
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _hip.hipMemcpy.restype = C.c_int
+    rc = _hip.hipMemcpy(dst, src, nbytes, 3)   # hipMemcpyDeviceToDevice
+    if rc != 0:
+        raise RuntimeError(f"hipMemcpy failed: {rc}")

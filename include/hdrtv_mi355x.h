@@ -1,0 +1,127 @@
+/*
+ * hdrtv_mi355x.h -- C ABI of libhdrtv_mi355x.so: the MI355X-native (gfx950) SDR->HDR
+ * per-frame inference path of HDRTVNet++ (AGCM -> LE -> HG) with its pre/post stages.
+ *
+ * The reference (DanHelmy/hdr-realtime-video-pipeline) has no FFI: its AMD backend is the
+ * Python class HDRTVNetTorch (src/models/hdrtvnet_torch.py:1513).  Each entry point below
+ * names the reference method/lines it replaces; the Python mirror that binds them is
+ * hdr-realtime-video-pipeline_amd/hdrtv_mi355x/processor.py.
+ *
+ * Conventions: plain pointers and sizes only.  Every "dev" pointer is device memory
+ * (hipMalloc / torch CUDA tensor .data_ptr()); `stream` is a hipStream_t passed as void*
+ * (NULL = default stream).  All calls are stream-ordered and never synchronise, except
+ * hdrtv_create / hdrtv_reserve / hdrtv_destroy and the hdrtv_ring_* host-side calls.
+ * Return 0 on success, a negative HDRTV_E* code otherwise; hdrtv_last_error() describes it.
+ * Not re-entrant per context (like the reference: one processor per worker thread).
+ */
+#ifndef HDRTV_MI355X_H
+#define HDRTV_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HDRTV_OK 0
+#define HDRTV_EINVAL (-1)   /* bad argument / shape                      */
+#define HDRTV_EWEIGHTS (-2) /* weight pack malformed or tensor missing   */
+#define HDRTV_EHIP (-3)     /* a HIP runtime call failed                 */
+#define HDRTV_ENOMEM (-4)
+#define HDRTV_ESTATE (-5)   /* call order (e.g. infer before reserve)    */
+
+typedef struct hdrtv_ctx hdrtv_ctx;
+
+/* Output element type of hdrtv_infer's `out` and input type of the post kernels. */
+#define HDRTV_F16 0
+#define HDRTV_F32 1
+
+/* Library / build info: "hdrtv_mi355x <ver> gfx950 ...".  Never NULL. */
+const char *hdrtv_version(void);
+
+/* Replaces HDRTVNetTorch.__init__/_load_model (hdrtvnet_torch.py:1532-1673, 2044-2169).
+ * hr_pack: HDRW1 weight pack (hdrtv_mi355x/weights.py) holding the 264 AGCM+LE tensors of
+ * HR.pt under their state_dict names.  hg_pack: HDRW1 pack of Hallucination_Generator's
+ * state_dict (conv*.0.*, conv*.1.* BatchNorm, Up_conv*.0.*, conv6..conv10, conv_last) or
+ * NULL/0 for the no-HG model (reference: use_hg=False).  Weights are repacked on the host
+ * into MFMA operand layouts and uploaded to `device_id`. */
+int hdrtv_create(const void *hr_pack, size_t hr_bytes, const void *hg_pack, size_t hg_bytes,
+                 int device_id, hdrtv_ctx **out);
+int hdrtv_destroy(hdrtv_ctx *ctx);
+
+/* 1 if the context was created with HG weights. */
+int hdrtv_has_hg(const hdrtv_ctx *ctx);
+
+/* Replaces HDRTVNetTorch._ensure_buffers (hdrtvnet_torch.py:2198-2233): (re)allocates the
+ * internal activation workspace for H x W frames.  No-op when the size is unchanged.
+ * Synchronises the device when it reallocates. */
+int hdrtv_reserve(hdrtv_ctx *ctx, int H, int W);
+
+/* Replaces the device half of HDRTVNetTorch.preprocess (hdrtvnet_torch.py:2255-2294).
+ * dev_bgr_hwc : u8  [H][W][3] BGR (the frame after the pinned H2D copy)
+ * dev_rgb_chw : f16 [3][H][W]     RGB, fp16(float(u8) * fp32(1/255))
+ * dev_cond    : f16 [3][H/4][W/4] 0.25x antialiased bicubic (a=-0.5), fp32 accumulate */
+int hdrtv_preprocess(hdrtv_ctx *ctx, void *stream, const uint8_t *dev_bgr_hwc, int H, int W,
+                     void *dev_rgb_chw, void *dev_cond);
+
+/* Replaces HDRTVNetTorch.infer -> model((tensor, cond)) (hdrtvnet_torch.py:2301-2346;
+ * Ensemble_AGCM_LE_arch.py:889-897, HG_Composite_arch.py:86-107).
+ * dev_rgb_chw, dev_cond: as produced by hdrtv_preprocess.
+ * dev_out      : [3][H][W] planar RGB; out_dtype HDRTV_F16 without HG.  With HG the reference's
+ *                result is fp32 (the fp32 highlight mask promotes it): pass HDRTV_F32, or
+ *                HDRTV_F16 to have it rounded once at the end.
+ * dev_agcm_out : f16 [3][H][W], second element of the reference's result tuple; may be NULL. */
+int hdrtv_infer(hdrtv_ctx *ctx, void *stream, const void *dev_rgb_chw, const void *dev_cond, int H,
+                int W, void *dev_out, int out_dtype, void *dev_agcm_out);
+
+/* Replaces HDRTVNetTorch.postprocess's device half (hdrtvnet_torch.py:2357-2361):
+ * trunc(clamp(x,0,1)*255 + 0.5) in the tensor's dtype semantics, RGB planar -> u8 [H][W][3] BGR. */
+int hdrtv_post_u8(hdrtv_ctx *ctx, void *stream, const void *dev_out, int dtype, int H, int W,
+                  uint8_t *dev_bgr_hwc);
+
+/* Replaces _tensor_to_rgb48_bytes' GPU branch (gui_pipeline_worker_feeders.py:223-227):
+ * fp32(x) -> clamp(0,1) -> *65535 -> +0.5 (two fp32 roundings) -> trunc u16, planar ->
+ * [H][W][3] RGB little-endian (mpv "rgb48le").  dst may be device memory or a device-visible
+ * pointer to pinned host memory (hdrtv_ring_* slots), making the D2H copy part of the kernel. */
+int hdrtv_post_rgb48(hdrtv_ctx *ctx, void *stream, const void *dev_out, int dtype, int H, int W,
+                     uint16_t *dst);
+
+/* North-star display variant with no counterpart on the reference's playback path
+ * (SURVEY.md 8a-14/15): treats x as linear-light BT.709 with 1.0 = peak_nits, applies the
+ * BT.709->BT.2020 matrix (ITU-R BT.2087), the ST.2084 PQ OETF
+ * (gui_objective_metrics.py:486-491 constants) and the u16 quantiser, same output layout. */
+int hdrtv_post_pq_rgb48(hdrtv_ctx *ctx, void *stream, const void *dev_out, int dtype, int H, int W,
+                        float peak_nits, uint16_t *dst);
+
+/* ---- pinned host RGB48 ring: replaces _pinned_u16_host_ring / _acquire_pinned_u16_slot /
+ * _PinnedMpvFrame (gui_pipeline_worker_feeders.py:38-70, 125-170).  `slots` in [2,8]
+ * (HDRTVNET_FEEDER_GPU_RGB48_RING_FRAMES).  A slot cycles free -> acquired -> (kernel
+ * writes, event recorded) -> waited -> released. */
+int hdrtv_ring_create(hdrtv_ctx *ctx, int slots, int H, int W);
+/* Returns the slot index (>=0) and its host / device-visible pointers, or HDRTV_ESTATE when no
+ * slot frees up within timeout_ms (reference: 250 ms, feeders.py:166). */
+int hdrtv_ring_acquire(hdrtv_ctx *ctx, int timeout_ms, uint16_t **host_ptr, uint16_t **dev_ptr);
+/* Records the slot's ready event on `stream` (after hdrtv_post_rgb48 into it). */
+int hdrtv_ring_commit(hdrtv_ctx *ctx, int slot, void *stream);
+/* Blocks the calling host thread until the slot's contents are complete (wait_ready). */
+int hdrtv_ring_wait(hdrtv_ctx *ctx, int slot);
+/* Marks the slot free again (payload.release()). */
+int hdrtv_ring_release(hdrtv_ctx *ctx, int slot);
+int hdrtv_ring_destroy(hdrtv_ctx *ctx);
+
+/* ---- introspection for parity tests and profiling (no reference counterpart) ----------
+ * Looks up an internal activation by name after hdrtv_infer (e.g. "le.cond1", "hg.conv4_2").
+ * layout: 0 = NHWC f16, 1 = planar CHW f16, 2 = planar CHW f32, 3 = f32 vector. */
+int hdrtv_get_tap(hdrtv_ctx *ctx, const char *name, void **dev_ptr, int *C, int *H, int *W,
+                  int *layout);
+/* Number of kernel launches one hdrtv_infer issues at the reserved size, and the algorithmic
+ * multiply-accumulates of Conv2d/Linear layers per frame. */
+int hdrtv_infer_stats(hdrtv_ctx *ctx, int *launches, double *macs);
+
+const char *hdrtv_last_error(const hdrtv_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HDRTV_MI355X_H */
