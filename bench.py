@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the MI355X-native SDR->HDR hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path over one batch of synthetic frames: one 3840x2160 frame
+per GPU (BASELINE.json configs[2]: full HDRTVNet++ AGCM+LE+HG fp16 + fused RGB48 post;
+at N > 1 frame i goes to GPU i mod N = configs[3], no data-path collective).  The u8 frames
+are resident in HBM before the timed region; per frame the timed work is
+pre_unpack + cond_resize + infer(AGCM, LE, HG) + post_rgb48 into device memory.
+`value` = N*K frames / max-over-ranks wall time.  The PCIe-inclusive rate (pinned H2D in,
+RGB48 written into the pinned host ring) is reported separately as `value_pcie_inclusive`.
+
+Extra objects on the JSON line:
+  roofline     dominant kernel (by summed time) of hdrtv_infer, timed with HIP events on the
+               launch stream (hdrtv_profile_*), in K extra steps right after the timed region
+               (kept out of it so `value` carries no event overhead): achieved = algorithmic
+               FLOPs per launch / average launch duration; peak = 2500 TFLOP/s dense fp16 MFMA.
+  cpu_baseline the oracle (C port of the reference's CPU fp32 path) timed on this box's host
+               cores on a bounded sample, rank 0 at N=1 only.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for _p in (REPO, os.path.join(REPO, "hdr-realtime-video-pipeline_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0     # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--no-hg", action="store_true", help="debug: AGCM+LE only (not the headline config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", default="640x360", help="WxH of the oracle's bounded sample")
+    ap.add_argument("--layers", action="store_true", help="print the per-layer profile to stderr")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, use_hg):
+    """Oracle on host cores: one frame at a reduced size, scaled by pixel count to the workload size."""
+    from hdrtv_mi355x import weights as W
+    from oracle import hdrtvnet_oracle as O
+    w, h = (int(v) for v in args.cpu_sample.lower().split("x"))
+    cores = min(16, os.cpu_count() or 1)
+    O.set_threads(cores)
+    hr = W.load_pack(os.path.join(REPO, "tests", "golden", "hr_weights.hdrw"))
+    hg = W.seeded_hg_state(1234) if use_hg else None
+    frame = W.synthetic_frame(h, w, seed=1234, kind="noise")
+    O.process(hr, W.synthetic_frame(64, 96, seed=1, kind="noise"), hg)      # page in, spin up threads
+    t0 = time.perf_counter()
+    O.process(hr, frame, hg)
+    dt = time.perf_counter() - t0
+    scale = (args.height * args.width) / float(h * w)
+    return {"value": round(1.0 / (dt * scale), 5), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"1 frame {w}x{h} (1/{scale:.1f} of the {args.width}x{args.height} pixels) through oracle "
+                      f"preprocess+AGCM+LE{'+HG' if use_hg else ''}+postprocess in {dt:.2f} s, scaled by pixel count"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from hdrtv_mi355x import lib as L
+    from hdrtv_mi355x import weights as W
+    from hdrtv_mi355x.processor import HDRTVNetMI355X
+
+    use_hg = not args.no_hg
+    H, Wd = args.height, args.width
+    proc = HDRTVNetMI355X(os.path.join(REPO, "tests", "golden", "hr_weights.hdrw"), device=f"cuda:{local_rank}",
+                          use_hg=use_hg, hg_weights="seeded:1234" if use_hg else None, warmup_passes=0)
+    proc._ensure_buffers(H, Wd)
+    lib, ctx = proc._lib, proc._ctx
+
+    # synthetic frames, resident in HBM: BASELINE.md section 3 noise protocol + gradient/highlight pattern
+    nfr = 4
+    frames = [W.synthetic_frame(H, Wd, seed=1234 + rank * nfr + i, kind="noise" if i % 2 == 0 else "gradient")
+              for i in range(nfr)]
+    dev_frames = [torch.from_numpy(f).to(dev) for f in frames]
+    rgb48 = torch.empty((H, Wd, 3), dtype=torch.uint16, device=dev)
+    out_dt = L.F32 if use_hg else L.F16
+
+    def stream():
+        return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def step(i, dst_ptr=None):
+        fr = dev_frames[i % nfr]
+        proc._chk(lib.hdrtv_preprocess(ctx, stream(), fr.data_ptr(), H, Wd, proc._gpu_input.data_ptr(),
+                                       proc._gpu_cond.data_ptr()), "preprocess")
+        proc._chk(lib.hdrtv_infer(ctx, stream(), proc._gpu_input.data_ptr(), proc._gpu_cond.data_ptr(), H, Wd,
+                                  proc._gpu_out.data_ptr(), out_dt, proc._gpu_agcm.data_ptr()), "infer")
+        proc._chk(lib.hdrtv_post_rgb48(ctx, stream(), proc._gpu_out.data_ptr(), out_dt, H, Wd,
+                                       dst_ptr if dst_ptr is not None else rgb48.data_ptr()), "post_rgb48")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize(dev)
+
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        evs[i][0].record()
+        step(i)
+        evs[i][1].record()
+    torch.cuda.synchronize(dev)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    per_frame_ms = sorted(a.elapsed_time(b) for a, b in evs)
+    p50 = per_frame_ms[len(per_frame_ms) // 2]
+    p99 = per_frame_ms[min(len(per_frame_ms) - 1, int(len(per_frame_ms) * 0.99))]
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        pp = torch.tensor([p50], device=dev, dtype=torch.float64)
+        dist.all_reduce(pp, op=dist.ReduceOp.MAX)
+        p50 = float(pp.item())
+    value = world * args.steps / elapsed
+
+    # ---- PCIe-inclusive variant (pinned H2D in, RGB48 straight into the pinned host ring): reported, never `value`
+    pcie = None
+    if rank == 0:
+        proc._chk(lib.hdrtv_ring_create(ctx, 3, H, Wd), "ring_create")
+        pin = [torch.from_numpy(f).pin_memory() for f in frames]
+        torch.cuda.synchronize(dev)
+        n2 = max(4, min(args.steps, 12))
+        t1 = time.perf_counter()
+        pending = []
+        for i in range(n2):
+            hp, dp = C.c_void_p(), C.c_void_p()
+            slot = proc._chk(lib.hdrtv_ring_acquire(ctx, 250, C.byref(hp), C.byref(dp)), "ring_acquire")
+            dev_frames[i % nfr].copy_(pin[i % nfr], non_blocking=True)
+            step(i, dp.value)
+            proc._chk(lib.hdrtv_ring_commit(ctx, slot, stream()), "ring_commit")
+            pending.append(slot)
+            if len(pending) == 2:                      # consumer side: wait + release one frame behind
+                s0 = pending.pop(0)
+                lib.hdrtv_ring_wait(ctx, s0)
+                lib.hdrtv_ring_release(ctx, s0)
+        for s0 in pending:
+            lib.hdrtv_ring_wait(ctx, s0)
+            lib.hdrtv_ring_release(ctx, s0)
+        torch.cuda.synchronize(dev)
+        pcie = n2 / (time.perf_counter() - t1)
+        lib.hdrtv_ring_destroy(ctx)
+
+    # ---- roofline of the dominant kernel: HIP events around every launch of hdrtv_infer
+    roof, layers = None, None
+    if rank == 0:
+        proc.profile_enable(True)
+        agg = {}
+        nprof = max(3, min(args.steps, 10))
+        for i in range(nprof):
+            step(i)
+            torch.cuda.synchronize(dev)
+            layers = proc.profile_read()
+            for layer, kern, ms, macs, nbytes in layers:
+                a = agg.setdefault(kern, [0.0, 0.0, 0.0, 0])
+                a[0] += ms; a[1] += macs; a[2] += nbytes; a[3] += 1
+        proc.profile_enable(False)
+        infer_ms = sum(v[0] for v in agg.values()) / nprof
+        kern, (ms, macs, nbytes, n) = max(agg.items(), key=lambda kv: kv[1][0])
+        avg_ms = ms / n
+        tflops = 2.0 * macs / n / (avg_ms * 1e-3) / 1e12
+        roof = {"kernel": kern, "bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(tflops / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                "launches_per_frame": n // nprof, "avg_launch_ms": round(avg_ms, 4),
+                "flop_per_launch": 2.0 * macs / n, "share_of_infer_time": round(ms / nprof / infer_ms, 3),
+                "infer_ms_profiled": round(infer_ms, 3)}
+        if args.layers:
+            for kname, (kms, kmacs, kb, kn) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+                print(f"[kernel] {kname:28s} n/frame={kn // nprof:3d} ms/frame={kms / nprof:8.3f} "
+                      f"TFLOP/s={2 * kmacs / max(kms, 1e-9) / 1e9:8.1f} GB/s={kb / max(kms, 1e-9) / 1e6:8.1f}", file=sys.stderr)
+            for layer, kname, lms, lmacs, lb in layers:
+                print(f"[layer] {layer:28s} {kname:26s} {lms:8.3f} ms  {2 * lmacs / max(lms, 1e-9) / 1e9:8.1f} TFLOP/s "
+                      f"{lb / max(lms, 1e-9) / 1e6:8.1f} GB/s", file=sys.stderr)
+
+    launches, macs_frame = proc.infer_stats()
+    if rank == 0:
+        line = {
+            "metric": "frames/sec (HDRTVNet++ AGCM+LE+HG fp16 3840x2160 + fused RGB48 post); p50 per-frame ms in p50_ms",
+            "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "p50_ms": round(p50, 3), "p99_ms": round(p99, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+            "data": "synthetic (seeded u8 noise + gradient/highlight frames; HR.pt weights, seeded HG weights)",
+            "config": {"workload": f"configs[2]: full HDRTVNet++ fp16 {Wd}x{H} + fused RGB48 post, 1 frame per GPU per step"
+                       if use_hg else f"DEBUG no-HG {Wd}x{H}",
+                       "frames_per_step": world, "sharding": "frame i -> GPU i mod N, no collective",
+                       "launches_per_frame": launches, "gmac_per_frame": round(macs_frame / 1e9, 1)},
+            "tflops_end_to_end": round(2 * macs_frame * value / world / 1e12, 1),
+            "value_pcie_inclusive": round(pcie, 3) if pcie else None,
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, use_hg)
+        print(json.dumps(line), flush=True)
+    proc.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -135,6 +135,11 @@ struct hdrtv_ctx {
     std::map<std::string, Tensor> t;
     int launches = 0;
     double macs = 0.0;
+    // per-launch profile (hdrtv_profile_*): event i is recorded after launch i-1
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;
+    struct ProfEntry { std::string layer, kernel; double macs, bytes; float ms; };
+    std::vector<ProfEntry> prof;
     // ring
     std::vector<RingSlot> ring;
     int ring_next = 0, ring_H = 0, ring_W = 0;
@@ -538,10 +543,27 @@ struct Seq {
     hipStream_t s;
     int rc = HDRTV_OK;
     bool ok() const { return rc == HDRTV_OK; }
-    void chk(hipError_t e, const char *what)
+    void mark()
+    {
+        if (!c->prof_on) return;
+        const size_t i = c->prof.size();
+        while (c->prof_ev.size() <= i) {
+            hipEvent_t ev;
+            if (hipEventCreate(&ev) != hipSuccess) { c->prof_on = false; return; }
+            c->prof_ev.push_back(ev);
+        }
+        (void)hipEventRecord(c->prof_ev[i], s);
+    }
+    // called after every launch: counts it, checks it and (profiling) closes its event interval
+    void chk(hipError_t e, const char *what, const char *kernel = "", double macs = 0.0, double bytes = 0.0)
     {
         ++c->launches;
+        c->macs += macs;
         if (e != hipSuccess && rc == HDRTV_OK) rc = fail(c, HDRTV_EHIP, "launch %s failed: %s", what, hipGetErrorString(e));
+        if (c->prof_on) {
+            c->prof.push_back({what, kernel, macs, bytes, 0.f});
+            mark();
+        }
     }
     // generic conv: src0 (+src1) -> dst
     void conv(const std::string &key, const f16 *src0, int c0, const f16 *src1, int c1, int Hi, int Wi, int act, int mode,
@@ -564,16 +586,22 @@ struct Seq {
         p.dst = dst; p.dst_full = dst_full; p.dstC = dstC; p.Hd = Hd; p.Wd = Wd;
         p.res1 = res1; p.res2 = res2; p.dst_planar = dst_planar; p.res_planar = res_planar;
         if (c0 + c1 != L.cin) { rc = fail(c, HDRTV_ESTATE, "conv %s: channel mismatch", key.c_str()); return; }
-        chk(conv_igemm_launch(p, L.cin_t, L.bn, L.ks, L.stride, s), key.c_str());
-        c->macs += (double)p.Ho * p.Wo * L.cin * L.ks * L.ks * L.cout;
+        char tag[64];
+        snprintf(tag, sizeof tag, "conv_igemm<%d,%d,%d,%d>", L.cin_t, L.bn, L.ks, L.stride);
+        const double macs = (double)p.Ho * p.Wo * L.cin * L.ks * L.ks * L.cout;
+        double bytes = 2.0 * Hi * Wi * L.cin + 2.0 * L.ks * L.ks * L.cin * L.coutPad;
+        const double outel = mode == ST_POOL ? (double)Hd * Wd * L.cout + (dst_full ? (double)p.Ho * p.Wo * L.cout : 0.0)
+                                              : (mode == ST_PLANAR3 ? 3.0 * Hd * Wd : (double)p.Ho * p.Wo * L.cout);
+        bytes += 2.0 * outel * (1 + (res1 ? 1 : 0) + (res2 ? 1 : 0) + (res_planar ? 1 : 0));
+        chk(conv_igemm_launch(p, L.cin_t, L.bn, L.ks, L.stride, s), key.c_str(), tag, macs, bytes);
     }
     void c3(const std::string &key, const f16 *in, int H, int W, int act, f16 *out, f16 *out_pool)
     {
         if (!ok()) return;
         const C3Layer &L = c->c3.at(key);
         chk(conv_c3_launch(in, H, W, wtp<f16>(c, L.wfrag), wtp<float>(c, L.scale), wtp<float>(c, L.shift), L.cout, act, out,
-                           out_pool, s), key.c_str());
-        c->macs += (double)H * W * 27 * L.cout;
+                           out_pool, s), key.c_str(), L.cout == 64 ? "conv_c3<64>" : "conv_c3<32>", (double)H * W * 27 * L.cout,
+            (double)H * W * (6.0 + 2.0 * L.cout * (out_pool ? 1.25 : 1.0)));
     }
     void sft(const std::string &key, const f16 *x, const f16 *cond, f16 *y, int npix)
     {
@@ -581,8 +609,7 @@ struct Seq {
         const SftLayer &L = c->sft.at(key);
         SftParams p;
         p.x = x; p.cond = cond; p.y = y; p.wfrag = wtp<f16>(c, L.wfrag); p.bias = wtp<float>(c, L.bias); p.npix = npix;
-        chk(sft_launch(p, s), key.c_str());
-        c->macs += (double)npix * 2 * (16 * 16 + 16 * 32);
+        chk(sft_launch(p, s), key.c_str(), "sft", (double)npix * 2 * (16 * 16 + 16 * 32), (double)npix * (64 + 32 + 64));
     }
     // ResBlock_with_SFT (arch_util.py:89-95): y = x + conv2(sft2(relu(conv1(sft1(x,c))),c))  [+ extra]
     void resblock(const std::string &base, const f16 *x, const f16 *cond, int H, int W, f16 *ta, f16 *tb, f16 *y,
@@ -618,12 +645,11 @@ int run_agcm(hdrtv_ctx *c, Seq &q, const f16 *rgb, const f16 *cond, f16 *agcm_ou
         snprintf(b, sizeof b, "cls%d.b", i);
         const float *bias = wtp<float>(c, c->f32v.at(b));
         q.chk(cls_block_launch(in, i == 0, cls_ci[i], s.ch[i], s.cw[i], nm, nr, ng, nb, w, bias, cls_co[i], out, s.ch[i + 1],
-                               s.cw[i + 1], q.s), "cls_block");
-        c->macs += (double)s.ch[i] * s.cw[i] * cls_ci[i] * cls_co[i];
+                               s.cw[i + 1], q.s), "cls_block", "cls_block", (double)s.ch[i] * s.cw[i] * cls_ci[i] * cls_co[i]);
         snprintf(a, sizeof a, "agcm.mean%d", i + 1);
         snprintf(b, sizeof b, "agcm.rstd%d", i + 1);
         q.chk(cls_stats_launch(out, cls_co[i], s.ch[i + 1] * s.cw[i + 1], 1e-5f, wsp<float>(c, a), wsp<float>(c, b), q.s),
-              "cls_stats");
+              "cls_stats", "cls_stats");
     }
     AgcmFoldArgs fa;
     fa.mean5 = wsp<float>(c, "agcm.mean5");
@@ -637,11 +663,10 @@ int run_agcm(hdrtv_ctx *c, Seq &q, const f16 *rgb, const f16 *cond, f16 *agcm_ou
     fa.w1 = wtp<float>(c, c->f32v.at("agcm.w1")); fa.b1 = wtp<float>(c, c->f32v.at("agcm.b1"));
     fa.w2 = wtp<float>(c, c->f32v.at("agcm.w2")); fa.b2 = wtp<float>(c, c->f32v.at("agcm.b2"));
     fa.w3 = wtp<float>(c, c->f32v.at("agcm.w3")); fa.b3 = wtp<float>(c, c->f32v.at("agcm.b3"));
-    q.chk(agcm_fold_launch(fa, wsp<f16>(c, "agcm.frags"), wsp<float>(c, "agcm.bias"), q.s), "agcm_fold");
-    c->macs += 128.0 * 6 + 6.0 * (64 + 64 + 3) * 2;
+    q.chk(agcm_fold_launch(fa, wsp<f16>(c, "agcm.frags"), wsp<float>(c, "agcm.bias"), q.s), "agcm_fold", "agcm_fold",
+          128.0 * 6 + 6.0 * (64 + 64 + 3) * 2);
     q.chk(agcm_mlp_launch(rgb, agcm_out, (size_t)c->H * c->W, wsp<f16>(c, "agcm.frags"), wsp<float>(c, "agcm.bias"), q.s),
-          "agcm_mlp");
-    c->macs += (double)c->H * c->W * (3 * 64 + 64 * 64 + 64 * 3);
+          "agcm_mlp", "agcm_mlp", (double)c->H * c->W * (3 * 64 + 64 * 64 + 64 * 3), 12.0 * c->H * c->W);
     return q.rc;
 }
 
@@ -710,7 +735,7 @@ int run_hg(hdrtv_ctx *c, Seq &q, const f16 *base, void *out, int out_f32)
     const int Hp = s.Hp, Wp = s.Wp;
     f16 *img = wsp<f16>(c, "hg.img");
     uint8_t *mask = wsp<uint8_t>(c, "hg.mask");
-    q.chk(hg_prep_launch(base, s.H, s.W, Hp, Wp, img, mask, 0.75f, 0.1f, q.s), "hg_prep");
+    q.chk(hg_prep_launch(base, s.H, s.W, Hp, Wp, img, mask, 0.75f, 0.1f, q.s), "hg_prep", "hg_prep", 0.0, 13.0 * Hp * Wp);
     f16 *c1 = wsp<f16>(c, "hg.conv1"), *p1 = wsp<f16>(c, "hg.p1"), *c2 = wsp<f16>(c, "hg.conv2"), *p3 = wsp<f16>(c, "hg.p3"),
         *c3 = wsp<f16>(c, "hg.conv3_2"), *p4 = wsp<f16>(c, "hg.p4"), *c4 = wsp<f16>(c, "hg.conv4_2"), *p5 = wsp<f16>(c, "hg.p5"),
         *c5 = wsp<f16>(c, "hg.conv5_2"), *pc = wsp<f16>(c, "hg.pc"), *code = wsp<f16>(c, "hg.conv_code2");
@@ -742,8 +767,8 @@ int run_hg(hdrtv_ctx *c, Seq &q, const f16 *base, void *out, int out_f32)
     fa.w10 = wtp<float>(c, c->f32v.at("hg.w10")); fa.b10 = wtp<float>(c, c->f32v.at("hg.b10"));
     fa.wl = wtp<float>(c, c->f32v.at("hg.wl")); fa.bl = wtp<float>(c, c->f32v.at("hg.bl"));
     fa.out = out; fa.out_f32 = out_f32; fa.H = s.H; fa.W = s.W; fa.Hp = Hp; fa.Wp = Wp;
-    q.chk(hg_final_launch(fa, q.s), "hg_final");
-    c->macs += (double)Hp * Wp * (128 * 3 + 6 * 3);
+    q.chk(hg_final_launch(fa, q.s), "hg_final", "hg_final", (double)Hp * Wp * (128 * 3 + 6 * 3),
+          (double)Hp * Wp * (256 + 7) + (double)s.H * s.W * 3 * (out_f32 ? 4 : 2));
     return q.rc;
 }
 
@@ -791,6 +816,7 @@ int hdrtv_destroy(hdrtv_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     hdrtv_ring_destroy(c);
+    for (hipEvent_t ev : c->prof_ev) (void)hipEventDestroy(ev);
     if (c->ws.dev) (void)hipFree(c->ws.dev);
     if (c->wts.dev) (void)hipFree(c->wts.dev);
     delete c;
@@ -830,6 +856,8 @@ int hdrtv_infer(hdrtv_ctx *c, void *stream, const void *rgb, const void *cond, i
     Seq q{c, (hipStream_t)stream};
     c->launches = 0;
     c->macs = 0.0;
+    c->prof.clear();
+    q.mark();
     f16 *agcm = agcm_out ? (f16 *)agcm_out : wsp<f16>(c, "agcm.out");
     if (run_agcm(c, q, (const f16 *)rgb, (const f16 *)cond, agcm) != HDRTV_OK) return q.rc;
     f16 *le_out = c->has_hg ? wsp<f16>(c, "le.out") : (f16 *)out;
@@ -960,6 +988,31 @@ int hdrtv_infer_stats(hdrtv_ctx *c, int *launches, double *macs)
     if (!c) return HDRTV_EINVAL;
     if (launches) *launches = c->launches;
     if (macs) *macs = c->macs;
+    return HDRTV_OK;
+}
+
+int hdrtv_profile_enable(hdrtv_ctx *c, int on)
+{
+    if (!c) return HDRTV_EINVAL;
+    c->prof_on = on != 0;
+    c->prof.clear();
+    return HDRTV_OK;
+}
+
+int hdrtv_profile_get(hdrtv_ctx *c, int i, const char **layer, const char **kernel, float *ms, double *macs, double *bytes)
+{
+    if (!c) return HDRTV_EINVAL;
+    const int n = (int)c->prof.size();
+    if (i < 0) return n;
+    if (i >= n || (size_t)i + 1 >= c->prof_ev.size()) return fail(c, HDRTV_EINVAL, "profile index out of range");
+    hdrtv_ctx::ProfEntry &e = c->prof[i];
+    HIPCHK(c, hipEventSynchronize(c->prof_ev[i + 1]));
+    HIPCHK(c, hipEventElapsedTime(&e.ms, c->prof_ev[i], c->prof_ev[i + 1]));
+    if (layer) *layer = e.layer.c_str();
+    if (kernel) *kernel = e.kernel.c_str();
+    if (ms) *ms = e.ms;
+    if (macs) *macs = e.macs;
+    if (bytes) *bytes = e.bytes;
     return HDRTV_OK;
 }
 

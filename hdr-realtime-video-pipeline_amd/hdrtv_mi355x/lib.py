@@ -36,6 +36,9 @@ SYMBOLS = [
     ("hdrtv_ring_destroy", _I, [_VP]),
     ("hdrtv_get_tap", _I, [_VP, C.c_char_p, C.POINTER(_VP), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     ("hdrtv_infer_stats", _I, [_VP, C.POINTER(_I), C.POINTER(C.c_double)]),
+    ("hdrtv_profile_enable", _I, [_VP, _I]),
+    ("hdrtv_profile_get", _I, [_VP, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_float),
+                               C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("hdrtv_last_error", C.c_char_p, [_VP]),
 ]
 

@@ -265,6 +265,21 @@ class HDRTVNetMI355X:
             return buf.view(h.value, w.value, c.value).permute(2, 0, 1).float().cpu()
         return buf.view(c.value, h.value, w.value).float().cpu()
 
+    def profile_enable(self, on=True):
+        """Per-launch HIP-event timing of subsequent infer() calls (bench.py roofline)."""
+        self._chk(self._lib.hdrtv_profile_enable(self._ctx, 1 if on else 0), "hdrtv_profile_enable")
+
+    def profile_read(self):
+        """[(layer, kernel, ms, macs, bytes)] of the last infer(); synchronises on its events."""
+        n = self._lib.hdrtv_profile_get(self._ctx, -1, None, None, None, None, None)
+        out = []
+        for i in range(max(n, 0)):
+            layer, kern, ms, macs, nbytes = C.c_char_p(), C.c_char_p(), C.c_float(), C.c_double(), C.c_double()
+            self._chk(self._lib.hdrtv_profile_get(self._ctx, i, C.byref(layer), C.byref(kern), C.byref(ms),
+                                                  C.byref(macs), C.byref(nbytes)), "hdrtv_profile_get")
+            out.append((layer.value.decode(), kern.value.decode(), ms.value, macs.value, nbytes.value))
+        return out
+
     def infer_stats(self):
         n, m = C.c_int(), C.c_double()
         self._lib.hdrtv_infer_stats(self._ctx, C.byref(n), C.byref(m))

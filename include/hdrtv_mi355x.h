@@ -119,6 +119,16 @@ int hdrtv_get_tap(hdrtv_ctx *ctx, const char *name, void **dev_ptr, int *C, int 
  * multiply-accumulates of Conv2d/Linear layers per frame. */
 int hdrtv_infer_stats(hdrtv_ctx *ctx, int *launches, double *macs);
 
+/* Per-launch timing of hdrtv_infer with HIP events on the launch stream (bench.py roofline).
+ * While enabled, every hdrtv_infer records one event after each kernel launch; interval i is
+ * launch i (plus its launch gap).  hdrtv_profile_get(ctx, -1, ...) returns the number of launches
+ * recorded by the last hdrtv_infer; index i returns the layer name, the kernel (template
+ * instance) name, its duration in ms, its algorithmic MACs and its algorithmic bytes
+ * (activations in + out + residuals + weights, each counted once). */
+int hdrtv_profile_enable(hdrtv_ctx *ctx, int on);
+int hdrtv_profile_get(hdrtv_ctx *ctx, int i, const char **layer, const char **kernel, float *ms, double *macs,
+                      double *bytes);
+
 const char *hdrtv_last_error(const hdrtv_ctx *ctx);
 
 #ifdef __cplusplus

@@ -64,7 +64,7 @@ def test_pre_exact_and_cond(proc_hr, golden_dir, torch_cuda):
     frame = np.zeros((16, 256, 3), np.uint8)
     frame[:, :, 0] = d["u8"][None]          # B
     frame[:, :, 1] = d["u8"][None, ::-1]    # G
-    frame[:, :, 2] = (d["u8"][None] * 7) % 256
+    frame[:, :, 2] = ((d["u8"][None].astype(np.int32) * 7) % 256).astype(np.uint8)
     # 16 rows is below the classifier's minimum, but preprocess alone has no such limit -> use 80 rows
     frame = np.ascontiguousarray(np.tile(frame, (5, 1, 1)))
     t, c = proc_hr.preprocess(frame)
