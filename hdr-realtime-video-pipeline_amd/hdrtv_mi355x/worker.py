@@ -1,0 +1,287 @@
+"""Headless counterparts of the reference's pipeline-worker mixins for the hot path.
+
+  _load_model / _silent_warmup   src/gui_pipeline_worker_model.py:39-257   (AMD branch 202-228)
+  _process_frame                 src/gui_pipeline_worker_frame_processing.py:168-331
+  _stage_hdr_display_tensor      src/gui_pipeline_worker_frame_processing.py:118-156
+  _tensor_to_rgb48_bytes + ring  src/gui_pipeline_worker_feeders.py:38-70, 125-249
+  _hdr_feeder_fn (core)          src/gui_pipeline_worker_feeders.py:440-496
+
+Same names, argument meaning and error behaviour (``_load_model`` swallows backend exceptions
+into a status message and returns False), without PyQt/cv2/mpv: status messages go to a list
+or callback, the display sink is any callable taking a ``PinnedFrame``.  Letterboxing
+(cv2, host) is out of scope: frames must arrive at the processing size.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import queue as _queue
+import sys
+import threading
+import time
+
+import numpy as np
+import torch
+
+from . import lib as _L
+from .processor import HDRTVNetMI355X
+
+_RING_FRAMES = max(2, min(8, int(os.environ.get("HDRTVNET_FEEDER_GPU_RGB48_RING_FRAMES", "3") or 3)))
+
+# preset table: the subset of gui_config.PRECISIONS (src/gui_config.py:19-160) this backend serves
+PRECISIONS = {
+    "FP16": {"precision": "fp16", "model": "original/HR.pt", "model_nohg": "original/HR.pt",
+             "hg_weights": "original/HG.pt"},
+}
+
+
+class PinnedFrame:
+    """_PinnedMpvFrame (feeders.py:38-70): a pinned host RGB48 frame whose ring slot is released
+    after the sink has consumed it."""
+
+    def __init__(self, worker, slot, host_ptr, shape):
+        self._w, self._slot, self._host, self._shape = worker, slot, host_ptr, shape
+        self._ready_waited = self._released = False
+
+    def wait_ready(self):
+        if not self._ready_waited:
+            p = self._w._processor
+            p._chk(p._lib.hdrtv_ring_wait(p._ctx, self._slot), "hdrtv_ring_wait")
+            self._ready_waited = True
+
+    def buffer_view(self):
+        self.wait_ready()
+        n = int(np.prod(self._shape))
+        return memoryview((C.c_uint16 * n).from_address(self._host)).cast("B")
+
+    def numpy(self):
+        self.wait_ready()
+        n = int(np.prod(self._shape))
+        return np.ctypeslib.as_array((C.c_uint16 * n).from_address(self._host)).reshape(self._shape)
+
+    def release(self):
+        if self._released:
+            return
+        self._released = True
+        try:
+            self.wait_ready()
+        finally:
+            p = self._w._processor
+            if p is not None:
+                p._lib.hdrtv_ring_release(p._ctx, self._slot)
+
+
+class HeadlessPipelineWorker:
+    def __init__(self, weights_dir, use_hg=True, proc_w=1920, proc_h=1080, hg_weights=None,
+                 status_cb=None, buffer_frames=1):
+        self._weights_dir = weights_dir
+        self._use_hg = bool(use_hg)
+        self._hg_override = hg_weights
+        self._proc_w, self._proc_h = int(proc_w), int(proc_h)
+        self._processor = None
+        self._precision_key = None
+        self.status_messages = []
+        self._status_cb = status_cb
+        self._video_playback_buffer_frames = int(buffer_frames)
+        self._pool, self._pool_key, self._pool_idx = None, None, 0
+        self._timing_events = None
+        self._hdr_queue = None
+        self._hdr_thread = None
+        self._hdr_stop = threading.Event()
+        self._ring_shape = None
+
+    # ---------------------------------------------------------------- status
+    def _emit(self, msg):
+        self.status_messages.append(msg)
+        if self._status_cb:
+            self._status_cb(msg)
+
+    # ---------------------------------------------------------------- model load / swap
+    @staticmethod
+    def _silent_warmup(processor, w, h):
+        """model.py:39-70: prime the runtime once (no compiled graph exists here)."""
+        if getattr(processor, "_compiled", False):
+            processor.warmup_compile(w, h)
+        else:
+            processor.process(np.zeros((max(1, int(h)), max(1, int(w)), 3), dtype=np.uint8))
+            torch.cuda.synchronize()
+
+    def _load_model(self, key, announce_ready=True, *, compile_model=None, force_compile=False,
+                    compile_mode=None, warmup=True):
+        """model.py:72-257.  Returns True on success; on any backend failure emits
+        ``ERROR: model backend failed - ...`` and returns False (model.py:229-235)."""
+        cfg = PRECISIONS.get(key, {})
+        if not cfg:
+            self._emit(f"ERROR: precision preset is not defined - {key}")
+            return False
+        path = cfg["model"] if self._use_hg else cfg["model_nohg"]
+        if not (isinstance(path, dict) or os.path.isabs(str(path))):
+            path = os.path.join(self._weights_dir, path)
+        if not isinstance(path, dict):
+            if not os.path.isfile(path) and os.path.isfile(os.path.splitext(path)[0] + ".hdrw"):
+                path = os.path.splitext(path)[0] + ".hdrw"
+            if not os.path.isfile(path):
+                self._emit(f"ERROR: weights not found - {path}")
+                return False
+        cw, ch = self._proc_w, self._proc_h
+        if announce_ready:
+            self._emit(f"Loading model: {key} ...")
+        if self._processor is not None:
+            self._stop_hdr_feeder()
+            self._processor.close()
+            self._processor = None
+            torch.cuda.empty_cache()
+        try:
+            hg = self._hg_override
+            if hg is None and self._use_hg:
+                cand = os.path.join(self._weights_dir, cfg.get("hg_weights", ""))
+                hg = cand if os.path.isfile(cand) else None        # missing -> no-HG, as model.py:208-209
+            self._processor = HDRTVNetMI355X(
+                path, device="auto", precision=cfg["precision"], compile_model=bool(compile_model),
+                force_compile=bool(force_compile), compile_mode=compile_mode or "default",
+                hg_weights=hg, use_hg=self._use_hg, warmup_passes=0)
+        except Exception as exc:  # noqa: BLE001  (the reference catches everything here)
+            self._processor = None
+            self._emit(f"ERROR: model backend failed - {exc}")
+            print(f"ERROR: model backend failed: {exc}", file=sys.stderr)
+            torch.cuda.empty_cache()
+            return False
+        if announce_ready and warmup:
+            self._emit(f"Priming model for {cw}x{ch} ({key}) ...")
+        if warmup:
+            self._silent_warmup(self._processor, cw, ch)
+        self._precision_key = key
+        if announce_ready:
+            self._emit(f"Ready - {key} [MI355X]")
+        return True
+
+    # ---------------------------------------------------------------- per-frame
+    def _prepare_hdr_output_tensor(self, raw_out, lower_res_processing=False):
+        return raw_out[0] if isinstance(raw_out, (tuple, list)) else raw_out
+
+    def _stage_hdr_display_tensor(self, prepared_out, use_cuda=True):
+        """frame_processing.py:118-156: copy the backend-owned output into a rotating pool so the
+        feeder never reads a tensor the next infer() overwrites."""
+        pool_size = max(2, min(16, self._video_playback_buffer_frames + 2))
+        key = (tuple(prepared_out.shape), str(prepared_out.device), str(prepared_out.dtype), pool_size)
+        if self._pool_key != key or not self._pool:
+            self._pool = [torch.empty_like(prepared_out) for _ in range(pool_size)]
+            self._pool_key, self._pool_idx = key, 0
+        staged = self._pool[self._pool_idx % len(self._pool)]
+        self._pool_idx = (self._pool_idx + 1) % len(self._pool)
+        staged.copy_(prepared_out, non_blocking=True)
+        return staged
+
+    def _cuda_timing_events(self):
+        if self._timing_events is None:
+            self._timing_events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        return self._timing_events
+
+    def _process_frame(self, *, frame, frame_idx, present_t=None, out_w=None, out_h=None, proc_w=None, proc_h=None,
+                       lower_res_processing=False, mpv_w=True, use_cuda=True, need_compare_frame=False):
+        """frame_processing.py:168-331 (SDR->HDR branch).  Returns the reference's 5-tuple
+        ``(display_frame, output, prepared_out, need_hdr_cpu, model_latency_ms)``; with a sink
+        attached (``mpv_w`` truthy and the HDR feeder running) the staged tensor and its ready
+        event are queued as ``(present_t, tensor, event)``."""
+        if self._processor is None:
+            raise RuntimeError("no model loaded")
+        start, end = self._cuda_timing_events()
+        start.record(torch.cuda.current_stream())
+        with torch.inference_mode():
+            tensor, cond = self._processor.preprocess(frame)
+            raw_out = self._processor.infer((tensor, cond))
+        end.record(torch.cuda.current_stream())
+        end.synchronize()
+        model_latency_ms = max(0.0, float(start.elapsed_time(end)))
+        prepared_out = self._prepare_hdr_output_tensor(raw_out, lower_res_processing)
+        if mpv_w and self._hdr_queue is not None:
+            staged = self._stage_hdr_display_tensor(prepared_out, use_cuda)
+            ready = torch.cuda.Event(enable_timing=False)
+            ready.record(torch.cuda.current_stream())
+            self._queue_display_item(self._hdr_queue, (present_t, staged, ready))
+        need_hdr_cpu = not mpv_w
+        output = self._processor.postprocess(prepared_out) if need_hdr_cpu else frame
+        return None, output, prepared_out, need_hdr_cpu, model_latency_ms
+
+    @staticmethod
+    def _queue_display_item(q, item):
+        try:
+            q.put(item, timeout=0.25)
+        except _queue.Full:
+            try:
+                q.get_nowait()          # drop the oldest frame rather than stall inference
+            except _queue.Empty:
+                pass
+            q.put_nowait(item)
+
+    # ---------------------------------------------------------------- RGB48 ring + feeder
+    def _tensor_to_rgb48_bytes(self, tensor, stream=None):
+        """feeders.py:193-249, GPU branch: quantise to RGB48 directly into a pinned ring slot and
+        return a ``PinnedFrame`` guarded by the slot's ready event.  Ring exhaustion (no slot free
+        within 250 ms) raises, where the reference falls back to a blocking single buffer."""
+        p = self._processor
+        t = tensor[0] if isinstance(tensor, (tuple, list)) else tensor
+        h, w = int(t.shape[-2]), int(t.shape[-1])
+        if self._ring_shape != (h, w):
+            p._chk(p._lib.hdrtv_ring_create(p._ctx, _RING_FRAMES, h, w), "hdrtv_ring_create")
+            self._ring_shape = (h, w)
+        host, dev = C.c_void_p(), C.c_void_p()
+        slot = p._chk(p._lib.hdrtv_ring_acquire(p._ctx, 250, C.byref(host), C.byref(dev)), "hdrtv_ring_acquire")
+        st = stream or torch.cuda.current_stream(p.device)
+        sp = C.c_void_p(st.cuda_stream)
+        dt = _L.F32 if t.dtype == torch.float32 else _L.F16
+        p._chk(p._lib.hdrtv_post_rgb48(p._ctx, sp, t.contiguous().data_ptr(), dt, h, w, dev), "hdrtv_post_rgb48")
+        p._chk(p._lib.hdrtv_ring_commit(p._ctx, slot, sp), "hdrtv_ring_commit")
+        return PinnedFrame(self, slot, host.value, (h, w, 3))
+
+    def _start_hdr_feeder(self, sink):
+        """feeders.py:632-657 + 440-496: a thread that waits for each frame's ready event,
+        converts on a side stream into the pinned ring and hands the frame to ``sink``."""
+        self._stop_hdr_feeder()
+        self._hdr_queue = _queue.Queue(maxsize=max(1, min(3, self._video_playback_buffer_frames + 1)))
+        self._hdr_stop.clear()
+        dev = self._processor.device
+
+        def run():
+            side = torch.cuda.Stream(device=dev)
+            while not self._hdr_stop.is_set():
+                try:
+                    item = self._hdr_queue.get(timeout=0.05)
+                except _queue.Empty:
+                    continue
+                if item is None:
+                    break
+                present_t, tensor, ready = item
+                ready.synchronize()                      # cross-thread device sync (feeders.py:469-473)
+                with torch.cuda.stream(side):
+                    payload = self._tensor_to_rgb48_bytes(tensor, side)
+                if present_t is not None:
+                    delay = present_t - time.perf_counter()
+                    if delay > 0:
+                        time.sleep(delay)
+                sink(payload)
+
+        self._hdr_thread = threading.Thread(target=run, name="hdr-feeder", daemon=True)
+        self._hdr_thread.start()
+
+    def _stop_hdr_feeder(self):
+        if self._hdr_thread is not None:
+            self._hdr_stop.set()
+            try:
+                self._hdr_queue.put_nowait(None)
+            except Exception:  # noqa: BLE001
+                pass
+            self._hdr_thread.join(timeout=2.0)
+        self._hdr_thread, self._hdr_queue = None, None
+
+    def close(self):
+        self._stop_hdr_feeder()
+        if self._processor is not None:
+            self._processor.close()
+            self._processor = None
+
+
+def shard_frames(n_frames: int, rank: int, world_size: int):
+    """Frame-parallel partition of BASELINE.json configs[3]: frame i -> GPU (rank) i mod N.
+    No data-path collective; order is restored on the host by frame index."""
+    return list(range(rank, n_frames, world_size))

@@ -1,0 +1,49 @@
+"""Headless _load_model / _process_frame / HDR feeder counterparts on a real MI355X."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_worker_load_process_feed(golden_dir, tmp_path):
+    import torch
+    from hdrtv_mi355x import weights as W
+    from hdrtv_mi355x.worker import HeadlessPipelineWorker
+    from oracle import hdrtvnet_oracle as O
+    wdir = tmp_path / "weights" / "original"
+    wdir.mkdir(parents=True)
+    os.symlink(os.path.join(golden_dir, "hr_weights.hdrw"), wdir / "HR.hdrw")
+    w = HeadlessPipelineWorker(str(tmp_path / "weights"), use_hg=False, proc_w=96, proc_h=64)
+    assert w._load_model("nope") is False and "not defined" in w.status_messages[-1]
+    assert w._load_model("FP16") is True and w.status_messages[-1].startswith("Ready - FP16")
+    d = np.load(os.path.join(golden_dir, "hr_64x96_noise_s0.npz"))
+    # CPU-output branch (mpv_w falsy): u8 BGR through postprocess
+    _, out, prepared, need_cpu, ms = w._process_frame(frame=d["frame"], frame_idx=0, mpv_w=None)
+    assert need_cpu and ms > 0 and np.abs(out.astype(int) - d["u8_bgr"].astype(int)).max() <= 1
+    # feeder branch: frames come back in order through the pinned RGB48 ring
+    got, done = [], threading.Event()
+
+    def sink(payload):
+        got.append(payload.numpy().copy())
+        payload.release()
+        if len(got) == 5:
+            done.set()
+
+    w._start_hdr_feeder(sink)
+    frames = [W.synthetic_frame(64, 96, seed=50 + i, kind="noise") for i in range(5)]
+    outs = []
+    for i, f in enumerate(frames):
+        _, _, prepared, need_cpu, _ = w._process_frame(frame=f, frame_idx=i, mpv_w=True)
+        assert not need_cpu
+        outs.append(prepared.float().cpu().numpy()[0])
+    assert done.wait(20.0)
+    w._stop_hdr_feeder()
+    for i in range(5):
+        assert np.array_equal(got[i], O.post_rgb48(outs[i]))        # exact: same float input
+    # a wrong weights dir is reported, not raised (model.py:229-235)
+    w2 = HeadlessPipelineWorker(str(tmp_path / "missing"), use_hg=False)
+    assert w2._load_model("FP16") is False and w2.status_messages[-1].startswith("ERROR: weights not found")
+    w.close()

@@ -1,0 +1,60 @@
+"""N > 1 path on CPU: two gloo ranks shard frames round-robin (frame i -> rank i mod N), process
+their share with the ORACLE standing in for the per-GPU device work, and the host restores order
+by frame index -- the same partitioning bench.py uses with one MI355X per rank (no data-path
+collective; the only collectives are the barrier and the max-over-ranks of the wall time)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_main(rank, world, port, n_frames, out_dir):
+    for p in (REPO, os.path.join(REPO, "hdr-realtime-video-pipeline_amd")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hdrtv_mi355x import weights as W
+    from hdrtv_mi355x.worker import shard_frames
+    from oracle import hdrtvnet_oracle as O
+    O.set_threads(2)
+    hr = W.load_pack(os.path.join(REPO, "tests", "golden", "hr_weights.hdrw"))
+    mine = shard_frames(n_frames, rank, world)
+    dist.barrier()
+    for i in mine:
+        frame = W.synthetic_frame(64, 96, seed=100 + i, kind="noise")
+        np.save(os.path.join(out_dir, f"f{i}.npy"), O.process(hr, frame))
+    t = torch.tensor([float(len(mine))], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)            # every frame processed exactly once
+    assert int(t.item()) == n_frames
+    tm = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(tm, op=dist.ReduceOp.MAX)            # bench.py's max-over-ranks timing
+    assert tm.item() == float(world)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_round_robin_two_ranks(tmp_path):
+    from hdrtv_mi355x import weights as W
+    from hdrtv_mi355x.worker import shard_frames
+    from oracle import hdrtvnet_oracle as O
+    assert shard_frames(8, 0, 8) == [0] and shard_frames(5, 1, 2) == [1, 3] and shard_frames(3, 3, 4) == []
+    assert sorted(sum((shard_frames(11, r, 4) for r in range(4)), [])) == list(range(11))
+    n = 5
+    mp.spawn(_rank_main, args=(2, _free_port(), n, str(tmp_path)), nprocs=2, join=True)
+    hr = W.load_pack(os.path.join(REPO, "tests", "golden", "hr_weights.hdrw"))
+    for i in range(n):       # order restored by index; results identical to a single-rank run
+        want = O.process(hr, W.synthetic_frame(64, 96, seed=100 + i, kind="noise"))
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), f"f{i}.npy")), want)
