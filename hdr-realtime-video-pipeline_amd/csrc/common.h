@@ -57,6 +57,7 @@ struct ConvParams {
     f16 *dst_planar;       // ST_PLANAR3: f16 [3][Hd][Wd]
     const f16 *res_planar; // ST_PLANAR3: residual planes
     int tiles_x, tiles_y;
+    const f16 *zeros;      // >= 256 B of zeros (source of out-of-image halo pixels for LDS-DMA staging)
 };
 
 struct SftParams {

@@ -1,0 +1,257 @@
+// conv3x3_glds.hip -- the MFMA-bound 3x3 convolutions of the HG head (Cin >= 64, Cout >= 128):
+// implicit GEMM with LDS-DMA staging (global_load_lds_dwordx4) and a counted-vmcnt pipeline.
+//
+// Same GEMM view and LDS images as conv_igemm.hip (M = 128 output channels, N = pixels,
+// K = 64-channel chunk x tap, activation halo tile re-read for all 9 taps, XOR-swizzled
+// 16-byte chunks) with what the first profile asked for:
+//   * 16x16-pixel tile, 8 waves (2 per SIMD): the weight tile is shared by 256 pixels and the
+//     halo overhead drops from 41 % to 27 %;
+//   * staging never touches VGPRs: every wave issues 1-KiB global_load_lds pieces whose
+//     per-lane SOURCE address carries the swizzle (the LDS image stays lane-linear; rule 21 of
+//     the CDNA4 guide); out-of-image halo pixels read a zero page;
+//   * weight tiles live in a 3-slot ring and are issued two iterations ahead, the next
+//     chunk's halo tile three iterations ahead; the only wait in the loop is a counted
+//     s_waitcnt vmcnt(N) in front of ONE raw s_barrier per iteration (never vmcnt(0), never
+//     __syncthreads(): its fence would drain the LDS-DMA queue).
+#include "launchers.h"
+
+namespace {
+
+constexpr int TH = 16, TW = 16;
+constexpr int HW = TW + 2, NPIX = (TH + 2) * (TW + 2);   // 18, 324
+constexpr int CT = 64, PIXB = CT * 2;                    // 64-channel chunk = 128 B per pixel
+constexpr int A_PIECES_PER_WAVE = 6;                     // 48 KiB halo buffer (324 px + dummy tail)
+constexpr int A_BYTES = 8 * A_PIECES_PER_WAVE * 1024;
+constexpr int BN = 128;
+constexpr int B_BYTES = BN * PIXB;                       // 16 KiB = 16 pieces = 2 per wave
+constexpr int B_PIECES_PER_WAVE = 2;
+constexpr int SMEM = 2 * A_BYTES + 3 * B_BYTES;          // 144 KiB
+constexpr int OUT_ROWB = BN * 2 + 16;
+static_assert(TH * TW * OUT_ROWB <= SMEM, "epilogue tile must fit");
+
+__device__ __forceinline__ int swz64(int row) { return (row >> 1) & 7; }
+
+__device__ __forceinline__ void glds16(const void *g, void *lds)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(512) void conv3x3_glds_kernel(ConvParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *sA = smem;
+    char *sB = smem + 2 * A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const int nwg = gridDim.x;
+    int t;
+    {
+        const int b = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const int ntn = p.CoutPad / BN;
+    const int nt_i = t % ntn, sp = t / ntn;
+    const int ty = sp / p.tiles_x, tx = sp % p.tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * TW, n0 = nt_i * BN;
+    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+
+    const int nchunk = (p.c0 + p.c1) / CT, nchunk0 = p.c0 / CT;
+    const int nit = nchunk * 9;
+
+    // ---- LDS-DMA issue helpers (wave-uniform LDS base, per-lane swizzled source) ------------
+    const int l_row = lane >> 3, l_slot = lane & 7;
+    auto issue_A = [&](int cc, int buf) {
+        const f16 *src;
+        int cs, coff;
+        if (cc < nchunk0) { src = p.src0; cs = p.c0; coff = cc * CT; }
+        else { src = p.src1; cs = p.c1; coff = (cc - nchunk0) * CT; }
+#pragma unroll
+        for (int it = 0; it < A_PIECES_PER_WAVE; ++it) {
+            const int piece = wave + it * 8;
+            const int hp = piece * 8 + l_row;
+            const int hy = hp / HW, hx = hp - hy * HW;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            const bool ok = hp < NPIX && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+            const f16 *g = ok ? src + ((size_t)iy * p.Wi + ix) * cs + coff + ((l_slot ^ swz64(hp)) << 3)
+                              : p.zeros + (l_slot << 3);
+            glds16(g, sA + buf * A_BYTES + piece * 1024);
+        }
+    };
+    auto issue_B = [&](int it_i, int slot) {
+        const int cc = it_i / 9, tap = it_i - cc * 9;
+        const f16 *base = p.wpk + ((size_t)(tap * nchunk + cc) * p.CoutPad + n0) * CT;
+#pragma unroll
+        for (int k = 0; k < B_PIECES_PER_WAVE; ++k) {
+            const int piece = wave * B_PIECES_PER_WAVE + k;
+            const int n = piece * 8 + l_row;
+            glds16(base + (size_t)n * CT + ((l_slot ^ swz64(n)) << 3), sB + slot * B_BYTES + piece * 1024);
+        }
+    };
+
+    // ---- wave tiling: 2 (channels) x 4 (pixels) waves, each 64 ch x 64 px = 2x2 MFMA tiles ---
+    const int wc = wave & 1, wp = wave >> 1;
+    int hp_base[2], wrow[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = (wp * 2 + j) * 32 + l31;
+        hp_base[j] = (q / TW) * HW + (q % TW);
+        wrow[j] = (wc * 2 + j) * 32 + l31;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+
+    // ---- prologue: halo(0), weights(0), weights(1) -------------------------------------------
+    issue_A(0, 0);
+    issue_B(0, 0);
+    if (nit > 1) {
+        issue_B(1, 1);
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+
+    int it_i = 0;
+    for (int cc = 0; cc < nchunk; ++cc) {
+        const char *a = sA + (cc & 1) * A_BYTES;
+        const bool next_chunk = cc + 1 < nchunk;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap, ++it_i) {
+            const bool pf = it_i + 2 < nit;
+            if (pf) issue_B(it_i + 2, (it_i + 2) % 3);
+            if (tap == 6 && next_chunk) issue_A(cc + 1, (cc + 1) & 1);
+
+            const char *b = sB + (it_i % 3) * B_BYTES;
+            const int tap_off = (tap / 3) * HW + (tap % 3);
+#pragma unroll
+            for (int ks = 0; ks < CT / 16; ++ks) {
+                const int chunk = ks * 2 + lh;
+                f16x8 wf[2], xf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    wf[i] = *reinterpret_cast<const f16x8 *>(b + wrow[i] * PIXB + ((chunk ^ swz64(wrow[i])) << 4));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int hp = hp_base[j] + tap_off;
+                    xf[j] = *reinterpret_cast<const f16x8 *>(a + hp * PIXB + ((chunk ^ swz64(hp)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+            }
+            // The next iteration reads weights(it+1) (issued one iteration ago) and, at a chunk
+            // boundary, halo(cc+1) (issued at tap 6).  Allow exactly the younger DMAs in flight.
+            if (!pf) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else if ((tap == 6 || tap == 7) && next_chunk) {
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // halo pieces (6) + weights(it+2) (2)
+            } else {
+                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // weights(it+2) only
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogue (LDS staged)
+    char *so = smem;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const int cl = (wc * 2 + i) * 32 + 8 * qd + 4 * lh;
+            const float4 sc = *reinterpret_cast<const float4 *>(p.scale + n0 + cl);
+            const float4 sh = *reinterpret_cast<const float4 *>(p.shift + n0 + cl);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = (wp * 2 + j) * 32 + l31;
+                f16x4 o;
+                o[0] = (f16)act_apply(acc[i][j][4 * qd + 0] * sc.x + sh.x, p.act);
+                o[1] = (f16)act_apply(acc[i][j][4 * qd + 1] * sc.y + sh.y, p.act);
+                o[2] = (f16)act_apply(acc[i][j][4 * qd + 2] * sc.z + sh.z, p.act);
+                o[3] = (f16)act_apply(acc[i][j][4 * qd + 3] * sc.w + sh.w, p.act);
+                *reinterpret_cast<f16x4 *>(so + q * OUT_ROWB + cl * 2) = o;
+            }
+        }
+    }
+    __syncthreads();
+
+    constexpr int CPP = BN / 8;
+    if (p.mode == ST_NHWC) {
+        for (int e = tid; e < TH * TW * CPP; e += 512) {
+            const int q = e / CPP, c8 = e % CPP;
+            const int oy = oy0 + q / TW, ox = ox0 + q % TW;
+            const int ch = n0 + c8 * 8;
+            if (oy < p.Ho && ox < p.Wo && ch < p.Cout)
+                *reinterpret_cast<f16x8 *>(p.dst + ((size_t)oy * p.Wo + ox) * p.dstC + ch) =
+                    *reinterpret_cast<const f16x8 *>(so + q * OUT_ROWB + c8 * 16);
+        }
+    } else if (p.mode == ST_PS) {
+        const int cps = p.dstC;
+        for (int e = tid; e < TH * TW * CPP; e += 512) {
+            const int q = e / CPP, c8 = e % CPP;
+            const int oy = oy0 + q / TW, ox = ox0 + q % TW;
+            const int ch = n0 + c8 * 8;
+            if (oy < p.Ho && ox < p.Wo && ch < p.Cout) {
+                const int sub = ch / cps, c = ch % cps;
+                const int Y = 2 * oy + (sub >> 1), X = 2 * ox + (sub & 1);
+                if (Y < p.Hd && X < p.Wd)
+                    *reinterpret_cast<f16x8 *>(p.dst + ((size_t)Y * p.Wd + X) * cps + c) =
+                        *reinterpret_cast<const f16x8 *>(so + q * OUT_ROWB + c8 * 16);
+            }
+        }
+    } else {   // ST_POOL
+        for (int e = tid; e < (TH / 2) * (TW / 2) * CPP; e += 512) {
+            const int pq = e / CPP, c8 = e % CPP;
+            const int py = pq / (TW / 2), px = pq % (TW / 2);
+            const int oy = oy0 / 2 + py, ox = ox0 / 2 + px;
+            const int ch = n0 + c8 * 8;
+            if (oy < p.Hd && ox < p.Wd && ch < p.Cout) {
+                const int q00 = (2 * py) * TW + 2 * px;
+                f16x8 v = *reinterpret_cast<const f16x8 *>(so + q00 * OUT_ROWB + c8 * 16);
+                const f16x8 v1 = *reinterpret_cast<const f16x8 *>(so + (q00 + 1) * OUT_ROWB + c8 * 16);
+                const f16x8 v2 = *reinterpret_cast<const f16x8 *>(so + (q00 + TW) * OUT_ROWB + c8 * 16);
+                const f16x8 v3 = *reinterpret_cast<const f16x8 *>(so + (q00 + TW + 1) * OUT_ROWB + c8 * 16);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const f16 m = v[k] > v1[k] ? v[k] : v1[k];
+                    const f16 m2 = v2[k] > v3[k] ? v2[k] : v3[k];
+                    v[k] = m > m2 ? m : m2;
+                }
+                *reinterpret_cast<f16x8 *>(p.dst + ((size_t)oy * p.Wd + ox) * p.dstC + ch) = v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// 3x3, stride 1, Cin multiple of 64, CoutPad multiple of 128; store modes NHWC / PS / POOL without
+// residuals (what the HG head needs).  Returns hipErrorInvalidValue otherwise.
+hipError_t conv3x3_glds_launch(ConvParams p, hipStream_t stream)
+{
+    if ((p.c0 % CT) || (p.c1 % CT) || (p.CoutPad % BN) || p.res1 || p.res2 || p.dst_full || p.mode == ST_PLANAR3 || !p.zeros)
+        return hipErrorInvalidValue;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_glds_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    p.tiles_x = (p.Wo + TW - 1) / TW;
+    p.tiles_y = (p.Ho + TH - 1) / TH;
+    const int grid = p.tiles_x * p.tiles_y * (p.CoutPad / BN);
+    hipLaunchKernelGGL(conv3x3_glds_kernel, dim3(grid), dim3(512), SMEM, stream, p);
+    return hipGetLastError();
+}

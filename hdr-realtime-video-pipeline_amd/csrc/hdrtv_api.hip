@@ -129,6 +129,7 @@ struct hdrtv_ctx {
     std::map<std::string, C3Layer> c3;
     std::map<std::string, SftLayer> sft;
     std::map<std::string, size_t> f32v;   // raw fp32 vectors/matrices in the weight arena
+    size_t zeros_off = 0;                 // 256 B of zeros in the weight arena
     // workspace
     int H = 0, W = 0;
     Arena ws;
@@ -288,6 +289,10 @@ bool put_f32(hdrtv_ctx *c, const Pack &pk, const std::string &key, const std::st
 
 bool build_weights(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
 {
+    {
+        const std::vector<unsigned char> z(256, 0);
+        c->zeros_off = c->wts.put(z.data(), z.size());
+    }
     // ---- AGCM (fp32 on device: tiny)
     const int cls_ci[5] = {3, 16, 32, 64, 128}, cls_co[5] = {16, 32, 64, 128, 128}, cls_idx[5] = {0, 4, 8, 12, 16};
     char nm[160], key[64];
@@ -586,14 +591,19 @@ struct Seq {
         p.dst = dst; p.dst_full = dst_full; p.dstC = dstC; p.Hd = Hd; p.Wd = Wd;
         p.res1 = res1; p.res2 = res2; p.dst_planar = dst_planar; p.res_planar = res_planar;
         if (c0 + c1 != L.cin) { rc = fail(c, HDRTV_ESTATE, "conv %s: channel mismatch", key.c_str()); return; }
+        p.zeros = wtp<f16>(c, c->zeros_off);
+        const bool glds = L.ks == 3 && L.stride == 1 && L.cin_t == 64 && L.bn == 128 && !res1 && !res2 && !dst_full &&
+                          mode != ST_PLANAR3;
         char tag[64];
-        snprintf(tag, sizeof tag, "conv_igemm<%d,%d,%d,%d>", L.cin_t, L.bn, L.ks, L.stride);
+        if (glds) snprintf(tag, sizeof tag, "conv3x3_glds<64,128>");
+        else snprintf(tag, sizeof tag, "conv_igemm<%d,%d,%d,%d>", L.cin_t, L.bn, L.ks, L.stride);
         const double macs = (double)p.Ho * p.Wo * L.cin * L.ks * L.ks * L.cout;
         double bytes = 2.0 * Hi * Wi * L.cin + 2.0 * L.ks * L.ks * L.cin * L.coutPad;
         const double outel = mode == ST_POOL ? (double)Hd * Wd * L.cout + (dst_full ? (double)p.Ho * p.Wo * L.cout : 0.0)
                                               : (mode == ST_PLANAR3 ? 3.0 * Hd * Wd : (double)p.Ho * p.Wo * L.cout);
         bytes += 2.0 * outel * (1 + (res1 ? 1 : 0) + (res2 ? 1 : 0) + (res_planar ? 1 : 0));
-        chk(conv_igemm_launch(p, L.cin_t, L.bn, L.ks, L.stride, s), key.c_str(), tag, macs, bytes);
+        chk(glds ? conv3x3_glds_launch(p, s) : conv_igemm_launch(p, L.cin_t, L.bn, L.ks, L.stride, s), key.c_str(), tag, macs,
+            bytes);
     }
     void c3(const std::string &key, const f16 *in, int H, int W, int act, f16 *out, f16 *out_pool)
     {
