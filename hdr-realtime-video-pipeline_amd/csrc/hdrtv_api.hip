@@ -130,6 +130,7 @@ struct hdrtv_ctx {
     std::map<std::string, SftLayer> sft;
     std::map<std::string, size_t> f32v;   // raw fp32 vectors/matrices in the weight arena
     size_t zeros_off = 0;                 // 256 B of zeros in the weight arena
+    size_t trunk_wfrag = 0, trunk_bias = 0;   // fused LE condition trunk (le_fused.hip)
     // workspace
     int H = 0, W = 0;
     Arena ws;
@@ -279,6 +280,51 @@ bool pack_sft(hdrtv_ctx *c, const Pack &pk, const std::string &key, const std::s
     return true;
 }
 
+// Fused LE condition trunk: cond_first.{0,2,4} + CondNet1.{0,2,4} as 40 A fragments + 352 biases
+bool pack_cond_trunk(hdrtv_ctx *c, const Pack &pk)
+{
+    const char *names[6] = {"LE.cond_first.0", "LE.cond_first.2", "LE.cond_first.4", "LE.CondNet1.0", "LE.CondNet1.2", "LE.CondNet1.4"};
+    std::vector<f16> fr((size_t)40 * 64 * 8, (f16)0.f);
+    std::vector<float> bias(64 * 5 + 32, 0.f);
+    std::vector<float> w, b;
+    // layer 1: 3x3 from 3 channels, natural k = (ky*3+kx)*3 + c
+    if (!pk.get(std::string(names[0]) + ".weight", 64 * 27, w, c->err) || !pk.get(std::string(names[0]) + ".bias", 64, b, c->err))
+        return false;
+    for (int i = 0; i < 64; ++i) bias[i] = b[i];
+    for (int mt = 0; mt < 2; ++mt)
+        for (int ks = 0; ks < 2; ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int m = mt * 32 + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
+                    if (k < 27) fr[(((size_t)mt * 2 + ks) * 64 + lane) * 8 + j] = (f16)w[((size_t)m * 3 + k % 3) * 9 + k / 3];
+                }
+    // layers 2..5: 64x64 1x1, k permuted (operand is the previous accumulator)
+    for (int l = 2; l <= 5; ++l) {
+        if (!pk.get(std::string(names[l - 1]) + ".weight", 64 * 64, w, c->err) || !pk.get(std::string(names[l - 1]) + ".bias", 64, b, c->err))
+            return false;
+        for (int i = 0; i < 64; ++i) bias[64 * (l - 1) + i] = b[i];
+        for (int mt = 0; mt < 2; ++mt)
+            for (int sidx = 0; sidx < 4; ++sidx)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int m = mt * 32 + (lane & 31), k = 16 * sidx + acc_kperm16(8 * (lane >> 5) + j);
+                        fr[((size_t)(4 + (l - 2) * 8 + mt * 4 + sidx) * 64 + lane) * 8 + j] = (f16)w[(size_t)m * 64 + k];
+                    }
+    }
+    // layer 6: 16x64, rows 16..31 zero
+    if (!pk.get(std::string(names[5]) + ".weight", 16 * 64, w, c->err) || !pk.get(std::string(names[5]) + ".bias", 16, b, c->err)) return false;
+    for (int i = 0; i < 16; ++i) bias[320 + i] = b[i];
+    for (int sidx = 0; sidx < 4; ++sidx)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+                const int m = lane & 31, k = 16 * sidx + acc_kperm16(8 * (lane >> 5) + j);
+                if (m < 16) fr[((size_t)(36 + sidx) * 64 + lane) * 8 + j] = (f16)w[(size_t)m * 64 + k];
+            }
+    c->trunk_wfrag = c->wts.put(fr.data(), fr.size() * sizeof(f16));
+    c->trunk_bias = c->wts.put(bias.data(), bias.size() * 4);
+    return true;
+}
+
 bool put_f32(hdrtv_ctx *c, const Pack &pk, const std::string &key, const std::string &name, size_t numel)
 {
     std::vector<float> v;
@@ -330,12 +376,9 @@ bool build_weights(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
         return false;
 
     // ---- LE
-    if (!pack_c3(c, hr, "le.cond_first.0", "LE.cond_first.0", 64, "") || !pack_c3(c, hr, "le.conv_first", "LE.conv_first", 32, ""))
-        return false;
+    if (!pack_cond_trunk(c, hr) || !pack_c3(c, hr, "le.conv_first", "LE.conv_first", 32, "")) return false;
     struct Spec { const char *name; int co, ci, ks, stride, ps; };
     const Spec le_convs[] = {
-        {"LE.cond_first.2", 64, 64, 1, 1, 0}, {"LE.cond_first.4", 64, 64, 1, 1, 0},
-        {"LE.CondNet1.0", 64, 64, 1, 1, 0}, {"LE.CondNet1.2", 64, 64, 1, 1, 0}, {"LE.CondNet1.4", 16, 64, 1, 1, 0},
         {"LE.CondNet2.0", 64, 64, 3, 2, 0}, {"LE.CondNet2.2", 64, 64, 1, 1, 0}, {"LE.CondNet2.4", 16, 64, 1, 1, 0},
         {"LE.CondNet3.0", 64, 64, 3, 2, 0}, {"LE.CondNet3.2", 64, 64, 3, 2, 0}, {"LE.CondNet3.4", 16, 64, 1, 1, 0},
         {"LE.CondNet4.0", 64, 64, 3, 2, 0}, {"LE.CondNet4.2", 64, 64, 3, 2, 0}, {"LE.CondNet4.4", 16, 64, 3, 2, 0},
@@ -494,7 +537,7 @@ int do_reserve(hdrtv_ctx *c, int H, int W)
     ws_add(c, "agcm.bias", 168, 1, 1, 3);
     ws_add(c, "agcm.out", 3, H, W, 1);
     // LE
-    ws_add(c, "le.t64a", 64, H, W, 0); ws_add(c, "le.t64b", 64, H, W, 0); ws_add(c, "le.cond", 64, H, W, 0);
+    ws_add(c, "le.cond", 64, H, W, 0);
     ws_add(c, "le.cond1", 16, H, W, 0);
     ws_add(c, "le.h1a", 64, s.H1, s.W1, 0); ws_add(c, "le.h1b", 64, s.H1, s.W1, 0);
     ws_add(c, "le.h2a", 64, s.H2, s.W2, 0);
@@ -685,17 +728,15 @@ int run_le(hdrtv_ctx *c, Seq &q, const f16 *img, f16 *out_planar)
 {
     const Shapes s = shapes_for(c->H, c->W);
     const int H = s.H, W = s.W;
-    f16 *t64a = wsp<f16>(c, "le.t64a"), *t64b = wsp<f16>(c, "le.t64b"), *cond = wsp<f16>(c, "le.cond");
+    f16 *cond = wsp<f16>(c, "le.cond");
     f16 *cond1 = wsp<f16>(c, "le.cond1"), *cond2 = wsp<f16>(c, "le.cond2"), *cond3 = wsp<f16>(c, "le.cond3"),
         *cond4 = wsp<f16>(c, "le.cond4");
     f16 *h1a = wsp<f16>(c, "le.h1a"), *h1b = wsp<f16>(c, "le.h1b"), *h2a = wsp<f16>(c, "le.h2a");
     // condition trunk
-    q.c3("le.cond_first.0", img, H, W, ACT_LRELU01, t64a, nullptr);
-    q.conv("LE.cond_first.2", t64a, 64, nullptr, 0, H, W, ACT_LRELU01, ST_NHWC, t64b, 64, H, W);
-    q.conv("LE.cond_first.4", t64b, 64, nullptr, 0, H, W, ACT_LRELU01, ST_NHWC, cond, 64, H, W);
-    q.conv("LE.CondNet1.0", cond, 64, nullptr, 0, H, W, ACT_LRELU01, ST_NHWC, t64a, 64, H, W);
-    q.conv("LE.CondNet1.2", t64a, 64, nullptr, 0, H, W, ACT_LRELU01, ST_NHWC, t64b, 64, H, W);
-    q.conv("LE.CondNet1.4", t64b, 64, nullptr, 0, H, W, ACT_NONE, ST_NHWC, cond1, 16, H, W);
+    // cond_first (3 layers) + CondNet1 (3 layers) in one launch: img -> cond (64 ch) and cond1 (16 ch)
+    if (q.ok())
+        q.chk(le_cond_trunk_launch(img, H, W, wtp<f16>(c, c->trunk_wfrag), wtp<float>(c, c->trunk_bias), cond, cond1, q.s),
+              "LE.cond_trunk", "le_cond_trunk", (double)H * W * (27 * 64 + 4 * 64 * 64 + 64 * 16), (double)H * W * (6 + 128 + 32));
     q.conv("LE.CondNet2.0", cond, 64, nullptr, 0, H, W, ACT_LRELU01, ST_NHWC, h1a, 64, s.H1, s.W1);
     q.conv("LE.CondNet2.2", h1a, 64, nullptr, 0, s.H1, s.W1, ACT_LRELU01, ST_NHWC, h1b, 64, s.H1, s.W1);
     q.conv("LE.CondNet2.4", h1b, 64, nullptr, 0, s.H1, s.W1, ACT_NONE, ST_NHWC, cond2, 16, s.H1, s.W1);

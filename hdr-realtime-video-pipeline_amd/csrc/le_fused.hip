@@ -1,0 +1,191 @@
+// le_fused.hip -- LE condition trunk as ONE kernel (gfx950).
+//
+// Reference: HDRUNet3T1.cond_first (conv3x3 3->64, 1x1 64->64, 1x1 64->64, LeakyReLU(0.1) after
+// each) followed by CondNet1 (1x1 64->64, 1x1 64->64, LeakyReLU(0.1), 1x1 64->16),
+// HDRUNet3T1_arch.py:41-46, 160-161.  Unfused these six layers stream a 64-channel full-resolution
+// tensor (1.06 GB at 4K) through HBM eleven times; here the whole chain runs per pixel in
+// registers: each layer's 32x32 fp32 MFMA accumulator tile is activated, packed to f16 and used
+// directly as the next layer's B operand (weights K-permuted at pack time, common.h
+// acc_kperm16).  HBM traffic per pixel: 6 B in, 128 B (cond) + 32 B (cond1) out.
+#include "launchers.h"
+
+namespace {
+
+constexpr int T_TH = 8, T_TW = 32;                 // pixels per workgroup: 8 rows x 32 cols
+constexpr int T_HH = T_TH + 2, T_HW = T_TW + 2;
+constexpr int NFRAG = 40;                          // 4 (L1) + 4x8 (L2..L5) + 4 (L6)
+constexpr int NBIAS = 64 * 5 + 32;
+constexpr int STG_ROWB = 128 + 16;                 // per-wave output staging row (64 ch f16 + pad)
+
+__device__ __forceinline__ f32x16 bias_tile_l(const float *b, int lh)
+{
+    f32x16 a;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 v = *reinterpret_cast<const float4 *>(b + 8 * g + 4 * lh);
+        a[4 * g + 0] = v.x; a[4 * g + 1] = v.y; a[4 * g + 2] = v.z; a[4 * g + 3] = v.w;
+    }
+    return a;
+}
+
+// LeakyReLU(0.1) then f16 pack of accumulator registers 8s..8s+7 (= next layer's k-step fragment)
+__device__ __forceinline__ f16x8 lrelu_pack(const f32x16 &a, int s)
+{
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = a[8 * s + j];
+        o[j] = (f16)fmaxf(v, 0.1f * v);
+    }
+    return o;
+}
+
+__global__ __launch_bounds__(256, 2) void le_cond_trunk_kernel(const f16 *__restrict__ img, int H, int W,
+                                                               const f16 *__restrict__ wfrag, const float *__restrict__ bias,
+                                                               f16 *__restrict__ cond, f16 *__restrict__ cond1)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f16x8 *s_w = reinterpret_cast<f16x8 *>(smem);                               // [NFRAG][64]
+    float *s_b = reinterpret_cast<float *>(smem + NFRAG * 64 * 16);              // [NBIAS]
+    f16 *s_in = reinterpret_cast<f16 *>(smem + NFRAG * 64 * 16 + ((NBIAS * 4 + 15) / 16) * 16);   // [3][T_HH][T_HW+2]
+    char *s_stg = reinterpret_cast<char *>(s_in) + ((3 * T_HH * (T_HW + 2) * 2 + 15) / 16) * 16;  // [4 waves][32][STG_ROWB]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int ox0 = blockIdx.x * T_TW, oy0 = blockIdx.y * T_TH;
+
+    for (int e = tid; e < NFRAG * 64; e += 256) s_w[e] = reinterpret_cast<const f16x8 *>(wfrag)[e];
+    for (int e = tid; e < NBIAS; e += 256) s_b[e] = bias[e];
+    for (int e = tid; e < 3 * T_HH * T_HW; e += 256) {
+        const int c = e / (T_HH * T_HW), r = (e / T_HW) % T_HH, q = e % T_HW;
+        const int iy = oy0 - 1 + r, ix = ox0 - 1 + q;
+        s_in[(c * T_HH + r) * (T_HW + 2) + q] =
+            (iy >= 0 && iy < H && ix >= 0 && ix < W) ? img[((size_t)c * H + iy) * W + ix] : (f16)0.f;
+    }
+    __syncthreads();
+
+    // ---- layer 1: 3x3 conv as a K = 27 (padded 32) GEMM, im2col fragments gathered from LDS
+    f16x8 bf[2][4];   // activations of the two 32-pixel groups (rows 2*wave, 2*wave+1) as B fragments
+    {
+        f16x8 xf[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int base = (2 * wave + j) * (T_HW + 2) + l31;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = 16 * ks + 8 * lh + e;
+                    const int tap = k / 3, c = k % 3;
+                    const int off = (c * T_HH + tap / 3) * (T_HW + 2) + tap % 3;
+                    xf[j][ks][e] = k < 27 ? s_in[base + off] : (f16)0.f;
+                }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const f16x8 w0 = s_w[(mt * 2 + 0) * 64 + lane], w1 = s_w[(mt * 2 + 1) * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x16 h = bias_tile_l(s_b + 32 * mt, lh);
+                h = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, xf[j][0], h, 0, 0, 0);
+                h = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, xf[j][1], h, 0, 0, 0);
+                bf[j][2 * mt] = lrelu_pack(h, 0);
+                bf[j][2 * mt + 1] = lrelu_pack(h, 1);
+            }
+        }
+    }
+
+    char *stg = s_stg + wave * 32 * STG_ROWB;
+    // ---- layers 2..5: 64 -> 64, LeakyReLU(0.1); the output of layer 3 is `cond`
+#pragma unroll
+    for (int layer = 2; layer <= 5; ++layer) {
+        f16x8 nf[2][4];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f32x16 g[2];
+            g[0] = bias_tile_l(s_b + 64 * (layer - 1) + 32 * mt, lh);
+            g[1] = g[0];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const f16x8 w = s_w[(4 + (layer - 2) * 8 + mt * 4 + s) * 64 + lane];
+                g[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, bf[0][s], g[0], 0, 0, 0);
+                g[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, bf[1][s], g[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                nf[j][2 * mt] = lrelu_pack(g[j], 0);
+                nf[j][2 * mt + 1] = lrelu_pack(g[j], 1);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) bf[j][s] = nf[j][s];
+        if (layer == 3) {
+            // store cond (NHWC 64): fragment s holds channels 16s+4lh+{0..3} and 16s+8+4lh+{0..3}
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int oy = oy0 + 2 * wave + j;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    f16x4 lo, hi;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { lo[k] = bf[j][s][k]; hi[k] = bf[j][s][4 + k]; }
+                    *reinterpret_cast<f16x4 *>(stg + l31 * STG_ROWB + (16 * s + 4 * lh) * 2) = lo;
+                    *reinterpret_cast<f16x4 *>(stg + l31 * STG_ROWB + (16 * s + 8 + 4 * lh) * 2) = hi;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                if (oy < H) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int e = lane + 64 * it, px = e >> 3, c8 = e & 7;
+                        if (ox0 + px < W)
+                            *reinterpret_cast<f16x8 *>(cond + ((size_t)oy * W + ox0 + px) * 64 + c8 * 8) =
+                                *reinterpret_cast<const f16x8 *>(stg + px * STG_ROWB + c8 * 16);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+    }
+    // ---- layer 6: 64 -> 16 (rows 0..15 of one tile), no activation -> cond1 (NHWC 16)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        f32x16 o = bias_tile_l(s_b + 320, lh);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(36 + s) * 64 + lane], bf[j][s], o, 0, 0, 0);
+        // rows 0..15 live in registers 0..3 (rows 0-3 / 4-7 by lane half) and 4..7 (rows 8-11 / 12-15)
+        f16x4 lo, hi;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { lo[k] = (f16)o[k]; hi[k] = (f16)o[4 + k]; }
+        *reinterpret_cast<f16x4 *>(stg + l31 * STG_ROWB + (4 * lh) * 2) = lo;
+        *reinterpret_cast<f16x4 *>(stg + l31 * STG_ROWB + (8 + 4 * lh) * 2) = hi;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        const int oy = oy0 + 2 * wave + j;
+        const int px = lane >> 1, c8 = lane & 1;
+        if (oy < H && ox0 + px < W)
+            *reinterpret_cast<f16x8 *>(cond1 + ((size_t)oy * W + ox0 + px) * 16 + c8 * 8) =
+                *reinterpret_cast<const f16x8 *>(stg + px * STG_ROWB + c8 * 16);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+constexpr int TRUNK_SMEM = NFRAG * 64 * 16 + ((NBIAS * 4 + 15) / 16) * 16 + ((3 * T_HH * (T_HW + 2) * 2 + 15) / 16) * 16 +
+                           4 * 32 * STG_ROWB;
+
+}  // namespace
+
+hipError_t le_cond_trunk_launch(const f16 *img, int H, int W, const f16 *wfrag, const float *bias, f16 *cond, f16 *cond1,
+                                hipStream_t s)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(le_cond_trunk_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, TRUNK_SMEM);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid((W + T_TW - 1) / T_TW, (H + T_TH - 1) / T_TH);
+    hipLaunchKernelGGL(le_cond_trunk_kernel, grid, dim3(256), TRUNK_SMEM, s, img, H, W, wfrag, bias, cond, cond1);
+    return hipGetLastError();
+}
