@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void cls_block_kernel(const void *__restrict__
                                                         const float *__restrict__ nmean, const float *__restrict__ nrstd,
                                                         const float *__restrict__ ngamma, const float *__restrict__ nbeta,
                                                         const float *__restrict__ Wt, const float *__restrict__ bias, int Co,
-                                                        float *__restrict__ out, int Ho, int Wo)
+                                                        float *__restrict__ out, int Ho, int Wo, float2 *__restrict__ part)
 {
     __shared__ float s_sum[128][17];
     __shared__ float s_cnt[16];
@@ -64,14 +64,22 @@ __global__ __launch_bounds__(256) void cls_block_kernel(const void *__restrict__
     __syncthreads();
     const int px = threadIdx.x & 15, cg = threadIdx.x >> 4;
     const int p = p0 + px;
-    if (p >= npix) return;
+    const bool ok = p < npix;
     for (int co = cg; co < Co; co += 16) {
         const float *w = Wt + (size_t)co * Ci;
         float acc = 0.f;
         for (int ci = 0; ci < Ci; ++ci) acc += w[ci] * s_sum[ci][px];
         float v = (acc + bias[co] * s_cnt[px]) / 9.f;
         v = v >= 0.f ? v : v * 0.2f;
-        out[(size_t)co * npix + p] = v;
+        if (ok) out[(size_t)co * npix + p] = v;
+        // per-block partial sums for the InstanceNorm statistics (fixed order: deterministic)
+        float s1 = ok ? v : 0.f, s2 = ok ? v * v : 0.f;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            s1 += __shfl_xor(s1, o);
+            s2 += __shfl_xor(s2, o);
+        }
+        if (px == 0) part[(size_t)co * gridDim.x + blockIdx.x] = make_float2(s1, s2);
     }
 }
 
@@ -86,23 +94,37 @@ __device__ __forceinline__ float block_sum(float v, float *scratch)
     return scratch[0] + scratch[1] + scratch[2] + scratch[3];
 }
 
-__global__ __launch_bounds__(256) void cls_stats_kernel(const float *__restrict__ x, int n, float eps,
+__device__ __forceinline__ double block_sum_d(double v, double *scratch)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[w] = v;
+    __syncthreads();
+    return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+}
+
+// one workgroup per channel: combine the per-block (sum, sum of squares) partials in fp64
+__global__ __launch_bounds__(256) void cls_stats_kernel(const float2 *__restrict__ part, int nblk, int n, float eps,
                                                         float *__restrict__ mean, float *__restrict__ rstd)
 {
-    __shared__ float scratch[4];
-    const float *p = x + (size_t)blockIdx.x * n;
-    float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) s += p[i];
-    const float m = block_sum(s, scratch) / (float)n;
-    float v = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const float d = p[i] - m;
-        v += d * d;
+    __shared__ double scratch[4];
+    const float2 *p = part + (size_t)blockIdx.x * nblk;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) {
+        const float2 v = p[i];
+        s1 += (double)v.x;
+        s2 += (double)v.y;
     }
-    const float var = block_sum(v, scratch) / (float)n;
+    s1 = block_sum_d(s1, scratch);
+    s2 = block_sum_d(s2, scratch);
     if (threadIdx.x == 0) {
-        mean[blockIdx.x] = m;
-        rstd[blockIdx.x] = 1.f / sqrtf(var + eps);
+        const double m = s1 / n;
+        double var = s2 / n - m * m;
+        if (var < 0.0) var = 0.0;
+        mean[blockIdx.x] = (float)m;
+        rstd[blockIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
     }
 }
 
@@ -252,21 +274,22 @@ __global__ __launch_bounds__(256) void agcm_mlp_kernel(const f16 *__restrict__ i
 
 hipError_t cls_block_launch(const void *in, int in_f16, int Ci, int Hi, int Wi, const float *nmean, const float *nrstd,
                             const float *ngamma, const float *nbeta, const float *Wt, const float *bias, int Co, float *out,
-                            int Ho, int Wo, hipStream_t s)
+                            int Ho, int Wo, float *part, hipStream_t s)
 {
     const int grid = (Ho * Wo + 15) / 16;
     if (in_f16)
         hipLaunchKernelGGL(cls_block_kernel<true>, dim3(grid), dim3(256), 0, s, in, Ci, Hi, Wi, nmean, nrstd, ngamma, nbeta, Wt,
-                           bias, Co, out, Ho, Wo);
+                           bias, Co, out, Ho, Wo, reinterpret_cast<float2 *>(part));
     else
         hipLaunchKernelGGL(cls_block_kernel<false>, dim3(grid), dim3(256), 0, s, in, Ci, Hi, Wi, nmean, nrstd, ngamma, nbeta,
-                           Wt, bias, Co, out, Ho, Wo);
+                           Wt, bias, Co, out, Ho, Wo, reinterpret_cast<float2 *>(part));
     return hipGetLastError();
 }
 
-hipError_t cls_stats_launch(const float *x, int C, int n, float eps, float *mean, float *rstd, hipStream_t s)
+hipError_t cls_stats_launch(const float *part, int C, int nblk, int n, float eps, float *mean, float *rstd, hipStream_t s)
 {
-    hipLaunchKernelGGL(cls_stats_kernel, dim3(C), dim3(256), 0, s, x, n, eps, mean, rstd);
+    hipLaunchKernelGGL(cls_stats_kernel, dim3(C), dim3(256), 0, s, reinterpret_cast<const float2 *>(part), nblk, n, eps, mean,
+                       rstd);
     return hipGetLastError();
 }
 

@@ -15,7 +15,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // Epilogue activation codes
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU01 = 2 };
 // Conv store modes
-enum { ST_NHWC = 0, ST_PS = 1, ST_POOL = 2, ST_PLANAR3 = 3 };
+enum { ST_NHWC = 0, ST_PS = 1, ST_POOL = 2, ST_PLANAR3 = 3, ST_PS_DOT3 = 4 };
 
 __device__ __forceinline__ float act_apply(float v, int act)
 {
@@ -58,6 +58,8 @@ struct ConvParams {
     const f16 *res_planar; // ST_PLANAR3: residual planes
     int tiles_x, tiles_y;
     const f16 *zeros;      // >= 256 B of zeros (source of out-of-image halo pixels for LDS-DMA staging)
+    const float *dotw;     // ST_PS_DOT3: [3][dstC] weights of the 1x1 conv fused behind the pixel shuffle
+    float *dst_dot;        // ST_PS_DOT3: f32 [Hd][Wd][4] partial sums (x,y,z used)
 };
 
 struct SftParams {

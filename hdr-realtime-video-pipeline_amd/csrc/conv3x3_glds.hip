@@ -27,7 +27,7 @@ constexpr int B_BYTES = BN * PIXB;                       // 16 KiB = 16 pieces =
 constexpr int B_PIECES_PER_WAVE = 2;
 constexpr int SMEM = 2 * A_BYTES + 3 * B_BYTES;          // 144 KiB
 constexpr int OUT_ROWB = BN * 2 + 16;
-static_assert(TH * TW * OUT_ROWB <= SMEM, "epilogue tile must fit");
+static_assert(TH * TW * OUT_ROWB + 3 * 64 * 4 <= SMEM, "epilogue tile must fit");
 
 __device__ __forceinline__ int swz64(int row) { return (row >> 1) & 7; }
 
@@ -210,6 +210,36 @@ __global__ __launch_bounds__(512) void conv3x3_glds_kernel(ConvParams p)
                         *reinterpret_cast<const f16x8 *>(so + q * OUT_ROWB + c8 * 16);
             }
         }
+    } else if (p.mode == ST_PS_DOT3) {
+        // Pixel shuffle followed by a 1x1 conv to 3 channels (HG Up_conv5 -> conv10, first half of
+        // the concat): the 64 shuffled channels of an output pixel are one 128-byte run of the
+        // LDS row, so the dot products are taken here and only 3 partial sums per pixel leave the CU.
+        float *s_w = reinterpret_cast<float *>(smem + TH * TW * OUT_ROWB);
+        for (int e = tid; e < 3 * 64; e += 512) s_w[e] = p.dotw[e];
+        __syncthreads();
+        for (int e = tid; e < TH * TW * 2; e += 512) {
+            const int q = e >> 1, s2 = e & 1;
+            const int oy = oy0 + q / TW, ox = ox0 + q % TW;
+            if (oy < p.Ho && ox < p.Wo) {
+                const char *row = so + q * OUT_ROWB + s2 * 128;
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int c8 = 0; c8 < 8; ++c8) {
+                    const f16x8 v = *reinterpret_cast<const f16x8 *>(row + c8 * 16);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float x = (float)v[k];
+                        a0 += s_w[c8 * 8 + k] * x;
+                        a1 += s_w[64 + c8 * 8 + k] * x;
+                        a2 += s_w[128 + c8 * 8 + k] * x;
+                    }
+                }
+                const int sub = n0 / 64 + s2;
+                const int Y = 2 * oy + (sub >> 1), X = 2 * ox + (sub & 1);
+                if (Y < p.Hd && X < p.Wd)
+                    *reinterpret_cast<float4 *>(p.dst_dot + ((size_t)Y * p.Wd + X) * 4) = make_float4(a0, a1, a2, 0.f);
+            }
+        }
     } else {   // ST_POOL
         for (int e = tid; e < (TH / 2) * (TW / 2) * CPP; e += 512) {
             const int pq = e / CPP, c8 = e % CPP;
@@ -240,7 +270,8 @@ __global__ __launch_bounds__(512) void conv3x3_glds_kernel(ConvParams p)
 // residuals (what the HG head needs).  Returns hipErrorInvalidValue otherwise.
 hipError_t conv3x3_glds_launch(ConvParams p, hipStream_t stream)
 {
-    if ((p.c0 % CT) || (p.c1 % CT) || (p.CoutPad % BN) || p.res1 || p.res2 || p.dst_full || p.mode == ST_PLANAR3 || !p.zeros)
+    if ((p.c0 % CT) || (p.c1 % CT) || (p.CoutPad % BN) || p.res1 || p.res2 || p.dst_full || p.mode == ST_PLANAR3 || !p.zeros ||
+        (p.mode == ST_PS_DOT3 && (p.dstC != 64 || !p.dotw || !p.dst_dot)))
         return hipErrorInvalidValue;
     static bool attr_set = false;
     if (!attr_set) {

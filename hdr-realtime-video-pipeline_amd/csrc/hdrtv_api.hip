@@ -131,6 +131,7 @@ struct hdrtv_ctx {
     std::map<std::string, size_t> f32v;   // raw fp32 vectors/matrices in the weight arena
     size_t zeros_off = 0;                 // 256 B of zeros in the weight arena
     size_t trunk_wfrag = 0, trunk_bias = 0;   // fused LE condition trunk (le_fused.hip)
+    size_t hgf_wfrag = 0, hg_w10a = 0;        // fused HG tail: conv1 + conv10(second half) fragments, conv10 first half
     // workspace
     int H = 0, W = 0;
     Arena ws;
@@ -422,6 +423,27 @@ bool build_weights(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
         if (!put_f32(c, *hg, "hg.w10", "conv10.weight", 3 * 128) || !put_f32(c, *hg, "hg.b10", "conv10.bias", 3) ||
             !put_f32(c, *hg, "hg.wl", "conv_last.weight", 18) || !put_f32(c, *hg, "hg.bl", "conv_last.bias", 3))
             return false;
+        {   // fused tail: conv10 = [first 64 inputs: Up_conv5 | last 64 inputs: conv1_out]
+            std::vector<float> w10, w1;
+            if (!hg->get("conv10.weight", 3 * 128, w10, c->err) || !hg->get("conv1.0.weight", 64 * 27, w1, c->err)) return false;
+            std::vector<float> w10a(3 * 64);
+            for (int o = 0; o < 3; ++o)
+                for (int k = 0; k < 64; ++k) w10a[o * 64 + k] = w10[o * 128 + k];
+            c->hg_w10a = c->wts.put(w10a.data(), w10a.size() * 4);
+            std::vector<f16> fr((size_t)8 * 64 * 8, (f16)0.f);
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int r = lane & 31, pslot = 8 * (lane >> 5) + j;
+                    for (int i = 0; i < 2; ++i)
+                        for (int ks = 0; ks < 2; ++ks) {
+                            const int k = 16 * ks + pslot;
+                            if (k < 27) fr[(((size_t)i * 2 + ks) * 64 + lane) * 8 + j] = (f16)w1[((size_t)(i * 32 + r) * 3 + k % 3) * 9 + k / 3];
+                        }
+                    for (int sidx = 0; sidx < 4; ++sidx)
+                        if (r < 3) fr[((size_t)(4 + sidx) * 64 + lane) * 8 + j] = (f16)w10[r * 128 + 64 + 16 * sidx + acc_kperm16(pslot)];
+                }
+            c->hgf_wfrag = c->wts.put(fr.data(), fr.size() * sizeof(f16));
+        }
     }
     return true;
 }
@@ -533,6 +555,7 @@ int do_reserve(hdrtv_ctx *c, int H, int W)
         snprintf(nm, sizeof nm, "agcm.rstd%d", i + 1);
         ws_add(c, nm, cls_co[i], 1, 1, 3);
     }
+    ws_add(c, "agcm.part", 2 * 128 * ((s.ch[1] * s.cw[1] + 15) / 16), 1, 1, 3);   // per-block (sum, sumsq) partials
     ws_add(c, "agcm.frags", 14 * 64 * 8 / 2, 1, 1, 3);   // f16 elements stored in an f32-sized slot
     ws_add(c, "agcm.bias", 168, 1, 1, 3);
     ws_add(c, "agcm.out", 3, H, W, 1);
@@ -557,7 +580,7 @@ int do_reserve(hdrtv_ctx *c, int H, int W)
     if (c->has_hg) {
         const int Hp = s.Hp, Wp = s.Wp;
         ws_add(c, "hg.img", 3, Hp, Wp, 1); ws_add(c, "hg.mask", 1, Hp, Wp, 4);
-        ws_add(c, "hg.conv1", 64, Hp, Wp, 0); ws_add(c, "hg.p1", 64, Hp / 2, Wp / 2, 0);
+        ws_add(c, "hg.p1", 64, Hp / 2, Wp / 2, 0); ws_add(c, "hg.part", 4, Hp, Wp, 3);
         ws_add(c, "hg.conv2", 128, Hp / 2, Wp / 2, 0);
         ws_add(c, "hg.p3", 256, Hp / 4, Wp / 4, 0); ws_add(c, "hg.conv3_2", 256, Hp / 4, Wp / 4, 0);
         ws_add(c, "hg.p4", 512, Hp / 8, Wp / 8, 0); ws_add(c, "hg.conv4_2", 512, Hp / 8, Wp / 8, 0);
@@ -567,7 +590,6 @@ int do_reserve(hdrtv_ctx *c, int H, int W)
         ws_add(c, "hg.up2", 512, Hp / 8, Wp / 8, 0); ws_add(c, "hg.conv7", 256, Hp / 8, Wp / 8, 0);
         ws_add(c, "hg.up3", 256, Hp / 4, Wp / 4, 0); ws_add(c, "hg.conv8", 128, Hp / 4, Wp / 4, 0);
         ws_add(c, "hg.up4", 128, Hp / 2, Wp / 2, 0); ws_add(c, "hg.conv9", 64, Hp / 2, Wp / 2, 0);
-        ws_add(c, "hg.up5", 64, Hp, Wp, 0);
     }
     if (hipMalloc((void **)&c->ws.dev, c->ws.size + 4096) != hipSuccess) {
         c->ws.dev = nullptr;
@@ -616,7 +638,7 @@ struct Seq {
     // generic conv: src0 (+src1) -> dst
     void conv(const std::string &key, const f16 *src0, int c0, const f16 *src1, int c1, int Hi, int Wi, int act, int mode,
               f16 *dst, int dstC, int Hd, int Wd, const f16 *res1 = nullptr, const f16 *res2 = nullptr, f16 *dst_full = nullptr,
-              f16 *dst_planar = nullptr, const f16 *res_planar = nullptr)
+              f16 *dst_planar = nullptr, const f16 *res_planar = nullptr, const float *dotw = nullptr, float *dst_dot = nullptr)
     {
         if (!ok()) return;
         auto it = c->conv.find(key);
@@ -633,6 +655,7 @@ struct Seq {
         p.CoutPad = L.coutPad; p.Cout = L.cout; p.act = act; p.mode = mode;
         p.dst = dst; p.dst_full = dst_full; p.dstC = dstC; p.Hd = Hd; p.Wd = Wd;
         p.res1 = res1; p.res2 = res2; p.dst_planar = dst_planar; p.res_planar = res_planar;
+        p.dotw = dotw; p.dst_dot = dst_dot;
         if (c0 + c1 != L.cin) { rc = fail(c, HDRTV_ESTATE, "conv %s: channel mismatch", key.c_str()); return; }
         p.zeros = wtp<f16>(c, c->zeros_off);
         const bool glds = L.ks == 3 && L.stride == 1 && L.cin_t == 64 && L.bn == 128 && !res1 && !res2 && !dst_full &&
@@ -643,7 +666,8 @@ struct Seq {
         const double macs = (double)p.Ho * p.Wo * L.cin * L.ks * L.ks * L.cout;
         double bytes = 2.0 * Hi * Wi * L.cin + 2.0 * L.ks * L.ks * L.cin * L.coutPad;
         const double outel = mode == ST_POOL ? (double)Hd * Wd * L.cout + (dst_full ? (double)p.Ho * p.Wo * L.cout : 0.0)
-                                              : (mode == ST_PLANAR3 ? 3.0 * Hd * Wd : (double)p.Ho * p.Wo * L.cout);
+                                              : (mode == ST_PLANAR3 ? 3.0 * Hd * Wd
+                                                                    : (mode == ST_PS_DOT3 ? 8.0 * Hd * Wd : (double)p.Ho * p.Wo * L.cout));
         bytes += 2.0 * outel * (1 + (res1 ? 1 : 0) + (res2 ? 1 : 0) + (res_planar ? 1 : 0));
         chk(glds ? conv3x3_glds_launch(p, s) : conv_igemm_launch(p, L.cin_t, L.bn, L.ks, L.stride, s), key.c_str(), tag, macs,
             bytes);
@@ -697,11 +721,13 @@ int run_agcm(hdrtv_ctx *c, Seq &q, const f16 *rgb, const f16 *cond, f16 *agcm_ou
         const float *w = wtp<float>(c, c->f32v.at(b));
         snprintf(b, sizeof b, "cls%d.b", i);
         const float *bias = wtp<float>(c, c->f32v.at(b));
+        const int nblk = (s.ch[i + 1] * s.cw[i + 1] + 15) / 16;
         q.chk(cls_block_launch(in, i == 0, cls_ci[i], s.ch[i], s.cw[i], nm, nr, ng, nb, w, bias, cls_co[i], out, s.ch[i + 1],
-                               s.cw[i + 1], q.s), "cls_block", "cls_block", (double)s.ch[i] * s.cw[i] * cls_ci[i] * cls_co[i]);
+                               s.cw[i + 1], wsp<float>(c, "agcm.part"), q.s), "cls_block", "cls_block", (double)s.ch[i] * s.cw[i] * cls_ci[i] * cls_co[i]);
         snprintf(a, sizeof a, "agcm.mean%d", i + 1);
         snprintf(b, sizeof b, "agcm.rstd%d", i + 1);
-        q.chk(cls_stats_launch(out, cls_co[i], s.ch[i + 1] * s.cw[i + 1], 1e-5f, wsp<float>(c, a), wsp<float>(c, b), q.s),
+        q.chk(cls_stats_launch(wsp<float>(c, "agcm.part"), cls_co[i], nblk, s.ch[i + 1] * s.cw[i + 1], 1e-5f, wsp<float>(c, a),
+                               wsp<float>(c, b), q.s),
               "cls_stats", "cls_stats");
     }
     AgcmFoldArgs fa;
@@ -787,10 +813,10 @@ int run_hg(hdrtv_ctx *c, Seq &q, const f16 *base, void *out, int out_f32)
     f16 *img = wsp<f16>(c, "hg.img");
     uint8_t *mask = wsp<uint8_t>(c, "hg.mask");
     q.chk(hg_prep_launch(base, s.H, s.W, Hp, Wp, img, mask, 0.75f, 0.1f, q.s), "hg_prep", "hg_prep", 0.0, 13.0 * Hp * Wp);
-    f16 *c1 = wsp<f16>(c, "hg.conv1"), *p1 = wsp<f16>(c, "hg.p1"), *c2 = wsp<f16>(c, "hg.conv2"), *p3 = wsp<f16>(c, "hg.p3"),
+    f16 *p1 = wsp<f16>(c, "hg.p1"), *c2 = wsp<f16>(c, "hg.conv2"), *p3 = wsp<f16>(c, "hg.p3"),
         *c3 = wsp<f16>(c, "hg.conv3_2"), *p4 = wsp<f16>(c, "hg.p4"), *c4 = wsp<f16>(c, "hg.conv4_2"), *p5 = wsp<f16>(c, "hg.p5"),
         *c5 = wsp<f16>(c, "hg.conv5_2"), *pc = wsp<f16>(c, "hg.pc"), *code = wsp<f16>(c, "hg.conv_code2");
-    q.c3("hg.conv1", img, Hp, Wp, ACT_RELU, c1, p1);
+    q.c3("hg.conv1", img, Hp, Wp, ACT_RELU, nullptr, p1);      // only the pooled map is kept; conv1_out is recomputed in hg_final_fused
     q.conv("hg.conv2", p1, 64, nullptr, 0, Hp / 2, Wp / 2, ACT_RELU, ST_NHWC, c2, 128, Hp / 2, Wp / 2);
     q.conv("hg.conv3_1", c2, 128, nullptr, 0, Hp / 2, Wp / 2, ACT_RELU, ST_POOL, p3, 256, Hp / 4, Wp / 4);
     q.conv("hg.conv3_2", p3, 256, nullptr, 0, Hp / 4, Wp / 4, ACT_RELU, ST_NHWC, c3, 256, Hp / 4, Wp / 4);
@@ -801,8 +827,8 @@ int run_hg(hdrtv_ctx *c, Seq &q, const f16 *base, void *out, int out_f32)
     q.conv("hg.conv_code1", c5, 512, nullptr, 0, Hp / 16, Wp / 16, ACT_RELU, ST_POOL, pc, 512, Hp / 32, Wp / 32);
     q.conv("hg.conv_code2", pc, 512, nullptr, 0, Hp / 32, Wp / 32, ACT_RELU, ST_NHWC, code, 512, Hp / 32, Wp / 32);
     f16 *u1 = wsp<f16>(c, "hg.up1"), *c6 = wsp<f16>(c, "hg.conv6"), *u2 = wsp<f16>(c, "hg.up2"), *c7 = wsp<f16>(c, "hg.conv7"),
-        *u3 = wsp<f16>(c, "hg.up3"), *c8 = wsp<f16>(c, "hg.conv8"), *u4 = wsp<f16>(c, "hg.up4"), *c9 = wsp<f16>(c, "hg.conv9"),
-        *u5 = wsp<f16>(c, "hg.up5");
+        *u3 = wsp<f16>(c, "hg.up3"), *c8 = wsp<f16>(c, "hg.conv8"), *u4 = wsp<f16>(c, "hg.up4"), *c9 = wsp<f16>(c, "hg.conv9");
+    float *part = wsp<float>(c, "hg.part");
     q.conv("hg.Up_conv1", code, 512, nullptr, 0, Hp / 32, Wp / 32, ACT_RELU, ST_PS, u1, 512, Hp / 16, Wp / 16);
     q.conv("hg.conv6", u1, 512, c5, 512, Hp / 16, Wp / 16, ACT_NONE, ST_NHWC, c6, 512, Hp / 16, Wp / 16);
     q.conv("hg.Up_conv2", c6, 512, nullptr, 0, Hp / 16, Wp / 16, ACT_RELU, ST_PS, u2, 512, Hp / 8, Wp / 8);
@@ -811,15 +837,19 @@ int run_hg(hdrtv_ctx *c, Seq &q, const f16 *base, void *out, int out_f32)
     q.conv("hg.conv8", u3, 256, c3, 256, Hp / 4, Wp / 4, ACT_NONE, ST_NHWC, c8, 128, Hp / 4, Wp / 4);
     q.conv("hg.Up_conv4", c8, 128, nullptr, 0, Hp / 4, Wp / 4, ACT_RELU, ST_PS, u4, 128, Hp / 2, Wp / 2);
     q.conv("hg.conv9", u4, 128, c2, 128, Hp / 2, Wp / 2, ACT_NONE, ST_NHWC, c9, 64, Hp / 2, Wp / 2);
-    q.conv("hg.Up_conv5", c9, 64, nullptr, 0, Hp / 2, Wp / 2, ACT_RELU, ST_PS, u5, 64, Hp, Wp);
+    // Up_conv5 -> pixel shuffle -> ReLU -> first half of conv10, fused: 3 partial sums per pixel leave the kernel
+    q.conv("hg.Up_conv5", c9, 64, nullptr, 0, Hp / 2, Wp / 2, ACT_RELU, ST_PS_DOT3, nullptr, 64, Hp, Wp, nullptr, nullptr, nullptr,
+           nullptr, nullptr, wtp<float>(c, c->hg_w10a), part);
     if (!q.ok()) return q.rc;
-    HgFinalArgs fa;
-    fa.up5 = u5; fa.c1 = c1; fa.img = img; fa.mask = mask;
-    fa.w10 = wtp<float>(c, c->f32v.at("hg.w10")); fa.b10 = wtp<float>(c, c->f32v.at("hg.b10"));
+    const C3Layer &L1 = c->c3.at("hg.conv1");
+    HgFinalFusedArgs fa;
+    fa.img = img; fa.mask = mask; fa.part = part; fa.wfrag = wtp<f16>(c, c->hgf_wfrag);
+    fa.scale = wtp<float>(c, L1.scale); fa.shift = wtp<float>(c, L1.shift);
+    fa.b10 = wtp<float>(c, c->f32v.at("hg.b10"));
     fa.wl = wtp<float>(c, c->f32v.at("hg.wl")); fa.bl = wtp<float>(c, c->f32v.at("hg.bl"));
     fa.out = out; fa.out_f32 = out_f32; fa.H = s.H; fa.W = s.W; fa.Hp = Hp; fa.Wp = Wp;
-    q.chk(hg_final_launch(fa, q.s), "hg_final", "hg_final", (double)Hp * Wp * (128 * 3 + 6 * 3),
-          (double)Hp * Wp * (256 + 7) + (double)s.H * s.W * 3 * (out_f32 ? 4 : 2));
+    q.chk(hg_final_fused_launch(fa, q.s), "hg_final", "hg_final_fused", (double)Hp * Wp * (128 * 3 + 6 * 3),
+          (double)s.H * s.W * (6 + 1 + 16 + 3 * (out_f32 ? 4 : 2)));
     return q.rc;
 }
 

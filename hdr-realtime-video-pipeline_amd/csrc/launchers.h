@@ -13,8 +13,8 @@ hipError_t post_rgb48_launch(const void *in, int is_f32, int H, int W, uint16_t 
 
 hipError_t cls_block_launch(const void *in, int in_f16, int Ci, int Hi, int Wi, const float *nmean, const float *nrstd,
                             const float *ngamma, const float *nbeta, const float *Wt, const float *bias, int Co, float *out,
-                            int Ho, int Wo, hipStream_t s);
-hipError_t cls_stats_launch(const float *x, int C, int n, float eps, float *mean, float *rstd, hipStream_t s);
+                            int Ho, int Wo, float *part, hipStream_t s);
+hipError_t cls_stats_launch(const float *part, int C, int nblk, int n, float eps, float *mean, float *rstd, hipStream_t s);
 struct AgcmFoldArgs {
     const float *mean5;
     const float *w20, *b20;
@@ -39,4 +39,14 @@ struct HgFinalArgs {
     int out_f32, H, W, Hp, Wp;
 };
 hipError_t hg_final_launch(const HgFinalArgs &a, hipStream_t s);
+struct HgFinalFusedArgs {
+    const f16 *img;
+    const uint8_t *mask;
+    const float *part;
+    const f16 *wfrag;
+    const float *scale, *shift, *b10, *wl, *bl;
+    void *out;
+    int out_f32, H, W, Hp, Wp;
+};
+hipError_t hg_final_fused_launch(const HgFinalFusedArgs &a, hipStream_t s);
 hipError_t maxpool2_launch(const f16 *in, int H, int W, int C, f16 *out, hipStream_t s);

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void conv_c3_kernel(const f16 *__restrict__ in
     for (int e = tid; e < C3_TH * C3_TW * CPP; e += 256) {
         const int q = e / CPP, c8 = e % CPP;
         const int oy = oy0 + q / C3_TW, ox = ox0 + q % C3_TW;
-        if (oy < H && ox < W)
+        if (out && oy < H && ox < W)
             *reinterpret_cast<f16x8 *>(out + ((size_t)oy * W + ox) * COUT + c8 * 8) =
                 *reinterpret_cast<const f16x8 *>(s_out + q * ROWB + c8 * 16);
     }
@@ -271,6 +271,102 @@ __global__ __launch_bounds__(256) void hg_final_kernel(HgFinalParams p)
     }
 }
 
+// ============================================================================ hg_final_fused
+// Same result as hg_final without ever materialising conv1_out or Up_conv5's output: conv1
+// (3x3, 3->64, BN, ReLU) is recomputed from the padded image exactly as conv_c3 computes it,
+// chained into the second half of conv10 (64->3) through the accumulator-as-operand trick, and
+// added to the first half's partial sums that conv3x3_glds' ST_PS_DOT3 epilogue left per pixel.
+struct HgFinalFusedParams {
+    const f16 *img;        // planar f16 [3][Hp][Wp]
+    const uint8_t *mask;   // [Hp][Wp]
+    const float *part;     // f32 [Hp][Wp][4]: conv10 over Up_conv5's 64 channels
+    const f16 *wfrag;      // 4 conv1 fragments (natural k) + 4 conv10-second-half fragments (k permuted)
+    const float *scale, *shift;   // conv1 folded BatchNorm [64]
+    const float *b10, *wl, *bl;   // conv10 bias [3], conv_last [3][6] + [3]
+    void *out;
+    int out_f32, H, W, Hp, Wp;
+};
+
+__global__ __launch_bounds__(256) void hg_final_fused_kernel(HgFinalFusedParams p)
+{
+    __shared__ f16 s_in[3][C3_HH][C3_HW + 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int ox0 = blockIdx.x * C3_TW, oy0 = blockIdx.y * C3_TH;
+    for (int e = tid; e < 3 * C3_HH * C3_HW; e += 256) {
+        const int c = e / (C3_HH * C3_HW), r = (e / C3_HW) % C3_HH, q = e % C3_HW;
+        const int iy = oy0 - 1 + r, ix = ox0 - 1 + q;
+        s_in[c][r][q] = (iy >= 0 && iy < p.Hp && ix >= 0 && ix < p.Wp) ? p.img[((size_t)c * p.Hp + iy) * p.Wp + ix] : (f16)0.f;
+    }
+    const f16x8 *fr = reinterpret_cast<const f16x8 *>(p.wfrag);
+    f16x8 w1[2][2], w2[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) w1[i][ks] = fr[(i * 2 + ks) * 64 + lane];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) w2[s] = fr[(4 + s) * 64 + lane];
+    f32x16 sc[2], sh[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { sc[i] = bias_tile_g(p.scale + 32 * i, lh); sh[i] = bias_tile_g(p.shift + 32 * i, lh); }
+    __syncthreads();
+    const f16 *sflat = &s_in[0][0][0];
+    const size_t plane_p = (size_t)p.Hp * p.Wp, plane_o = (size_t)p.H * p.W;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 2 * wave + j;
+        const int base = row * (C3_HW + 2) + l31;
+        f16x8 xf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = 16 * ks + 8 * lh + e;
+                const int tap = k / 3, c = k % 3;
+                xf[ks][e] = k < 27 ? sflat[base + (c * C3_HH + tap / 3) * (C3_HW + 2) + tap % 3] : (f16)0.f;
+            }
+        f16x8 bf[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f32x16 h;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) h[k] = 0.f;
+            h = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[i][0], xf[0], h, 0, 0, 0);
+            h = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[i][1], xf[1], h, 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bf[2 * i + s][e] = (f16)fmaxf(h[8 * s + e] * sc[i][8 * s + e] + sh[i][8 * s + e], 0.f);
+        }
+        f32x16 o;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) o[k] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) o = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[s], bf[s], o, 0, 0, 0);
+        const int y = oy0 + row, x = ox0 + l31;
+        if (lh == 0 && y < p.H && x < p.W) {
+            const size_t pix = (size_t)y * p.Wp + x;
+            const float4 pt = *reinterpret_cast<const float4 *>(p.part + pix * 4);
+            const float c10[3] = {(float)(f16)(o[0] + pt.x + p.b10[0]), (float)(f16)(o[1] + pt.y + p.b10[1]),
+                                  (float)(f16)(o[2] + pt.z + p.b10[2])};
+            const int ctr = (row + 1) * (C3_HW + 2) + l31 + 1;
+            const float im[3] = {(float)sflat[ctr], (float)sflat[C3_HH * (C3_HW + 2) + ctr], (float)sflat[2 * C3_HH * (C3_HW + 2) + ctr]};
+            const float m = (float)p.mask[pix];
+            const size_t oo = (size_t)y * p.W + x;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                float v = p.bl[ch];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) v += p.wl[ch * 6 + k] * c10[k] + p.wl[ch * 6 + 3 + k] * im[k];
+                v = (float)(f16)v;
+                const float res = m * v + im[ch];
+                if (p.out_f32) reinterpret_cast<float *>(p.out)[ch * plane_o + oo] = res;
+                else reinterpret_cast<f16 *>(p.out)[ch * plane_o + oo] = (f16)res;
+            }
+        }
+    }
+    (void)plane_p;
+}
+
 // ================================================================================= maxpool2
 __global__ __launch_bounds__(256) void maxpool2_kernel(const f16 *__restrict__ in, int H, int W, int C, f16 *__restrict__ out)
 {
@@ -340,6 +436,16 @@ hipError_t hg_final_launch(const HgFinalArgs &a, hipStream_t s)
     p.out = a.out; p.out_f32 = a.out_f32; p.H = a.H; p.W = a.W; p.Hp = a.Hp; p.Wp = a.Wp;
     const size_t nblk = ((size_t)a.Hp * a.Wp + 63) / 64;
     hipLaunchKernelGGL(hg_final_kernel, dim3(grid_for(nblk, 4)), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t hg_final_fused_launch(const HgFinalFusedArgs &a, hipStream_t s)
+{
+    HgFinalFusedParams p;
+    p.img = a.img; p.mask = a.mask; p.part = a.part; p.wfrag = a.wfrag; p.scale = a.scale; p.shift = a.shift;
+    p.b10 = a.b10; p.wl = a.wl; p.bl = a.bl; p.out = a.out; p.out_f32 = a.out_f32; p.H = a.H; p.W = a.W; p.Hp = a.Hp; p.Wp = a.Wp;
+    dim3 grid((a.W + C3_TW - 1) / C3_TW, (a.H + C3_TH - 1) / C3_TH);
+    hipLaunchKernelGGL(hg_final_fused_kernel, grid, dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
