@@ -62,6 +62,25 @@ struct ConvParams {
     float *dst_dot;        // ST_PS_DOT3: f32 [Hd][Wd][4] partial sums (x,y,z used)
 };
 
+// Parameter block of the persistent 32-channel conv (conv32p.hip): 3x3, stride 1, Cin = 32.
+struct Conv32Params {
+    const f16 *src;        // NHWC 32
+    const f16 *cond;       // NHWC 16 when an SFT layer is fused in front, else nullptr
+    const f16 *sft_wfrag;  // SFT A-fragments (as SftParams)
+    const float *sft_bias;
+    int H, W;              // input == conv output spatial size
+    const f16 *wpk;        // [9][CoutPad][32]
+    const float *scale, *shift;
+    int CoutPad, Cout, act, mode;
+    f16 *dst;
+    int dstC, Hd, Wd;
+    const f16 *res1, *res2;
+    f16 *dst_planar;
+    const f16 *res_planar;
+    const f16 *zeros;
+    int tiles_x, tiles_y;
+};
+
 struct SftParams {
     const f16 *x;      // NHWC 32
     const f16 *cond;   // NHWC 16

@@ -688,14 +688,41 @@ struct Seq {
         p.x = x; p.cond = cond; p.y = y; p.wfrag = wtp<f16>(c, L.wfrag); p.bias = wtp<float>(c, L.bias); p.npix = npix;
         chk(sft_launch(p, s), key.c_str(), "sft", (double)npix * 2 * (16 * 16 + 16 * 32), (double)npix * (64 + 32 + 64));
     }
-    // ResBlock_with_SFT (arch_util.py:89-95): y = x + conv2(sft2(relu(conv1(sft1(x,c))),c))  [+ extra]
-    void resblock(const std::string &base, const f16 *x, const f16 *cond, int H, int W, f16 *ta, f16 *tb, f16 *y,
+    // persistent 32-channel 3x3 conv, optionally with the SFT layer `sft_key` fused in front (conv32p.hip)
+    void conv32(const std::string &key, const f16 *src, const f16 *cond, const std::string &sft_key, int H, int W, int act,
+                int mode, f16 *dst, int dstC, int Hd, int Wd, const f16 *res1 = nullptr, const f16 *res2 = nullptr,
+                f16 *dst_planar = nullptr, const f16 *res_planar = nullptr)
+    {
+        if (!ok()) return;
+        auto it = c->conv.find(key);
+        if (it == c->conv.end()) { rc = fail(c, HDRTV_ESTATE, "no packed conv %s", key.c_str()); return; }
+        const ConvLayer &L = it->second;
+        Conv32Params p;
+        memset(&p, 0, sizeof p);
+        p.src = src; p.cond = cond; p.H = H; p.W = W;
+        if (cond) {
+            const SftLayer &S = c->sft.at(sft_key);
+            p.sft_wfrag = wtp<f16>(c, S.wfrag); p.sft_bias = wtp<float>(c, S.bias);
+        }
+        p.wpk = wtp<f16>(c, L.wpk); p.scale = wtp<float>(c, L.scale); p.shift = wtp<float>(c, L.shift);
+        p.CoutPad = L.coutPad; p.Cout = L.cout; p.act = act; p.mode = mode;
+        p.dst = dst; p.dstC = dstC; p.Hd = Hd; p.Wd = Wd; p.res1 = res1; p.res2 = res2;
+        p.dst_planar = dst_planar; p.res_planar = res_planar; p.zeros = wtp<f16>(c, c->zeros_off);
+        const double npx = (double)H * W;
+        const double macs = npx * 32 * 9 * L.cout + (cond ? npx * 2 * (16 * 16 + 16 * 32) : 0.0);
+        const double outb = mode == ST_PLANAR3 ? 6.0 * npx : 2.0 * npx * L.cout;
+        const double bytes = npx * (64 + (cond ? 32 : 0)) + outb * (1 + (res1 ? 1 : 0) + (res2 ? 1 : 0) + (res_planar ? 1 : 0)) +
+                             2.0 * 9 * 32 * L.coutPad;
+        char tag[48];
+        snprintf(tag, sizeof tag, "conv32p<%d,%s>", L.coutPad / 32, cond ? "sft" : "plain");
+        chk(conv32p_launch(p, s), key.c_str(), tag, macs, bytes);
+    }
+    // ResBlock_with_SFT (arch_util.py:89-95): y = x + conv2(sft2(relu(conv1(sft1(x,c))),c))  [+ extra]; 2 launches
+    void resblock(const std::string &base, const f16 *x, const f16 *cond, int H, int W, f16 *tb, f16 *y,
                   const f16 *extra = nullptr)
     {
-        sft(base + ".sft1", x, cond, ta, H * W);
-        conv(base + ".conv1", ta, 32, nullptr, 0, H, W, ACT_RELU, ST_NHWC, tb, 32, H, W);
-        sft(base + ".sft2", tb, cond, ta, H * W);
-        conv(base + ".conv2", ta, 32, nullptr, 0, H, W, ACT_NONE, ST_NHWC, y, 32, H, W, x, extra);
+        conv32(base + ".conv1", x, cond, base + ".sft1", H, W, ACT_RELU, ST_NHWC, tb, 32, H, W);
+        conv32(base + ".conv2", tb, cond, base + ".sft2", H, W, ACT_NONE, ST_NHWC, y, 32, H, W, x, extra);
     }
 };
 
@@ -772,36 +799,32 @@ int run_le(hdrtv_ctx *c, Seq &q, const f16 *img, f16 *out_planar)
     q.conv("LE.CondNet4.0", cond, 64, nullptr, 0, H, W, ACT_LRELU01, ST_NHWC, h1a, 64, s.H1, s.W1);
     q.conv("LE.CondNet4.2", h1a, 64, nullptr, 0, s.H1, s.W1, ACT_LRELU01, ST_NHWC, h2a, 64, s.H2, s.W2);
     q.conv("LE.CondNet4.4", h2a, 64, nullptr, 0, s.H2, s.W2, ACT_NONE, ST_NHWC, cond4, 16, s.H3, s.W3);
-    // main branch
+    // main branch: every SFT is fused into the 3x3 conv that follows it
     f16 *f0a = wsp<f16>(c, "le.f0a"), *f0b = wsp<f16>(c, "le.f0b"), *fea0 = wsp<f16>(c, "le.fea0"), *up3 = wsp<f16>(c, "le.up3");
     q.c3("le.conv_first", img, H, W, ACT_RELU, f0a, nullptr);
-    q.sft("LE.SFT_layer1", f0a, cond1, f0b, H * W);
-    q.conv("LE.HR_conv1", f0b, 32, nullptr, 0, H, W, ACT_RELU, ST_NHWC, fea0, 32, H, W);
-    f16 *fea1a = wsp<f16>(c, "le.fea1a"), *fea1 = wsp<f16>(c, "le.fea1"), *l1a = wsp<f16>(c, "le.l1a"), *l1b = wsp<f16>(c, "le.l1b");
+    q.conv32("LE.HR_conv1", f0a, cond1, "LE.SFT_layer1", H, W, ACT_RELU, ST_NHWC, fea0, 32, H, W);
+    f16 *fea1a = wsp<f16>(c, "le.fea1a"), *fea1 = wsp<f16>(c, "le.fea1"), *l1b = wsp<f16>(c, "le.l1b");
     q.conv("LE.down_conv1", fea0, 32, nullptr, 0, H, W, ACT_RELU, ST_NHWC, fea1a, 32, s.H1, s.W1);
-    q.resblock("LE.recon_trunk1.0", fea1a, cond2, s.H1, s.W1, l1a, l1b, fea1);
-    f16 *fea2a = wsp<f16>(c, "le.fea2a"), *fea2 = wsp<f16>(c, "le.fea2"), *l2a = wsp<f16>(c, "le.l2a"), *l2b = wsp<f16>(c, "le.l2b");
+    q.resblock("LE.recon_trunk1.0", fea1a, cond2, s.H1, s.W1, l1b, fea1);
+    f16 *fea2a = wsp<f16>(c, "le.fea2a"), *fea2 = wsp<f16>(c, "le.fea2"), *l2b = wsp<f16>(c, "le.l2b");
     q.conv("LE.down_conv2", fea1, 32, nullptr, 0, s.H1, s.W1, ACT_RELU, ST_NHWC, fea2a, 32, s.H2, s.W2);
-    q.resblock("LE.recon_trunk2.0", fea2a, cond3, s.H2, s.W2, l2a, l2b, fea2);
-    f16 *fea3 = wsp<f16>(c, "le.fea3"), *l3a = wsp<f16>(c, "le.l3a"), *l3b = wsp<f16>(c, "le.l3b"), *t3x = wsp<f16>(c, "le.t3x"),
-        *t3y = wsp<f16>(c, "le.t3y");
+    q.resblock("LE.recon_trunk2.0", fea2a, cond3, s.H2, s.W2, l2b, fea2);
+    f16 *fea3 = wsp<f16>(c, "le.fea3"), *l3b = wsp<f16>(c, "le.l3b"), *t3x = wsp<f16>(c, "le.t3x"), *t3y = wsp<f16>(c, "le.t3y");
     q.conv("LE.down_conv3", fea2, 32, nullptr, 0, s.H2, s.W2, ACT_RELU, ST_NHWC, fea3, 32, s.H3, s.W3);
-    q.resblock("LE.recon_trunk3.0", fea3, cond4, s.H3, s.W3, l3a, l3b, t3x);
-    q.resblock("LE.recon_trunk3.1", t3x, cond4, s.H3, s.W3, l3a, l3b, t3y);
-    q.resblock("LE.recon_trunk3.2", t3y, cond4, s.H3, s.W3, l3a, l3b, t3x);
-    q.resblock("LE.recon_trunk3.3", t3x, cond4, s.H3, s.W3, l3a, l3b, t3y, fea3);   // "+ fea3" (line 180) fused as 2nd residual
+    q.resblock("LE.recon_trunk3.0", fea3, cond4, s.H3, s.W3, l3b, t3x);
+    q.resblock("LE.recon_trunk3.1", t3x, cond4, s.H3, s.W3, l3b, t3y);
+    q.resblock("LE.recon_trunk3.2", t3y, cond4, s.H3, s.W3, l3b, t3x);
+    q.resblock("LE.recon_trunk3.3", t3x, cond4, s.H3, s.W3, l3b, t3y, fea3);   // "+ fea3" (line 180) fused as 2nd residual
     // up path: relu(shuffle(conv)) + skip, cropped to the skip's size (_align_to)
     f16 *up1 = wsp<f16>(c, "le.up1"), *t4 = wsp<f16>(c, "le.t4");
-    q.conv("LE.up_conv1.0", t3y, 32, nullptr, 0, s.H3, s.W3, ACT_RELU, ST_PS, up1, 32, s.H2, s.W2, fea2);
-    q.resblock("LE.recon_trunk4.0", up1, cond3, s.H2, s.W2, l2a, l2b, t4);
+    q.conv32("LE.up_conv1.0", t3y, nullptr, "", s.H3, s.W3, ACT_RELU, ST_PS, up1, 32, s.H2, s.W2, fea2);
+    q.resblock("LE.recon_trunk4.0", up1, cond3, s.H2, s.W2, l2b, t4);
     f16 *up2 = wsp<f16>(c, "le.up2"), *t5 = wsp<f16>(c, "le.t5");
-    q.conv("LE.up_conv2.0", t4, 32, nullptr, 0, s.H2, s.W2, ACT_RELU, ST_PS, up2, 32, s.H1, s.W1, fea1);
-    q.resblock("LE.recon_trunk5.0", up2, cond2, s.H1, s.W1, l1a, l1b, t5);
-    q.conv("LE.up_conv3.0", t5, 32, nullptr, 0, s.H1, s.W1, ACT_RELU, ST_PS, up3, 32, H, W, fea0);
-    q.sft("LE.SFT_layer2", up3, cond1, f0a, H * W);
-    q.conv("LE.HR_conv2", f0a, 32, nullptr, 0, H, W, ACT_RELU, ST_NHWC, f0b, 32, H, W);
-    q.conv("LE.conv_last", f0b, 32, nullptr, 0, H, W, ACT_NONE, ST_PLANAR3, nullptr, 0, H, W, nullptr, nullptr, nullptr,
-           out_planar, img);
+    q.conv32("LE.up_conv2.0", t4, nullptr, "", s.H2, s.W2, ACT_RELU, ST_PS, up2, 32, s.H1, s.W1, fea1);
+    q.resblock("LE.recon_trunk5.0", up2, cond2, s.H1, s.W1, l1b, t5);
+    q.conv32("LE.up_conv3.0", t5, nullptr, "", s.H1, s.W1, ACT_RELU, ST_PS, up3, 32, H, W, fea0);
+    q.conv32("LE.HR_conv2", up3, cond1, "LE.SFT_layer2", H, W, ACT_RELU, ST_NHWC, f0b, 32, H, W);
+    q.conv32("LE.conv_last", f0b, nullptr, "", H, W, ACT_NONE, ST_PLANAR3, nullptr, 0, H, W, nullptr, nullptr, out_planar, img);
     return q.rc;
 }
 
