@@ -78,6 +78,7 @@ struct Conv32Params {
     f16 *dst_planar;
     const f16 *res_planar;
     const f16 *zeros;
+    f16 *dump;             // >= 8 KiB scratch that masked-off lanes store to (keeps store counts exact)
     int tiles_x, tiles_y;
 };
 

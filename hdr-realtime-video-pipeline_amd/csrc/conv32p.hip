@@ -135,6 +135,34 @@ __global__ __launch_bounds__(512) void conv32p_kernel(Conv32Params p)
         const int oy0 = ty * TH, ox0 = tx * TW;
         char *a = sA + buf * A_BYTES;
 
+        // output offsets of this thread's two 16-byte chunks per pass (-1: outside) and residual prefetch
+        long ooff[NPASS][2];
+        f16x8 rs1[NPASS][2], rs2[NPASS][2];
+        if (p.mode != ST_PLANAR3) {
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int qq = (tid + it * 512) >> 2, c8 = tid & 3;
+                    const int oy = oy0 + qq / TW, ox = ox0 + qq % TW;
+                    long off = -1;
+                    if (oy < p.H && ox < p.W && c8 * 8 < p.Cout) {
+                        if (p.mode == ST_PS) {
+                            const int Y = 2 * oy + (pass >> 1), X = 2 * ox + (pass & 1);
+                            if (Y < p.Hd && X < p.Wd) off = ((long)Y * p.Wd + X) * 32 + c8 * 8;
+                        } else {
+                            off = ((long)oy * p.W + ox) * p.dstC + c8 * 8;
+                        }
+                    }
+                    ooff[pass][it] = off;
+                    f16x8 z;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) z[k] = (f16)0.f;
+                    rs1[pass][it] = (p.res1 && off >= 0) ? *reinterpret_cast<const f16x8 *>(p.res1 + off) : z;
+                    rs2[pass][it] = (p.res2 && off >= 0) ? *reinterpret_cast<const f16x8 *>(p.res2 + off) : z;
+                }
+        }
+
         if (SFT) {
             // y = x*(scale+1)+shift in place on the halo tile (arch_util.py:68-72)
             const char *cbuf = sC + buf * C_BYTES;
@@ -155,15 +183,16 @@ __global__ __launch_bounds__(512) void conv32p_kernel(Conv32Params p)
                 const f32x16 sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa1s, hs, sbs, 0, 0, 0);
                 const f32x16 sh = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa1t, ht, sbt, 0, 0, 0);
                 if (hp < NPIX) {
+                    // f16 arithmetic like the reference's fp16 model (x*(scale+1)+shift), 4 channels per op
+                    const f16 keep = inimg ? (f16)1.f : (f16)0.f;
 #pragma unroll
                     for (int qd = 0; qd < 4; ++qd) {
                         char *addr = a + hp * 64 + ((qd ^ swz32(hp)) << 4) + 8 * lh;
                         const f16x4 xv = *reinterpret_cast<const f16x4 *>(addr);
-                        f16x4 o;
+                        f16x4 s1, s0;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            o[k] = inimg ? (f16)((float)xv[k] * (sc[4 * qd + k] + 1.f) + sh[4 * qd + k]) : (f16)0.f;
-                        *reinterpret_cast<f16x4 *>(addr) = o;
+                        for (int k = 0; k < 4; ++k) { s1[k] = (f16)(sc[4 * qd + k] + 1.f); s0[k] = (f16)sh[4 * qd + k]; }
+                        *reinterpret_cast<f16x4 *>(addr) = (xv * s1 + s0) * keep;
                     }
                 }
             }
@@ -213,41 +242,26 @@ __global__ __launch_bounds__(512) void conv32p_kernel(Conv32Params p)
                     }
                 }
             } else {
+                // Exactly two 16-byte stores per thread and pass, UNCONDITIONALLY issued (lanes outside
+                // the image write to a dump area): the end-of-tile wait below counts on it.
 #pragma unroll
                 for (int it = 0; it < 2; ++it) {
-                    const int e = tid + it * 512, qq = e >> 2, c8 = e & 3;
-                    const int oy = oy0 + qq / TW, ox = ox0 + qq % TW;
-                    if (oy < p.H && ox < p.W && c8 * 8 < p.Cout) {
-                        size_t off;
-                        bool ok = true;
-                        if (p.mode == ST_PS) {
-                            const int Y = 2 * oy + (pass >> 1), X = 2 * ox + (pass & 1);
-                            ok = Y < p.Hd && X < p.Wd;
-                            off = ((size_t)Y * p.Wd + X) * 32 + c8 * 8;
-                        } else {
-                            off = ((size_t)oy * p.W + ox) * p.dstC + c8 * 8;
-                        }
-                        if (ok) {
-                            f16x8 v = *reinterpret_cast<const f16x8 *>(sO + qq * OUT_ROWB + c8 * 16);
-                            if (p.res1) {
-                                const f16x8 r = *reinterpret_cast<const f16x8 *>(p.res1 + off);
+                    const int qq = (tid + it * 512) >> 2, c8 = tid & 3;
+                    f16x8 v = *reinterpret_cast<const f16x8 *>(sO + qq * OUT_ROWB + c8 * 16);
+                    const f16x8 r1 = rs1[pass][it], r2 = rs2[pass][it];
 #pragma unroll
-                                for (int k = 0; k < 8; ++k) v[k] = (f16)((float)v[k] + (float)r[k]);
-                            }
-                            if (p.res2) {
-                                const f16x8 r = *reinterpret_cast<const f16x8 *>(p.res2 + off);
-#pragma unroll
-                                for (int k = 0; k < 8; ++k) v[k] = (f16)((float)v[k] + (float)r[k]);
-                            }
-                            *reinterpret_cast<f16x8 *>(p.dst + off) = v;
-                        }
-                    }
+                    for (int k = 0; k < 8; ++k) v[k] = (f16)(((float)v[k] + (float)r1[k]) + (float)r2[k]);
+                    f16 *dp = ooff[pass][it] >= 0 ? p.dst + ooff[pass][it] : p.dump + (size_t)tid * 8;
+                    *reinterpret_cast<f16x8 *>(dp) = v;
                 }
             }
             __syncthreads();
         }
-        // next tile's LDS-DMA must have landed (all waves) before anybody reads it
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // The next tile's LDS-DMA (issued at the top of this iteration, i.e. older than this tile's
+        // stores) must have landed before anybody reads it; the 2*NPASS stores may stay in flight.
+        if (p.mode == ST_PLANAR3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (NPASS == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __syncthreads();
     }
 }

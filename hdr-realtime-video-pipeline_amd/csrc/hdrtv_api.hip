@@ -130,6 +130,7 @@ struct hdrtv_ctx {
     std::map<std::string, SftLayer> sft;
     std::map<std::string, size_t> f32v;   // raw fp32 vectors/matrices in the weight arena
     size_t zeros_off = 0;                 // 256 B of zeros in the weight arena
+    size_t dump_off = 0;                  // 8 KiB write-only scratch (conv32p masked lanes)
     size_t trunk_wfrag = 0, trunk_bias = 0;   // fused LE condition trunk (le_fused.hip)
     size_t hgf_wfrag = 0, hg_w10a = 0;        // fused HG tail: conv1 + conv10(second half) fragments, conv10 first half
     // workspace
@@ -339,6 +340,8 @@ bool build_weights(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
     {
         const std::vector<unsigned char> z(256, 0);
         c->zeros_off = c->wts.put(z.data(), z.size());
+        const std::vector<unsigned char> d(8192, 0);
+        c->dump_off = c->wts.put(d.data(), d.size());
     }
     // ---- AGCM (fp32 on device: tiny)
     const int cls_ci[5] = {3, 16, 32, 64, 128}, cls_co[5] = {16, 32, 64, 128, 128}, cls_idx[5] = {0, 4, 8, 12, 16};
@@ -708,6 +711,7 @@ struct Seq {
         p.CoutPad = L.coutPad; p.Cout = L.cout; p.act = act; p.mode = mode;
         p.dst = dst; p.dstC = dstC; p.Hd = Hd; p.Wd = Wd; p.res1 = res1; p.res2 = res2;
         p.dst_planar = dst_planar; p.res_planar = res_planar; p.zeros = wtp<f16>(c, c->zeros_off);
+        p.dump = reinterpret_cast<f16 *>(c->wts.dev + c->dump_off);
         const double npx = (double)H * W;
         const double macs = npx * 32 * 9 * L.cout + (cond ? npx * 2 * (16 * 16 + 16 * 32) : 0.0);
         const double outb = mode == ST_PLANAR3 ? 6.0 * npx : 2.0 * npx * L.cout;
