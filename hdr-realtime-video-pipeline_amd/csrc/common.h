@@ -39,6 +39,7 @@ struct ConvParams {
     const f16 *src0;   // NHWC, c0 channels
     const f16 *src1;   // NHWC, c1 channels (channel concat after src0) or nullptr
     int c0, c1;        // multiples of the kernel's CIN_T
+    int s0_stride, s1_stride;   // elements per pixel of src0 / src1 (>= c0 / c1: channel slices of wider tensors)
     int Hi, Wi;        // input spatial size
     int Ho, Wo;        // conv output spatial size
     const f16 *wpk;    // [KS*KS][Cin/CIN_T][CoutPad][CIN_T]

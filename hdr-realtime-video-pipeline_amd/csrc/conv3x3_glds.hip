@@ -67,8 +67,8 @@ __global__ __launch_bounds__(512) void conv3x3_glds_kernel(ConvParams p)
     auto issue_A = [&](int cc, int buf) {
         const f16 *src;
         int cs, coff;
-        if (cc < nchunk0) { src = p.src0; cs = p.c0; coff = cc * CT; }
-        else { src = p.src1; cs = p.c1; coff = (cc - nchunk0) * CT; }
+        if (cc < nchunk0) { src = p.src0; cs = p.s0_stride; coff = cc * CT; }
+        else { src = p.src1; cs = p.s1_stride; coff = (cc - nchunk0) * CT; }
 #pragma unroll
         for (int it = 0; it < A_PIECES_PER_WAVE; ++it) {
             const int piece = wave + it * 8;

@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p)
     auto load_A = [&](int cc) {
         const f16 *src;
         int cs, coff;
-        if (cc < nchunk0) { src = p.src0; cs = p.c0; coff = cc * CIN_T; }
-        else { src = p.src1; cs = p.c1; coff = (cc - nchunk0) * CIN_T; }
+        if (cc < nchunk0) { src = p.src0; cs = p.s0_stride; coff = cc * CIN_T; }
+        else { src = p.src1; cs = p.s1_stride; coff = (cc - nchunk0) * CIN_T; }
 #pragma unroll
         for (int it = 0; it < C::A_LD; ++it) {
             const int e = tid + it * 256;

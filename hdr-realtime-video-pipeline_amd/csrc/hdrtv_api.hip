@@ -175,16 +175,33 @@ int fail(hdrtv_ctx *c, int code, const char *fmt, ...)
 // ps_cps > 0: output channels are re-ordered for a fused PixelShuffle(2): packed row
 // n' = sub*cps + c holds original channel 4*c + sub.
 bool pack_conv(hdrtv_ctx *c, const Pack &pk, const std::string &key, const std::string &wname, int co, int ci, int ks,
-               int stride, const std::string &bn_name, int ps_cps)
+               int stride, const std::string &bn_name, int ps_cps, int force_ct = 0)
 {
+    // wname may list several layers separated by '+': their output channels are concatenated
     std::vector<float> w, b;
-    if (!pk.get(wname + ".weight", (size_t)co * ci * ks * ks, w, c->err)) return false;
-    if (!pk.get(wname + ".bias", (size_t)co, b, c->err)) return false;
+    {
+        size_t pos = 0;
+        int parts = 1;
+        for (char ch : wname) parts += ch == '+';
+        const int co1 = co / parts;
+        while (pos <= wname.size()) {
+            size_t nx = wname.find('+', pos);
+            if (nx == std::string::npos) nx = wname.size();
+            const std::string one = wname.substr(pos, nx - pos);
+            std::vector<float> w1, b1;
+            if (!pk.get(one + ".weight", (size_t)co1 * ci * ks * ks, w1, c->err)) return false;
+            if (!pk.get(one + ".bias", (size_t)co1, b1, c->err)) return false;
+            w.insert(w.end(), w1.begin(), w1.end());
+            b.insert(b.end(), b1.begin(), b1.end());
+            pos = nx + 1;
+        }
+    }
     ConvLayer L;
     L.cin = ci; L.cout = co; L.ks = ks; L.stride = stride;
     L.coutPad = (co + 31) / 32 * 32;
-    L.cin_t = (stride == 2 || ci == 32) ? 32 : 64;
+    L.cin_t = force_ct ? force_ct : ((stride == 2 || ci == 32) ? 32 : 64);
     L.bn = L.coutPad >= 128 ? 128 : L.coutPad;
+    if (force_ct) L.bn = L.coutPad;     // whole-Cout kernels (conv3x3s2_glds)
     if (ci % L.cin_t != 0 || L.coutPad % L.bn != 0) { c->err = "unsupported conv shape: " + wname; return false; }
     std::vector<float> scale(L.coutPad, 1.f), shift(L.coutPad, 0.f);
     std::vector<float> g, be, mu, var;
@@ -383,15 +400,19 @@ bool build_weights(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
     if (!pack_cond_trunk(c, hr) || !pack_c3(c, hr, "le.conv_first", "LE.conv_first", 32, "")) return false;
     struct Spec { const char *name; int co, ci, ks, stride, ps; };
     const Spec le_convs[] = {
-        {"LE.CondNet2.0", 64, 64, 3, 2, 0}, {"LE.CondNet2.2", 64, 64, 1, 1, 0}, {"LE.CondNet2.4", 16, 64, 1, 1, 0},
-        {"LE.CondNet3.0", 64, 64, 3, 2, 0}, {"LE.CondNet3.2", 64, 64, 3, 2, 0}, {"LE.CondNet3.4", 16, 64, 1, 1, 0},
-        {"LE.CondNet4.0", 64, 64, 3, 2, 0}, {"LE.CondNet4.2", 64, 64, 3, 2, 0}, {"LE.CondNet4.4", 16, 64, 3, 2, 0},
+        {"LE.CondNet2.2", 64, 64, 1, 1, 0}, {"LE.CondNet2.4", 16, 64, 1, 1, 0},
+        {"LE.CondNet3.4", 16, 64, 1, 1, 0}, {"LE.CondNet4.4", 16, 64, 3, 2, 0},
         {"LE.HR_conv1", 32, 32, 3, 1, 0}, {"LE.HR_conv2", 32, 32, 3, 1, 0}, {"LE.conv_last", 3, 32, 3, 1, 0},
         {"LE.down_conv1", 32, 32, 3, 2, 0}, {"LE.down_conv2", 32, 32, 3, 2, 0}, {"LE.down_conv3", 32, 32, 3, 2, 0},
         {"LE.up_conv1.0", 128, 32, 3, 1, 32}, {"LE.up_conv2.0", 128, 32, 3, 1, 32}, {"LE.up_conv3.0", 128, 32, 3, 1, 32},
     };
     for (const Spec &s : le_convs)
         if (!pack_conv(c, hr, s.name, s.name, s.co, s.ci, s.ks, s.stride, "", s.ps)) return false;
+    // stride-2 layers from the 64-channel condition map: CondNet{2,3,4}.0 merged (192 outputs), .2 layers alone
+    if (!pack_conv(c, hr, "LE.CondNet234.0", "LE.CondNet2.0+LE.CondNet3.0+LE.CondNet4.0", 192, 64, 3, 2, "", 0, 64) ||
+        !pack_conv(c, hr, "LE.CondNet3.2", "LE.CondNet3.2", 64, 64, 3, 2, "", 0, 64) ||
+        !pack_conv(c, hr, "LE.CondNet4.2", "LE.CondNet4.2", 64, 64, 3, 2, "", 0, 64))
+        return false;
     const char *trunks[5] = {"recon_trunk1", "recon_trunk2", "recon_trunk3", "recon_trunk4", "recon_trunk5"};
     const int trunk_n[5] = {1, 1, 4, 1, 1};
     for (int t = 0; t < 5; ++t)
@@ -565,8 +586,8 @@ int do_reserve(hdrtv_ctx *c, int H, int W)
     // LE
     ws_add(c, "le.cond", 64, H, W, 0);
     ws_add(c, "le.cond1", 16, H, W, 0);
-    ws_add(c, "le.h1a", 64, s.H1, s.W1, 0); ws_add(c, "le.h1b", 64, s.H1, s.W1, 0);
-    ws_add(c, "le.h2a", 64, s.H2, s.W2, 0);
+    ws_add(c, "le.x192", 192, s.H1, s.W1, 0); ws_add(c, "le.h1b", 64, s.H1, s.W1, 0);
+    ws_add(c, "le.h2a", 64, s.H2, s.W2, 0); ws_add(c, "le.h2b", 64, s.H2, s.W2, 0);
     ws_add(c, "le.cond2", 16, s.H1, s.W1, 0); ws_add(c, "le.cond3", 16, s.H2, s.W2, 0); ws_add(c, "le.cond4", 16, s.H3, s.W3, 0);
     ws_add(c, "le.f0a", 32, H, W, 0); ws_add(c, "le.f0b", 32, H, W, 0); ws_add(c, "le.fea0", 32, H, W, 0);
     ws_add(c, "le.up3", 32, H, W, 0);
@@ -641,7 +662,8 @@ struct Seq {
     // generic conv: src0 (+src1) -> dst
     void conv(const std::string &key, const f16 *src0, int c0, const f16 *src1, int c1, int Hi, int Wi, int act, int mode,
               f16 *dst, int dstC, int Hd, int Wd, const f16 *res1 = nullptr, const f16 *res2 = nullptr, f16 *dst_full = nullptr,
-              f16 *dst_planar = nullptr, const f16 *res_planar = nullptr, const float *dotw = nullptr, float *dst_dot = nullptr)
+              f16 *dst_planar = nullptr, const f16 *res_planar = nullptr, const float *dotw = nullptr, float *dst_dot = nullptr,
+              int s0_stride = 0)
     {
         if (!ok()) return;
         auto it = c->conv.find(key);
@@ -650,6 +672,7 @@ struct Seq {
         ConvParams p;
         memset(&p, 0, sizeof p);
         p.src0 = src0; p.src1 = src1; p.c0 = c0; p.c1 = c1;
+        p.s0_stride = s0_stride ? s0_stride : c0; p.s1_stride = c1;
         p.Hi = Hi; p.Wi = Wi;
         const int pad = L.ks / 2;
         p.Ho = (Hi + 2 * pad - L.ks) / L.stride + 1;
@@ -663,8 +686,10 @@ struct Seq {
         p.zeros = wtp<f16>(c, c->zeros_off);
         const bool glds = L.ks == 3 && L.stride == 1 && L.cin_t == 64 && L.bn == 128 && !res1 && !res2 && !dst_full &&
                           mode != ST_PLANAR3;
+        const bool s2g = L.ks == 3 && L.stride == 2 && L.cin_t == 64 && L.bn == L.coutPad && (L.coutPad == 64 || L.coutPad == 192);
         char tag[64];
-        if (glds) snprintf(tag, sizeof tag, "conv3x3_glds<64,128>");
+        if (s2g) snprintf(tag, sizeof tag, "conv3x3s2_glds<%d>", L.coutPad);
+        else if (glds) snprintf(tag, sizeof tag, "conv3x3_glds<64,128>");
         else snprintf(tag, sizeof tag, "conv_igemm<%d,%d,%d,%d>", L.cin_t, L.bn, L.ks, L.stride);
         const double macs = (double)p.Ho * p.Wo * L.cin * L.ks * L.ks * L.cout;
         double bytes = 2.0 * Hi * Wi * L.cin + 2.0 * L.ks * L.ks * L.cin * L.coutPad;
@@ -672,8 +697,9 @@ struct Seq {
                                               : (mode == ST_PLANAR3 ? 3.0 * Hd * Wd
                                                                     : (mode == ST_PS_DOT3 ? 8.0 * Hd * Wd : (double)p.Ho * p.Wo * L.cout));
         bytes += 2.0 * outel * (1 + (res1 ? 1 : 0) + (res2 ? 1 : 0) + (res_planar ? 1 : 0));
-        chk(glds ? conv3x3_glds_launch(p, s) : conv_igemm_launch(p, L.cin_t, L.bn, L.ks, L.stride, s), key.c_str(), tag, macs,
-            bytes);
+        chk(s2g ? conv3x3s2_glds_launch(p, s)
+                : (glds ? conv3x3_glds_launch(p, s) : conv_igemm_launch(p, L.cin_t, L.bn, L.ks, L.stride, s)),
+            key.c_str(), tag, macs, bytes);
     }
     void c3(const std::string &key, const f16 *in, int H, int W, int act, f16 *out, f16 *out_pool)
     {
@@ -788,21 +814,24 @@ int run_le(hdrtv_ctx *c, Seq &q, const f16 *img, f16 *out_planar)
     f16 *cond = wsp<f16>(c, "le.cond");
     f16 *cond1 = wsp<f16>(c, "le.cond1"), *cond2 = wsp<f16>(c, "le.cond2"), *cond3 = wsp<f16>(c, "le.cond3"),
         *cond4 = wsp<f16>(c, "le.cond4");
-    f16 *h1a = wsp<f16>(c, "le.h1a"), *h1b = wsp<f16>(c, "le.h1b"), *h2a = wsp<f16>(c, "le.h2a");
+    f16 *h1b = wsp<f16>(c, "le.h1b"), *h2a = wsp<f16>(c, "le.h2a");
     // condition trunk
     // cond_first (3 layers) + CondNet1 (3 layers) in one launch: img -> cond (64 ch) and cond1 (16 ch)
     if (q.ok())
         q.chk(le_cond_trunk_launch(img, H, W, wtp<f16>(c, c->trunk_wfrag), wtp<float>(c, c->trunk_bias), cond, cond1, q.s),
               "LE.cond_trunk", "le_cond_trunk", (double)H * W * (27 * 64 + 4 * 64 * 64 + 64 * 16), (double)H * W * (6 + 128 + 32));
-    q.conv("LE.CondNet2.0", cond, 64, nullptr, 0, H, W, ACT_LRELU01, ST_NHWC, h1a, 64, s.H1, s.W1);
-    q.conv("LE.CondNet2.2", h1a, 64, nullptr, 0, s.H1, s.W1, ACT_LRELU01, ST_NHWC, h1b, 64, s.H1, s.W1);
+    // CondNet2/3/4: the three 3x3/s2 first layers read `cond` once (one launch, 192 channels)
+    f16 *x192 = wsp<f16>(c, "le.x192"), *h2b = wsp<f16>(c, "le.h2b");
+    q.conv("LE.CondNet234.0", cond, 64, nullptr, 0, H, W, ACT_LRELU01, ST_NHWC, x192, 192, s.H1, s.W1);
+    q.conv("LE.CondNet2.2", x192, 64, nullptr, 0, s.H1, s.W1, ACT_LRELU01, ST_NHWC, h1b, 64, s.H1, s.W1, nullptr, nullptr, nullptr,
+           nullptr, nullptr, nullptr, nullptr, 192);
     q.conv("LE.CondNet2.4", h1b, 64, nullptr, 0, s.H1, s.W1, ACT_NONE, ST_NHWC, cond2, 16, s.H1, s.W1);
-    q.conv("LE.CondNet3.0", cond, 64, nullptr, 0, H, W, ACT_LRELU01, ST_NHWC, h1a, 64, s.H1, s.W1);
-    q.conv("LE.CondNet3.2", h1a, 64, nullptr, 0, s.H1, s.W1, ACT_LRELU01, ST_NHWC, h2a, 64, s.H2, s.W2);
+    q.conv("LE.CondNet3.2", x192 + 64, 64, nullptr, 0, s.H1, s.W1, ACT_LRELU01, ST_NHWC, h2a, 64, s.H2, s.W2, nullptr, nullptr,
+           nullptr, nullptr, nullptr, nullptr, nullptr, 192);
     q.conv("LE.CondNet3.4", h2a, 64, nullptr, 0, s.H2, s.W2, ACT_NONE, ST_NHWC, cond3, 16, s.H2, s.W2);
-    q.conv("LE.CondNet4.0", cond, 64, nullptr, 0, H, W, ACT_LRELU01, ST_NHWC, h1a, 64, s.H1, s.W1);
-    q.conv("LE.CondNet4.2", h1a, 64, nullptr, 0, s.H1, s.W1, ACT_LRELU01, ST_NHWC, h2a, 64, s.H2, s.W2);
-    q.conv("LE.CondNet4.4", h2a, 64, nullptr, 0, s.H2, s.W2, ACT_NONE, ST_NHWC, cond4, 16, s.H3, s.W3);
+    q.conv("LE.CondNet4.2", x192 + 128, 64, nullptr, 0, s.H1, s.W1, ACT_LRELU01, ST_NHWC, h2b, 64, s.H2, s.W2, nullptr, nullptr,
+           nullptr, nullptr, nullptr, nullptr, nullptr, 192);
+    q.conv("LE.CondNet4.4", h2b, 64, nullptr, 0, s.H2, s.W2, ACT_NONE, ST_NHWC, cond4, 16, s.H3, s.W3);
     // main branch: every SFT is fused into the 3x3 conv that follows it
     f16 *f0a = wsp<f16>(c, "le.f0a"), *f0b = wsp<f16>(c, "le.f0b"), *fea0 = wsp<f16>(c, "le.fea0"), *up3 = wsp<f16>(c, "le.up3");
     q.c3("le.conv_first", img, H, W, ACT_RELU, f0a, nullptr);
