@@ -29,6 +29,10 @@ constexpr int SMEM = 2 * A_BYTES + 3 * B_BYTES;          // 144 KiB
 constexpr int OUT_ROWB = BN * 2 + 16;
 static_assert(TH * TW * OUT_ROWB + 3 * 64 * 4 <= SMEM, "epilogue tile must fit");
 
+// 16-byte chunk swizzle.  Weight rows use their row index; halo pixels use their COLUMN in the
+// 18-wide halo tile: a 32-lane fragment covers 16 columns of two tile rows, and with the column as
+// key every ds_read_b128 lane group hits 16 distinct 16-byte slots of the 256-byte bank row
+// (keying on the linear pixel index costs a 2-way conflict on every activation read).
 __device__ __forceinline__ int swz64(int row) { return (row >> 1) & 7; }
 
 __device__ __forceinline__ void glds16(const void *g, void *lds)
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(512) void conv3x3_glds_kernel(ConvParams p)
             const int hy = hp / HW, hx = hp - hy * HW;
             const int iy = iy0 + hy, ix = ix0 + hx;
             const bool ok = hp < NPIX && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
-            const f16 *g = ok ? src + ((size_t)iy * p.Wi + ix) * cs + coff + ((l_slot ^ swz64(hp)) << 3)
+            const f16 *g = ok ? src + ((size_t)iy * p.Wi + ix) * cs + coff + ((l_slot ^ swz64(hx)) << 3)
                               : p.zeros + (l_slot << 3);
             glds16(g, sA + buf * A_BYTES + piece * 1024);
         }
@@ -94,11 +98,12 @@ __global__ __launch_bounds__(512) void conv3x3_glds_kernel(ConvParams p)
 
     // ---- wave tiling: 2 (channels) x 4 (pixels) waves, each 64 ch x 64 px = 2x2 MFMA tiles ---
     const int wc = wave & 1, wp = wave >> 1;
-    int hp_base[2], wrow[2];
+    int hp_base[2], hx_base[2], wrow[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int q = (wp * 2 + j) * 32 + l31;
         hp_base[j] = (q / TW) * HW + (q % TW);
+        hx_base[j] = q % TW;
         wrow[j] = (wc * 2 + j) * 32 + l31;
     }
     f32x16 acc[2][2];
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(512) void conv3x3_glds_kernel(ConvParams p)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int hp = hp_base[j] + tap_off;
-                    xf[j] = *reinterpret_cast<const f16x8 *>(a + hp * PIXB + ((chunk ^ swz64(hp)) << 4));
+                    xf[j] = *reinterpret_cast<const f16x8 *>(a + hp * PIXB + ((chunk ^ swz64(hx_base[j] + tap % 3)) << 4));
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
