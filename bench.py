@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--no-hg", action="store_true", help="debug: AGCM+LE only (not the headline config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", default="640x360", help="WxH of the oracle's bounded sample")
+    ap.add_argument("--cpu-sample", default="1920x1080", help="WxH of the oracle's bounded sample")
     ap.add_argument("--layers", action="store_true", help="print the per-layer profile to stderr")
     return ap.parse_args()
 
@@ -93,8 +93,10 @@ def main():
 
     use_hg = not args.no_hg
     H, Wd = args.height, args.width
-    proc = HDRTVNetMI355X(os.path.join(REPO, "tests", "golden", "hr_weights.hdrw"), device=f"cuda:{local_rank}",
-                          use_hg=use_hg, hg_weights="seeded:1234" if use_hg else None, warmup_passes=0)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):       # stdout carries exactly one JSON line
+        proc = HDRTVNetMI355X(os.path.join(REPO, "tests", "golden", "hr_weights.hdrw"), device=f"cuda:{local_rank}",
+                              use_hg=use_hg, hg_weights="seeded:1234" if use_hg else None, warmup_passes=0)
     proc._ensure_buffers(H, Wd)
     lib, ctx = proc._lib, proc._ctx
 

@@ -22,13 +22,16 @@
 
 namespace {
 
-constexpr int TH = 16, TW = 16, HW = TW + 2, NPIX = (TH + 2) * (TW + 2);   // 324 halo pixels
+// Halo tile: 18 x 18 pixels stored with an LDS row pitch of 20 pixels.  With 64-byte pixels the
+// pitch makes (pixel index mod 4) == (column mod 4), and the chunk swizzle (column >> 2) & 3 then
+// spreads every ds_read_b128 lane group of a fragment read over all 16 slots of the bank row.
+constexpr int TH = 16, TW = 16, HC = TW + 2, HW = 20, NPIX = (TH + 2) * HW;   // 360 slots, 324 real
 constexpr int A_PIECES = 24, A_BYTES = A_PIECES * 1024;   // 16 px x 64 B per piece, 3 per wave
 constexpr int C_PIECES = 16, C_BYTES = C_PIECES * 1024;   // 32 px x 32 B per piece, 2 per wave
 constexpr int OUT_ROWB = 64 + 16;
 constexpr int OUT_BYTES = TH * TW * OUT_ROWB;
 
-__device__ __forceinline__ int swz32(int row) { return (row >> 2) & 3; }
+__device__ __forceinline__ int swz32(int row) { return (row >> 2) & 3; }   // weight rows: by row; halo: by column
 
 __device__ __forceinline__ void glds16(const void *g, void *lds)
 {
@@ -84,8 +87,8 @@ __global__ __launch_bounds__(512) void conv32p_kernel(Conv32Params p)
             const int hp = piece * 16 + (lane >> 2), slot = lane & 3;
             const int hy = hp / HW, hx = hp - hy * HW;
             const int iy = iy0 + hy, ix = ix0 + hx;
-            const bool ok = hp < NPIX && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            const f16 *g = ok ? p.src + ((size_t)iy * p.W + ix) * 32 + ((slot ^ swz32(hp)) << 3) : p.zeros + (slot << 3);
+            const bool ok = hp < NPIX && hx < HC && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const f16 *g = ok ? p.src + ((size_t)iy * p.W + ix) * 32 + ((slot ^ swz32(hx)) << 3) : p.zeros + (slot << 3);
             glds16(g, sA + buf * A_BYTES + piece * 1024);
         }
         if (SFT) {
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(512) void conv32p_kernel(Conv32Params p)
                 const int hp = piece * 32 + (lane >> 1), half = lane & 1;
                 const int hy = hp / HW, hx = hp - hy * HW;
                 const int iy = iy0 + hy, ix = ix0 + hx;
-                const bool ok = hp < NPIX && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                const bool ok = hp < NPIX && hx < HC && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
                 const f16 *g = ok ? p.cond + ((size_t)iy * p.W + ix) * 16 + (half << 3) : p.zeros + (half << 3);
                 glds16(g, sC + buf * C_BYTES + piece * 1024);
             }
@@ -112,11 +115,6 @@ __global__ __launch_bounds__(512) void conv32p_kernel(Conv32Params p)
         sSS[e] = p.scale[e];
         sSS[L::COUTP + e] = p.shift[e];
     }
-    int t = blockIdx.x;
-    if (t < ntiles) issue_tile(t, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
     f16x8 sa0, sa1s, sa1t;
     f32x16 sbh, sbs, sbt;
     if (SFT) {
@@ -124,16 +122,65 @@ __global__ __launch_bounds__(512) void conv32p_kernel(Conv32Params p)
         sa0 = fr[lane]; sa1s = fr[64 + lane]; sa1t = fr[128 + lane];
         sbh = tile16(p.sft_bias, lh); sbs = tile16(p.sft_bias + 32, lh); sbt = tile16(p.sft_bias + 64, lh);
     }
-
-    const int q = wave * 32 + l31;                       // this lane's output pixel in the tile
-    const int hp_base = (q / TW) * HW + (q % TW);
-
-    for (int buf = 0; t < ntiles; t += gridDim.x, buf ^= 1) {
-        const int tn = t + gridDim.x;
-        if (tn < ntiles) issue_tile(tn, buf ^ 1);        // next tile's halo(s) fly during this tile
-        const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+    // y = x*(scale+1)+shift in place on a landed halo tile (arch_util.py:68-72)
+    auto sft_tile = [&](int tt, int buf) {
+        const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
         const int oy0 = ty * TH, ox0 = tx * TW;
         char *a = sA + buf * A_BYTES;
+        const char *cbuf = sC + buf * C_BYTES;
+        for (int g = wave; g < (NPIX + 31) / 32; g += 8) {
+            const int hp = g * 32 + l31;
+            const int hy = hp / HW, hx = hp - hy * HW;
+            const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+            const bool inimg = hp < NPIX && hx < HC && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const f16x8 cf = *reinterpret_cast<const f16x8 *>(cbuf + hp * 32 + lh * 16);
+            const f32x16 h = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa0, cf, sbh, 0, 0, 0);
+            f16x8 hs, ht;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float u = h[j], v = h[8 + j];
+                hs[j] = (f16)fmaxf(u, 0.1f * u);
+                ht[j] = (f16)fmaxf(v, 0.1f * v);
+            }
+            const f32x16 sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa1s, hs, sbs, 0, 0, 0);
+            const f32x16 sh = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa1t, ht, sbt, 0, 0, 0);
+            if (hp < NPIX) {
+                // f16 arithmetic like the reference's fp16 model (x*(scale+1)+shift), 4 channels per op
+                const f16 keep = inimg ? (f16)1.f : (f16)0.f;
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    char *addr = a + hp * 64 + ((qd ^ swz32(hx)) << 4) + 8 * lh;
+                    const f16x4 xv = *reinterpret_cast<const f16x4 *>(addr);
+                    f16x4 s1, s0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { s1[k] = (f16)(sc[4 * qd + k] + 1.f); s0[k] = (f16)sh[4 * qd + k]; }
+                    *reinterpret_cast<f16x4 *>(addr) = (xv * s1 + s0) * keep;
+                }
+            }
+        }
+    };
+
+    // ---- prologue: tile 0 landed (and SFT-transformed), tile 1 in flight
+    int t = blockIdx.x;
+    const int step = gridDim.x;
+    if (t < ntiles) issue_tile(t, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (SFT && t < ntiles) sft_tile(t, 0);
+    if (t + step < ntiles) issue_tile(t + step, 1);
+    __syncthreads();
+
+    const int q = wave * 32 + l31;                       // this lane's output pixel in the tile
+    const int qx = q % TW;
+    const int hp_base = (q / TW) * HW + qx;
+
+    // Steady state, two barriers per tile:
+    //   conv(t) -> stage result in LDS -> [DMA(t+1) landed] -> barrier -> stores(t) fly while the SFT of
+    //   tile t+1 runs and DMA(t+2) is issued into the buffer conv(t) just released -> barrier.
+    for (int buf = 0; t < ntiles; t += step, buf ^= 1) {
+        const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        const char *a = sA + buf * A_BYTES;
 
         // output offsets of this thread's two 16-byte chunks per pass (-1: outside) and residual prefetch
         long ooff[NPASS][2];
@@ -163,42 +210,6 @@ __global__ __launch_bounds__(512) void conv32p_kernel(Conv32Params p)
                 }
         }
 
-        if (SFT) {
-            // y = x*(scale+1)+shift in place on the halo tile (arch_util.py:68-72)
-            const char *cbuf = sC + buf * C_BYTES;
-            for (int g = wave; g < (NPIX + 31) / 32; g += 8) {
-                const int hp = g * 32 + l31;
-                const int hy = hp / HW, hx = hp - hy * HW;
-                const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-                const bool inimg = hp < NPIX && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-                const f16x8 cf = *reinterpret_cast<const f16x8 *>(cbuf + hp * 32 + lh * 16);
-                const f32x16 h = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa0, cf, sbh, 0, 0, 0);
-                f16x8 hs, ht;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float u = h[j], v = h[8 + j];
-                    hs[j] = (f16)fmaxf(u, 0.1f * u);
-                    ht[j] = (f16)fmaxf(v, 0.1f * v);
-                }
-                const f32x16 sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa1s, hs, sbs, 0, 0, 0);
-                const f32x16 sh = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa1t, ht, sbt, 0, 0, 0);
-                if (hp < NPIX) {
-                    // f16 arithmetic like the reference's fp16 model (x*(scale+1)+shift), 4 channels per op
-                    const f16 keep = inimg ? (f16)1.f : (f16)0.f;
-#pragma unroll
-                    for (int qd = 0; qd < 4; ++qd) {
-                        char *addr = a + hp * 64 + ((qd ^ swz32(hp)) << 4) + 8 * lh;
-                        const f16x4 xv = *reinterpret_cast<const f16x4 *>(addr);
-                        f16x4 s1, s0;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) { s1[k] = (f16)(sc[4 * qd + k] + 1.f); s0[k] = (f16)sh[4 * qd + k]; }
-                        *reinterpret_cast<f16x4 *>(addr) = (xv * s1 + s0) * keep;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
             f32x16 acc;
@@ -208,15 +219,16 @@ __global__ __launch_bounds__(512) void conv32p_kernel(Conv32Params p)
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int hp = hp_base + (tap / 3) * HW + (tap % 3);
+                const int hx = qx + tap % 3;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const int chunk = ks * 2 + lh;
                     const f16x8 wf = *reinterpret_cast<const f16x8 *>(sW + (tap * L::COUTP + n) * 64 + ((chunk ^ swz32(n)) << 4));
-                    const f16x8 xf = *reinterpret_cast<const f16x8 *>(a + hp * 64 + ((chunk ^ swz32(hp)) << 4));
+                    const f16x8 xf = *reinterpret_cast<const f16x8 *>(a + hp * 64 + ((chunk ^ swz32(hx)) << 4));
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xf, acc, 0, 0, 0);
                 }
             }
-            // ---- epilogue of this pass: 32 channels x 256 pixels through LDS
+            // ---- this pass's 32 channels x 256 pixels into the LDS staging tile
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
                 const int cl = 8 * qd + 4 * lh;
@@ -229,6 +241,8 @@ __global__ __launch_bounds__(512) void conv32p_kernel(Conv32Params p)
                 o[3] = (f16)act_apply(acc[4 * qd + 3] * sc.w + sh.w, p.act);
                 *reinterpret_cast<f16x4 *>(sO + q * OUT_ROWB + cl * 2) = o;
             }
+            // the last pass also makes sure the next tile's LDS-DMA has landed before the barrier
+            if (pass == NPASS - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (p.mode == ST_PLANAR3) {
                 for (int e = tid; e < TH * TW * 3; e += 512) {
@@ -242,8 +256,6 @@ __global__ __launch_bounds__(512) void conv32p_kernel(Conv32Params p)
                     }
                 }
             } else {
-                // Exactly two 16-byte stores per thread and pass, UNCONDITIONALLY issued (lanes outside
-                // the image write to a dump area): the end-of-tile wait below counts on it.
 #pragma unroll
                 for (int it = 0; it < 2; ++it) {
                     const int qq = (tid + it * 512) >> 2, c8 = tid & 3;
@@ -255,13 +267,12 @@ __global__ __launch_bounds__(512) void conv32p_kernel(Conv32Params p)
                     *reinterpret_cast<f16x8 *>(dp) = v;
                 }
             }
-            __syncthreads();
+            if (pass < NPASS - 1) __syncthreads();      // staging tile is reused by the next pass
         }
-        // The next tile's LDS-DMA (issued at the top of this iteration, i.e. older than this tile's
-        // stores) must have landed before anybody reads it; the 2*NPASS stores may stay in flight.
-        if (p.mode == ST_PLANAR3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (NPASS == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        // stores of tile t are in flight; prepare tile t+1 and prefetch tile t+2
+        const int t1 = t + step, t2 = t + 2 * step;
+        if (SFT && t1 < ntiles) sft_tile(t1, buf ^ 1);
+        if (t2 < ntiles) issue_tile(t2, buf);
         __syncthreads();
     }
 }

@@ -591,14 +591,11 @@ int do_reserve(hdrtv_ctx *c, int H, int W)
     ws_add(c, "le.cond2", 16, s.H1, s.W1, 0); ws_add(c, "le.cond3", 16, s.H2, s.W2, 0); ws_add(c, "le.cond4", 16, s.H3, s.W3, 0);
     ws_add(c, "le.f0a", 32, H, W, 0); ws_add(c, "le.f0b", 32, H, W, 0); ws_add(c, "le.fea0", 32, H, W, 0);
     ws_add(c, "le.up3", 32, H, W, 0);
-    ws_add(c, "le.fea1a", 32, s.H1, s.W1, 0); ws_add(c, "le.fea1", 32, s.H1, s.W1, 0);
-    ws_add(c, "le.l1a", 32, s.H1, s.W1, 0); ws_add(c, "le.l1b", 32, s.H1, s.W1, 0); ws_add(c, "le.l1c", 32, s.H1, s.W1, 0);
+    ws_add(c, "le.fea1a", 32, s.H1, s.W1, 0); ws_add(c, "le.fea1", 32, s.H1, s.W1, 0); ws_add(c, "le.l1b", 32, s.H1, s.W1, 0);
     ws_add(c, "le.up2", 32, s.H1, s.W1, 0); ws_add(c, "le.t5", 32, s.H1, s.W1, 0);
-    ws_add(c, "le.fea2a", 32, s.H2, s.W2, 0); ws_add(c, "le.fea2", 32, s.H2, s.W2, 0);
-    ws_add(c, "le.l2a", 32, s.H2, s.W2, 0); ws_add(c, "le.l2b", 32, s.H2, s.W2, 0); ws_add(c, "le.l2c", 32, s.H2, s.W2, 0);
+    ws_add(c, "le.fea2a", 32, s.H2, s.W2, 0); ws_add(c, "le.fea2", 32, s.H2, s.W2, 0); ws_add(c, "le.l2b", 32, s.H2, s.W2, 0);
     ws_add(c, "le.up1", 32, s.H2, s.W2, 0); ws_add(c, "le.t4", 32, s.H2, s.W2, 0);
-    ws_add(c, "le.fea3", 32, s.H3, s.W3, 0);
-    ws_add(c, "le.l3a", 32, s.H3, s.W3, 0); ws_add(c, "le.l3b", 32, s.H3, s.W3, 0); ws_add(c, "le.l3c", 32, s.H3, s.W3, 0);
+    ws_add(c, "le.fea3", 32, s.H3, s.W3, 0); ws_add(c, "le.l3b", 32, s.H3, s.W3, 0);
     ws_add(c, "le.t3x", 32, s.H3, s.W3, 0); ws_add(c, "le.t3y", 32, s.H3, s.W3, 0);
     ws_add(c, "le.out", 3, H, W, 1);
     if (c->has_hg) {
