@@ -18,14 +18,20 @@
 namespace {
 
 constexpr int TH = 16, TW = 16;
-constexpr int HW = TW + 2, NPIX = (TH + 2) * (TW + 2);   // 18, 324
 constexpr int CT = 64, PIXB = CT * 2;                    // 64-channel chunk = 128 B per pixel
-constexpr int A_PIECES_PER_WAVE = 6;                     // 48 KiB halo buffer (324 px + dummy tail)
-constexpr int A_BYTES = 8 * A_PIECES_PER_WAVE * 1024;
+// KS = 3: 18x18 halo tile (324 px -> 6 pieces per wave, 48 KiB), double-buffered per channel chunk.
+// KS = 1: 16x16 tile (256 px -> 4 pieces per wave, 32 KiB), one buffer per iteration in a 3-slot ring.
+template <int KS> struct Geo {
+    static constexpr int HW = TW + KS - 1, NPIX = (TH + KS - 1) * (TW + KS - 1);
+    static constexpr int A_PIECES_PER_WAVE = KS == 3 ? 6 : 4;
+    static constexpr int A_BYTES = 8 * A_PIECES_PER_WAVE * 1024;
+    static constexpr int A_SLOTS = KS == 3 ? 2 : 3;
+};
 constexpr int BN = 128;
 constexpr int B_BYTES = BN * PIXB;                       // 16 KiB = 16 pieces = 2 per wave
 constexpr int B_PIECES_PER_WAVE = 2;
-constexpr int SMEM = 2 * A_BYTES + 3 * B_BYTES;          // 144 KiB
+constexpr int SMEM = 2 * Geo<3>::A_BYTES + 3 * B_BYTES;  // 144 KiB (== 3 * Geo<1>::A_BYTES + 3 * B_BYTES)
+static_assert(3 * Geo<1>::A_BYTES + 3 * B_BYTES == SMEM, "both geometries use the same LDS budget");
 constexpr int OUT_ROWB = BN * 2 + 16;
 static_assert(TH * TW * OUT_ROWB + 3 * 64 * 4 <= SMEM, "epilogue tile must fit");
 
@@ -41,11 +47,15 @@ __device__ __forceinline__ void glds16(const void *g, void *lds)
                                      (__attribute__((address_space(3))) void *)lds, 16, 0, 0);
 }
 
-__global__ __launch_bounds__(512) void conv3x3_glds_kernel(ConvParams p)
+template <int KS>
+__global__ __launch_bounds__(512) void conv_glds_kernel(ConvParams p)
 {
+    using G = Geo<KS>;
+    constexpr int HW = G::HW, NPIX = G::NPIX, A_BYTES = G::A_BYTES, A_PIECES_PER_WAVE = G::A_PIECES_PER_WAVE;
+    constexpr int NTAP = KS * KS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *sA = smem;
-    char *sB = smem + 2 * A_BYTES;
+    char *sB = smem + G::A_SLOTS * A_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -61,10 +71,10 @@ __global__ __launch_bounds__(512) void conv3x3_glds_kernel(ConvParams p)
     const int nt_i = t % ntn, sp = t / ntn;
     const int ty = sp / p.tiles_x, tx = sp % p.tiles_x;
     const int oy0 = ty * TH, ox0 = tx * TW, n0 = nt_i * BN;
-    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+    const int iy0 = oy0 - KS / 2, ix0 = ox0 - KS / 2;
 
     const int nchunk = (p.c0 + p.c1) / CT, nchunk0 = p.c0 / CT;
-    const int nit = nchunk * 9;
+    const int nit = nchunk * NTAP;
 
     // ---- LDS-DMA issue helpers (wave-uniform LDS base, per-lane swizzled source) ------------
     const int l_row = lane >> 3, l_slot = lane & 7;
@@ -86,7 +96,7 @@ __global__ __launch_bounds__(512) void conv3x3_glds_kernel(ConvParams p)
         }
     };
     auto issue_B = [&](int it_i, int slot) {
-        const int cc = it_i / 9, tap = it_i - cc * 9;
+        const int cc = it_i / NTAP, tap = it_i - cc * NTAP;
         const f16 *base = p.wpk + ((size_t)(tap * nchunk + cc) * p.CoutPad + n0) * CT;
 #pragma unroll
         for (int k = 0; k < B_PIECES_PER_WAVE; ++k) {
@@ -114,6 +124,49 @@ __global__ __launch_bounds__(512) void conv3x3_glds_kernel(ConvParams p)
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
 
+    if constexpr (KS == 1) {
+        // 1x1: every iteration is a new 64-channel chunk (of src0, then of src1 = channel concat);
+        // activations and weights both ride 3-slot rings, issued two iterations ahead.
+        issue_A(0, 0);
+        issue_B(0, 0);
+        if (nit > 1) {
+            issue_A(1, 1);
+            issue_B(1, 1);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        int slot = 0;
+#pragma unroll 1
+        for (int it_i = 0; it_i < nit; ++it_i) {
+            const bool pf = it_i + 2 < nit;
+            const int s2 = slot == 0 ? 2 : slot - 1;          // (slot + 2) % 3
+            if (pf) { issue_A(it_i + 2, s2); issue_B(it_i + 2, s2); }
+            const char *a = sA + slot * A_BYTES;
+            const char *b = sB + slot * B_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < CT / 16; ++ks) {
+                const int chunk = ks * 2 + lh;
+                f16x8 wf[2], xf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    wf[i] = *reinterpret_cast<const f16x8 *>(b + wrow[i] * PIXB + ((chunk ^ swz64(wrow[i])) << 4));
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    xf[j] = *reinterpret_cast<const f16x8 *>(a + hp_base[j] * PIXB + ((chunk ^ swz64(hx_base[j])) << 4));
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+            }
+            if (pf) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // A(it+2): 4 pieces, B(it+2): 2 pieces
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+    } else {
     // ---- prologue: halo(0), weights(0), weights(1) -------------------------------------------
     issue_A(0, 0);
     issue_B(0, 0);
@@ -166,6 +219,8 @@ __global__ __launch_bounds__(512) void conv3x3_glds_kernel(ConvParams p)
             }
             __builtin_amdgcn_s_barrier();
         }
+    }
+
     }
 
     // ---------------------------------------------------------------- epilogue (LDS staged)
@@ -271,23 +326,26 @@ __global__ __launch_bounds__(512) void conv3x3_glds_kernel(ConvParams p)
 
 }  // namespace
 
-// 3x3, stride 1, Cin multiple of 64, CoutPad multiple of 128; store modes NHWC / PS / POOL without
-// residuals (what the HG head needs).  Returns hipErrorInvalidValue otherwise.
-hipError_t conv3x3_glds_launch(ConvParams p, hipStream_t stream)
+// KS x KS (3 or 1), stride 1, Cin (src0 [+ src1 concat]) multiple of 64, CoutPad multiple of 128; store modes
+// NHWC / PS / POOL / PS_DOT3 without residuals (what the HG head needs).  hipErrorInvalidValue otherwise.
+hipError_t conv_glds_launch(ConvParams p, int ks, hipStream_t stream)
 {
-    if ((p.c0 % CT) || (p.c1 % CT) || (p.CoutPad % BN) || p.res1 || p.res2 || p.dst_full || p.mode == ST_PLANAR3 || !p.zeros ||
-        (p.mode == ST_PS_DOT3 && (p.dstC != 64 || !p.dotw || !p.dst_dot)))
+    if ((ks != 1 && ks != 3) || (p.c0 % CT) || (p.c1 % CT) || (p.CoutPad % BN) || p.res1 || p.res2 || p.dst_full ||
+        p.mode == ST_PLANAR3 || !p.zeros || (p.mode == ST_PS_DOT3 && (p.dstC != 64 || !p.dotw || !p.dst_dot)))
         return hipErrorInvalidValue;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_glds_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_glds_kernel<3>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_glds_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     p.tiles_x = (p.Wo + TW - 1) / TW;
     p.tiles_y = (p.Ho + TH - 1) / TH;
     const int grid = p.tiles_x * p.tiles_y * (p.CoutPad / BN);
-    hipLaunchKernelGGL(conv3x3_glds_kernel, dim3(grid), dim3(512), SMEM, stream, p);
+    if (ks == 3) hipLaunchKernelGGL(conv_glds_kernel<3>, dim3(grid), dim3(512), SMEM, stream, p);
+    else hipLaunchKernelGGL(conv_glds_kernel<1>, dim3(grid), dim3(512), SMEM, stream, p);
     return hipGetLastError();
 }

@@ -199,6 +199,7 @@ bool pack_conv(hdrtv_ctx *c, const Pack &pk, const std::string &key, const std::
     ConvLayer L;
     L.cin = ci; L.cout = co; L.ks = ks; L.stride = stride;
     L.coutPad = (co + 31) / 32 * 32;
+    if (ks == 1 && stride == 1 && ci % 64 == 0 && ci >= 128 && co == 64) L.coutPad = 128;   // 1x1 64-out layers ride the 128-wide LDS-DMA kernel
     L.cin_t = force_ct ? force_ct : ((stride == 2 || ci == 32) ? 32 : 64);
     L.bn = L.coutPad >= 128 ? 128 : L.coutPad;
     if (force_ct) L.bn = L.coutPad;     // whole-Cout kernels (conv3x3s2_glds)
@@ -681,12 +682,12 @@ struct Seq {
         p.dotw = dotw; p.dst_dot = dst_dot;
         if (c0 + c1 != L.cin) { rc = fail(c, HDRTV_ESTATE, "conv %s: channel mismatch", key.c_str()); return; }
         p.zeros = wtp<f16>(c, c->zeros_off);
-        const bool glds = L.ks == 3 && L.stride == 1 && L.cin_t == 64 && L.bn == 128 && !res1 && !res2 && !dst_full &&
+        const bool glds = (L.ks == 3 || L.ks == 1) && L.stride == 1 && L.cin_t == 64 && L.bn == 128 && !res1 && !res2 && !dst_full &&
                           mode != ST_PLANAR3;
         const bool s2g = L.ks == 3 && L.stride == 2 && L.cin_t == 64 && L.bn == L.coutPad && (L.coutPad == 64 || L.coutPad == 192);
         char tag[64];
         if (s2g) snprintf(tag, sizeof tag, "conv3x3s2_glds<%d>", L.coutPad);
-        else if (glds) snprintf(tag, sizeof tag, "conv3x3_glds<64,128>");
+        else if (glds) snprintf(tag, sizeof tag, "conv_glds<%d,64,128>", L.ks);
         else snprintf(tag, sizeof tag, "conv_igemm<%d,%d,%d,%d>", L.cin_t, L.bn, L.ks, L.stride);
         const double macs = (double)p.Ho * p.Wo * L.cin * L.ks * L.ks * L.cout;
         double bytes = 2.0 * Hi * Wi * L.cin + 2.0 * L.ks * L.ks * L.cin * L.coutPad;
@@ -695,7 +696,7 @@ struct Seq {
                                                                     : (mode == ST_PS_DOT3 ? 8.0 * Hd * Wd : (double)p.Ho * p.Wo * L.cout));
         bytes += 2.0 * outel * (1 + (res1 ? 1 : 0) + (res2 ? 1 : 0) + (res_planar ? 1 : 0));
         chk(s2g ? conv3x3s2_glds_launch(p, s)
-                : (glds ? conv3x3_glds_launch(p, s) : conv_igemm_launch(p, L.cin_t, L.bn, L.ks, L.stride, s)),
+                : (glds ? conv_glds_launch(p, L.ks, s) : conv_igemm_launch(p, L.cin_t, L.bn, L.ks, L.stride, s)),
             key.c_str(), tag, macs, bytes);
     }
     void c3(const std::string &key, const f16 *in, int H, int W, int act, f16 *out, f16 *out_pool)
