@@ -197,8 +197,19 @@ def main():
         kern, (ms, macs, nbytes, n) = max(agg.items(), key=lambda kv: kv[1][0])
         avg_ms = ms / n
         tflops = 2.0 * macs / n / (avg_ms * 1e-3) / 1e12
+        # HBM bytes per launch of that kernel from the PMC counters: collected by rocprofv3 in separate
+        # --pmc passes of this same command (tools/pmc_pass.sh, tools/pmc_to_json.py) and committed
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))["kernels"]
+            key = {"conv_glds<3,64,128>": "conv_glds_kernel<3>", "conv_glds<1,64,128>": "conv_glds_kernel<1>"}.get(kern, kern)
+            if (H, Wd) == (2160, 3840) and use_hg and key in pmc:
+                traffic = pmc[key]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            traffic = None
         roof = {"kernel": kern, "bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(tflops / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(tflops / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": round(nbytes / n),
                 "launches_per_frame": n // nprof, "avg_launch_ms": round(avg_ms, 4),
                 "flop_per_launch": 2.0 * macs / n, "share_of_infer_time": round(ms / nprof / infer_ms, 3),
                 "infer_ms_profiled": round(infer_ms, 3)}

@@ -305,9 +305,20 @@ __global__ __launch_bounds__(256) void hg_final_fused_kernel(HgFinalFusedParams 
         for (int ks = 0; ks < 2; ++ks) w1[i][ks] = fr[(i * 2 + ks) * 64 + lane];
 #pragma unroll
     for (int s = 0; s < 4; ++s) w2[s] = fr[(4 + s) * 64 + lane];
-    f32x16 sc[2], sh[2];
+    // folded-BatchNorm scale/shift through LDS (kept out of registers: this kernel is latency-bound and
+    // lives on occupancy), and the per-pixel inputs of the tail prefetched before any arithmetic
+    __shared__ __attribute__((aligned(16))) float s_ss[128];
+    if (tid < 64) { s_ss[tid] = p.scale[tid]; s_ss[64 + tid] = p.shift[tid]; }
+    float4 pt_pre[2];
+    float m_pre[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { sc[i] = bias_tile_g(p.scale + 32 * i, lh); sh[i] = bias_tile_g(p.shift + 32 * i, lh); }
+    for (int j = 0; j < 2; ++j) {
+        const int y = oy0 + 2 * wave + j, x = ox0 + l31;
+        const bool ok = lh == 0 && y < p.H && x < p.W;
+        const size_t pix = ok ? (size_t)y * p.Wp + x : 0;
+        pt_pre[j] = *reinterpret_cast<const float4 *>(p.part + pix * 4);
+        m_pre[j] = (float)p.mask[pix];
+    }
     __syncthreads();
     const f16 *sflat = &s_in[0][0][0];
     const size_t plane_p = (size_t)p.Hp * p.Wp, plane_o = (size_t)p.H * p.W;
@@ -335,7 +346,14 @@ __global__ __launch_bounds__(256) void hg_final_fused_kernel(HgFinalFusedParams 
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) bf[2 * i + s][e] = (f16)fmaxf(h[8 * s + e] * sc[i][8 * s + e] + sh[i][8 * s + e], 0.f);
+                for (int g = 0; g < 2; ++g) {
+                    const float4 sc = *reinterpret_cast<const float4 *>(s_ss + 32 * i + 8 * (2 * s + g) + 4 * lh);
+                    const float4 sh = *reinterpret_cast<const float4 *>(s_ss + 64 + 32 * i + 8 * (2 * s + g) + 4 * lh);
+                    bf[2 * i + s][4 * g + 0] = (f16)fmaxf(h[8 * s + 4 * g + 0] * sc.x + sh.x, 0.f);
+                    bf[2 * i + s][4 * g + 1] = (f16)fmaxf(h[8 * s + 4 * g + 1] * sc.y + sh.y, 0.f);
+                    bf[2 * i + s][4 * g + 2] = (f16)fmaxf(h[8 * s + 4 * g + 2] * sc.z + sh.z, 0.f);
+                    bf[2 * i + s][4 * g + 3] = (f16)fmaxf(h[8 * s + 4 * g + 3] * sc.w + sh.w, 0.f);
+                }
         }
         f32x16 o;
 #pragma unroll
@@ -344,13 +362,12 @@ __global__ __launch_bounds__(256) void hg_final_fused_kernel(HgFinalFusedParams 
         for (int s = 0; s < 4; ++s) o = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[s], bf[s], o, 0, 0, 0);
         const int y = oy0 + row, x = ox0 + l31;
         if (lh == 0 && y < p.H && x < p.W) {
-            const size_t pix = (size_t)y * p.Wp + x;
-            const float4 pt = *reinterpret_cast<const float4 *>(p.part + pix * 4);
+            const float4 pt = pt_pre[j];
             const float c10[3] = {(float)(f16)(o[0] + pt.x + p.b10[0]), (float)(f16)(o[1] + pt.y + p.b10[1]),
                                   (float)(f16)(o[2] + pt.z + p.b10[2])};
             const int ctr = (row + 1) * (C3_HW + 2) + l31 + 1;
             const float im[3] = {(float)sflat[ctr], (float)sflat[C3_HH * (C3_HW + 2) + ctr], (float)sflat[2 * C3_HH * (C3_HW + 2) + ctr]};
-            const float m = (float)p.mask[pix];
+            const float m = m_pre[j];
             const size_t oo = (size_t)y * p.W + x;
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {

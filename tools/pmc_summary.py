@@ -8,7 +8,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     name = r["Kernel_Name"]
     if flt and flt not in name: continue
-    short = name.split("(")[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")[:44]
+    short = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    short = short.split("(")[0][:44]
     agg[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in sorted(agg.items(), key=lambda kv: -sum(kv[1].get("SQ_WAVE_CYCLES", [0]))):
     n = max(len(v) for v in d.values())
