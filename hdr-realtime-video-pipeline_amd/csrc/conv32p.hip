@@ -18,6 +18,8 @@
 //     the modulated tensor never exists in HBM (saves 128 B/pixel per SFT);
 //   * epilogue through LDS: fp32 scale/shift/activation, residual adds, PixelShuffle (one pass
 //     per sub-position for the 128-channel up-convs) or the planar 3-channel head.
+#include <cstdlib>
+
 #include "launchers.h"
 
 namespace {
@@ -25,11 +27,20 @@ namespace {
 // Halo tile: 18 x 18 pixels stored with an LDS row pitch of 20 pixels.  With 64-byte pixels the
 // pitch makes (pixel index mod 4) == (column mod 4), and the chunk swizzle (column >> 2) & 3 then
 // spreads every ds_read_b128 lane group of a fragment read over all 16 slots of the bank row.
-constexpr int TH = 16, TW = 16, HC = TW + 2, HW = 20, NPIX = (TH + 2) * HW;   // 360 slots, 324 real
-constexpr int A_PIECES = 24, A_BYTES = A_PIECES * 1024;   // 16 px x 64 B per piece, 3 per wave
-constexpr int C_PIECES = 16, C_BYTES = C_PIECES * 1024;   // 32 px x 32 B per piece, 2 per wave
+constexpr int TW = 16, HC = TW + 2, HW = 20;
 constexpr int OUT_ROWB = 64 + 16;
-constexpr int OUT_BYTES = TH * TW * OUT_ROWB;
+// NW waves per workgroup, each owning 2 tile rows of 16 pixels: NW = 8 -> 16x16 tile, one workgroup
+// per CU; NW = 4 -> 8x16 tile, 76 KiB of LDS, TWO independent workgroups per CU whose phases
+// (DMA wait, SFT, conv, store) interleave instead of running in lockstep.
+template <int NW> struct Til {
+    static constexpr int TH = 2 * NW, NT = 64 * NW;
+    static constexpr int NPIX = (TH + 2) * HW;                       // 360 / 200 slots (324 / 180 real)
+    static constexpr int A_PW = NW == 8 ? 3 : 4;                     // 1-KiB pieces (16 px x 64 B) per wave
+    static constexpr int C_PW = 2;                                   // 1-KiB pieces (32 px x 32 B) per wave
+    static constexpr int A_BYTES = NW * A_PW * 1024, C_BYTES = NW * C_PW * 1024;
+    static constexpr int OUT_BYTES = TH * TW * OUT_ROWB;
+    static_assert(NW * A_PW * 16 >= NPIX && NW * C_PW * 32 >= NPIX, "halo buffers must hold the tile");
+};
 
 __device__ __forceinline__ int swz32(int row) { return (row >> 2) & 3; }   // weight rows: by row; halo: by column
 
@@ -50,8 +61,9 @@ __device__ __forceinline__ f32x16 tile16(const float *b, int lh)
     return a;
 }
 
-template <int NPASS, bool SFT>
+template <int NPASS, bool SFT, int NW>
 struct Lay {
+    static constexpr int A_BYTES = Til<NW>::A_BYTES, C_BYTES = Til<NW>::C_BYTES, OUT_BYTES = Til<NW>::OUT_BYTES;
     static constexpr int COUTP = 32 * NPASS;
     static constexpr int W_BYTES = 9 * COUTP * 64;
     static constexpr int SS_BYTES = COUTP * 8;
@@ -62,10 +74,12 @@ struct Lay {
     static constexpr int SMEM = OFF_OUT + OUT_BYTES;
 };
 
-template <int NPASS, bool SFT>
-__global__ __launch_bounds__(512) void conv32p_kernel(Conv32Params p)
+template <int NPASS, bool SFT, int NW>
+__global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
 {
-    using L = Lay<NPASS, SFT>;
+    using L = Lay<NPASS, SFT, NW>;
+    using T = Til<NW>;
+    constexpr int TH = T::TH, NT = T::NT, NPIX = T::NPIX, A_BYTES = T::A_BYTES, C_BYTES = T::C_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *sW = smem;
     float *sSS = reinterpret_cast<float *>(smem + L::OFF_SS);
@@ -82,8 +96,8 @@ __global__ __launch_bounds__(512) void conv32p_kernel(Conv32Params p)
         const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
         const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
 #pragma unroll
-        for (int it = 0; it < 3; ++it) {
-            const int piece = wave + it * 8;
+        for (int it = 0; it < T::A_PW; ++it) {
+            const int piece = wave + it * NW;
             const int hp = piece * 16 + (lane >> 2), slot = lane & 3;
             const int hy = hp / HW, hx = hp - hy * HW;
             const int iy = iy0 + hy, ix = ix0 + hx;
@@ -93,8 +107,8 @@ __global__ __launch_bounds__(512) void conv32p_kernel(Conv32Params p)
         }
         if (SFT) {
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int piece = wave + it * 8;
+            for (int it = 0; it < T::C_PW; ++it) {
+                const int piece = wave + it * NW;
                 const int hp = piece * 32 + (lane >> 1), half = lane & 1;
                 const int hy = hp / HW, hx = hp - hy * HW;
                 const int iy = iy0 + hy, ix = ix0 + hx;
@@ -106,12 +120,12 @@ __global__ __launch_bounds__(512) void conv32p_kernel(Conv32Params p)
     };
 
     // ---- once per workgroup: the whole weight set and the per-channel scale/shift into LDS
-    for (int piece = wave; piece < 9 * L::COUTP / 16; piece += 8) {
+    for (int piece = wave; piece < 9 * L::COUTP / 16; piece += NW) {
         const int r = piece * 16 + (lane >> 2), slot = lane & 3;     // r = tap*COUTP + n
         const int n = r % L::COUTP;
         glds16(p.wpk + (size_t)r * 32 + ((slot ^ swz32(n)) << 3), sW + piece * 1024);
     }
-    for (int e = tid; e < L::COUTP; e += 512) {
+    for (int e = tid; e < L::COUTP; e += NT) {
         sSS[e] = p.scale[e];
         sSS[L::COUTP + e] = p.shift[e];
     }
@@ -128,7 +142,7 @@ __global__ __launch_bounds__(512) void conv32p_kernel(Conv32Params p)
         const int oy0 = ty * TH, ox0 = tx * TW;
         char *a = sA + buf * A_BYTES;
         const char *cbuf = sC + buf * C_BYTES;
-        for (int g = wave; g < (NPIX + 31) / 32; g += 8) {
+        for (int g = wave; g < (NPIX + 31) / 32; g += NW) {
             const int hp = g * 32 + l31;
             const int hy = hp / HW, hx = hp - hy * HW;
             const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
@@ -190,7 +204,7 @@ __global__ __launch_bounds__(512) void conv32p_kernel(Conv32Params p)
             for (int pass = 0; pass < NPASS; ++pass)
 #pragma unroll
                 for (int it = 0; it < 2; ++it) {
-                    const int qq = (tid + it * 512) >> 2, c8 = tid & 3;
+                    const int qq = (tid + it * NT) >> 2, c8 = tid & 3;
                     const int oy = oy0 + qq / TW, ox = ox0 + qq % TW;
                     long off = -1;
                     if (oy < p.H && ox < p.W && c8 * 8 < p.Cout) {
@@ -245,7 +259,7 @@ __global__ __launch_bounds__(512) void conv32p_kernel(Conv32Params p)
             if (pass == NPASS - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (p.mode == ST_PLANAR3) {
-                for (int e = tid; e < TH * TW * 3; e += 512) {
+                for (int e = tid; e < TH * TW * 3; e += NT) {
                     const int ch = e / (TH * TW), qq = e % (TH * TW);
                     const int oy = oy0 + qq / TW, ox = ox0 + qq % TW;
                     if (oy < p.H && ox < p.W) {
@@ -258,7 +272,7 @@ __global__ __launch_bounds__(512) void conv32p_kernel(Conv32Params p)
             } else {
 #pragma unroll
                 for (int it = 0; it < 2; ++it) {
-                    const int qq = (tid + it * 512) >> 2, c8 = tid & 3;
+                    const int qq = (tid + it * NT) >> 2, c8 = tid & 3;
                     f16x8 v = *reinterpret_cast<const f16x8 *>(sO + qq * OUT_ROWB + c8 * 16);
                     const f16x8 r1 = rs1[pass][it], r2 = rs2[pass][it];
 #pragma unroll
@@ -277,20 +291,21 @@ __global__ __launch_bounds__(512) void conv32p_kernel(Conv32Params p)
     }
 }
 
-template <int NPASS, bool SFT>
+template <int NPASS, bool SFT, int NW>
 hipError_t launch_t(const Conv32Params &p, hipStream_t s)
 {
-    using L = Lay<NPASS, SFT>;
+    using L = Lay<NPASS, SFT, NW>;
     static bool attr_set = false;
-    auto kern = conv32p_kernel<NPASS, SFT>;
+    auto kern = conv32p_kernel<NPASS, SFT, NW>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L::SMEM);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int ntiles = p.tiles_x * p.tiles_y;
-    const int grid = ntiles < 256 ? ntiles : 256;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), L::SMEM, s, p);
+    const int cap = 256 * (160 * 1024 / L::SMEM);          // persistent: as many workgroups as fit the chip
+    const int grid = ntiles < cap ? ntiles : cap;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), L::SMEM, s, p);
     return hipGetLastError();
 }
 
@@ -298,10 +313,20 @@ hipError_t launch_t(const Conv32Params &p, hipStream_t s)
 
 hipError_t conv32p_launch(Conv32Params p, hipStream_t s)
 {
-    p.tiles_x = (p.W + TW - 1) / TW;
-    p.tiles_y = (p.H + TH - 1) / TH;
+    static int nw = 0;
+    if (!nw) {
+        const char *e = getenv("HDRTV_CONV32_NW");      // developer A/B switch: 8 = 16x16 tile, 4 = 8x16 tile x 2 workgroups/CU
+        nw = (e && atoi(e) == 8) ? 8 : 4;
+    }
     const bool sft = p.cond != nullptr;
-    if (p.CoutPad == 32) return sft ? launch_t<1, true>(p, s) : launch_t<1, false>(p, s);
-    if (p.CoutPad == 128 && !sft) return launch_t<4, false>(p, s);
+    p.tiles_x = (p.W + TW - 1) / TW;
+    if (nw == 8 || p.CoutPad == 128) {                   // the 72 KiB weight set of the up-convs leaves room for one workgroup only
+        p.tiles_y = (p.H + 15) / 16;
+        if (p.CoutPad == 32) return sft ? launch_t<1, true, 8>(p, s) : launch_t<1, false, 8>(p, s);
+        if (p.CoutPad == 128 && !sft) return launch_t<4, false, 8>(p, s);
+        return hipErrorInvalidValue;
+    }
+    p.tiles_y = (p.H + 7) / 8;
+    if (p.CoutPad == 32) return sft ? launch_t<1, true, 4>(p, s) : launch_t<1, false, 4>(p, s);
     return hipErrorInvalidValue;
 }
