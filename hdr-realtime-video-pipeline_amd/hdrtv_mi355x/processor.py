@@ -79,6 +79,19 @@ class HDRTVNetMI355X:
         self._ctx = C.c_void_p()
 
         hr_state = _load_state(model_path, "model weights")
+        if self.precision.startswith("int8"):
+            # hdrtvnet_torch.py:1748-1963: an INT8 runtime checkpoint.  On ROCm the reference
+            # pre-dequantizes it to native fp16 convs at load time ("auto", 1893-1899): INT8 is
+            # compressed storage, compute is fp16 -- exactly what is done here.
+            if not _W.is_int8_state(hr_state):
+                raise ValueError(f"precision '{self.precision}' needs an INT8 checkpoint (weight_int8 tensors)")
+            if str(predequantize).lower() in ("off", "false", "0", "no"):
+                raise ValueError("predequantize='off' (fake-quant activations / native int8 MFMA) is not implemented "
+                                 "by the MI355X backend yet; use 'auto'")
+            hr_state = _W.dequantize_int8_state(hr_state, "fp16")
+            self._is_w8_model = False          # as the reference after pre-dequantization (1919)
+        elif _W.is_int8_state(hr_state):
+            raise ValueError("INT8 checkpoint given with a floating-point precision; use precision='int8-full'/'int8-mixed'")
         try:
             _W.check_hr_state(hr_state)
         except ValueError as exc:
@@ -135,7 +148,9 @@ class HDRTVNetMI355X:
             raise ValueError("precision must be one of: auto, fp16, fp32, int8-full, int8-mixed")
         if p in ("auto", "fp16"):
             return "fp16"
-        raise ValueError(f"precision '{p}' is not implemented by the MI355X backend yet (fp16 only)")
+        if p in ("int8-full", "int8-mixed"):
+            return p          # INT8 storage, fp16 compute (the reference's own ROCm behaviour)
+        raise ValueError("precision 'fp32' is not implemented by the MI355X backend (fp16 compute only)")
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

@@ -106,6 +106,36 @@ def check_hr_state(state) -> None:
             raise ValueError(f"bad shape for {k}: {tuple(state[k].shape)} != {shp}")
 
 
+def is_int8_state(state) -> bool:
+    return any(k.endswith(".weight_int8") for k in state)
+
+
+def dequantize_int8_state(state, compute: str = "fp16") -> "OrderedDict[str, np.ndarray]":
+    """INT8 runtime checkpoint (W8Conv2d / W8A8Conv2d / W8Linear / W8A8Linear state,
+    hdrtvnet_torch.py:233-410) -> plain ``<layer>.weight`` / ``<layer>.bias`` tensors, the way the
+    reference itself runs these checkpoints on ROCm: ``predequantize="auto"`` replaces every
+    quantised layer by a native conv with ``w = weight_int8.to(cd) * scale`` and DROPS the
+    activation fake-quant (``_predequantize_conv`` 444-462, auto rule 1893-1899).  ``compute``
+    is the dtype of that product: "fp16" on a GPU, "fp32" on CPU (1766-1773)."""
+    cd = np.float16 if compute == "fp16" else np.float32
+    out = OrderedDict()
+    for k, v in state.items():
+        a = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+        if k.endswith(".weight_int8"):
+            base = k[: -len(".weight_int8")]
+            sc = state.get(base + ".w_scale", state.get(base + ".scale"))
+            if sc is None:
+                raise ValueError(f"INT8 checkpoint has no scale for {base}")
+            sc = sc.detach().cpu().numpy() if hasattr(sc, "detach") else np.asarray(sc)
+            shape = (-1,) + (1,) * (a.ndim - 1)
+            out[base + ".weight"] = (a.astype(cd) * sc.astype(cd).reshape(shape)).astype(cd).astype(np.float32)
+        elif k.endswith((".w_scale", ".scale", ".x_scale", ".x_zero")):
+            continue
+        else:
+            out[k] = a.astype(np.float32)
+    return out
+
+
 def seeded_hg_state(seed: int = 1234) -> "OrderedDict[str, np.ndarray]":
     """Deterministic stand-in for the absent HG.pt (keys as Hallucination_Generator's).
 

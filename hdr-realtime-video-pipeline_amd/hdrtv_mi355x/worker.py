@@ -32,6 +32,10 @@ _RING_FRAMES = max(2, min(8, int(os.environ.get("HDRTVNET_FEEDER_GPU_RGB48_RING_
 PRECISIONS = {
     "FP16": {"precision": "fp16", "model": "original/HR.pt", "model_nohg": "original/HR.pt",
              "hg_weights": "original/HG.pt"},
+    "INT8 Full (QAT)": {"precision": "int8-full", "model": "original/pytorch_int8/hg/HR_HG_original_int8_full_qat.pt",
+                        "model_nohg": "original/pytorch_int8/hr/HR_original_int8_full_qat.pt"},
+    "INT8 Mixed (QAT)": {"precision": "int8-mixed", "model": "original/pytorch_int8/hg/HR_HG_original_int8_mixed_qat.pt",
+                         "model_nohg": "original/pytorch_int8/hr/HR_original_int8_mixed_qat.pt"},
 }
 
 

@@ -153,6 +153,17 @@ def main():
                 r.pop(k)
         np.savez_compressed(os.path.join(OUT, f"hg_{h}x{w}_gradient_s{seed}.npz"), **r)
 
+    # -- INT8 runtime checkpoints (config 5 storage format): the reference pre-dequantizes them on ROCm
+    # builds of torch ("auto", hdrtvnet_torch.py:1893-1899; this container's torch is one) -------------
+    for tag, prec in (("full_qat", "int8-full"), ("mixed_qat", "int8-mixed")):
+        ipath = os.path.join(REF, f"src/models/weights/original/pytorch_int8/hr/HR_original_int8_{tag}.pt")
+        ck = torch.load(ipath, map_location="cpu", weights_only=True)
+        W.save_pack(os.path.join(OUT, f"hr_int8_{tag}.hdrw"), ck["state_dict"])       # int8 + f16 tensors as shipped
+        pi = HDRTVNetTorch(ipath, device="cpu", precision=prec, compile_model=False, use_hg=False, warmup_passes=0)
+        assert not pi._is_w8_model, "expected the reference to pre-dequantize on a ROCm torch build"
+        f = W.synthetic_frame(64, 96, seed=6, kind="gradient")
+        np.savez_compressed(os.path.join(OUT, f"int8_{tag}_64x96_gradient_s6.npz"), **run_case(pi, f))
+
     # -- scalar known-answer tables ---------------------------------------------
     u8 = np.arange(256, dtype=np.uint8)
     pre32 = torch.from_numpy(u8).to(torch.float32).mul_(1.0 / 255.0).numpy()

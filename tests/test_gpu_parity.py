@@ -267,3 +267,26 @@ def test_process_api_and_errors(proc_hr, golden_dir, torch_cuda):
         HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), device="cpu")
     with pytest.raises(Exception):
         proc_hr.process(np.zeros((16, 16, 3), np.uint8))        # too small for the classifier's InstanceNorm
+
+
+@pytest.mark.parametrize("tag,prec", [("full_qat", "int8-full"), ("mixed_qat", "int8-mixed")])
+def test_int8_checkpoint_storage(golden_dir, torch_cuda, tag, prec):
+    """precision='int8-*': INT8 storage, fp16 compute -- the reference's own behaviour on ROCm
+    (pre-dequantize at load).  Bars: the fp16 tolerances above (its quantised-graph bar is u8 MAE <= 5)."""
+    from hdrtv_mi355x.processor import HDRTVNetMI355X
+    p = HDRTVNetMI355X(os.path.join(golden_dir, f"hr_int8_{tag}.hdrw"), precision=prec, use_hg=False, warmup_passes=0)
+    try:
+        assert p.precision == prec and p._is_w8_model is False
+        d = np.load(os.path.join(golden_dir, f"int8_{tag}_64x96_gradient_s6.npz"))
+        t, c = p.preprocess(d["frame"])
+        out, agcm = p.infer((t, c))
+        mx, mean = _stats(f"int8 {tag} out", out.float().cpu().numpy()[0], d["out"])
+        assert mx <= OUT_MAX and mean <= OUT_MEAN
+        du8 = np.abs(p.postprocess(out).astype(int) - d["u8_bgr"].astype(int))
+        assert du8.max() <= U8_MAX and du8.mean() <= U8_MEAN
+        with pytest.raises(ValueError):
+            HDRTVNetMI355X(os.path.join(golden_dir, f"hr_int8_{tag}.hdrw"), precision="fp16", use_hg=False)
+        with pytest.raises(ValueError):
+            HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), precision=prec, use_hg=False)
+    finally:
+        p.close()

@@ -111,3 +111,24 @@ def test_gamut_known_answers():
     assert np.allclose(O.gamut709_2020(r).ravel(), [0.6274, 0.0691, 0.0164], atol=1e-7)
     img = np.array([1.0, 1.0, 1.0], np.float32).reshape(3, 1, 1)
     assert O.post_pq_rgb48(img, 1000.0).ravel().tolist() == [49271, 49271, 49271]
+
+
+@pytest.mark.parametrize("tag", ["full_qat", "mixed_qat"])
+def test_int8_checkpoints_predequantized(golden_dir, tag):
+    """INT8 runtime checkpoints (BASELINE.json configs[4] storage format).  The reference, on a ROCm
+    torch build, pre-dequantizes them at load (hdrtvnet_torch.py:1893-1899, 444-476): weights
+    int8*scale in the compute dtype, activation fake-quant dropped.  weights.dequantize_int8_state
+    restates that; the oracle on its fp32 result must match the reference's CPU output."""
+    from hdrtv_mi355x import weights as W
+    st = W.load_pack(os.path.join(golden_dir, f"hr_int8_{tag}.hdrw"))
+    assert W.is_int8_state(st) and st["LE.down_conv1.weight_int8"].dtype == np.int8
+    deq = W.dequantize_int8_state(st, "fp32")
+    W.check_hr_state(deq)
+    d = _load(golden_dir, f"int8_{tag}_64x96_gradient_s6.npz")
+    out, a = O.hr_forward(deq, d["tensor"], d["cond"])
+    assert np.abs(a - d["agcm_out"]).max() <= TOL
+    assert np.abs(out - d["out"]).max() <= TOL
+    # the fp16 product the GPU path uses differs from the fp32 one by at most one fp16 rounding
+    d16 = W.dequantize_int8_state(st, "fp16")
+    k = "LE.down_conv1.weight"
+    assert np.abs(d16[k] - deq[k]).max() <= np.abs(deq[k]).max() * 2 ** -10
