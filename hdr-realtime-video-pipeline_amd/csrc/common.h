@@ -23,6 +23,10 @@ __device__ __forceinline__ float act_apply(float v, int act)
     if (act == ACT_LRELU01) return v >= 0.f ? v : v * 0.1f;
     return v;
 }
+// Branch-free form for hot epilogues: act(v) = max(v, slope*v) with slope = 1 (none), 0 (ReLU),
+// 0.1 (LeakyReLU 0.1).  A runtime `act` switch per element costs two scalar branches each.
+__host__ __device__ __forceinline__ float act_slope(int act) { return act == ACT_RELU ? 0.f : (act == ACT_LRELU01 ? 0.1f : 1.f); }
+__device__ __forceinline__ float act_fast(float v, float slope) { return fmaxf(v, slope * v); }
 
 // K-dimension permutation that lets a 32x32 MFMA accumulator tile be re-used, packed to f16,
 // as the B operand of the next MFMA (cdna_hip_programming.md section 3, "An accumulator tile as

@@ -5,36 +5,54 @@
 // HR_conv2, ResBlock_with_SFT's sft1 -> conv1 and sft2 -> conv2; HDRUNet3T1_arch.py:168-200,
 // arch_util.py:60-95), the three up-convs (3x3 32->128 + PixelShuffle + ReLU + skip) and conv_last.
 //
-// These layers are HBM-bound (32 channels: 64 B per pixel in, 64 B out, 288 MAC per output
-// channel), so the kernel is organised around bytes, not MFMA rate:
-//   * one persistent workgroup per CU (8 waves) walks 16x16-pixel tiles; the layer's whole weight
-//     set (18 KiB for 32->32, 72 KiB for 32->128) is staged into LDS ONCE per workgroup;
+// These layers are HBM-bound on paper (32 channels: 64 B per pixel in, 64 B out, 288 MAC per output
+// channel) and were instruction-issue-bound in practice (PMC + ISA count: ~1100 VALU and ~800 SALU
+// instructions per tile and wave against 24 MFMAs), so the kernel is organised around bytes AND
+// around not recomputing lane constants:
+//   * persistent workgroups walk pixel tiles; the layer's whole weight set (18 KiB for 32->32,
+//     72 KiB for 32->128) is staged into LDS ONCE per workgroup;
 //   * the activation halo tile (and the 16-channel condition halo tile when SFT is fused) of tile
-//     t+1 is in flight by LDS-DMA (global_load_lds_dwordx4, swizzle on the source address) while
-//     tile t is transformed, convolved and stored: double-buffered, no VGPR staging;
+//     t+2 is put in flight by LDS-DMA (global_load_lds_dwordx4, swizzle on the source address) while
+//     tile t is convolved and tile t+1 is SFT-transformed: double-buffered, no VGPR staging; every
+//     per-lane halo coordinate, source offset and LDS address is computed once per workgroup, a tile
+//     costs one scalar base plus two unsigned compares per DMA piece;
 //   * fused SFT: the two 16->16->32 1x1 MLPs run as three MFMAs per 32 halo pixels on the
-//     condition tile, and x*(scale+1)+shift rewrites the activation tile IN PLACE in LDS before
-//     the conv reads it (out-of-image halo pixels are forced to 0 = the conv's zero padding), so
-//     the modulated tensor never exists in HBM (saves 128 B/pixel per SFT);
+//     condition tile, LeakyReLU / modulation in packed f16 (the reference's fp16 model computes them
+//     in f16 too), and x*(scale+1)+shift rewrites the activation tile IN PLACE in LDS before the
+//     conv reads it (out-of-image halo pixels are forced to 0 = the conv's zero padding), so the
+//     modulated tensor never exists in HBM (saves 128 B/pixel per SFT);
+//   * LDS halo rows have a pitch of 20 pixels of 64 B: (pixel mod 4) == (column mod 4) and the
+//     chunk swizzle (column >> 2) & 3 make every ds_read_b128 fragment read conflict-free;
+//     fragment addresses are base ^ (k-step << 5) plus immediates for kernel row and tap;
 //   * epilogue through LDS: fp32 scale/shift/activation, residual adds, PixelShuffle (one pass
 //     per sub-position for the 128-channel up-convs) or the planar 3-channel head.
+// Out-of-image DMA lanes read the zeroed guard that the workspace keeps behind every tensor
+// (hdrtv_api.hip ws_add), so one scalar base + a 32-bit lane offset addresses every piece.
 #include <cstdlib>
 
 #include "launchers.h"
 
 namespace {
 
-// Halo tile: 18 x 18 pixels stored with an LDS row pitch of 20 pixels.  With 64-byte pixels the
-// pitch makes (pixel index mod 4) == (column mod 4), and the chunk swizzle (column >> 2) & 3 then
-// spreads every ds_read_b128 lane group of a fragment read over all 16 slots of the bank row.
+// Diagnostic build only (make STAMP=1): per-phase s_memtime sums, written by lane 0 of every wave to
+// p.dump[(block*NW + wave)*8 + phase] as cycles.  Never compiled into the shipped library.
+#ifdef HDRTV_STAMP
+#define STAMP_DECL unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define STAMP(i) do { const unsigned long long st_t1 = __builtin_amdgcn_s_memtime(); st_acc[i] += st_t1 - st_t0; st_t0 = st_t1; } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#endif
+
 constexpr int TW = 16, HC = TW + 2, HW = 20;
 constexpr int OUT_ROWB = 64 + 16;
 // NW waves per workgroup, each owning 2 tile rows of 16 pixels: NW = 8 -> 16x16 tile, one workgroup
-// per CU; NW = 4 -> 8x16 tile, 76 KiB of LDS, TWO independent workgroups per CU whose phases
-// (DMA wait, SFT, conv, store) interleave instead of running in lockstep.
+// per CU; NW = 4 -> 8x16 tile, 76 KiB of LDS, two independent workgroups per CU.
 template <int NW> struct Til {
     static constexpr int TH = 2 * NW, NT = 64 * NW;
     static constexpr int NPIX = (TH + 2) * HW;                       // 360 / 200 slots (324 / 180 real)
+    static constexpr int NG = (NPIX + 31) / 32;                      // 32-pixel SFT groups per tile
+    static constexpr int G_PW = (NG + NW - 1) / NW;
     static constexpr int A_PW = NW == 8 ? 3 : 4;                     // 1-KiB pieces (16 px x 64 B) per wave
     static constexpr int C_PW = 2;                                   // 1-KiB pieces (32 px x 32 B) per wave
     static constexpr int A_BYTES = NW * A_PW * 1024, C_BYTES = NW * C_PW * 1024;
@@ -42,7 +60,7 @@ template <int NW> struct Til {
     static_assert(NW * A_PW * 16 >= NPIX && NW * C_PW * 32 >= NPIX, "halo buffers must hold the tile");
 };
 
-__device__ __forceinline__ int swz32(int row) { return (row >> 2) & 3; }   // weight rows: by row; halo: by column
+__device__ __forceinline__ int swz32(int v) { return (v >> 2) & 3; }   // weight rows: by row; halo: by column
 
 __device__ __forceinline__ void glds16(const void *g, void *lds)
 {
@@ -59,6 +77,15 @@ __device__ __forceinline__ f32x16 tile16(const float *b, int lh)
         a[4 * g + 0] = v.x; a[4 * g + 1] = v.y; a[4 * g + 2] = v.z; a[4 * g + 3] = v.w;
     }
     return a;
+}
+
+// LeakyReLU(0.1) on accumulator registers 8s..8s+7, in packed f16 -> next MFMA's B fragment
+__device__ __forceinline__ f16x8 lrelu_pack16(const f32x16 &a, int s)
+{
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (f16)a[8 * s + j];
+    return __builtin_elementwise_max(o, o * (f16)0.1f);
 }
 
 template <int NPASS, bool SFT, int NW>
@@ -91,30 +118,44 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
     const int ntiles = p.tiles_x * p.tiles_y;
+    const unsigned uH = (unsigned)p.H, uW = (unsigned)p.W;
+    const unsigned src_guard = (unsigned)p.H * p.W * 64u;     // byte offset of the zero guard behind src (32 ch f16)
+    const unsigned cond_guard = (unsigned)p.H * p.W * 32u;    // ... behind cond (16 ch f16)
 
+    // ---- lane constants of the LDS-DMA pieces: halo row/column and byte offset from the halo origin
+    int a_pos[T::A_PW], a_off[T::A_PW], c_pos[T::C_PW], c_off[T::C_PW];
+#pragma unroll
+    for (int it = 0; it < T::A_PW; ++it) {
+        const int hp = (wave + it * NW) * 16 + (lane >> 2), slot = lane & 3;
+        const int hy = hp / HW, hx = hp - hy * HW;
+        a_pos[it] = (hp < NPIX && hx < HC) ? (hy | (hx << 8)) : -1;
+        a_off[it] = (hy * p.W + hx) * 64 + ((slot ^ swz32(hx)) << 4);
+    }
+    if (SFT) {
+#pragma unroll
+        for (int it = 0; it < T::C_PW; ++it) {
+            const int hp = (wave + it * NW) * 32 + (lane >> 1), half = lane & 1;
+            const int hy = hp / HW, hx = hp - hy * HW;
+            c_pos[it] = (hp < NPIX && hx < HC) ? (hy | (hx << 8)) : -1;
+            c_off[it] = (hy * p.W + hx) * 32 + (half << 4);
+        }
+    }
     auto issue_tile = [&](int t, int buf) {
         const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
         const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
+        const int pix0 = iy0 * p.W + ix0;                      // may be negative; valid lanes land >= 0
 #pragma unroll
         for (int it = 0; it < T::A_PW; ++it) {
-            const int piece = wave + it * NW;
-            const int hp = piece * 16 + (lane >> 2), slot = lane & 3;
-            const int hy = hp / HW, hx = hp - hy * HW;
-            const int iy = iy0 + hy, ix = ix0 + hx;
-            const bool ok = hp < NPIX && hx < HC && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            const f16 *g = ok ? p.src + ((size_t)iy * p.W + ix) * 32 + ((slot ^ swz32(hx)) << 3) : p.zeros + (slot << 3);
-            glds16(g, sA + buf * A_BYTES + piece * 1024);
+            const bool ok = a_pos[it] >= 0 && (unsigned)(iy0 + (a_pos[it] & 255)) < uH && (unsigned)(ix0 + (a_pos[it] >> 8)) < uW;
+            const unsigned off = ok ? (unsigned)(pix0 * 64 + a_off[it]) : src_guard + ((lane & 3) << 4);
+            glds16(reinterpret_cast<const char *>(p.src) + off, sA + buf * A_BYTES + (wave + it * NW) * 1024);
         }
         if (SFT) {
 #pragma unroll
             for (int it = 0; it < T::C_PW; ++it) {
-                const int piece = wave + it * NW;
-                const int hp = piece * 32 + (lane >> 1), half = lane & 1;
-                const int hy = hp / HW, hx = hp - hy * HW;
-                const int iy = iy0 + hy, ix = ix0 + hx;
-                const bool ok = hp < NPIX && hx < HC && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-                const f16 *g = ok ? p.cond + ((size_t)iy * p.W + ix) * 16 + (half << 3) : p.zeros + (half << 3);
-                glds16(g, sC + buf * C_BYTES + piece * 1024);
+                const bool ok = c_pos[it] >= 0 && (unsigned)(iy0 + (c_pos[it] & 255)) < uH && (unsigned)(ix0 + (c_pos[it] >> 8)) < uW;
+                const unsigned off = ok ? (unsigned)(pix0 * 32 + c_off[it]) : cond_guard + ((lane & 1) << 4);
+                glds16(reinterpret_cast<const char *>(p.cond) + off, sC + buf * C_BYTES + (wave + it * NW) * 1024);
             }
         }
     };
@@ -129,46 +170,54 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
         sSS[e] = p.scale[e];
         sSS[L::COUTP + e] = p.shift[e];
     }
+
+    // ---- SFT: lane constants of this wave's 32-pixel groups, fragments and biases
     f16x8 sa0, sa1s, sa1t;
     f32x16 sbh, sbs, sbt;
+    int g_pos[T::G_PW], g_c[T::G_PW], g_x[T::G_PW];
     if (SFT) {
         const f16x8 *fr = reinterpret_cast<const f16x8 *>(p.sft_wfrag);
         sa0 = fr[lane]; sa1s = fr[64 + lane]; sa1t = fr[128 + lane];
         sbh = tile16(p.sft_bias, lh); sbs = tile16(p.sft_bias + 32, lh); sbt = tile16(p.sft_bias + 64, lh);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sbs[k] += 1.f;            // (scale + 1) enters through the accumulator init
+#pragma unroll
+        for (int gi = 0; gi < T::G_PW; ++gi) {
+            const int hp = (wave + gi * NW) * 32 + l31;
+            const int hy = hp / HW, hx = hp - hy * HW;
+            g_pos[gi] = (hp < NPIX && hx < HC) ? (hy | (hx << 8)) : -1;
+            g_c[gi] = hp * 32 + lh * 16;
+            g_x[gi] = hp * 64 + (swz32(hx) << 4) + 8 * lh;      // channel quad qd lives at g_x ^ (qd << 4)
+        }
     }
     // y = x*(scale+1)+shift in place on a landed halo tile (arch_util.py:68-72)
     auto sft_tile = [&](int tt, int buf) {
         const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
-        const int oy0 = ty * TH, ox0 = tx * TW;
+        const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
         char *a = sA + buf * A_BYTES;
         const char *cbuf = sC + buf * C_BYTES;
-        for (int g = wave; g < (NPIX + 31) / 32; g += NW) {
-            const int hp = g * 32 + l31;
-            const int hy = hp / HW, hx = hp - hy * HW;
-            const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-            const bool inimg = hp < NPIX && hx < HC && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            const f16x8 cf = *reinterpret_cast<const f16x8 *>(cbuf + hp * 32 + lh * 16);
-            const f32x16 h = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa0, cf, sbh, 0, 0, 0);
-            f16x8 hs, ht;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float u = h[j], v = h[8 + j];
-                hs[j] = (f16)fmaxf(u, 0.1f * u);
-                ht[j] = (f16)fmaxf(v, 0.1f * v);
-            }
-            const f32x16 sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa1s, hs, sbs, 0, 0, 0);
-            const f32x16 sh = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa1t, ht, sbt, 0, 0, 0);
-            if (hp < NPIX) {
-                // f16 arithmetic like the reference's fp16 model (x*(scale+1)+shift), 4 channels per op
-                const f16 keep = inimg ? (f16)1.f : (f16)0.f;
+        for (int gi = 0; gi < T::G_PW; ++gi) {
+            if (wave + gi * NW < T::NG) {                      // wave-uniform
+                const bool inimg = g_pos[gi] >= 0 && (unsigned)(iy0 + (g_pos[gi] & 255)) < uH &&
+                                   (unsigned)(ix0 + (g_pos[gi] >> 8)) < uW;
+                const f16x8 cf = *reinterpret_cast<const f16x8 *>(cbuf + g_c[gi]);
+                const f32x16 h = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa0, cf, sbh, 0, 0, 0);
+                const f16x8 hs = lrelu_pack16(h, 0), ht = lrelu_pack16(h, 1);
+                const f32x16 sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa1s, hs, sbs, 0, 0, 0);
+                const f32x16 sh = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa1t, ht, sbt, 0, 0, 0);
+                if (g_pos[gi] >= 0) {
 #pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                    char *addr = a + hp * 64 + ((qd ^ swz32(hx)) << 4) + 8 * lh;
-                    const f16x4 xv = *reinterpret_cast<const f16x4 *>(addr);
-                    f16x4 s1, s0;
+                    for (int qd = 0; qd < 4; ++qd) {
+                        char *addr = a + (g_x[gi] ^ (qd << 4));
+                        const f16x4 xv = *reinterpret_cast<const f16x4 *>(addr);
+                        f16x4 s1, s0;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) { s1[k] = (f16)(sc[4 * qd + k] + 1.f); s0[k] = (f16)sh[4 * qd + k]; }
-                    *reinterpret_cast<f16x4 *>(addr) = (xv * s1 + s0) * keep;
+                        for (int k = 0; k < 4; ++k) { s1[k] = (f16)sc[4 * qd + k]; s0[k] = (f16)sh[4 * qd + k]; }
+                        f16x4 y = xv * s1 + s0;
+                        if (!inimg) { y[0] = (f16)0.f; y[1] = (f16)0.f; y[2] = (f16)0.f; y[3] = (f16)0.f; }
+                        *reinterpret_cast<f16x4 *>(addr) = y;
+                    }
                 }
             }
         }
@@ -184,36 +233,48 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
     if (t + step < ntiles) issue_tile(t + step, 1);
     __syncthreads();
 
+    // ---- conv fragment addresses (lane constants): activations per kernel column, weights per k-step
     const int q = wave * 32 + l31;                       // this lane's output pixel in the tile
-    const int qx = q % TW;
-    const int hp_base = (q / TW) * HW + qx;
+    const int qy = q / TW, qx = q % TW;
+    int xoff[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) xoff[kx] = (qy * HW + qx + kx) * 64 + ((lh ^ swz32(qx + kx)) << 4);
+    const int woff = l31 * 64 + ((lh ^ swz32(l31)) << 4);
+    // this thread's two 16-byte output chunks: pixel (q2y[it], q2x) of the tile, channel chunk c8
+    const int c8 = tid & 3;
+    int q2y[2];
+    const int q2x = ((tid >> 2) % TW);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) q2y[it] = ((tid + it * NT) >> 2) / TW;
+    const bool c8_ok = c8 * 8 < p.Cout;
+    const float aslope = act_slope(p.act);
 
     // Steady state, two barriers per tile:
-    //   conv(t) -> stage result in LDS -> [DMA(t+1) landed] -> barrier -> stores(t) fly while the SFT of
-    //   tile t+1 runs and DMA(t+2) is issued into the buffer conv(t) just released -> barrier.
+    //   conv(t) -> stage result in LDS -> [DMA(t+1) landed] -> barrier -> stores(t) -> DMA(t+2) issued into
+    //   the buffer conv(t) released -> SFT of tile t+1 -> barrier.
+    STAMP_DECL;
     for (int buf = 0; t < ntiles; t += step, buf ^= 1) {
         const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
         const int oy0 = ty * TH, ox0 = tx * TW;
         const char *a = sA + buf * A_BYTES;
+        STAMP(7);
 
-        // output offsets of this thread's two 16-byte chunks per pass (-1: outside) and residual prefetch
-        long ooff[NPASS][2];
+        // output element offsets (-1: outside) and residual prefetch
+        int ooff[NPASS][2];
         f16x8 rs1[NPASS][2], rs2[NPASS][2];
         if (p.mode != ST_PLANAR3) {
 #pragma unroll
-            for (int pass = 0; pass < NPASS; ++pass)
+            for (int it = 0; it < 2; ++it) {
+                const int oy = oy0 + q2y[it], ox = ox0 + q2x;
+                const bool in = c8_ok && oy < p.H && ox < p.W;
 #pragma unroll
-                for (int it = 0; it < 2; ++it) {
-                    const int qq = (tid + it * NT) >> 2, c8 = tid & 3;
-                    const int oy = oy0 + qq / TW, ox = ox0 + qq % TW;
-                    long off = -1;
-                    if (oy < p.H && ox < p.W && c8 * 8 < p.Cout) {
-                        if (p.mode == ST_PS) {
-                            const int Y = 2 * oy + (pass >> 1), X = 2 * ox + (pass & 1);
-                            if (Y < p.Hd && X < p.Wd) off = ((long)Y * p.Wd + X) * 32 + c8 * 8;
-                        } else {
-                            off = ((long)oy * p.W + ox) * p.dstC + c8 * 8;
-                        }
+                for (int pass = 0; pass < NPASS; ++pass) {
+                    int off = -1;
+                    if (p.mode == ST_PS) {
+                        const int Y = 2 * oy + (pass >> 1), X = 2 * ox + (pass & 1);
+                        if (in && Y < p.Hd && X < p.Wd) off = (Y * p.Wd + X) * 32 + c8 * 8;
+                    } else if (in) {
+                        off = (oy * p.W + ox) * p.dstC + c8 * 8;
                     }
                     ooff[pass][it] = off;
                     f16x8 z;
@@ -222,42 +283,57 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
                     rs1[pass][it] = (p.res1 && off >= 0) ? *reinterpret_cast<const f16x8 *>(p.res1 + off) : z;
                     rs2[pass][it] = (p.res2 && off >= 0) ? *reinterpret_cast<const f16x8 *>(p.res2 + off) : z;
                 }
+            }
         }
 
+        STAMP(0);      // offsets + residual prefetch
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
             f32x16 acc;
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[k] = 0.f;
-            const int n = pass * 32 + l31;
+            // 18 k-steps (9 taps x 2); fragment reads run three steps ahead of the MFMA that consumes them
+            f16x8 wfr[18], xfr[18];
+            auto ldfrag = [&](int st) {
+                const int tap = st >> 1, ks = st & 1;
+                wfr[st] = *reinterpret_cast<const f16x8 *>(sW + (woff ^ (ks << 5)) + (tap * L::COUTP + pass * 32) * 64);
+                xfr[st] = *reinterpret_cast<const f16x8 *>(a + (xoff[tap % 3] ^ (ks << 5)) + (tap / 3) * HW * 64);
+            };
+            ldfrag(0); ldfrag(1); ldfrag(2);
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int hp = hp_base + (tap / 3) * HW + (tap % 3);
-                const int hx = qx + tap % 3;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const int chunk = ks * 2 + lh;
-                    const f16x8 wf = *reinterpret_cast<const f16x8 *>(sW + (tap * L::COUTP + n) * 64 + ((chunk ^ swz32(n)) << 4));
-                    const f16x8 xf = *reinterpret_cast<const f16x8 *>(a + hp * 64 + ((chunk ^ swz32(hx)) << 4));
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xf, acc, 0, 0, 0);
-                }
+            for (int st = 0; st < 18; ++st) {
+                if (st + 3 < 18) ldfrag(st + 3);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfr[st], xfr[st], acc, 0, 0, 0);
             }
-            // ---- this pass's 32 channels x 256 pixels into the LDS staging tile
+            // pin the interleave (hipcc otherwise sinks every read pair down to its MFMA and waits
+            // lgkmcnt(0) eighteen times): 6 reads up front, then {1 MFMA, 2 reads} x 15, then 3 MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+            for (int st = 0; st < 15; ++st) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            STAMP(1);  // conv MFMAs
+            // ---- this pass's 32 channels x (TH*16) pixels into the LDS staging tile
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
                 const int cl = 8 * qd + 4 * lh;
                 const float4 sc = *reinterpret_cast<const float4 *>(sSS + pass * 32 + cl);
                 const float4 sh = *reinterpret_cast<const float4 *>(sSS + L::COUTP + pass * 32 + cl);
                 f16x4 o;
-                o[0] = (f16)act_apply(acc[4 * qd + 0] * sc.x + sh.x, p.act);
-                o[1] = (f16)act_apply(acc[4 * qd + 1] * sc.y + sh.y, p.act);
-                o[2] = (f16)act_apply(acc[4 * qd + 2] * sc.z + sh.z, p.act);
-                o[3] = (f16)act_apply(acc[4 * qd + 3] * sc.w + sh.w, p.act);
+                o[0] = (f16)act_fast(acc[4 * qd + 0] * sc.x + sh.x, aslope);
+                o[1] = (f16)act_fast(acc[4 * qd + 1] * sc.y + sh.y, aslope);
+                o[2] = (f16)act_fast(acc[4 * qd + 2] * sc.z + sh.z, aslope);
+                o[3] = (f16)act_fast(acc[4 * qd + 3] * sc.w + sh.w, aslope);
                 *reinterpret_cast<f16x4 *>(sO + q * OUT_ROWB + cl * 2) = o;
             }
             // the last pass also makes sure the next tile's LDS-DMA has landed before the barrier
+            STAMP(2);  // staging write
             if (pass == NPASS - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            STAMP(3);  // wait for DMA(t+1) / outstanding memory ops
             __syncthreads();
+            STAMP(4);  // barrier 1
             if (p.mode == ST_PLANAR3) {
                 for (int e = tid; e < TH * TW * 3; e += NT) {
                     const int ch = e / (TH * TW), qq = e % (TH * TW);
@@ -272,23 +348,32 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
             } else {
 #pragma unroll
                 for (int it = 0; it < 2; ++it) {
-                    const int qq = (tid + it * NT) >> 2, c8 = tid & 3;
-                    f16x8 v = *reinterpret_cast<const f16x8 *>(sO + qq * OUT_ROWB + c8 * 16);
-                    const f16x8 r1 = rs1[pass][it], r2 = rs2[pass][it];
+                    if (ooff[pass][it] >= 0) {
+                        const int qq = (tid + it * NT) >> 2;
+                        f16x8 v = *reinterpret_cast<const f16x8 *>(sO + qq * OUT_ROWB + c8 * 16);
+                        const f16x8 r1 = rs1[pass][it], r2 = rs2[pass][it];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = (f16)(((float)v[k] + (float)r1[k]) + (float)r2[k]);
-                    f16 *dp = ooff[pass][it] >= 0 ? p.dst + ooff[pass][it] : p.dump + (size_t)tid * 8;
-                    *reinterpret_cast<f16x8 *>(dp) = v;
+                        for (int k = 0; k < 8; ++k) v[k] = (f16)(((float)v[k] + (float)r1[k]) + (float)r2[k]);
+                        *reinterpret_cast<f16x8 *>(p.dst + ooff[pass][it]) = v;
+                    }
                 }
             }
             if (pass < NPASS - 1) __syncthreads();      // staging tile is reused by the next pass
+            STAMP(5);  // DMA issue + stores
         }
-        // stores of tile t are in flight; prepare tile t+1 and prefetch tile t+2
-        const int t1 = t + step, t2 = t + 2 * step;
-        if (SFT && t1 < ntiles) sft_tile(t1, buf ^ 1);
-        if (t2 < ntiles) issue_tile(t2, buf);
+        // conv(t) released its halo buffer at the barrier: tile t+2 goes in flight AFTER the stores (an
+        // LDS-DMA in flight makes hipcc wait vmcnt(0) at the next use of any plain load result -- the
+        // prefetched residuals -- which would park the store phase on the DMA) and BEFORE the SFT of
+        // tile t+1, so it has a whole tile period to land
+        if (t + 2 * step < ntiles) issue_tile(t + 2 * step, buf);
+        if (SFT && t + step < ntiles) sft_tile(t + step, buf ^ 1);
+        STAMP(6);      // SFT of the next tile
         __syncthreads();
     }
+#ifdef HDRTV_STAMP
+    if (p.dump && lane == 0)
+        for (int i = 0; i < 8; ++i) reinterpret_cast<unsigned long long *>(p.dump)[((size_t)blockIdx.x * NW + wave) * 8 + i] = st_acc[i];
+#endif
 }
 
 template <int NPASS, bool SFT, int NW>
@@ -311,13 +396,15 @@ hipError_t launch_t(const Conv32Params &p, hipStream_t s)
 
 }  // namespace
 
+// src (and cond) must be followed by >= 64 zero bytes (the workspace guard): out-of-image halo lanes read them.
 hipError_t conv32p_launch(Conv32Params p, hipStream_t s)
 {
     static int nw = 0;
     if (!nw) {
         const char *e = getenv("HDRTV_CONV32_NW");      // developer A/B switch: 8 = 16x16 tile, 4 = 8x16 tile x 2 workgroups/CU
-        nw = (e && atoi(e) == 8) ? 8 : 4;
+        nw = (e && atoi(e) == 4) ? 4 : 8;
     }
+    if ((size_t)p.H * p.W * 64 >= 0xf0000000ull) return hipErrorInvalidValue;     // 32-bit byte offsets
     const bool sft = p.cond != nullptr;
     p.tiles_x = (p.W + TW - 1) / TW;
     if (nw == 8 || p.CoutPad == 128) {                   // the 72 KiB weight set of the up-convs leaves room for one workgroup only

@@ -224,6 +224,7 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(ConvParams p)
     }
 
     // ---------------------------------------------------------------- epilogue (LDS staged)
+    const float aslope = act_slope(p.act);
     char *so = smem;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -236,10 +237,10 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(ConvParams p)
             for (int j = 0; j < 2; ++j) {
                 const int q = (wp * 2 + j) * 32 + l31;
                 f16x4 o;
-                o[0] = (f16)act_apply(acc[i][j][4 * qd + 0] * sc.x + sh.x, p.act);
-                o[1] = (f16)act_apply(acc[i][j][4 * qd + 1] * sc.y + sh.y, p.act);
-                o[2] = (f16)act_apply(acc[i][j][4 * qd + 2] * sc.z + sh.z, p.act);
-                o[3] = (f16)act_apply(acc[i][j][4 * qd + 3] * sc.w + sh.w, p.act);
+                o[0] = (f16)act_fast(acc[i][j][4 * qd + 0] * sc.x + sh.x, aslope);
+                o[1] = (f16)act_fast(acc[i][j][4 * qd + 1] * sc.y + sh.y, aslope);
+                o[2] = (f16)act_fast(acc[i][j][4 * qd + 2] * sc.z + sh.z, aslope);
+                o[3] = (f16)act_fast(acc[i][j][4 * qd + 3] * sc.w + sh.w, aslope);
                 *reinterpret_cast<f16x4 *>(so + q * OUT_ROWB + cl * 2) = o;
             }
         }

@@ -114,6 +114,7 @@ __global__ __launch_bounds__(512) void conv3x3s2_glds_kernel(ConvParams p)
     }
 
     // ---- epilogue through LDS (aliases the halo buffer)
+    const float aslope = act_slope(p.act);
     char *so = smem;
 #pragma unroll
     for (int i = 0; i < NCT; ++i)
@@ -123,10 +124,10 @@ __global__ __launch_bounds__(512) void conv3x3s2_glds_kernel(ConvParams p)
             const float4 sc = *reinterpret_cast<const float4 *>(p.scale + cl);
             const float4 sh = *reinterpret_cast<const float4 *>(p.shift + cl);
             f16x4 o;
-            o[0] = (f16)act_apply(acc[i][4 * qd + 0] * sc.x + sh.x, p.act);
-            o[1] = (f16)act_apply(acc[i][4 * qd + 1] * sc.y + sh.y, p.act);
-            o[2] = (f16)act_apply(acc[i][4 * qd + 2] * sc.z + sh.z, p.act);
-            o[3] = (f16)act_apply(acc[i][4 * qd + 3] * sc.w + sh.w, p.act);
+            o[0] = (f16)act_fast(acc[i][4 * qd + 0] * sc.x + sh.x, aslope);
+            o[1] = (f16)act_fast(acc[i][4 * qd + 1] * sc.y + sh.y, aslope);
+            o[2] = (f16)act_fast(acc[i][4 * qd + 2] * sc.z + sh.z, aslope);
+            o[3] = (f16)act_fast(acc[i][4 * qd + 3] * sc.w + sh.w, aslope);
             *reinterpret_cast<f16x4 *>(so + q * C::OUT_ROWB + cl * 2) = o;
         }
     __syncthreads();

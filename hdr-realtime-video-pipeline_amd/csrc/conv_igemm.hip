@@ -214,6 +214,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p)
 
     // ---------------------------------------------------------------- epilogue (LDS staged)
     // acc[i][j][r]: channel = (wc*MT+i)*32 + (r&3) + 8*(r>>2) + 4*lh, pixel = (wp*NT+j)*32 + l31
+    const float aslope = act_slope(p.act);
     char *so = smem;
 #pragma unroll
     for (int i = 0; i < C::MT; ++i) {
@@ -226,10 +227,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p)
             for (int j = 0; j < C::NT; ++j) {
                 const int q = (wp * C::NT + j) * 32 + l31;
                 f16x4 o;
-                o[0] = (f16)act_apply(acc[i][j][4 * qd + 0] * sc.x + sh.x, p.act);
-                o[1] = (f16)act_apply(acc[i][j][4 * qd + 1] * sc.y + sh.y, p.act);
-                o[2] = (f16)act_apply(acc[i][j][4 * qd + 2] * sc.z + sh.z, p.act);
-                o[3] = (f16)act_apply(acc[i][j][4 * qd + 3] * sc.w + sh.w, p.act);
+                o[0] = (f16)act_fast(acc[i][j][4 * qd + 0] * sc.x + sh.x, aslope);
+                o[1] = (f16)act_fast(acc[i][j][4 * qd + 1] * sc.y + sh.y, aslope);
+                o[2] = (f16)act_fast(acc[i][j][4 * qd + 2] * sc.z + sh.z, aslope);
+                o[3] = (f16)act_fast(acc[i][j][4 * qd + 3] * sc.w + sh.w, aslope);
                 *reinterpret_cast<f16x4 *>(so + q * C::OUT_ROWB + cl * 2) = o;
             }
         }

@@ -585,6 +585,7 @@ int do_reserve(hdrtv_ctx *c, int H, int W)
     ws_add(c, "agcm.bias", 168, 1, 1, 3);
     ws_add(c, "agcm.out", 3, H, W, 1);
     // LE
+    ws_add(c, "dbg.stamps", 8 * 8 * 512 * 2, 1, 1, 3);     // diagnostic builds only: [workgroup*NW + wave][8] u64 cycle sums
     ws_add(c, "le.cond", 64, H, W, 0);
     ws_add(c, "le.cond1", 16, H, W, 0);
     ws_add(c, "le.x192", 192, s.H1, s.W1, 0); ws_add(c, "le.h1b", 64, s.H1, s.W1, 0);
@@ -735,7 +736,9 @@ struct Seq {
         p.CoutPad = L.coutPad; p.Cout = L.cout; p.act = act; p.mode = mode;
         p.dst = dst; p.dstC = dstC; p.Hd = Hd; p.Wd = Wd; p.res1 = res1; p.res2 = res2;
         p.dst_planar = dst_planar; p.res_planar = res_planar; p.zeros = wtp<f16>(c, c->zeros_off);
-        p.dump = reinterpret_cast<f16 *>(c->wts.dev + c->dump_off);
+        // diagnostic builds (make STAMP=1) write per-phase cycle sums of launch #HDRTV_STAMP_LAUNCH here
+        static const int stamp_launch = [] { const char *e = getenv("HDRTV_STAMP_LAUNCH"); return e ? atoi(e) : -1; }();
+        p.dump = (stamp_launch >= 0 && c->launches == stamp_launch) ? wsp<f16>(c, "dbg.stamps") : nullptr;
         const double npx = (double)H * W;
         const double macs = npx * 32 * 9 * L.cout + (cond ? npx * 2 * (16 * 16 + 16 * 32) : 0.0);
         const double outb = mode == ST_PLANAR3 ? 6.0 * npx : 2.0 * npx * L.cout;

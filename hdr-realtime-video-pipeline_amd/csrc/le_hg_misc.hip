@@ -68,6 +68,7 @@ __global__ __launch_bounds__(256) void conv_c3_kernel(const f16 *__restrict__ in
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i][1], xf[1], acc[i][j], 0, 0, 0);
         }
     }
+    const float aslope = act_slope(act);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -79,10 +80,10 @@ __global__ __launch_bounds__(256) void conv_c3_kernel(const f16 *__restrict__ in
             for (int j = 0; j < 2; ++j) {
                 const int q = (2 * wave + j) * C3_TW + l31;
                 f16x4 o;
-                o[0] = (f16)act_apply(acc[i][j][4 * qd + 0] * sc.x + sh.x, act);
-                o[1] = (f16)act_apply(acc[i][j][4 * qd + 1] * sc.y + sh.y, act);
-                o[2] = (f16)act_apply(acc[i][j][4 * qd + 2] * sc.z + sh.z, act);
-                o[3] = (f16)act_apply(acc[i][j][4 * qd + 3] * sc.w + sh.w, act);
+                o[0] = (f16)act_fast(acc[i][j][4 * qd + 0] * sc.x + sh.x, aslope);
+                o[1] = (f16)act_fast(acc[i][j][4 * qd + 1] * sc.y + sh.y, aslope);
+                o[2] = (f16)act_fast(acc[i][j][4 * qd + 2] * sc.z + sh.z, aslope);
+                o[3] = (f16)act_fast(acc[i][j][4 * qd + 3] * sc.w + sh.w, aslope);
                 *reinterpret_cast<f16x4 *>(s_out + q * ROWB + cl * 2) = o;
             }
         }
