@@ -17,6 +17,9 @@
 
 namespace {
 
+#ifndef GLDS_PIN
+#define GLDS_PIN 1
+#endif
 constexpr int TH = 16, TW = 16;
 constexpr int CT = 64, PIXB = CT * 2;                    // 64-channel chunk = 128 B per pixel
 // KS = 3: 18x18 halo tile (324 px -> 6 pieces per wave, 48 KiB), double-buffered per channel chunk.
@@ -190,23 +193,38 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(ConvParams p)
 
             const char *b = sB + (it_i % 3) * B_BYTES;
             const int tap_off = (tap / 3) * HW + (tap % 3);
-#pragma unroll
-            for (int ks = 0; ks < CT / 16; ++ks) {
+            // fragment reads one k-step ahead of the MFMAs that consume them; the interleave is pinned
+            // below (hipcc otherwise sinks each read group down to its MFMAs behind an lgkmcnt(0))
+            f16x8 wf[4][2], xf[4][2];
+            auto ldfrag = [&](int ks) {
                 const int chunk = ks * 2 + lh;
-                f16x8 wf[2], xf[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
-                    wf[i] = *reinterpret_cast<const f16x8 *>(b + wrow[i] * PIXB + ((chunk ^ swz64(wrow[i])) << 4));
+                    wf[ks][i] = *reinterpret_cast<const f16x8 *>(b + wrow[i] * PIXB + ((chunk ^ swz64(wrow[i])) << 4));
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int hp = hp_base[j] + tap_off;
-                    xf[j] = *reinterpret_cast<const f16x8 *>(a + hp * PIXB + ((chunk ^ swz64(hx_base[j] + tap % 3)) << 4));
+                    xf[ks][j] = *reinterpret_cast<const f16x8 *>(a + hp * PIXB + ((chunk ^ swz64(hx_base[j] + tap % 3)) << 4));
                 }
+            };
+            ldfrag(0);
+#pragma unroll
+            for (int ks = 0; ks < CT / 16; ++ks) {
+                if (ks + 1 < CT / 16) ldfrag(ks + 1);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][i], xf[ks][j], acc[i][j], 0, 0, 0);
+            }
+            if (GLDS_PIN) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);           // reads of k-steps 0 and 1
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {                                 // MFMAs of k-steps 0,1 with reads of 2,3
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             }
             // The next iteration reads weights(it+1) (issued one iteration ago) and, at a chunk
             // boundary, halo(cc+1) (issued at tap 6).  Allow exactly the younger DMAs in flight.
