@@ -43,6 +43,9 @@ static_assert(TH * TW * OUT_ROWB + 3 * 64 * 4 <= SMEM, "epilogue tile must fit")
 // key every ds_read_b128 lane group hits 16 distinct 16-byte slots of the 256-byte bank row
 // (keying on the linear pixel index costs a 2-way conflict on every activation read).
 __device__ __forceinline__ int swz64(int row) { return (row >> 1) & 7; }
+// The 16x16x32 variant reads 16 rows x 4 k-groups per fragment: there the plain low bits of the
+// row / halo column are the conflict-free key (emulated over all 9 taps and 4 lane groups).
+template <bool M16> __device__ __forceinline__ int swzk(int row) { return M16 ? (row & 7) : ((row >> 1) & 7); }
 
 __device__ __forceinline__ void glds16(const void *g, void *lds)
 {
@@ -50,7 +53,7 @@ __device__ __forceinline__ void glds16(const void *g, void *lds)
                                      (__attribute__((address_space(3))) void *)lds, 16, 0, 0);
 }
 
-template <int KS>
+template <int KS, bool M16>
 __global__ __launch_bounds__(512) void conv_glds_kernel(ConvParams p)
 {
     using G = Geo<KS>;
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(ConvParams p)
             const int hy = hp / HW, hx = hp - hy * HW;
             const int iy = iy0 + hy, ix = ix0 + hx;
             const bool ok = hp < NPIX && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
-            const f16 *g = ok ? src + ((size_t)iy * p.Wi + ix) * cs + coff + ((l_slot ^ swz64(hx)) << 3)
+            const f16 *g = ok ? src + ((size_t)iy * p.Wi + ix) * cs + coff + ((l_slot ^ swzk<M16>(hx)) << 3)
                               : p.zeros + (l_slot << 3);
             glds16(g, sA + buf * A_BYTES + piece * 1024);
         }
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(ConvParams p)
         for (int k = 0; k < B_PIECES_PER_WAVE; ++k) {
             const int piece = wave * B_PIECES_PER_WAVE + k;
             const int n = piece * 8 + l_row;
-            glds16(base + (size_t)n * CT + ((l_slot ^ swz64(n)) << 3), sB + slot * B_BYTES + piece * 1024);
+            glds16(base + (size_t)n * CT + ((l_slot ^ swzk<M16>(n)) << 3), sB + slot * B_BYTES + piece * 1024);
         }
     };
 
@@ -120,6 +123,13 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(ConvParams p)
         wrow[j] = (wc * 2 + j) * 32 + l31;
     }
     f32x16 acc[2][2];
+    f32x4 acc16[4][4];
+    if constexpr (M16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -193,6 +203,39 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(ConvParams p)
 
             const char *b = sB + (it_i % 3) * B_BYTES;
             const int tap_off = (tap / 3) * HW + (tap % 3);
+            if constexpr (M16) {
+                // 16x16x32 MFMAs: wave tile 64 ch x 64 px = 4x4 tiles, k-step 32, lane = (row & 15, k-group)
+                const int l15 = lane & 15, kg = lane >> 4;
+                const char *bw = b + ((wc * 64 + l15) * PIXB);
+                const char *ax = a + ((wp * 4 * HW + l15 + tap_off) * PIXB);
+                const int kw = l15 & 7, kx = (l15 + tap % 3) & 7;
+                f16x8 wf[2][4], xf[2][4];
+                auto ldw = [&](int ks, int i) {
+                    wf[ks][i] = *reinterpret_cast<const f16x8 *>(bw + i * 16 * PIXB + (((ks * 4 + kg) ^ kw) << 4));
+                };
+                auto ldx = [&](int ks, int j) {
+                    xf[ks][j] = *reinterpret_cast<const f16x8 *>(ax + j * HW * PIXB + (((ks * 4 + kg) ^ kx) << 4));
+                };
+                // program order IS the schedule: sched_barrier(0) lets nothing cross
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { ldw(0, i); ldx(0, i); }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    // k-step 1 fragments in the order its MFMAs want them: w0 x0 x1 x2 x3 w1 w2 w3
+                    acc16[g >> 2][g & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0][g >> 2], xf[0][g & 3], acc16[g >> 2][g & 3], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g == 0) ldw(1, 0); else if (g < 5) ldx(1, g - 1); else ldw(1, g - 4);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int m = 8; m < 16; ++m)
+                    acc16[m >> 2][m & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0][m >> 2], xf[0][m & 3], acc16[m >> 2][m & 3], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < 16; ++m)
+                    acc16[m >> 2][m & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1][m >> 2], xf[1][m & 3], acc16[m >> 2][m & 3], 0, 0, 0);
+            } else {
             // fragment reads one k-step ahead of the MFMAs that consume them; the interleave is pinned
             // below (hipcc otherwise sinks each read group down to its MFMAs behind an lgkmcnt(0))
             f16x8 wf[4][2], xf[4][2];
@@ -226,6 +269,7 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(ConvParams p)
                 }
                 __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             }
+            }
             // The next iteration reads weights(it+1) (issued one iteration ago) and, at a chunk
             // boundary, halo(cc+1) (issued at tap 6).  Allow exactly the younger DMAs in flight.
             if (!pf) {
@@ -244,6 +288,25 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(ConvParams p)
     // ---------------------------------------------------------------- epilogue (LDS staged)
     const float aslope = act_slope(p.act);
     char *so = smem;
+    if constexpr (M16) {
+        const int l15 = lane & 15, kg = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cl = wc * 64 + i * 16 + 4 * kg;
+            const float4 sc = *reinterpret_cast<const float4 *>(p.scale + n0 + cl);
+            const float4 sh = *reinterpret_cast<const float4 *>(p.shift + n0 + cl);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = (wp * 4 + j) * 16 + l15;
+                f16x4 o;
+                o[0] = (f16)act_fast(acc16[i][j][0] * sc.x + sh.x, aslope);
+                o[1] = (f16)act_fast(acc16[i][j][1] * sc.y + sh.y, aslope);
+                o[2] = (f16)act_fast(acc16[i][j][2] * sc.z + sh.z, aslope);
+                o[3] = (f16)act_fast(acc16[i][j][3] * sc.w + sh.w, aslope);
+                *reinterpret_cast<f16x4 *>(so + q * OUT_ROWB + cl * 2) = o;
+            }
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -262,6 +325,7 @@ __global__ __launch_bounds__(512) void conv_glds_kernel(ConvParams p)
                 *reinterpret_cast<f16x4 *>(so + q * OUT_ROWB + cl * 2) = o;
             }
         }
+    }
     }
     __syncthreads();
 
@@ -353,18 +417,24 @@ hipError_t conv_glds_launch(ConvParams p, int ks, hipStream_t stream)
         p.mode == ST_PLANAR3 || !p.zeros || (p.mode == ST_PS_DOT3 && (p.dstC != 64 || !p.dotw || !p.dst_dot)))
         return hipErrorInvalidValue;
     static bool attr_set = false;
+    static bool m16 = true;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_glds_kernel<3>),
+        if (const char *e = getenv("HDRTV_GLDS_M16")) m16 = atoi(e) != 0;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_glds_kernel<3, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_glds_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_glds_kernel<3, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_glds_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     p.tiles_x = (p.Wo + TW - 1) / TW;
     p.tiles_y = (p.Ho + TH - 1) / TH;
     const int grid = p.tiles_x * p.tiles_y * (p.CoutPad / BN);
-    if (ks == 3) hipLaunchKernelGGL(conv_glds_kernel<3>, dim3(grid), dim3(512), SMEM, stream, p);
-    else hipLaunchKernelGGL(conv_glds_kernel<1>, dim3(grid), dim3(512), SMEM, stream, p);
+    if (ks == 3 && m16) hipLaunchKernelGGL((conv_glds_kernel<3, true>), dim3(grid), dim3(512), SMEM, stream, p);
+    else if (ks == 3) hipLaunchKernelGGL((conv_glds_kernel<3, false>), dim3(grid), dim3(512), SMEM, stream, p);
+    else hipLaunchKernelGGL((conv_glds_kernel<1, false>), dim3(grid), dim3(512), SMEM, stream, p);
     return hipGetLastError();
 }

@@ -93,17 +93,32 @@ __global__ __launch_bounds__(512) void conv3x3s2_glds_kernel(ConvParams p)
         if (tap + 2 < 9) issue_B(tap + 2, (tap + 2) % 3);
         const char *b = sB + (tap % 3) * C::B_BYTES;
         const int hp = hp_base + (tap / 3) * HWD + (tap % 3);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        // fragments one k-step ahead of their MFMAs, read/MFMA order pinned (see conv3x3_glds.hip)
+        f16x8 xf[2], wf[2][NCT];
+        auto ldfrag = [&](int ks) {
             const int chunk = ks * 2 + lh;
-            const f16x8 xf = *reinterpret_cast<const f16x8 *>(sA + hp * PIXB + ((chunk ^ swz64(hp)) << 4));
+            xf[ks & 1] = *reinterpret_cast<const f16x8 *>(sA + hp * PIXB + ((chunk ^ swz64(hp)) << 4));
 #pragma unroll
             for (int i = 0; i < NCT; ++i) {
                 const int n = (cg * NCT + i) * 32 + l31;
-                const f16x8 wf = *reinterpret_cast<const f16x8 *>(b + n * PIXB + ((chunk ^ swz64(n)) << 4));
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xf, acc[i], 0, 0, 0);
+                wf[ks & 1][i] = *reinterpret_cast<const f16x8 *>(b + n * PIXB + ((chunk ^ swz64(n)) << 4));
             }
+        };
+        ldfrag(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks + 1 < 4) ldfrag(ks + 1);
+#pragma unroll
+            for (int i = 0; i < NCT; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks & 1][i], xf[ks & 1], acc[i], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_group_barrier(0x100, 1 + NCT, 0);
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1 + NCT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NCT, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NCT, 0);
         if (tap + 2 < 9) {
             if (C::B_PER_WAVE == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
