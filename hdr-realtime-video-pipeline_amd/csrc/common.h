@@ -65,6 +65,7 @@ struct ConvParams {
     const f16 *zeros;      // >= 256 B of zeros (source of out-of-image halo pixels for LDS-DMA staging)
     const float *dotw;     // ST_PS_DOT3: [3][dstC] weights of the 1x1 conv fused behind the pixel shuffle
     float *dst_dot;        // ST_PS_DOT3: f32 [Hd][Wd][4] partial sums (x,y,z used)
+    void *trash;           // conv_pglds: >= 2 KiB scratch that out-of-image lanes store to (never read)
 };
 
 // Parameter block of the persistent 32-channel conv (conv32p.hip): 3x3, stride 1, Cin = 32.

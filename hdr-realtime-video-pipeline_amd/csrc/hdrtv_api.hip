@@ -122,6 +122,7 @@ struct RingSlot {
 
 struct hdrtv_ctx {
     int device = 0;
+    int n_cu = 256;
     bool has_hg = false;
     std::string err;
     Arena wts;
@@ -685,6 +686,10 @@ struct Seq {
         p.zeros = wtp<f16>(c, c->zeros_off);
         const bool glds = (L.ks == 3 || L.ks == 1) && L.stride == 1 && L.cin_t == 64 && L.bn == 128 && !res1 && !res2 && !dst_full &&
                           mode != ST_PLANAR3;
+        // persistent variant for the HG 3x3 convs (HDRTV_PGLDS=0 selects the one-tile-per-block kernel, for A/B runs)
+        static const bool use_pglds = [] { const char *e = getenv("HDRTV_PGLDS"); return !e || atoi(e) != 0; }();
+        const bool pglds = glds && use_pglds && L.ks == 3 && L.cout == L.coutPad && mode != ST_PLANAR3;
+        p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
         const bool s2g = L.ks == 3 && L.stride == 2 && L.cin_t == 64 && L.bn == L.coutPad && (L.coutPad == 64 || L.coutPad == 192);
         char tag[64];
         if (s2g) snprintf(tag, sizeof tag, "conv3x3s2_glds<%d>", L.coutPad);
@@ -697,7 +702,8 @@ struct Seq {
                                                                     : (mode == ST_PS_DOT3 ? 8.0 * Hd * Wd : (double)p.Ho * p.Wo * L.cout));
         bytes += 2.0 * outel * (1 + (res1 ? 1 : 0) + (res2 ? 1 : 0) + (res_planar ? 1 : 0));
         chk(s2g ? conv3x3s2_glds_launch(p, s)
-                : (glds ? conv_glds_launch(p, L.ks, s) : conv_igemm_launch(p, L.cin_t, L.bn, L.ks, L.stride, s)),
+                : (pglds ? conv_pglds_launch(p, c->n_cu, s)
+                         : (glds ? conv_glds_launch(p, L.ks, s) : conv_igemm_launch(p, L.cin_t, L.bn, L.ks, L.stride, s))),
             key.c_str(), tag, macs, bytes);
     }
     void c3(const std::string &key, const f16 *in, int H, int W, int act, f16 *out, f16 *out_pool)
@@ -938,6 +944,7 @@ int hdrtv_create(const void *hr_pack, size_t hr_bytes, const void *hg_pack, size
     HIPCHK(c, hipGetDeviceProperties(&prop, device_id));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(c, HDRTV_EINVAL, "device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
+    c->n_cu = prop.multiProcessorCount;
     if (hipMalloc((void **)&c->wts.dev, c->wts.size + 256) != hipSuccess) {
         c->wts.dev = nullptr;
         return fail(c, HDRTV_ENOMEM, "weight allocation failed");

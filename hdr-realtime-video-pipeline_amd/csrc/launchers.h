@@ -4,6 +4,7 @@
 
 hipError_t conv_igemm_launch(ConvParams p, int cin_t, int bn, int ks, int stride, hipStream_t stream);
 hipError_t conv_glds_launch(ConvParams p, int ks, hipStream_t stream);
+hipError_t conv_pglds_launch(ConvParams p, int n_cu, hipStream_t stream);
 hipError_t conv32p_launch(Conv32Params p, hipStream_t stream);
 hipError_t conv3x3s2_glds_launch(ConvParams p, hipStream_t stream);
 
