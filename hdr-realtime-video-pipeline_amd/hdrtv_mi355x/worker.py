@@ -242,6 +242,11 @@ class HeadlessPipelineWorker:
         """feeders.py:632-657 + 440-496: a thread that waits for each frame's ready event,
         converts on a side stream into the pinned ring and hands the frame to ``sink``."""
         self._stop_hdr_feeder()
+        if self._processor is not None and self._ring_shape != (self._proc_h, self._proc_w):
+            # pin the ring now (3 x 50 MB at 4K takes tens of ms) rather than inside the first frame's deadline
+            p = self._processor
+            p._chk(p._lib.hdrtv_ring_create(p._ctx, _RING_FRAMES, self._proc_h, self._proc_w), "hdrtv_ring_create")
+            self._ring_shape = (self._proc_h, self._proc_w)
         self._hdr_queue = _queue.Queue(maxsize=max(1, min(3, self._video_playback_buffer_frames + 1)))
         self._hdr_stop.clear()
         dev = self._processor.device

@@ -47,3 +47,44 @@ def test_worker_load_process_feed(golden_dir, tmp_path):
     w2 = HeadlessPipelineWorker(str(tmp_path / "missing"), use_hg=False)
     assert w2._load_model("FP16") is False and w2.status_messages[-1].startswith("ERROR: weights not found")
     w.close()
+
+
+def test_realtime_playback_into_rgb48le_sink(golden_dir, tmp_path):
+    """SURVEY 8f rows 1 + 3: source -> pacing loop -> worker -> feeder -> rgb48le byte stream, in order."""
+    import io
+    import time
+    import torch
+    from hdrtv_mi355x import playback as P
+    from hdrtv_mi355x.worker import HeadlessPipelineWorker
+    from oracle import hdrtvnet_oracle as O
+    wdir = tmp_path / "weights" / "original"
+    wdir.mkdir(parents=True)
+    os.symlink(os.path.join(golden_dir, "hr_weights.hdrw"), wdir / "HR.hdrw")
+    w = HeadlessPipelineWorker(str(tmp_path / "weights"), use_hg=True, proc_w=96, proc_h=64, hg_weights="seeded:1234",
+                               buffer_frames=2)
+    assert w._load_model("FP16")
+    src = P.SyntheticSource(96, 64, fps=120.0, n_frames=12, pool=2, kind="gradient")
+    expect = []
+    for f in src._pool:                                            # what each pooled frame must come out as
+        out = w._processor.infer(w._processor.preprocess(f))[0]
+        expect.append(O.post_rgb48(out.float().cpu().numpy()[0]))
+    buf = io.BytesIO()
+    sink = P.Rgb48leSink(buf, 96, 64, 120.0)
+    w._start_hdr_feeder(sink)
+    got = []
+    pb = P.RealtimePlayback(w, src, sink=True, realtime=True, metrics_cb=got.append, csv_path=str(tmp_path / "m.csv"))
+    t0 = time.perf_counter()
+    res = pb.run()
+    elapsed = time.perf_counter() - t0
+    deadline = time.perf_counter() + 10.0
+    while sink.frames < res["frames_processed"] and time.perf_counter() < deadline:
+        time.sleep(0.01)
+    w._stop_hdr_feeder()
+    assert res["frames_processed"] == 12 and res["catchup_dropped_frames"] == 0 and sink.frames == 12
+    assert elapsed >= 11 / 120.0                                   # paced to the 120 fps source, not free-running
+    data = np.frombuffer(buf.getvalue(), dtype="<u2").reshape(12, 64, 96, 3)
+    for i in range(12):
+        assert np.array_equal(data[i], expect[i % 2]), i
+    assert got and got[-1]["precision"] == "FP16" and got[-1]["proc_res"] == "96x64" and got[-1]["model_latency_ms"] > 0
+    w.close()
+    torch.cuda.synchronize()
