@@ -134,6 +134,7 @@ class HeadlessPipelineWorker:
             self._stop_hdr_feeder()
             self._processor.close()
             self._processor = None
+            self._ring_shape = None            # the pinned ring lived in the closed context
             torch.cuda.empty_cache()
         try:
             hg = self._hg_override
