@@ -67,9 +67,25 @@ def cpu_baseline(args, use_hg):
     O.process(hr, frame, hg)
     dt = time.perf_counter() - t0
     scale = (args.height * args.width) / float(h * w)
-    return {"value": round(1.0 / (dt * scale), 5), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"1 frame {w}x{h} (1/{scale:.1f} of the {args.width}x{args.height} pixels) through oracle "
-                      f"preprocess+AGCM+LE{'+HG' if use_hg else ''}+postprocess in {dt:.2f} s, scaled by pixel count"}
+    out = {"value": round(1.0 / (dt * scale), 5), "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": f"1 frame {w}x{h} (1/{scale:.1f} of the {args.width}x{args.height} pixels) through oracle "
+                     f"preprocess+AGCM+LE{'+HG' if use_hg else ''}+postprocess in {dt:.2f} s, scaled by pixel count"}
+    # the same graphs on PyTorch's CPU kernels (what the reference's CPU path executes), on a 960x540 sample
+    import torch
+    torch.set_num_threads(cores)
+    O.use_backend("aten")
+    try:
+        small = W.synthetic_frame(540, 960, seed=1234, kind="noise")
+        O.process(hr, W.synthetic_frame(64, 96, seed=1, kind="noise"), hg)
+        t0 = time.perf_counter()
+        O.process(hr, small, hg)
+        dt2 = time.perf_counter() - t0
+    finally:
+        O.use_backend("c")
+    sc2 = (args.height * args.width) / float(540 * 960)
+    out["aten_eager"] = {"value": round(1.0 / (dt2 * sc2), 5), "unit": "frames/s", "cores": cores,
+                         "sample": f"1 frame 960x540 in {dt2:.2f} s with oracle/aten_backend.py, scaled by pixel count"}
+    return out
 
 
 def main():

@@ -137,6 +137,22 @@ def bicubic_aa_quarter(x):
     return y
 
 
+_C_OPS = {k: globals()[k] for k in ("conv2d", "avgpool3s2p1", "instnorm", "batchnorm", "maxpool2", "pixelshuffle2",
+                                    "bicubic_aa_quarter", "relu", "leaky")}
+
+
+def use_backend(name: str) -> None:
+    """"c": the plain-C operators above (default).  "aten": PyTorch's CPU kernels (oracle/aten_backend.py) under the
+    same graphs, i.e. the network as the reference runs it eagerly on a CPU."""
+    if name == "c":
+        globals().update(_C_OPS)
+    elif name == "aten":
+        from . import aten_backend
+        globals().update(aten_backend.OPS)
+    else:
+        raise ValueError(name)
+
+
 # --------------------------------------------------------------- pre / post stages
 def preprocess(frame_bgr):
     """HDRTVNetTorch.preprocess, hdrtvnet_torch.py:2238-2296 -> (tensor[3,H,W], cond[3,H//4,W//4])."""

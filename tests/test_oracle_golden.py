@@ -132,3 +132,26 @@ def test_int8_checkpoints_predequantized(golden_dir, tag):
     d16 = W.dequantize_int8_state(st, "fp16")
     k = "LE.down_conv1.weight"
     assert np.abs(d16[k] - deq[k]).max() <= np.abs(deq[k]).max() * 2 ** -10
+
+
+def test_c_operators_agree_with_aten(hr_state, hg_state):
+    """The plain-C operators against PyTorch's CPU kernels under the same graphs (oracle/aten_backend.py):
+    a second pin on the oracle besides the reference-generated goldens, at a size the goldens do not cover."""
+    from hdrtv_mi355x import weights as W
+    f = W.synthetic_frame(72, 104, seed=77, kind="gradient")           # unaligned: _align_to and reflect pad paths
+    t, c = O.preprocess(f)
+    taps_c, taps_a = {}, {}
+    out_c = O.hg_composite(hr_state, hg_state, t, c, taps_c)
+    O.use_backend("aten")
+    try:
+        t2, c2 = O.preprocess(f)
+        out_a = O.hg_composite(hr_state, hg_state, t2, c2, taps_a)
+    finally:
+        O.use_backend("c")
+    oc = out_c[0] if isinstance(out_c, (tuple, list)) else out_c
+    oa = out_a[0] if isinstance(out_a, (tuple, list)) else out_a
+    assert np.abs(c - c2).max() <= 2e-6                                # AA-bicubic vs F.interpolate(antialias=True)
+    assert np.abs(oc - oa).max() <= 1e-4
+    for k in taps_c:
+        if k in taps_a and isinstance(taps_c[k], np.ndarray) and taps_c[k].dtype == np.float32:
+            assert np.abs(taps_c[k] - taps_a[k]).max() <= 2e-4, k
