@@ -286,6 +286,27 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
             }
         }
 
+        // planar head (conv_last): element offsets and the residual plane values, fetched before the conv
+        // so the store phase does not sit behind two dependent global loads
+        constexpr int PR = (TH * TW * 3 + NT - 1) / NT;
+        long pl_off[PR];
+        unsigned pl_res[PR];       // raw f16 bits
+        if (p.mode == ST_PLANAR3) {
+#pragma unroll
+            for (int it = 0; it < PR; ++it) {
+                const int e = tid + it * NT;
+                const int ch = e / (TH * TW), qq = e % (TH * TW);
+                const int oy = oy0 + qq / TW, ox = ox0 + qq % TW;
+                const bool ok = e < TH * TW * 3 && oy < p.H && ox < p.W;
+                pl_off[it] = ok ? (long)((size_t)ch * p.H * p.W + (size_t)oy * p.W + ox) : -1;
+                // unconditional load (offset 0 when masked): a load under a branch is waited for at the branch's end
+                // issued as inline asm: hipcc touches (masks / packs) a plain load's result at once, which
+                // parks the wave on the load before the conv; the s_waitcnt vmcnt(0) in front of barrier 1
+                // covers it, and the value is first read after that barrier
+                const f16 *rp = (p.res_planar ? p.res_planar : p.src) + (ok ? pl_off[it] : 0);
+                asm volatile("global_load_ushort %0, %1, off" : "=v"(pl_res[it]) : "v"(rp) : "memory");
+            }
+        }
         STAMP(0);      // offsets + residual prefetch
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
@@ -335,14 +356,13 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
             __syncthreads();
             STAMP(4);  // barrier 1
             if (p.mode == ST_PLANAR3) {
-                for (int e = tid; e < TH * TW * 3; e += NT) {
-                    const int ch = e / (TH * TW), qq = e % (TH * TW);
-                    const int oy = oy0 + qq / TW, ox = ox0 + qq % TW;
-                    if (oy < p.H && ox < p.W) {
-                        float v = (float)*reinterpret_cast<const f16 *>(sO + qq * OUT_ROWB + ch * 2);
-                        const size_t off = (size_t)ch * p.H * p.W + (size_t)oy * p.W + ox;
-                        if (p.res_planar) v += (float)p.res_planar[off];
-                        p.dst_planar[off] = (f16)v;
+#pragma unroll
+                for (int it = 0; it < PR; ++it) {
+                    if (pl_off[it] >= 0) {
+                        const int e = tid + it * NT;
+                        const int ch = e / (TH * TW), qq = e % (TH * TW);
+                        const float v = (float)*reinterpret_cast<const f16 *>(sO + qq * OUT_ROWB + ch * 2) + (p.res_planar ? (float)__builtin_bit_cast(f16, (unsigned short)pl_res[it]) : 0.f);
+                        p.dst_planar[pl_off[it]] = (f16)v;
                     }
                 }
             } else {
