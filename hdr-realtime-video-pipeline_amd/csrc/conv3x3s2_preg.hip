@@ -1,0 +1,176 @@
+// conv3x3s2_preg.hip -- 3x3 / stride-2 convolution from 64 channels (gfx950): the first layers of
+// LE's CondNet2/3/4 (HDRUNet3T1_arch.py:47-55), merged into ONE launch with 192 output channels
+// that reads the 64-channel full-resolution condition map once, and the 64->64 second layers.
+//
+// Persistent, weights in registers.  Cin = 64 makes the whole filter bank small (9 x 64 x Cout f16:
+// 216 KiB at Cout = 192), so instead of streaming it through LDS for every tile, wave w keeps the
+// complete K = 576 filter rows of output channels 16w..16w+15 in 72 VGPRs for the life of the
+// block (12 waves at Cout = 192, 4 at Cout = 64) and the block walks output tiles of 8 x 16 pixels:
+//   * the (17 x 33 pixel) x 64-channel input halo of a tile is staged by LDS-DMA into one of two
+//     72-KiB buffers, two tiles ahead of its use; there is no per-tap weight traffic and no per-tap
+//     barrier, a tile is 144 MFMAs (16x16x32) per wave against 144 ds_read_b128;
+//   * stride-2 taps read every second halo column.  At 128 bytes per pixel that keeps all 16 lanes
+//     of a ds_read_b128 group in one half of the 256-byte bank row (2-way conflict whatever the
+//     swizzle), so the halo is staged column-de-interleaved -- even columns first, then the odd
+//     ones; the per-lane DMA source address makes that free -- and a tap's 16 pixels are again 16
+//     consecutive LDS rows, conflict-free under the (row & 7) chunk swizzle;
+//   * epilogue through the halo buffer the tile just released: bias + LeakyReLU, padded pixel
+//     rows, 16-byte stores of whole NHWC pixels.
+#include "launchers.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 16;
+constexpr int HH = 2 * TH + 1, HWD = 2 * TW + 1, NPIX = HH * HWD;   // 17 x 33 = 561 halo pixels
+constexpr int NEVEN = TW + 1;                                       // even halo columns 0,2,..,32 come first
+constexpr int PIXB = 128;
+constexpr int A_PIECES = (NPIX + 7) / 8;                            // 71 one-KiB pieces (8 pixels each)
+constexpr int A_BYTES = 72 * 1024;
+constexpr int SMEM = 2 * A_BYTES;
+
+__device__ __forceinline__ void glds16(const void *g, void *lds)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds, 16, 0, 0);
+}
+
+template <int NW>   // waves = 16-channel tiles: Cout = 16 * NW
+__global__ __launch_bounds__(64 * NW, 1) void conv3x3s2_preg_kernel(ConvParams p)   // 1 block per CU: LDS-limited anyway
+{
+    constexpr int NT = 64 * NW, COUT = 16 * NW;
+    constexpr int OUT_ROWB = COUT * 2 + 16;
+    static_assert(TH * TW * OUT_ROWB <= A_BYTES, "epilogue tile aliases a halo buffer");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int l_row = lane >> 3, l_slot = lane & 7;
+    const int ntiles = p.tiles_x * p.tiles_y;
+
+    // ---- this wave's filter rows: A fragments of all 18 k-steps (tap x 32-channel half) --------
+    f16x8 wfr[18];
+#pragma unroll
+    for (int s = 0; s < 18; ++s)
+        wfr[s] = *reinterpret_cast<const f16x8 *>(p.wpk + ((size_t)(s >> 1) * p.CoutPad + wave * 16 + l15) * 64 + (s & 1) * 32 + kg * 8);
+    const float4 sc = *reinterpret_cast<const float4 *>(p.scale + wave * 16 + 4 * kg);
+    const float4 sh = *reinterpret_cast<const float4 *>(p.shift + wave * 16 + 4 * kg);
+    const float aslope = act_slope(p.act);
+
+    // ---- halo staging: LDS row q = hy * 33 + col, col = even columns first; chunk swizzle = q & 7 = l_row
+    auto issue_tile = [&](int t, int buf) {
+        const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+        const int iy0 = 2 * ty * TH - 1, ix0 = 2 * tx * TW - 1;
+        for (int piece = wave; piece < A_PIECES; piece += NW) {
+            const int q = piece * 8 + l_row;
+            const int hy = q / HWD, col = q - hy * HWD;
+            const int hx = col < NEVEN ? 2 * col : 2 * (col - NEVEN) + 1;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            const bool ok = q < NPIX && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+            const f16 *g = ok ? p.src0 + ((size_t)iy * p.Wi + ix) * p.s0_stride + ((l_slot ^ l_row) << 3) : p.zeros + (l_slot << 3);
+            glds16(g, smem + buf * A_BYTES + piece * 1024);
+        }
+    };
+
+    // per-lane read offsets: LDS row = c + l15 for a compile-time c; the swizzle needs (c + l15) & 7
+    // (the second 32-channel half is the same offset with bit 6 flipped)
+    int xo[8];
+#pragma unroll
+    for (int c7 = 0; c7 < 8; ++c7) xo[c7] = l15 * PIXB + ((kg ^ ((c7 + l15) & 7)) << 4);
+
+    // ---- prologue: tile 0 landed, tile 1 in flight ---------------------------------------------
+    int t = blockIdx.x;
+    const int step = gridDim.x;
+    if (t < ntiles) issue_tile(t, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + step < ntiles) issue_tile(t + step, 1);
+
+    for (int buf = 0; t < ntiles; t += step, buf ^= 1) {
+        const char *a = smem + buf * A_BYTES;
+        f32x4 acc[TH];
+#pragma unroll
+        for (int i = 0; i < TH; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // 144 MFMAs: k-step s = (tap, half) outer, output row inner; activation reads 4 MFMAs ahead
+        auto ldx = [&](int m) -> f16x8 {
+            const int s = m >> 3, pt = m & 7;
+            const int tap = s >> 1, ks = s & 1, ky = tap / 3, kx = tap % 3;
+            const int c = (2 * pt + ky) * HWD + (kx & 1) * NEVEN + (kx >> 1);
+            return *reinterpret_cast<const f16x8 *>(a + c * PIXB + (xo[c & 7] ^ (ks << 6)));
+        };
+        f16x8 xq[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) xq[m] = ldx(m);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 18; ++s) {
+#pragma unroll
+            for (int pt = 0; pt < 8; ++pt) {
+                const int m = s * 8 + pt;
+                const f16x8 x = xq[m & 3];
+                if (m + 4 < 144) xq[m & 3] = ldx(m + 4);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfr[s], x, acc[pt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+
+        // ---- epilogue: everyone is done reading this halo buffer -> it becomes the output tile
+        __syncthreads();
+        char *so = smem + buf * A_BYTES;
+#pragma unroll
+        for (int pt = 0; pt < TH; ++pt) {
+            f16x4 o;
+            o[0] = (f16)act_fast(acc[pt][0] * sc.x + sh.x, aslope);
+            o[1] = (f16)act_fast(acc[pt][1] * sc.y + sh.y, aslope);
+            o[2] = (f16)act_fast(acc[pt][2] * sc.z + sh.z, aslope);
+            o[3] = (f16)act_fast(acc[pt][3] * sc.w + sh.w, aslope);
+            *reinterpret_cast<f16x4 *>(so + (pt * TW + l15) * OUT_ROWB + (wave * 16 + 4 * kg) * 2) = o;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // next tile's halo landed (and older stores retired)
+        __syncthreads();
+        const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        constexpr int CPP = COUT / 8;
+        for (int e = tid; e < TH * TW * CPP; e += NT) {
+            const int qq = e / CPP, c8 = e % CPP;
+            const int oy = oy0 + qq / TW, ox = ox0 + qq % TW;
+            if (oy < p.Ho && ox < p.Wo)
+                *reinterpret_cast<f16x8 *>(p.dst + ((size_t)oy * p.Wo + ox) * p.dstC + c8 * 8) =
+                    *reinterpret_cast<const f16x8 *>(so + qq * OUT_ROWB + c8 * 16);
+        }
+        __syncthreads();                                       // output tile read out: the buffer is free again
+        if (t + 2 * step < ntiles) issue_tile(t + 2 * step, buf);
+    }
+}
+
+template <int NW>
+hipError_t launch_s2(ConvParams p, int n_cu, hipStream_t s)
+{
+    static bool attr_set = false;
+    auto kern = conv3x3s2_preg_kernel<NW>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int ntiles = p.tiles_x * p.tiles_y;
+    hipLaunchKernelGGL(kern, dim3(ntiles < n_cu ? ntiles : n_cu), dim3(64 * NW), SMEM, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// 3x3, stride 2, pad 1, Cin = 64 (src0 only, pixel stride p.s0_stride), Cout == CoutPad in {64, 192}, NHWC store.
+hipError_t conv3x3s2_preg_launch(ConvParams p, int n_cu, hipStream_t s)
+{
+    if (p.c0 != 64 || p.c1 != 0 || p.mode != ST_NHWC || p.res1 || p.res2 || !p.zeros || p.s0_stride < 64 ||
+        p.Cout != p.CoutPad || p.dstC < p.Cout || n_cu < 1)
+        return hipErrorInvalidValue;
+    p.tiles_x = (p.Wo + TW - 1) / TW;
+    p.tiles_y = (p.Ho + TH - 1) / TH;
+    if (p.CoutPad == 64) return launch_s2<4>(p, n_cu, s);
+    if (p.CoutPad == 192) return launch_s2<12>(p, n_cu, s);
+    return hipErrorInvalidValue;
+}

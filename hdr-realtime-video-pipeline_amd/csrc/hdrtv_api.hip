@@ -203,7 +203,7 @@ bool pack_conv(hdrtv_ctx *c, const Pack &pk, const std::string &key, const std::
     if (ks == 1 && stride == 1 && ci % 64 == 0 && ci >= 128 && co == 64) L.coutPad = 128;   // 1x1 64-out layers ride the 128-wide LDS-DMA kernel
     L.cin_t = force_ct ? force_ct : ((stride == 2 || ci == 32) ? 32 : 64);
     L.bn = L.coutPad >= 128 ? 128 : L.coutPad;
-    if (force_ct) L.bn = L.coutPad;     // whole-Cout kernels (conv3x3s2_glds)
+    if (force_ct) L.bn = L.coutPad;     // whole-Cout kernels (conv3x3s2_preg)
     if (ci % L.cin_t != 0 || L.coutPad % L.bn != 0) { c->err = "unsupported conv shape: " + wname; return false; }
     std::vector<float> scale(L.coutPad, 1.f), shift(L.coutPad, 0.f);
     std::vector<float> g, be, mu, var;
@@ -692,7 +692,7 @@ struct Seq {
         p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
         const bool s2g = L.ks == 3 && L.stride == 2 && L.cin_t == 64 && L.bn == L.coutPad && (L.coutPad == 64 || L.coutPad == 192);
         char tag[64];
-        if (s2g) snprintf(tag, sizeof tag, "conv3x3s2_glds<%d>", L.coutPad);
+        if (s2g) snprintf(tag, sizeof tag, "conv3x3s2_preg<%d>", L.coutPad);
         else if (glds) snprintf(tag, sizeof tag, "conv_glds<%d,64,128>", L.ks);
         else snprintf(tag, sizeof tag, "conv_igemm<%d,%d,%d,%d>", L.cin_t, L.bn, L.ks, L.stride);
         const double macs = (double)p.Ho * p.Wo * L.cin * L.ks * L.ks * L.cout;
@@ -701,7 +701,7 @@ struct Seq {
                                               : (mode == ST_PLANAR3 ? 3.0 * Hd * Wd
                                                                     : (mode == ST_PS_DOT3 ? 8.0 * Hd * Wd : (double)p.Ho * p.Wo * L.cout));
         bytes += 2.0 * outel * (1 + (res1 ? 1 : 0) + (res2 ? 1 : 0) + (res_planar ? 1 : 0));
-        chk(s2g ? conv3x3s2_glds_launch(p, s)
+        chk(s2g ? conv3x3s2_preg_launch(p, c->n_cu, s)
                 : (pglds ? conv_pglds_launch(p, c->n_cu, s)
                          : (glds ? conv_glds_launch(p, L.ks, s) : conv_igemm_launch(p, L.cin_t, L.bn, L.ks, L.stride, s))),
             key.c_str(), tag, macs, bytes);

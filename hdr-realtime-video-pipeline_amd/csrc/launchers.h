@@ -6,7 +6,7 @@ hipError_t conv_igemm_launch(ConvParams p, int cin_t, int bn, int ks, int stride
 hipError_t conv_glds_launch(ConvParams p, int ks, hipStream_t stream);
 hipError_t conv_pglds_launch(ConvParams p, int n_cu, hipStream_t stream);
 hipError_t conv32p_launch(Conv32Params p, hipStream_t stream);
-hipError_t conv3x3s2_glds_launch(ConvParams p, hipStream_t stream);
+hipError_t conv3x3s2_preg_launch(ConvParams p, int n_cu, hipStream_t stream);
 
 hipError_t pre_unpack_launch(const uint8_t *bgr, f16 *out, int H, int W, hipStream_t s);
 hipError_t cond_resize_launch(const f16 *in, f16 *out, int H, int W, int Ho, int Wo, const float *wx, const int *xmn,
