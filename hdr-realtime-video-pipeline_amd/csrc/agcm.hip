@@ -209,10 +209,10 @@ __device__ __forceinline__ f32x16 bias_tile(const float *b, int lh)
 
 __device__ __forceinline__ f16x8 relu_pack(const f32x16 &a, int s)
 {
-    f16x8 o;
+    f16x8 o, z;                // f16(max(v, 0)) == max(f16(v), 0): rounding is monotonic; packed max is 3x cheaper
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (f16)fmaxf(a[8 * s + j], 0.f);
-    return o;
+    for (int j = 0; j < 8; ++j) { o[j] = (f16)a[8 * s + j]; z[j] = (f16)0.f; }
+    return __builtin_elementwise_max(o, z);
 }
 
 __global__ __launch_bounds__(256) void agcm_mlp_kernel(const f16 *__restrict__ in, f16 *__restrict__ out, size_t npix,

@@ -825,7 +825,7 @@ int run_le(hdrtv_ctx *c, Seq &q, const f16 *img, f16 *out_planar)
     // condition trunk
     // cond_first (3 layers) + CondNet1 (3 layers) in one launch: img -> cond (64 ch) and cond1 (16 ch)
     if (q.ok())
-        q.chk(le_cond_trunk_launch(img, H, W, wtp<f16>(c, c->trunk_wfrag), wtp<float>(c, c->trunk_bias), cond, cond1, q.s),
+        q.chk(le_cond_trunk_launch(img, H, W, wtp<f16>(c, c->trunk_wfrag), wtp<float>(c, c->trunk_bias), cond, cond1, c->n_cu, q.s),
               "LE.cond_trunk", "le_cond_trunk", (double)H * W * (27 * 64 + 4 * 64 * 64 + 64 * 16), (double)H * W * (6 + 128 + 32));
     // CondNet2/3/4: the three 3x3/s2 first layers read `cond` once (one launch, 192 channels)
     f16 *x192 = wsp<f16>(c, "le.x192"), *h2b = wsp<f16>(c, "le.h2b");

@@ -31,7 +31,7 @@ hipError_t conv_c3_launch(const f16 *in, int H, int W, const f16 *wfrag, const f
                           int act, f16 *out, f16 *out_pool, hipStream_t s);
 hipError_t sft_launch(const SftParams &p, hipStream_t s);
 hipError_t le_cond_trunk_launch(const f16 *img, int H, int W, const f16 *wfrag, const float *bias, f16 *cond, f16 *cond1,
-                                hipStream_t s);
+                                int n_cu, hipStream_t s);
 hipError_t hg_prep_launch(const f16 *base, int H, int W, int Hp, int Wp, f16 *img_pad, uint8_t *mask, float r, float thresh,
                           hipStream_t s);
 struct HgFinalArgs {

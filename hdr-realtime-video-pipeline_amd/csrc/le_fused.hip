@@ -31,13 +31,13 @@ __device__ __forceinline__ f32x16 bias_tile_l(const float *b, int lh)
 // LeakyReLU(0.1) then f16 pack of accumulator registers 8s..8s+7 (= next layer's k-step fragment)
 __device__ __forceinline__ f16x8 lrelu_pack(const f32x16 &a, int s)
 {
+    // round to f16 first, LeakyReLU in packed f16 (the reference's fp16 GPU graph does exactly this: the conv
+    // result is an f16 tensor before nn.LeakyReLU sees it).  In fp32 the max costs 3.5 VALU ops per value
+    // (hipcc canonicalises the MFMA result with an extra v_max); packed it is 1.5.
     f16x8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float v = a[8 * s + j];
-        o[j] = (f16)fmaxf(v, 0.1f * v);
-    }
-    return o;
+    for (int j = 0; j < 8; ++j) o[j] = (f16)a[8 * s + j];
+    return __builtin_elementwise_max(o, o * (f16)0.1f);
 }
 
 __global__ __launch_bounds__(256, 2) void le_cond_trunk_kernel(const f16 *__restrict__ img, int H, int W,
@@ -51,17 +51,40 @@ __global__ __launch_bounds__(256, 2) void le_cond_trunk_kernel(const f16 *__rest
     char *s_stg = reinterpret_cast<char *>(s_in) + ((3 * T_HH * (T_HW + 2) * 2 + 15) / 16) * 16;  // [4 waves][32][STG_ROWB]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-    const int ox0 = blockIdx.x * T_TW, oy0 = blockIdx.y * T_TH;
+    const int tiles_x = (W + T_TW - 1) / T_TW, ntiles = tiles_x * ((H + T_TH - 1) / T_TH);
 
+    // persistent: the 40 KiB of weight fragments are staged once per workgroup, not once per 256 pixels
     for (int e = tid; e < NFRAG * 64; e += 256) s_w[e] = reinterpret_cast<const f16x8 *>(wfrag)[e];
     for (int e = tid; e < NBIAS; e += 256) s_b[e] = bias[e];
-    for (int e = tid; e < 3 * T_HH * T_HW; e += 256) {
+
+    // this thread's share of a tile's 3 x 10 x 34 input patch, fetched one tile ahead
+    constexpr int NE = (3 * T_HH * T_HW + 255) / 256;
+    f16 pre[NE];
+    auto fetch = [&](int t) {
+        const int ox0 = (t % tiles_x) * T_TW, oy0 = (t / tiles_x) * T_TH;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = tid + 256 * i;
+            const int c = e / (T_HH * T_HW), r = (e / T_HW) % T_HH, q = e % T_HW;
+            const int iy = oy0 - 1 + r, ix = ox0 - 1 + q;
+            const bool ok = e < 3 * T_HH * T_HW && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            pre[i] = img[ok ? ((size_t)c * H + iy) * W + ix : 0];
+            if (!ok) pre[i] = (f16)0.f;
+        }
+    };
+    int t = blockIdx.x;
+    if (t < ntiles) fetch(t);
+    for (; t < ntiles; t += gridDim.x) {
+    const int ox0 = (t % tiles_x) * T_TW, oy0 = (t / tiles_x) * T_TH;
+    __syncthreads();                                   // layer 1 of the previous tile is done with s_in
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = tid + 256 * i;
         const int c = e / (T_HH * T_HW), r = (e / T_HW) % T_HH, q = e % T_HW;
-        const int iy = oy0 - 1 + r, ix = ox0 - 1 + q;
-        s_in[(c * T_HH + r) * (T_HW + 2) + q] =
-            (iy >= 0 && iy < H && ix >= 0 && ix < W) ? img[((size_t)c * H + iy) * W + ix] : (f16)0.f;
+        if (e < 3 * T_HH * T_HW) s_in[(c * T_HH + r) * (T_HW + 2) + q] = pre[i];
     }
     __syncthreads();
+    if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
 
     // ---- layer 1: 3x3 conv as a K = 27 (padded 32) GEMM, im2col fragments gathered from LDS
     f16x8 bf[2][4];   // activations of the two 32-pixel groups (rows 2*wave, 2*wave+1) as B fragments
@@ -168,6 +191,7 @@ __global__ __launch_bounds__(256, 2) void le_cond_trunk_kernel(const f16 *__rest
                 *reinterpret_cast<const f16x8 *>(stg + px * STG_ROWB + c8 * 16);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    }   // tile loop
 }
 
 constexpr int TRUNK_SMEM = NFRAG * 64 * 16 + ((NBIAS * 4 + 15) / 16) * 16 + ((3 * T_HH * (T_HW + 2) * 2 + 15) / 16) * 16 +
@@ -176,7 +200,7 @@ constexpr int TRUNK_SMEM = NFRAG * 64 * 16 + ((NBIAS * 4 + 15) / 16) * 16 + ((3 
 }  // namespace
 
 hipError_t le_cond_trunk_launch(const f16 *img, int H, int W, const f16 *wfrag, const float *bias, f16 *cond, f16 *cond1,
-                                hipStream_t s)
+                                int n_cu, hipStream_t s)
 {
     static bool attr_set = false;
     if (!attr_set) {
@@ -185,7 +209,8 @@ hipError_t le_cond_trunk_launch(const f16 *img, int H, int W, const f16 *wfrag, 
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    dim3 grid((W + T_TW - 1) / T_TW, (H + T_TH - 1) / T_TH);
-    hipLaunchKernelGGL(le_cond_trunk_kernel, grid, dim3(256), TRUNK_SMEM, s, img, H, W, wfrag, bias, cond, cond1);
+    const int ntiles = ((W + T_TW - 1) / T_TW) * ((H + T_TH - 1) / T_TH);
+    const int grid = ntiles < 2 * n_cu ? ntiles : 2 * n_cu;          // two workgroups per CU (LDS: ~60 KiB each)
+    hipLaunchKernelGGL(le_cond_trunk_kernel, dim3(grid), dim3(256), TRUNK_SMEM, s, img, H, W, wfrag, bias, cond, cond1);
     return hipGetLastError();
 }

@@ -248,7 +248,10 @@ class HeadlessPipelineWorker:
             p = self._processor
             p._chk(p._lib.hdrtv_ring_create(p._ctx, _RING_FRAMES, self._proc_h, self._proc_w), "hdrtv_ring_create")
             self._ring_shape = (self._proc_h, self._proc_w)
-        self._hdr_queue = _queue.Queue(maxsize=max(1, min(3, self._video_playback_buffer_frames + 1)))
+        # feeders.py:634-644: queue depth = buffer_frames (1..3).  With the staging pool of buffer_frames + 2
+        # (_stage_hdr_display_tensor) that is exactly enough: queued + the one in the feeder's hands + the one
+        # being staged; one more queued frame and the main stream overwrites a tensor the side stream still reads.
+        self._hdr_queue = _queue.Queue(maxsize=min(3, max(1, self._video_playback_buffer_frames)))
         self._hdr_stop.clear()
         dev = self._processor.device
 
