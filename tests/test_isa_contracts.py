@@ -1,0 +1,73 @@
+"""Compiler-output contracts two kernels rely on (hipcc cross-compiles gfx950 without a GPU).
+
+conv3x3_pglds.hip counts vector-memory operations by hand: its `s_waitcnt vmcnt(N)` after a tile boundary
+assumes every wave issued exactly NStores<MODE>::N global stores in the epilogue.  If a compiler change merged
+two stores (fewer than assumed) the wait would let a weight DMA be read before it landed, so the count is pinned
+here.  conv32p.hip issues its planar-residual loads as inline asm (the compiler does not know they are
+outstanding): the loaded registers must not be read before the `s_waitcnt vmcnt(0)` that precedes barrier 1."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(REPO, "hdr-realtime-video-pipeline_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+
+
+def _asm(src, tmp_path):
+    out = tmp_path / (src + ".s")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                    os.path.join(CSRC, src), "-o", str(out)], check=True, capture_output=True)
+    text = out.read_text()
+    kernels = {}
+    for m in re.finditer(r"^(_Z\w+):.*?\n(.*?)s_endpgm", text, re.S | re.M):
+        kernels[m.group(1)] = m.group(2)
+    return kernels
+
+
+def test_pglds_store_counts_match_the_counted_waits(tmp_path):
+    kernels = _asm("conv3x3_pglds.hip", tmp_path)
+    src = open(os.path.join(CSRC, "conv3x3_pglds.hip")).read()
+    m = re.search(r"MODE == ST_POOL \? (\d+) : \(MODE == ST_PS_DOT3 \? (\d+) : (\d+)\)", src)
+    n_pool, n_dot3, n_other = (int(v) for v in m.groups())
+    expect = {0: n_other, 1: n_other, 2: n_pool, 4: n_dot3}          # ST_NHWC, ST_PS, ST_POOL, ST_PS_DOT3 (common.h)
+    seen = 0
+    for name, body in kernels.items():
+        km = re.search(r"conv_pglds_kernelILi(\d+)E", name)
+        if not km:
+            continue
+        mode = int(km.group(1))
+        stores = len(re.findall(r"^\s*(?:global|buffer|flat)_store", body, re.M))
+        assert stores == expect[mode], (name, stores, expect[mode])
+        waits = set(int(v) for v in re.findall(r"s_waitcnt vmcnt\((\d+)\)", body))
+        assert expect[mode] + 2 in waits, (name, sorted(waits))
+        seen += 1
+    assert seen == 4
+
+
+def test_conv32p_asm_loads_are_read_only_after_the_wait(tmp_path):
+    kernels = _asm("conv32p.hip", tmp_path)
+    checked = 0
+    for name, body in kernels.items():
+        if "conv32p_kernel" not in name:
+            continue
+        lines = body.split("\n")
+        for i, ln in enumerate(lines):
+            m = re.match(r"\s*global_load_ushort (v\d+),", ln)
+            if not m:
+                continue
+            reg = m.group(1)
+            waited = False
+            for later in lines[i + 1:]:
+                if re.search(r"s_waitcnt vmcnt\(0\)", later):
+                    waited = True
+                if re.search(rf"\b{reg}\b", later) and not re.match(r"\s*global_load_ushort", later):
+                    assert waited, (name, reg, later.strip())
+                    break
+            checked += 1
+    assert checked >= 2
