@@ -26,13 +26,10 @@ __global__ __launch_bounds__(256) void conv_c3_kernel(const f16 *__restrict__ in
     constexpr int ROWB = COUT * 2 + 16;
     __shared__ f16 s_in[3][C3_HH][C3_HW + 2];
     __shared__ __attribute__((aligned(16))) char s_out[C3_TH * C3_TW * ROWB];
+    __shared__ __attribute__((aligned(16))) float s_ss[2 * COUT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-    const int ox0 = blockIdx.x * C3_TW, oy0 = blockIdx.y * C3_TH;
-    for (int e = tid; e < 3 * C3_HH * C3_HW; e += 256) {
-        const int c = e / (C3_HH * C3_HW), r = (e / C3_HW) % C3_HH, q = e % C3_HW;
-        const int iy = oy0 - 1 + r, ix = ox0 - 1 + q;
-        s_in[c][r][q] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? in[((size_t)c * H + iy) * W + ix] : (f16)0.f;
-    }
+    const int tiles_x = (W + C3_TW - 1) / C3_TW, ntiles = tiles_x * ((H + C3_TH - 1) / C3_TH);
+    if (tid < COUT) { s_ss[tid] = scale[tid]; s_ss[COUT + tid] = shift[tid]; }
     f16x8 wf[MT][2];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -48,7 +45,35 @@ __global__ __launch_bounds__(256) void conv_c3_kernel(const f16 *__restrict__ in
             const int tap = k / 3, c = k % 3;
             koff[ks][j] = k < 27 ? (c * C3_HH + tap / 3) * (C3_HW + 2) + tap % 3 : -1;
         }
+    // persistent over 8x32-pixel tiles, the next tile's image patch fetched while this one computes
+    constexpr int NE = (3 * C3_HH * C3_HW + 255) / 256;
+    f16 pre[NE];
+    auto fetch = [&](int t) {
+        const int ox0 = (t % tiles_x) * C3_TW, oy0 = (t / tiles_x) * C3_TH;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = tid + 256 * i;
+            const int c = e / (C3_HH * C3_HW), r = (e / C3_HW) % C3_HH, q = e % C3_HW;
+            const int iy = oy0 - 1 + r, ix = ox0 - 1 + q;
+            const bool ok = e < 3 * C3_HH * C3_HW && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            pre[i] = in[ok ? ((size_t)c * H + iy) * W + ix : 0];
+            if (!ok) pre[i] = (f16)0.f;
+        }
+    };
+    const float aslope = act_slope(act);
+    int t = blockIdx.x;
+    if (t < ntiles) fetch(t);
+    for (; t < ntiles; t += gridDim.x) {
+    const int ox0 = (t % tiles_x) * C3_TW, oy0 = (t / tiles_x) * C3_TH;
+    __syncthreads();                                   // the previous tile is done with s_in and s_out
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = tid + 256 * i;
+        const int c = e / (C3_HH * C3_HW), r = (e / C3_HW) % C3_HH, q = e % C3_HW;
+        if (e < 3 * C3_HH * C3_HW) s_in[c][r][q] = pre[i];
+    }
     __syncthreads();
+    if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
     const f16 *sflat = &s_in[0][0][0];
     f32x16 acc[MT][2];
 #pragma unroll
@@ -68,14 +93,13 @@ __global__ __launch_bounds__(256) void conv_c3_kernel(const f16 *__restrict__ in
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i][1], xf[1], acc[i][j], 0, 0, 0);
         }
     }
-    const float aslope = act_slope(act);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
             const int cl = i * 32 + 8 * qd + 4 * lh;
-            const float4 sc = *reinterpret_cast<const float4 *>(scale + cl);
-            const float4 sh = *reinterpret_cast<const float4 *>(shift + cl);
+            const float4 sc = *reinterpret_cast<const float4 *>(s_ss + cl);
+            const float4 sh = *reinterpret_cast<const float4 *>(s_ss + COUT + cl);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int q = (2 * wave + j) * C3_TW + l31;
@@ -118,6 +142,7 @@ __global__ __launch_bounds__(256) void conv_c3_kernel(const f16 *__restrict__ in
             }
         }
     }
+    }   // tile loop
 }
 
 // ====================================================================================== sft
@@ -292,12 +317,7 @@ __global__ __launch_bounds__(256) void hg_final_fused_kernel(HgFinalFusedParams 
 {
     __shared__ f16 s_in[3][C3_HH][C3_HW + 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-    const int ox0 = blockIdx.x * C3_TW, oy0 = blockIdx.y * C3_TH;
-    for (int e = tid; e < 3 * C3_HH * C3_HW; e += 256) {
-        const int c = e / (C3_HH * C3_HW), r = (e / C3_HW) % C3_HH, q = e % C3_HW;
-        const int iy = oy0 - 1 + r, ix = ox0 - 1 + q;
-        s_in[c][r][q] = (iy >= 0 && iy < p.Hp && ix >= 0 && ix < p.Wp) ? p.img[((size_t)c * p.Hp + iy) * p.Wp + ix] : (f16)0.f;
-    }
+    const int tiles_x = (p.W + C3_TW - 1) / C3_TW, ntiles = tiles_x * ((p.H + C3_TH - 1) / C3_TH);
     const f16x8 *fr = reinterpret_cast<const f16x8 *>(p.wfrag);
     f16x8 w1[2][2], w2[4];
 #pragma unroll
@@ -310,19 +330,49 @@ __global__ __launch_bounds__(256) void hg_final_fused_kernel(HgFinalFusedParams 
     // lives on occupancy), and the per-pixel inputs of the tail prefetched before any arithmetic
     __shared__ __attribute__((aligned(16))) float s_ss[128];
     if (tid < 64) { s_ss[tid] = p.scale[tid]; s_ss[64 + tid] = p.shift[tid]; }
+    // persistent over 8x32-pixel tiles; the next tile's image patch, partial sums and mask are fetched while
+    // this one computes (a tile is ~10 MFMAs per wave: unpipelined, the kernel was all load latency)
+    constexpr int NE = (3 * C3_HH * C3_HW + 255) / 256;
+    f16 pre[NE];
     float4 pt_pre[2];
-    float m_pre[2];
+    uint8_t m_pre[2];
+    auto fetch = [&](int t) {
+        const int ox0 = (t % tiles_x) * C3_TW, oy0 = (t / tiles_x) * C3_TH;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int y = oy0 + 2 * wave + j, x = ox0 + l31;
-        const bool ok = lh == 0 && y < p.H && x < p.W;
-        const size_t pix = ok ? (size_t)y * p.Wp + x : 0;
-        pt_pre[j] = *reinterpret_cast<const float4 *>(p.part + pix * 4);
-        m_pre[j] = (float)p.mask[pix];
-    }
-    __syncthreads();
+        for (int i = 0; i < NE; ++i) {
+            const int e = tid + 256 * i;
+            const int c = e / (C3_HH * C3_HW), r = (e / C3_HW) % C3_HH, q = e % C3_HW;
+            const int iy = oy0 - 1 + r, ix = ox0 - 1 + q;
+            const bool ok = e < 3 * C3_HH * C3_HW && iy >= 0 && iy < p.Hp && ix >= 0 && ix < p.Wp;
+            pre[i] = p.img[ok ? ((size_t)c * p.Hp + iy) * p.Wp + ix : 0];
+            if (!ok) pre[i] = (f16)0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int y = oy0 + 2 * wave + j, x = ox0 + l31;
+            const bool ok = lh == 0 && y < p.H && x < p.W;
+            const size_t pix = ok ? (size_t)y * p.Wp + x : 0;
+            pt_pre[j] = *reinterpret_cast<const float4 *>(p.part + pix * 4);
+            m_pre[j] = p.mask[pix];
+        }
+    };
     const f16 *sflat = &s_in[0][0][0];
-    const size_t plane_p = (size_t)p.Hp * p.Wp, plane_o = (size_t)p.H * p.W;
+    const size_t plane_o = (size_t)p.H * p.W;
+    int t = blockIdx.x;
+    if (t < ntiles) fetch(t);
+    for (; t < ntiles; t += gridDim.x) {
+    const int ox0 = (t % tiles_x) * C3_TW, oy0 = (t / tiles_x) * C3_TH;
+    __syncthreads();                                   // the previous tile is done with s_in
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = tid + 256 * i;
+        const int c = e / (C3_HH * C3_HW), r = (e / C3_HW) % C3_HH, q = e % C3_HW;
+        if (e < 3 * C3_HH * C3_HW) s_in[c][r][q] = pre[i];
+    }
+    const float4 pt_cur[2] = {pt_pre[0], pt_pre[1]};
+    const float m_cur[2] = {(float)m_pre[0], (float)m_pre[1]};
+    __syncthreads();
+    if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int row = 2 * wave + j;
@@ -363,12 +413,12 @@ __global__ __launch_bounds__(256) void hg_final_fused_kernel(HgFinalFusedParams 
         for (int s = 0; s < 4; ++s) o = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[s], bf[s], o, 0, 0, 0);
         const int y = oy0 + row, x = ox0 + l31;
         if (lh == 0 && y < p.H && x < p.W) {
-            const float4 pt = pt_pre[j];
+            const float4 pt = pt_cur[j];
             const float c10[3] = {(float)(f16)(o[0] + pt.x + p.b10[0]), (float)(f16)(o[1] + pt.y + p.b10[1]),
                                   (float)(f16)(o[2] + pt.z + p.b10[2])};
             const int ctr = (row + 1) * (C3_HW + 2) + l31 + 1;
             const float im[3] = {(float)sflat[ctr], (float)sflat[C3_HH * (C3_HW + 2) + ctr], (float)sflat[2 * C3_HH * (C3_HW + 2) + ctr]};
-            const float m = m_pre[j];
+            const float m = m_cur[j];
             const size_t oo = (size_t)y * p.W + x;
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
@@ -382,7 +432,7 @@ __global__ __launch_bounds__(256) void hg_final_fused_kernel(HgFinalFusedParams 
             }
         }
     }
-    (void)plane_p;
+    }   // tile loop
 }
 
 // ================================================================================= maxpool2
@@ -409,6 +459,18 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(const f16 *__restrict__ i
     }
 }
 
+// CUs of the current device (one process drives one GPU)
+inline int num_cus()
+{
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1)
+            v = 256;
+        return v;
+    }();
+    return n;
+}
+
 inline int grid_for(size_t n, int per_block)
 {
     size_t g = (n + per_block - 1) / per_block;
@@ -422,7 +484,9 @@ inline int grid_for(size_t n, int per_block)
 hipError_t conv_c3_launch(const f16 *in, int H, int W, const f16 *wfrag, const float *scale, const float *shift, int cout,
                           int act, f16 *out, f16 *out_pool, hipStream_t s)
 {
-    dim3 grid((W + C3_TW - 1) / C3_TW, (H + C3_TH - 1) / C3_TH);
+    const int ntiles = ((W + C3_TW - 1) / C3_TW) * ((H + C3_TH - 1) / C3_TH);
+    const int per_cu = cout == 32 ? 6 : 4;                        // LDS: 22 KiB / 39 KiB per workgroup
+    const dim3 grid(ntiles < per_cu * num_cus() ? ntiles : per_cu * num_cus());
     if (cout == 32)
         hipLaunchKernelGGL(conv_c3_kernel<32>, grid, dim3(256), 0, s, in, H, W, wfrag, scale, shift, act, out, out_pool);
     else if (cout == 64)
@@ -462,8 +526,9 @@ hipError_t hg_final_fused_launch(const HgFinalFusedArgs &a, hipStream_t s)
     HgFinalFusedParams p;
     p.img = a.img; p.mask = a.mask; p.part = a.part; p.wfrag = a.wfrag; p.scale = a.scale; p.shift = a.shift;
     p.b10 = a.b10; p.wl = a.wl; p.bl = a.bl; p.out = a.out; p.out_f32 = a.out_f32; p.H = a.H; p.W = a.W; p.Hp = a.Hp; p.Wp = a.Wp;
-    dim3 grid((a.W + C3_TW - 1) / C3_TW, (a.H + C3_TH - 1) / C3_TH);
-    hipLaunchKernelGGL(hg_final_fused_kernel, grid, dim3(256), 0, s, p);
+    const int ntiles = ((a.W + C3_TW - 1) / C3_TW) * ((a.H + C3_TH - 1) / C3_TH);
+    const int grid = ntiles < 4 * num_cus() ? ntiles : 4 * num_cus();
+    hipLaunchKernelGGL(hg_final_fused_kernel, dim3(grid), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
