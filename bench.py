@@ -218,7 +218,10 @@ def main():
         traffic = None
         try:
             pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))["kernels"]
-            key = {"conv_glds<3,64,128>": "conv_glds_kernel<3>", "conv_glds<1,64,128>": "conv_glds_kernel<1>"}.get(kern, kern)
+            # profile tag -> kernel name in the rocprofv3 counter CSV (template argument = store mode, common.h)
+            key = {"conv_pglds<nhwc>": "conv_pglds_kernel<0>", "conv_pglds<ps>": "conv_pglds_kernel<1>",
+                   "conv_pglds<pool>": "conv_pglds_kernel<2>", "conv_pglds<ps_dot3>": "conv_pglds_kernel<4>",
+                   "conv_glds1": "conv_glds1_kernel"}.get(kern, kern)
             if (H, Wd) == (2160, 3840) and use_hg and key in pmc:
                 traffic = pmc[key]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):

@@ -72,8 +72,8 @@ struct ConvParams {
 struct Conv32Params {
     const f16 *src;        // NHWC 32
     const f16 *cond;       // NHWC 16 when an SFT layer is fused in front, else nullptr
-    const f16 *sft_wfrag;  // SFT A-fragments (as SftParams)
-    const float *sft_bias;
+    const f16 *sft_wfrag;  // SFT A-fragments [3][64 lanes][8]: hidden stack (scale16|shift16), scale-out, shift-out
+    const float *sft_bias; // [32 hidden] [32 scale-out] [32 shift-out]
     int H, W;              // input == conv output spatial size
     const f16 *wpk;        // [9][CoutPad][32]
     const float *scale, *shift;
@@ -88,11 +88,3 @@ struct Conv32Params {
     int tiles_x, tiles_y;
 };
 
-struct SftParams {
-    const f16 *x;      // NHWC 32
-    const f16 *cond;   // NHWC 16
-    f16 *y;            // NHWC 32
-    const f16 *wfrag;  // 3 A-fragments [3][64 lanes][8] (hidden stack, scale, shift), f16
-    const float *bias; // [32 hidden (scale16|shift16)] [32 scale-out] [32 shift-out]
-    int npix;
-};

@@ -1,0 +1,200 @@
+// conv1x1_glds.hip -- the HG head's 1x1 fuse convolutions conv6..conv9 over a channel concat
+// (Hallucination_arch.py:116-134: cat(Up_convN, skip) -> 1x1): implicit GEMM with LDS-DMA staging.
+//
+// GEMM view: M = 128 output channels (A operand = packed weights), N = a 16x16-pixel tile, K = the
+// 64-channel chunks of src0 then of src1 (the concat is never materialised).  These layers are
+// HBM-bound (2 x C in, C/2 out per pixel), so the design goal is simply to keep enough bytes in
+// flight: activations and weights of a chunk ride 3-slot LDS rings filled by global_load_lds two
+// chunks ahead, one raw s_barrier per chunk behind a counted s_waitcnt vmcnt (never
+// __syncthreads(): its fence would drain the DMA queue), XOR-swizzled 16-byte chunks on the SOURCE
+// side (the LDS image of a DMA is lane-linear), epilogue through LDS with 16-byte NHWC stores.
+#include "launchers.h"
+
+namespace {
+
+constexpr int TH = 16, TW = 16, NPIX = TH * TW;
+constexpr int CT = 64, PIXB = CT * 2;                    // 64-channel chunk = 128 B per pixel
+constexpr int A_PIECES_PER_WAVE = 4, A_BYTES = 8 * A_PIECES_PER_WAVE * 1024;   // 256 px -> 32 KiB per slot
+constexpr int BN = 128;
+constexpr int B_BYTES = BN * PIXB;                       // 16 KiB = 16 pieces = 2 per wave
+constexpr int B_PIECES_PER_WAVE = 2;
+constexpr int SMEM = 3 * A_BYTES + 3 * B_BYTES;          // 144 KiB
+constexpr int OUT_ROWB = BN * 2 + 16;
+static_assert(NPIX * OUT_ROWB <= SMEM, "epilogue tile must fit");
+
+// 16-byte chunk swizzle: weight rows by row index, pixels by their column in the tile (with the column as key
+// every ds_read_b128 lane group of a 32x32x16 fragment hits 16 distinct 16-byte slots of the 256-byte bank row)
+__device__ __forceinline__ int swz64(int row) { return (row >> 1) & 7; }
+
+__device__ __forceinline__ void glds16(const void *g, void *lds)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(512) void conv_glds1_kernel(ConvParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *sA = smem;
+    char *sB = smem + 3 * A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // bijective XCD-aware remap: each XCD (own L2) gets a contiguous run of tiles
+    const int nwg = gridDim.x;
+    int t;
+    {
+        const int b = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const int ntn = p.CoutPad / BN;
+    const int nt_i = t % ntn, sp = t / ntn;
+    const int ty = sp / p.tiles_x, tx = sp % p.tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * TW, n0 = nt_i * BN;
+
+    const int nchunk = (p.c0 + p.c1) / CT, nchunk0 = p.c0 / CT;
+
+    // ---- LDS-DMA issue helpers (wave-uniform LDS base, per-lane swizzled source) ------------
+    const int l_row = lane >> 3, l_slot = lane & 7;
+    auto issue_A = [&](int cc, int buf) {
+        const f16 *src;
+        int cs, coff;
+        if (cc < nchunk0) { src = p.src0; cs = p.s0_stride; coff = cc * CT; }
+        else { src = p.src1; cs = p.s1_stride; coff = (cc - nchunk0) * CT; }
+#pragma unroll
+        for (int it = 0; it < A_PIECES_PER_WAVE; ++it) {
+            const int piece = wave + it * 8;
+            const int hp = piece * 8 + l_row;
+            const int hy = hp / TW, hx = hp - hy * TW;
+            const int iy = oy0 + hy, ix = ox0 + hx;
+            const bool ok = iy < p.Hi && ix < p.Wi;
+            const f16 *g = ok ? src + ((size_t)iy * p.Wi + ix) * cs + coff + ((l_slot ^ swz64(hx)) << 3)
+                              : p.zeros + (l_slot << 3);
+            glds16(g, sA + buf * A_BYTES + piece * 1024);
+        }
+    };
+    auto issue_B = [&](int cc, int slot) {
+        const f16 *base = p.wpk + ((size_t)cc * p.CoutPad + n0) * CT;
+#pragma unroll
+        for (int k = 0; k < B_PIECES_PER_WAVE; ++k) {
+            const int piece = wave * B_PIECES_PER_WAVE + k;
+            const int n = piece * 8 + l_row;
+            glds16(base + (size_t)n * CT + ((l_slot ^ swz64(n)) << 3), sB + slot * B_BYTES + piece * 1024);
+        }
+    };
+
+    // ---- wave tiling: 2 (channels) x 4 (pixels) waves, each 64 ch x 64 px = 2x2 MFMA tiles ---
+    const int wc = wave & 1, wp = wave >> 1;
+    int hp_base[2], hx_base[2], wrow[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = (wp * 2 + j) * 32 + l31;
+        hp_base[j] = q;
+        hx_base[j] = q % TW;
+        wrow[j] = (wc * 2 + j) * 32 + l31;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+
+    issue_A(0, 0);
+    issue_B(0, 0);
+    if (nchunk > 1) {
+        issue_A(1, 1);
+        issue_B(1, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    int slot = 0;
+#pragma unroll 1
+    for (int cc = 0; cc < nchunk; ++cc) {
+        const bool pf = cc + 2 < nchunk;
+        const int s2 = slot == 0 ? 2 : slot - 1;          // (slot + 2) % 3
+        if (pf) { issue_A(cc + 2, s2); issue_B(cc + 2, s2); }
+        const char *a = sA + slot * A_BYTES;
+        const char *b = sB + slot * B_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < CT / 16; ++ks) {
+            const int chunk = ks * 2 + lh;
+            f16x8 wf[2], xf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                wf[i] = *reinterpret_cast<const f16x8 *>(b + wrow[i] * PIXB + ((chunk ^ swz64(wrow[i])) << 4));
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                xf[j] = *reinterpret_cast<const f16x8 *>(a + hp_base[j] * PIXB + ((chunk ^ swz64(hx_base[j])) << 4));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+        if (pf) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // A(cc+2): 4 pieces, B(cc+2): 2 pieces
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+
+    // ---------------------------------------------------------------- epilogue (LDS staged)
+    const float aslope = act_slope(p.act);
+    char *so = smem;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const int cl = (wc * 2 + i) * 32 + 8 * qd + 4 * lh;
+            const float4 sc = *reinterpret_cast<const float4 *>(p.scale + n0 + cl);
+            const float4 sh = *reinterpret_cast<const float4 *>(p.shift + n0 + cl);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = (wp * 2 + j) * 32 + l31;
+                f16x4 o;
+                o[0] = (f16)act_fast(acc[i][j][4 * qd + 0] * sc.x + sh.x, aslope);
+                o[1] = (f16)act_fast(acc[i][j][4 * qd + 1] * sc.y + sh.y, aslope);
+                o[2] = (f16)act_fast(acc[i][j][4 * qd + 2] * sc.z + sh.z, aslope);
+                o[3] = (f16)act_fast(acc[i][j][4 * qd + 3] * sc.w + sh.w, aslope);
+                *reinterpret_cast<f16x4 *>(so + q * OUT_ROWB + cl * 2) = o;
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int CPP = BN / 8;
+    for (int e = tid; e < NPIX * CPP; e += 512) {
+        const int q = e / CPP, c8 = e % CPP;
+        const int oy = oy0 + q / TW, ox = ox0 + q % TW;
+        const int ch = n0 + c8 * 8;
+        if (oy < p.Ho && ox < p.Wo && ch < p.Cout)
+            *reinterpret_cast<f16x8 *>(p.dst + ((size_t)oy * p.Wo + ox) * p.dstC + ch) =
+                *reinterpret_cast<const f16x8 *>(so + q * OUT_ROWB + c8 * 16);
+    }
+}
+
+}  // namespace
+
+// 1x1, stride 1, Cin (src0 [+ src1 concat]) multiple of 64, CoutPad multiple of 128, NHWC store, no residuals.
+hipError_t conv_glds1_launch(ConvParams p, hipStream_t stream)
+{
+    if ((p.c0 % CT) || (p.c1 % CT) || p.c0 + p.c1 < CT || (p.CoutPad % BN) || p.res1 || p.res2 || p.dst_full ||
+        p.mode != ST_NHWC || !p.zeros)
+        return hipErrorInvalidValue;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_glds1_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    p.tiles_x = (p.Wo + TW - 1) / TW;
+    p.tiles_y = (p.Ho + TH - 1) / TH;
+    const int grid = p.tiles_x * p.tiles_y * (p.CoutPad / BN);
+    hipLaunchKernelGGL(conv_glds1_kernel, dim3(grid), dim3(512), SMEM, stream, p);
+    return hipGetLastError();
+}

@@ -349,15 +349,9 @@ hipError_t conv_igemm_launch(ConvParams p, int cin_t, int bn, int ks, int stride
     p.tiles_y = (p.Ho + TH - 1) / TH;
 #define HDRTV_CASE(CT, BN_, KS_, S_) \
     if (cin_t == CT && bn == BN_ && ks == KS_ && stride == S_) return launch_cfg<CT, BN_, KS_, S_>(p, stream);
-    HDRTV_CASE(32, 32, 3, 1)
     HDRTV_CASE(32, 32, 3, 2)
-    HDRTV_CASE(32, 64, 3, 2)
-    HDRTV_CASE(32, 128, 3, 1)
     HDRTV_CASE(64, 32, 1, 1)
     HDRTV_CASE(64, 64, 1, 1)
-    HDRTV_CASE(64, 64, 3, 1)
-    HDRTV_CASE(64, 128, 1, 1)
-    HDRTV_CASE(64, 128, 3, 1)
 #undef HDRTV_CASE
     return hipErrorInvalidValue;
 }

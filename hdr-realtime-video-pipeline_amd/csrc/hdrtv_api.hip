@@ -684,16 +684,15 @@ struct Seq {
         p.dotw = dotw; p.dst_dot = dst_dot;
         if (c0 + c1 != L.cin) { rc = fail(c, HDRTV_ESTATE, "conv %s: channel mismatch", key.c_str()); return; }
         p.zeros = wtp<f16>(c, c->zeros_off);
-        const bool glds = (L.ks == 3 || L.ks == 1) && L.stride == 1 && L.cin_t == 64 && L.bn == 128 && !res1 && !res2 && !dst_full &&
-                          mode != ST_PLANAR3;
-        // persistent variant for the HG 3x3 convs (HDRTV_PGLDS=0 selects the one-tile-per-block kernel, for A/B runs)
-        static const bool use_pglds = [] { const char *e = getenv("HDRTV_PGLDS"); return !e || atoi(e) != 0; }();
-        const bool pglds = glds && use_pglds && L.ks == 3 && L.cout == L.coutPad && mode != ST_PLANAR3;
+        const bool g64 = L.stride == 1 && L.cin_t == 64 && L.bn == 128 && !res1 && !res2 && !dst_full && mode != ST_PLANAR3;
+        const bool pglds = g64 && L.ks == 3 && L.cout == L.coutPad;      // HG 3x3 convs: persistent LDS-DMA kernel
+        const bool glds1 = g64 && L.ks == 1 && mode == ST_NHWC;          // HG 1x1 fuse convs
         p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
         const bool s2g = L.ks == 3 && L.stride == 2 && L.cin_t == 64 && L.bn == L.coutPad && (L.coutPad == 64 || L.coutPad == 192);
         char tag[64];
         if (s2g) snprintf(tag, sizeof tag, "conv3x3s2_preg<%d>", L.coutPad);
-        else if (glds) snprintf(tag, sizeof tag, "conv_glds<%d,64,128>", L.ks);
+        else if (pglds) snprintf(tag, sizeof tag, "conv_pglds<%s>", mode == ST_POOL ? "pool" : (mode == ST_PS ? "ps" : (mode == ST_PS_DOT3 ? "ps_dot3" : "nhwc")));
+        else if (glds1) snprintf(tag, sizeof tag, "conv_glds1");
         else snprintf(tag, sizeof tag, "conv_igemm<%d,%d,%d,%d>", L.cin_t, L.bn, L.ks, L.stride);
         const double macs = (double)p.Ho * p.Wo * L.cin * L.ks * L.ks * L.cout;
         double bytes = 2.0 * Hi * Wi * L.cin + 2.0 * L.ks * L.ks * L.cin * L.coutPad;
@@ -703,7 +702,7 @@ struct Seq {
         bytes += 2.0 * outel * (1 + (res1 ? 1 : 0) + (res2 ? 1 : 0) + (res_planar ? 1 : 0));
         chk(s2g ? conv3x3s2_preg_launch(p, c->n_cu, s)
                 : (pglds ? conv_pglds_launch(p, c->n_cu, s)
-                         : (glds ? conv_glds_launch(p, L.ks, s) : conv_igemm_launch(p, L.cin_t, L.bn, L.ks, L.stride, s))),
+                         : (glds1 ? conv_glds1_launch(p, s) : conv_igemm_launch(p, L.cin_t, L.bn, L.ks, L.stride, s))),
             key.c_str(), tag, macs, bytes);
     }
     void c3(const std::string &key, const f16 *in, int H, int W, int act, f16 *out, f16 *out_pool)
@@ -713,14 +712,6 @@ struct Seq {
         chk(conv_c3_launch(in, H, W, wtp<f16>(c, L.wfrag), wtp<float>(c, L.scale), wtp<float>(c, L.shift), L.cout, act, out,
                            out_pool, s), key.c_str(), L.cout == 64 ? "conv_c3<64>" : "conv_c3<32>", (double)H * W * 27 * L.cout,
             (double)H * W * (6.0 + 2.0 * L.cout * (out_pool ? 1.25 : 1.0)));
-    }
-    void sft(const std::string &key, const f16 *x, const f16 *cond, f16 *y, int npix)
-    {
-        if (!ok()) return;
-        const SftLayer &L = c->sft.at(key);
-        SftParams p;
-        p.x = x; p.cond = cond; p.y = y; p.wfrag = wtp<f16>(c, L.wfrag); p.bias = wtp<float>(c, L.bias); p.npix = npix;
-        chk(sft_launch(p, s), key.c_str(), "sft", (double)npix * 2 * (16 * 16 + 16 * 32), (double)npix * (64 + 32 + 64));
     }
     // persistent 32-channel 3x3 conv, optionally with the SFT layer `sft_key` fused in front (conv32p.hip)
     void conv32(const std::string &key, const f16 *src, const f16 *cond, const std::string &sft_key, int H, int W, int act,

@@ -3,7 +3,7 @@
 #include "common.h"
 
 hipError_t conv_igemm_launch(ConvParams p, int cin_t, int bn, int ks, int stride, hipStream_t stream);
-hipError_t conv_glds_launch(ConvParams p, int ks, hipStream_t stream);
+hipError_t conv_glds1_launch(ConvParams p, hipStream_t stream);
 hipError_t conv_pglds_launch(ConvParams p, int n_cu, hipStream_t stream);
 hipError_t conv32p_launch(Conv32Params p, hipStream_t stream);
 hipError_t conv3x3s2_preg_launch(ConvParams p, int n_cu, hipStream_t stream);
@@ -29,19 +29,10 @@ hipError_t agcm_mlp_launch(const f16 *in, f16 *out, size_t npix, const f16 *frag
 
 hipError_t conv_c3_launch(const f16 *in, int H, int W, const f16 *wfrag, const float *scale, const float *shift, int cout,
                           int act, f16 *out, f16 *out_pool, hipStream_t s);
-hipError_t sft_launch(const SftParams &p, hipStream_t s);
 hipError_t le_cond_trunk_launch(const f16 *img, int H, int W, const f16 *wfrag, const float *bias, f16 *cond, f16 *cond1,
                                 int n_cu, hipStream_t s);
 hipError_t hg_prep_launch(const f16 *base, int H, int W, int Hp, int Wp, f16 *img_pad, uint8_t *mask, float r, float thresh,
                           hipStream_t s);
-struct HgFinalArgs {
-    const f16 *up5, *c1, *img;
-    const uint8_t *mask;
-    const float *w10, *b10, *wl, *bl;
-    void *out;
-    int out_f32, H, W, Hp, Wp;
-};
-hipError_t hg_final_launch(const HgFinalArgs &a, hipStream_t s);
 struct HgFinalFusedArgs {
     const f16 *img;
     const uint8_t *mask;
@@ -52,4 +43,3 @@ struct HgFinalFusedArgs {
     int out_f32, H, W, Hp, Wp;
 };
 hipError_t hg_final_fused_launch(const HgFinalFusedArgs &a, hipStream_t s);
-hipError_t maxpool2_launch(const f16 *in, int H, int W, int C, f16 *out, hipStream_t s);

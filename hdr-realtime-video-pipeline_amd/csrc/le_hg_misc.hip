@@ -3,12 +3,11 @@
 //  conv_c3     3x3 conv from a planar 3-channel image (K = 27, padded to 32) to NHWC f16:
 //              LE.conv_first, LE.cond_first.0 (HDRUNet3T1_arch.py:14,41), HG.conv1
 //              (Hallucination_arch.py:59).  im2col fragments are built from an LDS halo tile.
-//  sft         SFTLayer (arch_util.py:60-72): two 16->16->32 1x1 MLPs on the condition map and
-//              y = x*(scale+1)+shift, three MFMAs per 32 pixels, hidden layer kept in registers.
 //  hg_prep     HG_Composite._make_mask + reflect pad to a multiple of 32 (HG_Composite_arch.py:78-101)
-//  hg_final    conv10 (1x1 over cat(Up_conv5, conv1)), conv_last (1x1 over cat(conv10, img)) and
-//              out = mask*out + img, cropped (Hallucination_arch.py:130-137, HG_Composite_arch.py:103)
-//  maxpool2    nn.MaxPool2d(2) on NHWC f16
+//  hg_final_fused   the HG tail: conv1 recomputed, second half of conv10 (1x1 over cat(Up_conv5, conv1)),
+//              conv_last (1x1 over cat(conv10, img)) and out = mask*out + img, cropped
+//              (Hallucination_arch.py:130-137, HG_Composite_arch.py:103)
+// (the SFT layers run inside conv32p.hip, the 2x2 max-pools inside the producing convolutions' epilogues)
 #include "launchers.h"
 
 namespace {
@@ -145,57 +144,6 @@ __global__ __launch_bounds__(256) void conv_c3_kernel(const f16 *__restrict__ in
     }   // tile loop
 }
 
-// ====================================================================================== sft
-__device__ __forceinline__ f32x16 bias_tile_g(const float *b, int lh)
-{
-    f32x16 a;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const float4 v = *reinterpret_cast<const float4 *>(b + 8 * g + 4 * lh);
-        a[4 * g + 0] = v.x; a[4 * g + 1] = v.y; a[4 * g + 2] = v.z; a[4 * g + 3] = v.w;
-    }
-    return a;
-}
-
-__global__ __launch_bounds__(256) void sft_kernel(SftParams p)
-{
-    const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
-    const f16x8 *fr = reinterpret_cast<const f16x8 *>(p.wfrag);
-    const f16x8 a0 = fr[lane], a1s = fr[64 + lane], a1t = fr[128 + lane];
-    const f32x16 bh = bias_tile_g(p.bias, lh), bs = bias_tile_g(p.bias + 32, lh), bt = bias_tile_g(p.bias + 64, lh);
-    const int ngrp = (p.npix + 31) / 32;
-    const int wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwave = (gridDim.x * blockDim.x) >> 6;
-    for (int g = wave_id; g < ngrp; g += nwave) {
-        const int pix = g * 32 + l31;
-        const bool ok = pix < p.npix;
-        const int pc = ok ? pix : p.npix - 1;
-        const f16x8 cf = *reinterpret_cast<const f16x8 *>(p.cond + (size_t)pc * 16 + 8 * lh);
-        f16x4 xv[4];
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) xv[qd] = *reinterpret_cast<const f16x4 *>(p.x + (size_t)pc * 32 + 8 * qd + 4 * lh);
-        f32x16 h = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, cf, bh, 0, 0, 0);
-        f16x8 hs, ht;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float u = h[j], v = h[8 + j];
-            hs[j] = (f16)(u >= 0.f ? u : 0.1f * u);
-            ht[j] = (f16)(v >= 0.f ? v : 0.1f * v);
-        }
-        const f32x16 sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1s, hs, bs, 0, 0, 0);
-        const f32x16 sh = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1t, ht, bt, 0, 0, 0);
-        if (ok) {
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                f16x4 o;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) o[k] = (f16)((float)xv[qd][k] * (sc[4 * qd + k] + 1.f) + sh[4 * qd + k]);
-                *reinterpret_cast<f16x4 *>(p.y + (size_t)pix * 32 + 8 * qd + 4 * lh) = o;
-            }
-        }
-    }
-}
-
 // ================================================================================== hg_prep
 __global__ __launch_bounds__(256) void hg_prep_kernel(const f16 *__restrict__ base, int H, int W, int Hp, int Wp,
                                                       f16 *__restrict__ img_pad, uint8_t *__restrict__ mask, float r,
@@ -215,85 +163,6 @@ __global__ __launch_bounds__(256) void hg_prep_kernel(const f16 *__restrict__ ba
         m = (m - r) / (1.f - r);
         m = fminf(fmaxf(m, 0.f), 1.f);
         mask[i] = m > thresh ? 1 : 0;
-    }
-}
-
-// ================================================================================= hg_final
-struct HgFinalParams {
-    const f16 *up5;     // NHWC 64, Hp x Wp
-    const f16 *c1;      // NHWC 64, Hp x Wp
-    const f16 *img;     // planar f16 [3][Hp][Wp]
-    const uint8_t *mask;
-    const float *w10;   // [3][128]
-    const float *b10;   // [3]
-    const float *wl;    // [3][6]
-    const float *bl;    // [3]
-    void *out;          // planar [3][H][W]
-    int out_f32;
-    int H, W, Hp, Wp;
-};
-
-__global__ __launch_bounds__(256) void hg_final_kernel(HgFinalParams p)
-{
-    const int lane = threadIdx.x & 63, sub = lane & 7, grp = lane >> 3;
-    float wu[3][8], wc[3][8];
-#pragma unroll
-    for (int o = 0; o < 3; ++o)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            wu[o][j] = p.w10[o * 128 + 8 * sub + j];
-            wc[o][j] = p.w10[o * 128 + 64 + 8 * sub + j];
-        }
-    const size_t npix = (size_t)p.Hp * p.Wp;
-    const size_t nblk = (npix + 63) / 64;
-    const size_t wave_id = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const size_t nwave = ((size_t)gridDim.x * blockDim.x) >> 6;
-    for (size_t b = wave_id; b < nblk; b += nwave) {
-        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            size_t pix = b * 64 + r * 8 + grp;
-            if (pix >= npix) pix = npix - 1;
-            const f16x8 u = *reinterpret_cast<const f16x8 *>(p.up5 + pix * 64 + 8 * sub);
-            const f16x8 c = *reinterpret_cast<const f16x8 *>(p.c1 + pix * 64 + 8 * sub);
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float uf = (float)u[j], cf = (float)c[j];
-                s0 += wu[0][j] * uf + wc[0][j] * cf;
-                s1 += wu[1][j] * uf + wc[1][j] * cf;
-                s2 += wu[2][j] * uf + wc[2][j] * cf;
-            }
-#pragma unroll
-            for (int o = 1; o < 8; o <<= 1) {
-                s0 += __shfl_xor(s0, o);
-                s1 += __shfl_xor(s1, o);
-                s2 += __shfl_xor(s2, o);
-            }
-            if (sub == r) { t0 = s0; t1 = s1; t2 = s2; }
-        }
-        // this lane now owns pixel b*64 + sub*8 + grp
-        const size_t pix = b * 64 + sub * 8 + grp;
-        if (pix < npix) {
-            const int y = (int)(pix / p.Wp), x = (int)(pix % p.Wp);
-            if (y < p.H && x < p.W) {
-                // conv10 and conv_last outputs are f16 tensors in the reference's fp16 model
-                const float c10[3] = {(float)(f16)(t0 + p.b10[0]), (float)(f16)(t1 + p.b10[1]), (float)(f16)(t2 + p.b10[2])};
-                const float im[3] = {(float)p.img[pix], (float)p.img[npix + pix], (float)p.img[2 * npix + pix]};
-                const float m = (float)p.mask[pix];
-                const size_t oo = (size_t)y * p.W + x, plane = (size_t)p.H * p.W;
-#pragma unroll
-                for (int o = 0; o < 3; ++o) {
-                    float v = p.bl[o];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) v += p.wl[o * 6 + k] * c10[k] + p.wl[o * 6 + 3 + k] * im[k];
-                    v = (float)(f16)v;
-                    const float res = m * v + im[o];
-                    if (p.out_f32) reinterpret_cast<float *>(p.out)[o * plane + oo] = res;
-                    else reinterpret_cast<f16 *>(p.out)[o * plane + oo] = (f16)res;
-                }
-            }
-        }
     }
 }
 
@@ -435,30 +304,6 @@ __global__ __launch_bounds__(256) void hg_final_fused_kernel(HgFinalFusedParams 
     }   // tile loop
 }
 
-// ================================================================================= maxpool2
-__global__ __launch_bounds__(256) void maxpool2_kernel(const f16 *__restrict__ in, int H, int W, int C, f16 *__restrict__ out)
-{
-    const int Ho = H / 2, Wo = W / 2, cpp = C / 8;
-    const size_t n = (size_t)Ho * Wo * cpp;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
-        const int c8 = (int)(e % cpp);
-        const size_t pq = e / cpp;
-        const int oy = (int)(pq / Wo), ox = (int)(pq % Wo);
-        const f16 *s = in + ((size_t)(2 * oy) * W + 2 * ox) * C + c8 * 8;
-        f16x8 v = *reinterpret_cast<const f16x8 *>(s);
-        const f16x8 v1 = *reinterpret_cast<const f16x8 *>(s + C);
-        const f16x8 v2 = *reinterpret_cast<const f16x8 *>(s + (size_t)W * C);
-        const f16x8 v3 = *reinterpret_cast<const f16x8 *>(s + (size_t)W * C + C);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const f16 m = v[k] > v1[k] ? v[k] : v1[k];
-            const f16 m2 = v2[k] > v3[k] ? v2[k] : v3[k];
-            v[k] = m > m2 ? m : m2;
-        }
-        *reinterpret_cast<f16x8 *>(out + pq * C + c8 * 8) = v;
-    }
-}
-
 // CUs of the current device (one process drives one GPU)
 inline int num_cus()
 {
@@ -496,28 +341,11 @@ hipError_t conv_c3_launch(const f16 *in, int H, int W, const f16 *wfrag, const f
     return hipGetLastError();
 }
 
-hipError_t sft_launch(const SftParams &p, hipStream_t s)
-{
-    hipLaunchKernelGGL(sft_kernel, dim3(grid_for((size_t)(p.npix + 31) / 32, 4)), dim3(256), 0, s, p);
-    return hipGetLastError();
-}
-
 hipError_t hg_prep_launch(const f16 *base, int H, int W, int Hp, int Wp, f16 *img_pad, uint8_t *mask, float r, float thresh,
                           hipStream_t s)
 {
     hipLaunchKernelGGL(hg_prep_kernel, dim3(grid_for((size_t)Hp * Wp, 256)), dim3(256), 0, s, base, H, W, Hp, Wp, img_pad,
                        mask, r, thresh);
-    return hipGetLastError();
-}
-
-hipError_t hg_final_launch(const HgFinalArgs &a, hipStream_t s)
-{
-    HgFinalParams p;
-    p.up5 = a.up5; p.c1 = a.c1; p.img = a.img; p.mask = a.mask;
-    p.w10 = a.w10; p.b10 = a.b10; p.wl = a.wl; p.bl = a.bl;
-    p.out = a.out; p.out_f32 = a.out_f32; p.H = a.H; p.W = a.W; p.Hp = a.Hp; p.Wp = a.Wp;
-    const size_t nblk = ((size_t)a.Hp * a.Wp + 63) / 64;
-    hipLaunchKernelGGL(hg_final_kernel, dim3(grid_for(nblk, 4)), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
@@ -529,12 +357,5 @@ hipError_t hg_final_fused_launch(const HgFinalFusedArgs &a, hipStream_t s)
     const int ntiles = ((a.W + C3_TW - 1) / C3_TW) * ((a.H + C3_TH - 1) / C3_TH);
     const int grid = ntiles < 4 * num_cus() ? ntiles : 4 * num_cus();
     hipLaunchKernelGGL(hg_final_fused_kernel, dim3(grid), dim3(256), 0, s, p);
-    return hipGetLastError();
-}
-
-hipError_t maxpool2_launch(const f16 *in, int H, int W, int C, f16 *out, hipStream_t s)
-{
-    const size_t n = (size_t)(H / 2) * (W / 2) * (C / 8);
-    hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, in, H, W, C, out);
     return hipGetLastError();
 }
