@@ -243,7 +243,8 @@ def main():
     launches, macs_frame = proc.infer_stats()
     if rank == 0:
         line = {
-            "metric": "frames/sec (HDRTVNet++ AGCM+LE+HG fp16 3840x2160 + fused RGB48 post); p50 per-frame ms in p50_ms",
+            "metric": f"frames/sec (HDRTVNet++ AGCM+LE{'+HG' if use_hg else ''} fp16 {args.width}x{args.height} + fused RGB48 post); "
+                      "p50 per-frame ms in p50_ms",
             "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "p50_ms": round(p50, 3), "p99_ms": round(p99, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
