@@ -397,7 +397,7 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
 }
 
 template <int NPASS, bool SFT, int NW>
-hipError_t launch_t(const Conv32Params &p, hipStream_t s)
+hipError_t launch_t(const Conv32Params &p, int n_cu, hipStream_t s)
 {
     using L = Lay<NPASS, SFT, NW>;
     static bool attr_set = false;
@@ -408,8 +408,8 @@ hipError_t launch_t(const Conv32Params &p, hipStream_t s)
         attr_set = true;
     }
     const int ntiles = p.tiles_x * p.tiles_y;
-    const int cap = 256 * (160 * 1024 / L::SMEM);          // persistent: as many workgroups as fit the chip
-    const int grid = ntiles < cap ? ntiles : cap;
+    const long cap = (long)n_cu * (160 * 1024 / L::SMEM);  // persistent: as many workgroups as fit the chip
+    const int grid = ntiles < cap ? ntiles : (int)cap;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), L::SMEM, s, p);
     return hipGetLastError();
 }
@@ -417,7 +417,7 @@ hipError_t launch_t(const Conv32Params &p, hipStream_t s)
 }  // namespace
 
 // src (and cond) must be followed by >= 64 zero bytes (the workspace guard): out-of-image halo lanes read them.
-hipError_t conv32p_launch(Conv32Params p, hipStream_t s)
+hipError_t conv32p_launch(Conv32Params p, int n_cu, hipStream_t s)
 {
     static int nw = 0;
     if (!nw) {
@@ -432,11 +432,11 @@ hipError_t conv32p_launch(Conv32Params p, hipStream_t s)
     const bool small_tile = nw == 4 || (p.CoutPad == 32 && !sft && p.mode == ST_PLANAR3 && !getenv("HDRTV_CONV32_NW"));
     if (!small_tile || p.CoutPad == 128) {               // the 72 KiB weight set of the up-convs leaves room for one workgroup only
         p.tiles_y = (p.H + 15) / 16;
-        if (p.CoutPad == 32) return sft ? launch_t<1, true, 8>(p, s) : launch_t<1, false, 8>(p, s);
-        if (p.CoutPad == 128 && !sft) return launch_t<4, false, 8>(p, s);
+        if (p.CoutPad == 32) return sft ? launch_t<1, true, 8>(p, n_cu, s) : launch_t<1, false, 8>(p, n_cu, s);
+        if (p.CoutPad == 128 && !sft) return launch_t<4, false, 8>(p, n_cu, s);
         return hipErrorInvalidValue;
     }
     p.tiles_y = (p.H + 7) / 8;
-    if (p.CoutPad == 32) return sft ? launch_t<1, true, 4>(p, s) : launch_t<1, false, 4>(p, s);
+    if (p.CoutPad == 32) return sft ? launch_t<1, true, 4>(p, n_cu, s) : launch_t<1, false, 4>(p, n_cu, s);
     return hipErrorInvalidValue;
 }

@@ -30,10 +30,7 @@ constexpr int DOTW_OFF = SS_OFF + 2048;                  // ST_PS_DOT3: 3 x 64 f
 constexpr int SMEM = DOTW_OFF + 1024;                    // 147 KiB
 
 // stores per wave and tile, by store mode (see the epilogues)
-#ifndef PG_EXP
-#define PG_EXP 0
-#endif
-template <int MODE> struct NStores { static constexpr int N = (PG_EXP == 1 || PG_EXP == 2) ? 0 : MODE == ST_POOL ? 2 : (MODE == ST_PS_DOT3 ? 4 : 8); };
+template <int MODE> struct NStores { static constexpr int N = MODE == ST_POOL ? 2 : (MODE == ST_PS_DOT3 ? 1 : 8); };
 
 __device__ __forceinline__ void glds16(const void *g, void *lds)
 {
@@ -222,14 +219,6 @@ __global__ __launch_bounds__(512) void conv_pglds_kernel(ConvParams p)
         if (has_next) issue_B(2, nxt.n0, 2);
         // ------------------------------------------------------------ epilogue, from registers
         // lane: pixel (row wp*4 + j, column l15), channels wc*64 + i*16 + 4*kg + {0..3}
-#if PG_EXP == 2
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        cur = nxt;
-        continue;
-#endif
         const float *ss = reinterpret_cast<const float *>(smem + SS_OFF + (k & 1) * 1024);
         char *trash = reinterpret_cast<char *>(p.trash) + lane * 16;
         const int cw = wc * 64 + 4 * kg;
@@ -248,18 +237,6 @@ __global__ __launch_bounds__(512) void conv_pglds_kernel(ConvParams p)
             }
         }
         const int ox = cur.ox0 + l15;   // (ST_PS_DOT3)
-#if PG_EXP == 1
-        {
-            float sum = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) sum += (float)o[i][j][0] + (float)o[i][j][1] + (float)o[i][j][2] + (float)o[i][j][3];
-            if (sum == 123456.789f) *reinterpret_cast<float *>(trash) = sum;
-            cur = nxt;
-            continue;
-        }
-#endif
         // NHWC / PS / POOL: transpose through a wave-private strip of the halo buffer this tile just finished
         // with (free until the next tile's tap 6), so that global stores are 16 bytes per lane and 8 lanes
         // cover a pixel's 128-byte channel run (8-byte quads straight from the accumulator layout cost ~25 %
@@ -337,17 +314,26 @@ __global__ __launch_bounds__(512) void conv_pglds_kernel(ConvParams p)
                     a2[j] += w2.x * x0 + w2.y * x1 + w2.z * x2 + w2.w * x3;
                 }
             }
+            // Sum the four k-groups of a pixel through the wave-private strip (ordinary LDS writes and reads), NOT with
+            // ds_bpermute: with LDS-DMA of the workgroup in flight -- the next tile's weights are -- bpermute
+            // sporadically returned wrong lanes' data on gfx950 (tests/test_gpu_parity.py:
+            // test_persistent_schedules_do_not_change_results caught ~5000 of 8.3 M pixels per frame).  Lane
+            // (kg, l15) then finishes row j = kg of the wave's four rows: one float4 store per lane, none wasted.
             const int sub = cur.n0 / 64 + wc;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                a0[j] += __shfl_xor(a0[j], 16); a1[j] += __shfl_xor(a1[j], 16); a2[j] += __shfl_xor(a2[j], 16);
-                a0[j] += __shfl_xor(a0[j], 32); a1[j] += __shfl_xor(a1[j], 32); a2[j] += __shfl_xor(a2[j], 32);
-                const int oy = cur.oy0 + wp * 4 + j;
-                const int Y = 2 * oy + (sub >> 1), X = 2 * ox + (sub & 1);
-                const bool ok = kg == 0 && oy < p.Ho && ox < p.Wo && Y < p.Hd && X < p.Wd;
-                float4 *d = ok ? reinterpret_cast<float4 *>(p.dst_dot + ((size_t)Y * p.Wd + X) * 4) : reinterpret_cast<float4 *>(trash);
-                *d = make_float4(a0[j], a1[j], a2[j], 0.f);
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<float4 *>(stg + j * 1024 + kg * 256 + l15 * 16) = make_float4(a0[j], a1[j], a2[j], 0.f);
+            float4 r = *reinterpret_cast<const float4 *>(stg + kg * 1024 + l15 * 16);
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                const float4 v = *reinterpret_cast<const float4 *>(stg + kg * 1024 + k * 256 + l15 * 16);
+                r.x += v.x; r.y += v.y; r.z += v.z;
             }
+            const int oy = cur.oy0 + wp * 4 + kg;
+            const int Y = 2 * oy + (sub >> 1), X = 2 * ox + (sub & 1);
+            const bool ok = oy < p.Ho && ox < p.Wo && Y < p.Hd && X < p.Wd;
+            float4 *d = ok ? reinterpret_cast<float4 *>(p.dst_dot + ((size_t)Y * p.Wd + X) * 4) : reinterpret_cast<float4 *>(trash);
+            *d = make_float4(r.x, r.y, r.z, 0.f);
         }
         cur = nxt;
     }

@@ -710,7 +710,7 @@ struct Seq {
         if (!ok()) return;
         const C3Layer &L = c->c3.at(key);
         chk(conv_c3_launch(in, H, W, wtp<f16>(c, L.wfrag), wtp<float>(c, L.scale), wtp<float>(c, L.shift), L.cout, act, out,
-                           out_pool, s), key.c_str(), L.cout == 64 ? "conv_c3<64>" : "conv_c3<32>", (double)H * W * 27 * L.cout,
+                           out_pool, c->n_cu, s), key.c_str(), L.cout == 64 ? "conv_c3<64>" : "conv_c3<32>", (double)H * W * 27 * L.cout,
             (double)H * W * (6.0 + 2.0 * L.cout * (out_pool ? 1.25 : 1.0)));
     }
     // persistent 32-channel 3x3 conv, optionally with the SFT layer `sft_key` fused in front (conv32p.hip)
@@ -743,7 +743,7 @@ struct Seq {
                              2.0 * 9 * 32 * L.coutPad;
         char tag[48];
         snprintf(tag, sizeof tag, "conv32p<%d,%s>", L.coutPad / 32, cond ? "sft" : "plain");
-        chk(conv32p_launch(p, s), key.c_str(), tag, macs, bytes);
+        chk(conv32p_launch(p, c->n_cu, s), key.c_str(), tag, macs, bytes);
     }
     // ResBlock_with_SFT (arch_util.py:89-95): y = x + conv2(sft2(relu(conv1(sft1(x,c))),c))  [+ extra]; 2 launches
     void resblock(const std::string &base, const f16 *x, const f16 *cond, int H, int W, f16 *tb, f16 *y,
@@ -902,7 +902,7 @@ int run_hg(hdrtv_ctx *c, Seq &q, const f16 *base, void *out, int out_f32)
     fa.b10 = wtp<float>(c, c->f32v.at("hg.b10"));
     fa.wl = wtp<float>(c, c->f32v.at("hg.wl")); fa.bl = wtp<float>(c, c->f32v.at("hg.bl"));
     fa.out = out; fa.out_f32 = out_f32; fa.H = s.H; fa.W = s.W; fa.Hp = Hp; fa.Wp = Wp;
-    q.chk(hg_final_fused_launch(fa, q.s), "hg_final", "hg_final_fused", (double)Hp * Wp * (128 * 3 + 6 * 3),
+    q.chk(hg_final_fused_launch(fa, c->n_cu, q.s), "hg_final", "hg_final_fused", (double)Hp * Wp * (128 * 3 + 6 * 3),
           (double)s.H * s.W * (6 + 1 + 16 + 3 * (out_f32 ? 4 : 2)));
     return q.rc;
 }
@@ -936,6 +936,9 @@ int hdrtv_create(const void *hr_pack, size_t hr_bytes, const void *hg_pack, size
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(c, HDRTV_EINVAL, "device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
     c->n_cu = prop.multiProcessorCount;
+    // test switch: a huge value gives every persistent kernel one tile per workgroup (tests/test_gpu_parity.py
+    // compares that schedule bit for bit with the real one)
+    if (const char *e = getenv("HDRTV_FORCE_NCU")) { if (atoi(e) > 0) c->n_cu = atoi(e); }
     if (hipMalloc((void **)&c->wts.dev, c->wts.size + 256) != hipSuccess) {
         c->wts.dev = nullptr;
         return fail(c, HDRTV_ENOMEM, "weight allocation failed");

@@ -5,7 +5,7 @@
 hipError_t conv_igemm_launch(ConvParams p, int cin_t, int bn, int ks, int stride, hipStream_t stream);
 hipError_t conv_glds1_launch(ConvParams p, hipStream_t stream);
 hipError_t conv_pglds_launch(ConvParams p, int n_cu, hipStream_t stream);
-hipError_t conv32p_launch(Conv32Params p, hipStream_t stream);
+hipError_t conv32p_launch(Conv32Params p, int n_cu, hipStream_t stream);
 hipError_t conv3x3s2_preg_launch(ConvParams p, int n_cu, hipStream_t stream);
 
 hipError_t pre_unpack_launch(const uint8_t *bgr, f16 *out, int H, int W, hipStream_t s);
@@ -28,7 +28,7 @@ hipError_t agcm_fold_launch(const AgcmFoldArgs &a, f16 *frags, float *biasbuf, h
 hipError_t agcm_mlp_launch(const f16 *in, f16 *out, size_t npix, const f16 *frags, const float *biasbuf, hipStream_t s);
 
 hipError_t conv_c3_launch(const f16 *in, int H, int W, const f16 *wfrag, const float *scale, const float *shift, int cout,
-                          int act, f16 *out, f16 *out_pool, hipStream_t s);
+                          int act, f16 *out, f16 *out_pool, int n_cu, hipStream_t s);
 hipError_t le_cond_trunk_launch(const f16 *img, int H, int W, const f16 *wfrag, const float *bias, f16 *cond, f16 *cond1,
                                 int n_cu, hipStream_t s);
 hipError_t hg_prep_launch(const f16 *base, int H, int W, int Hp, int Wp, f16 *img_pad, uint8_t *mask, float r, float thresh,
@@ -42,4 +42,4 @@ struct HgFinalFusedArgs {
     void *out;
     int out_f32, H, W, Hp, Wp;
 };
-hipError_t hg_final_fused_launch(const HgFinalFusedArgs &a, hipStream_t s);
+hipError_t hg_final_fused_launch(const HgFinalFusedArgs &a, int n_cu, hipStream_t s);

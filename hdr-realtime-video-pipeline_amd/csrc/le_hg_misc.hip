@@ -304,18 +304,6 @@ __global__ __launch_bounds__(256) void hg_final_fused_kernel(HgFinalFusedParams 
     }   // tile loop
 }
 
-// CUs of the current device (one process drives one GPU)
-inline int num_cus()
-{
-    static const int n = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1)
-            v = 256;
-        return v;
-    }();
-    return n;
-}
-
 inline int grid_for(size_t n, int per_block)
 {
     size_t g = (n + per_block - 1) / per_block;
@@ -327,11 +315,11 @@ inline int grid_for(size_t n, int per_block)
 }  // namespace
 
 hipError_t conv_c3_launch(const f16 *in, int H, int W, const f16 *wfrag, const float *scale, const float *shift, int cout,
-                          int act, f16 *out, f16 *out_pool, hipStream_t s)
+                          int act, f16 *out, f16 *out_pool, int n_cu, hipStream_t s)
 {
     const int ntiles = ((W + C3_TW - 1) / C3_TW) * ((H + C3_TH - 1) / C3_TH);
     const int per_cu = cout == 32 ? 6 : 4;                        // LDS: 22 KiB / 39 KiB per workgroup
-    const dim3 grid(ntiles < per_cu * num_cus() ? ntiles : per_cu * num_cus());
+    const dim3 grid(ntiles < per_cu * n_cu ? ntiles : per_cu * n_cu);
     if (cout == 32)
         hipLaunchKernelGGL(conv_c3_kernel<32>, grid, dim3(256), 0, s, in, H, W, wfrag, scale, shift, act, out, out_pool);
     else if (cout == 64)
@@ -349,13 +337,13 @@ hipError_t hg_prep_launch(const f16 *base, int H, int W, int Hp, int Wp, f16 *im
     return hipGetLastError();
 }
 
-hipError_t hg_final_fused_launch(const HgFinalFusedArgs &a, hipStream_t s)
+hipError_t hg_final_fused_launch(const HgFinalFusedArgs &a, int n_cu, hipStream_t s)
 {
     HgFinalFusedParams p;
     p.img = a.img; p.mask = a.mask; p.part = a.part; p.wfrag = a.wfrag; p.scale = a.scale; p.shift = a.shift;
     p.b10 = a.b10; p.wl = a.wl; p.bl = a.bl; p.out = a.out; p.out_f32 = a.out_f32; p.H = a.H; p.W = a.W; p.Hp = a.Hp; p.Wp = a.Wp;
     const int ntiles = ((a.W + C3_TW - 1) / C3_TW) * ((a.H + C3_TH - 1) / C3_TH);
-    const int grid = ntiles < 4 * num_cus() ? ntiles : 4 * num_cus();
+    const int grid = ntiles < 4 * n_cu ? ntiles : 4 * n_cu;
     hipLaunchKernelGGL(hg_final_fused_kernel, dim3(grid), dim3(256), 0, s, p);
     return hipGetLastError();
 }

@@ -1,0 +1,39 @@
+"""Run-to-run and schedule-to-schedule determinism of one tensor at 3840x2160 (default: hg.part), on the GPU box.
+The one-tile-per-workgroup schedule (HDRTV_FORCE_NCU) is the reference; prints where the real schedule deviates.
+usage: python tools/schedule_determinism.py"""
+import os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "hdr-realtime-video-pipeline_amd"))
+import numpy as np, torch
+from hdrtv_mi355x import weights as W
+from hdrtv_mi355x.processor import HDRTVNetMI355X
+f = W.synthetic_frame(2160, 3840, seed=21, kind="gradient")
+res = {}
+for force in (None, "4000000"):
+    if force: os.environ["HDRTV_FORCE_NCU"] = force
+    else: os.environ.pop("HDRTV_FORCE_NCU", None)
+    p = HDRTVNetMI355X(os.path.join(REPO, "tests/golden/hr_weights.hdrw"), use_hg=True, hg_weights="seeded:1234", warmup_passes=0)
+    tc = p.preprocess(f)
+    parts = []
+    for r in range(3):
+        p.infer(tc); parts.append(p.tap("hg.part").clone())
+    res[force] = parts
+    for r in range(1, 3):
+        n = (parts[0] != parts[r]).sum().item()
+        print("force", force, "run0 vs run", r, "diff elements", n)
+    p.close()
+a, b = res[None][0], res["4000000"][0]
+neq = (a != b)
+print("default vs forced:", int(neq.sum()))
+idx = neq.nonzero()
+# storage is [Hp][Wp][4] f32; tap gives a (4,Hp,Wp)-shaped view of the raw buffer: recover linear offsets
+lin = (idx[:, 0] * a.shape[1] * a.shape[2] + idx[:, 1] * a.shape[2] + idx[:, 2])
+pix = torch.unique(lin // 4)
+ys, xs = pix // 3840, pix % 3840
+print("pixels differing:", len(pix), "y range", int(ys.min()), int(ys.max()), "x range", int(xs.min()), int(xs.max()))
+print("sample (y,x):", [(int(y), int(x)) for y, x in zip(ys[:12], xs[:12])])
+print("x mod 32 histogram:", torch.bincount((xs % 32).long(), minlength=32).tolist())
+print("y mod 32 histogram:", torch.bincount((ys % 32).long(), minlength=32).tolist())
+fa = a.flatten(); fb = b.flatten()
+for q in pix[:6]:
+    print(int(q), fa[q*4:q*4+4].tolist(), fb[q*4:q*4+4].tolist())
