@@ -88,3 +88,16 @@ struct Conv32Params {
     int tiles_x, tiles_y;
 };
 
+// Letterbox (letterbox.hip): u8 BGR [sh][sw][3] -> u8 BGR [dh][dw][3], resized region [y0, y0+new_h) x [x0, x0+new_w)
+enum { LB_COPY = 0, LB_AREA_INT = 1, LB_AREA_FRAC = 2, LB_CUBIC = 3 };
+struct LetterboxParams {
+    const uint8_t *src;
+    uint8_t *dst;
+    int sh, sw, dh, dw, new_w, new_h, x0, y0, mode;
+    int ix, iy;                      // LB_AREA_INT: integer shrink factors
+    // LB_AREA_FRAC: run starts [new+1], source indices and float weights per run entry.  LB_CUBIC: xsrc/ysrc = first
+    // of four source taps per destination index, xc/yc = four 11-bit fixed-point coefficients per index.
+    const int *xbeg, *ybeg, *xsrc, *ysrc;
+    const float *xw, *yw;
+    const int *xc, *yc;
+};

@@ -3,6 +3,8 @@
 // management and the per-frame launch sequence.  No kernel lives in this file.
 #include "../../include/hdrtv_mi355x.h"
 
+#include <algorithm>
+#include <cfloat>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -145,6 +147,11 @@ struct hdrtv_ctx {
     std::vector<hipEvent_t> prof_ev;
     struct ProfEntry { std::string layer, kernel; double macs, bytes; float ms; };
     std::vector<ProfEntry> prof;
+    // letterbox tables (hdrtv_letterbox_u8): device copy for the last geometry
+    int lb_key[4] = {0, 0, 0, 0};
+    LetterboxParams lb{};
+    void *lb_dev = nullptr;
+    size_t lb_cap = 0;
     // ring
     std::vector<RingSlot> ring;
     int ring_next = 0, ring_H = 0, ring_W = 0;
@@ -956,6 +963,7 @@ int hdrtv_destroy(hdrtv_ctx *c)
     (void)hipDeviceSynchronize();
     hdrtv_ring_destroy(c);
     for (hipEvent_t ev : c->prof_ev) (void)hipEventDestroy(ev);
+    if (c->lb_dev) (void)hipFree(c->lb_dev);
     if (c->ws.dev) (void)hipFree(c->ws.dev);
     if (c->wts.dev) (void)hipFree(c->wts.dev);
     delete c;
@@ -1024,6 +1032,109 @@ int hdrtv_post_pq_rgb48(hdrtv_ctx *c, void *stream, const void *in, int dtype, i
     if (!c || !in || !dst || H <= 0 || W <= 0 || !(peak_nits > 0.f)) return fail(c, HDRTV_EINVAL, "bad argument");
     hipError_t e = post_rgb48_launch(in, dtype == HDRTV_F32, H, W, dst, 1, peak_nits, (hipStream_t)stream);
     return e == hipSuccess ? HDRTV_OK : fail(c, HDRTV_EHIP, "post_pq_rgb48: %s", hipGetErrorString(e));
+}
+
+// ------------------------------------------------------------------------------- letterbox
+// Geometry and tables of _letterbox_bgr (gui_scaling.py:228-244) as restated in oracle/letterbox_oracle.py.
+static bool letterbox_setup(hdrtv_ctx *c, int sh, int sw, int dh, int dw)
+{
+    if (c->lb_key[0] == sh && c->lb_key[1] == sw && c->lb_key[2] == dh && c->lb_key[3] == dw) return true;
+    LetterboxParams &L = c->lb;
+    memset(&L, 0, sizeof L);
+    L.sh = sh; L.sw = sw; L.dh = dh; L.dw = dw;
+    const double scale = std::min(dw / (double)std::max(sw, 1), dh / (double)std::max(sh, 1));
+    L.new_w = std::max(1, (int)std::nearbyint(sw * scale));          // Python round(): half to even
+    L.new_h = std::max(1, (int)std::nearbyint(sh * scale));
+    L.x0 = (dw - L.new_w) / 2; L.y0 = (dh - L.new_h) / 2;
+    std::vector<int> ints;
+    std::vector<float> flts;
+    size_t o_xbeg = 0, o_ybeg = 0, o_xsrc = 0, o_ysrc = 0, o_xc = 0, o_yc = 0, o_xw = 0, o_yw = 0;
+    if (L.new_w == sw && L.new_h == sh) {
+        L.mode = LB_COPY;
+    } else if (scale < 1.0) {
+        const double sx = sw / (double)L.new_w, sy = sh / (double)L.new_h;
+        const int ix = (int)std::nearbyint(sx), iy = (int)std::nearbyint(sy);
+        if (std::fabs(sx - ix) < DBL_EPSILON && std::fabs(sy - iy) < DBL_EPSILON) {
+            L.mode = LB_AREA_INT; L.ix = ix; L.iy = iy;
+        } else {
+            L.mode = LB_AREA_FRAC;
+            auto tab = [&](int ssize, int dsize, size_t &o_beg, size_t &o_src, size_t &o_w) {
+                const double sc = ssize / (double)dsize;
+                std::vector<int> beg(dsize + 1), src;
+                std::vector<float> w;
+                for (int dx = 0; dx < dsize; ++dx) {
+                    beg[dx] = (int)src.size();
+                    const double f1 = dx * sc, f2 = f1 + sc, cell = std::min(sc, ssize - f1);
+                    int s1 = (int)std::ceil(f1), s2 = (int)std::floor(f2);
+                    s2 = std::min(s2, ssize - 1); s1 = std::min(s1, s2);
+                    if (s1 - f1 > 1e-3) { src.push_back(s1 - 1); w.push_back((float)((s1 - f1) / cell)); }
+                    for (int q = s1; q < s2; ++q) { src.push_back(q); w.push_back((float)(1.0 / cell)); }
+                    if (f2 - s2 > 1e-3) { src.push_back(s2); w.push_back((float)(std::min(std::min(f2 - s2, 1.0), cell) / cell)); }
+                }
+                beg[dsize] = (int)src.size();
+                o_beg = ints.size(); ints.insert(ints.end(), beg.begin(), beg.end());
+                o_src = ints.size(); ints.insert(ints.end(), src.begin(), src.end());
+                o_w = flts.size(); flts.insert(flts.end(), w.begin(), w.end());
+            };
+            tab(sw, L.new_w, o_xbeg, o_xsrc, o_xw);
+            tab(sh, L.new_h, o_ybeg, o_ysrc, o_yw);
+        }
+    } else {
+        L.mode = LB_CUBIC;
+        auto tab = [&](int ssize, int dsize, size_t &o_src, size_t &o_c) {
+            const double sc = ssize / (double)dsize;
+            std::vector<int> src(dsize), co(4 * (size_t)dsize);
+            const float A = -0.75f;
+            for (int d = 0; d < dsize; ++d) {
+                float fx = (float)((d + 0.5) * sc - 0.5);
+                const int s0 = (int)std::floor(fx);
+                fx = fx - (float)s0;
+                src[d] = s0 - 1;
+                volatile float c0 = ((A * (fx + 1.f) - 5.f * A) * (fx + 1.f) + 8.f * A) * (fx + 1.f) - 4.f * A;
+                volatile float c1 = ((A + 2.f) * fx - (A + 3.f)) * fx * fx + 1.f;
+                volatile float c2 = ((A + 2.f) * (1.f - fx) - (A + 3.f)) * (1.f - fx) * (1.f - fx) + 1.f;
+                volatile float c3 = 1.f - c0 - c1 - c2;
+                const float cs[4] = {c0, c1, c2, c3};
+                for (int k = 0; k < 4; ++k) {
+                    const float r = std::nearbyint(cs[k] * 2048.f);
+                    co[4 * (size_t)d + k] = (int)std::max(-32768.f, std::min(32767.f, r));
+                }
+            }
+            o_src = ints.size(); ints.insert(ints.end(), src.begin(), src.end());
+            o_c = ints.size(); ints.insert(ints.end(), co.begin(), co.end());
+        };
+        tab(sw, L.new_w, o_xsrc, o_xc);
+        tab(sh, L.new_h, o_ysrc, o_yc);
+    }
+    const size_t bytes = ints.size() * 4 + flts.size() * 4 + 16;
+    if (bytes > c->lb_cap) {
+        if (c->lb_dev) (void)hipFree(c->lb_dev);
+        c->lb_dev = nullptr; c->lb_cap = 0;
+        if (hipMalloc(&c->lb_dev, bytes) != hipSuccess) { c->lb_dev = nullptr; return false; }
+        c->lb_cap = bytes;
+    }
+    int *di = (int *)c->lb_dev;
+    float *df = (float *)(di + ints.size());
+    if (!ints.empty() && hipMemcpy(di, ints.data(), ints.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return false;
+    if (!flts.empty() && hipMemcpy(df, flts.data(), flts.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return false;
+    L.xbeg = di + o_xbeg; L.ybeg = di + o_ybeg; L.xsrc = di + o_xsrc; L.ysrc = di + o_ysrc;
+    L.xc = di + o_xc; L.yc = di + o_yc; L.xw = df + o_xw; L.yw = df + o_yw;
+    c->lb_key[0] = sh; c->lb_key[1] = sw; c->lb_key[2] = dh; c->lb_key[3] = dw;
+    return true;
+}
+
+int hdrtv_letterbox_u8(hdrtv_ctx *c, void *stream, const uint8_t *src_bgr, int sh, int sw, uint8_t *dst_bgr, int dh, int dw)
+{
+    if (!c || !src_bgr || !dst_bgr || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0) return fail(c, HDRTV_EINVAL, "letterbox: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!letterbox_setup(c, sh, sw, dh, dw)) {
+        c->lb_key[0] = 0;
+        return fail(c, HDRTV_ENOMEM, "letterbox: table allocation failed");
+    }
+    LetterboxParams p = c->lb;
+    p.src = src_bgr; p.dst = dst_bgr;
+    hipError_t e = letterbox_launch(p, (hipStream_t)stream);
+    return e == hipSuccess ? HDRTV_OK : fail(c, HDRTV_EHIP, "letterbox: %s", hipGetErrorString(e));
 }
 
 // ------------------------------------------------------------------------------------ ring

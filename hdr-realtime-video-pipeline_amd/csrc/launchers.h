@@ -43,3 +43,4 @@ struct HgFinalFusedArgs {
     int out_f32, H, W, Hp, Wp;
 };
 hipError_t hg_final_fused_launch(const HgFinalFusedArgs &a, int n_cu, hipStream_t s);
+hipError_t letterbox_launch(const LetterboxParams &p, hipStream_t s);

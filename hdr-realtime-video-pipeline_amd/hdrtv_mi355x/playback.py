@@ -290,9 +290,6 @@ class RealtimePlayback:
                 self.fps_limiter_dropped_frames += 1
                 continue
 
-            if frame.shape[0] != proc_h or frame.shape[1] != proc_w:
-                raise ValueError(f"frame {frame.shape[1]}x{frame.shape[0]} is not the processing size {proc_w}x{proc_h} "
-                                 "(letterboxing is not part of this path)")
             present_t = max(next_frame_t, self._clock()) if self.realtime else None
             t0 = self._clock()
             _, _, _, _, model_latency_ms = w._process_frame(frame=frame, frame_idx=frame_idx, present_t=present_t,

@@ -203,6 +203,32 @@ class HDRTVNetMI355X:
         return self._gpu_input, self._gpu_cond
 
     @torch.inference_mode()
+    def preprocess_letterboxed(self, frame_bgr, out_w, out_h):
+        """``preprocess(_letterbox_bgr(frame, out_w, out_h))`` (gui_scaling.py:228-244 followed by
+        hdrtvnet_torch.py:2238-2296) with the resize on the device: the source frame is uploaded at ITS size and
+        ``hdrtv_letterbox_u8`` writes the letterboxed u8 frame the ordinary unpack/condition kernels read.  The resize
+        arithmetic is oracle/letterbox_oracle.py's restatement of OpenCV (parity with cv2 unpinned)."""
+        if frame_bgr.ndim != 3 or frame_bgr.shape[2] != 3 or frame_bgr.dtype != np.uint8:
+            raise ValueError("frame_bgr must be uint8 [H,W,3]")
+        sh, sw = frame_bgr.shape[:2]
+        out_w, out_h = int(out_w), int(out_h)
+        if (sw, sh) == (out_w, out_h):
+            return self.preprocess(frame_bgr)
+        self._ensure_buffers(out_h, out_w)
+        if getattr(self, "_lb_shape", None) != (sh, sw):
+            self._lb_pin = torch.empty((sh, sw, 3), dtype=torch.uint8, pin_memory=True)
+            self._lb_dev = torch.empty((sh, sw, 3), dtype=torch.uint8, device=self.device)
+            self._lb_shape = (sh, sw)
+        src = np.ascontiguousarray(frame_bgr)
+        C.memmove(self._lb_pin.data_ptr(), src.ctypes.data, src.nbytes)
+        self._lb_dev.copy_(self._lb_pin, non_blocking=True)
+        self._chk(self._lib.hdrtv_letterbox_u8(self._ctx, self._stream(), self._lb_dev.data_ptr(), sh, sw,
+                                               self._gpu_raw.data_ptr(), out_h, out_w), "hdrtv_letterbox_u8")
+        self._chk(self._lib.hdrtv_preprocess(self._ctx, self._stream(), self._gpu_raw.data_ptr(), out_h, out_w,
+                                             self._gpu_input.data_ptr(), self._gpu_cond.data_ptr()), "hdrtv_preprocess")
+        return self._gpu_input, self._gpu_cond
+
+    @torch.inference_mode()
     def infer(self, input_cond):
         """hdrtvnet_torch.py:2301-2346.  Returns ``(out, agcm_out)`` like the eager model; both are
         processor-owned and overwritten by the next call (as HDRTVNetTensorRT's output is)."""

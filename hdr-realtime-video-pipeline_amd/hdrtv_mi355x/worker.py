@@ -8,8 +8,8 @@
 
 Same names, argument meaning and error behaviour (``_load_model`` swallows backend exceptions
 into a status message and returns False), without PyQt/cv2/mpv: status messages go to a list
-or callback, the display sink is any callable taking a ``PinnedFrame``.  Letterboxing
-(cv2, host) is out of scope: frames must arrive at the processing size.
+or callback, the display sink is any callable taking a ``PinnedFrame``.  Frames that are not at
+the processing size are letterboxed on the device (``preprocess_letterboxed``).
 """
 from __future__ import annotations
 
@@ -192,8 +192,14 @@ class HeadlessPipelineWorker:
             raise RuntimeError("no model loaded")
         start, end = self._cuda_timing_events()
         start.record(torch.cuda.current_stream())
+        pw, ph = int(proc_w or self._proc_w), int(proc_h or self._proc_h)
         with torch.inference_mode():
-            tensor, cond = self._processor.preprocess(frame)
+            if frame.shape[1] != pw or frame.shape[0] != ph:
+                # the reference letterboxes on the host with cv2 before preprocess (gui_export.py:1080,
+                # gui_scaling.py:228-244); here the resize runs on the device
+                tensor, cond = self._processor.preprocess_letterboxed(frame, pw, ph)
+            else:
+                tensor, cond = self._processor.preprocess(frame)
             raw_out = self._processor.infer((tensor, cond))
         end.record(torch.cuda.current_stream())
         end.synchronize()

@@ -94,6 +94,14 @@ int hdrtv_post_rgb48(hdrtv_ctx *ctx, void *stream, const void *dev_out, int dtyp
 int hdrtv_post_pq_rgb48(hdrtv_ctx *ctx, void *stream, const void *dev_out, int dtype, int H, int W,
                         float peak_nits, uint16_t *dst);
 
+/* The host step in front of preprocess, on the device: _letterbox_bgr
+ * (src/gui_scaling.py:228-244), i.e. cv2.resize preserving the aspect ratio -- INTER_AREA when shrinking,
+ * INTER_CUBIC when enlarging -- centred on a black [dh][dw] canvas.  src / dst are device u8 BGR HWC.
+ * Parity with cv2 itself is UNPINNED (OpenCV is not part of the reference tree); the arithmetic is the
+ * restatement in oracle/letterbox_oracle.py, which the GPU tests hold this entry point to bit for bit. */
+int hdrtv_letterbox_u8(hdrtv_ctx *ctx, void *stream, const uint8_t *dev_src_bgr, int sh, int sw,
+                       uint8_t *dev_dst_bgr, int dh, int dw);
+
 /* ---- pinned host RGB48 ring: replaces _pinned_u16_host_ring / _acquire_pinned_u16_slot /
  * _PinnedMpvFrame (gui_pipeline_worker_feeders.py:38-70, 125-170).  `slots` in [2,8]
  * (HDRTVNET_FEEDER_GPU_RGB48_RING_FRAMES).  A slot cycles free -> acquired -> (kernel

@@ -113,13 +113,14 @@ def test_hot_swap_precision_resolution_and_prebuffer():
     r = pb.run()
     assert w.loaded == ["INT8 Mixed (QAT)"] and r["last_metrics"]["precision"] == "INT8 Mixed (QAT)"
     assert ready == [(3, 3)]
-    # a resolution switch warms the backend up and then refuses frames of the old size
+    # a resolution switch warms the backend up; later frames are processed at the new size (the worker letterboxes
+    # frames that arrive at another size on the device)
     src2 = P.SyntheticSource(96, 64, fps=60.0, n_frames=10, pool=1, kind="noise")
     pb2 = P.RealtimePlayback(w, src2, clock=clk, sleep=clk.sleep_until, status_cb=status.append)
     pb2.request_resolution(128, 96)
-    with pytest.raises(ValueError, match="processing size 128x96"):
-        pb2.run()
+    r2 = pb2.run()
     assert w.warmups == [(128, 96)] and status[-2:] == ["Switching to 128x96 ...", "Ready - INT8 Mixed (QAT) @ 128x96"]
+    assert r2["frames_processed"] == 10 and r2["last_metrics"]["proc_res"] == "128x96" and (w._proc_w, w._proc_h) == (128, 96)
 
 
 def test_metrics_dict_and_csv_schema(tmp_path):
