@@ -53,9 +53,58 @@ def _f(a):
     return a, a.ctypes.data_as(F32P)
 
 
+# ------------------------------------------------------------- INT8 fake-quant (configs[4])
+class QWeight(np.ndarray):
+    """A dequantised weight that remembers its layer's activation quantiser (W8A8 layers only)."""
+    x_scale = None
+    x_zero = None
+
+
+def _fq(x, w):
+    """Activation fake-quant in front of a W8A8 layer, fp32 as the reference's CPU path computes it
+    (W8A8Conv2d.forward / W8A8Linear.forward, hdrtvnet_torch.py:351-364, 398-409): asymmetric
+    ``round((x - zero) / scale).clamp(0, 255) * scale + zero``, symmetric ``round(x / scale).clamp(-128, 127) * scale``;
+    round = half to even.  Every other weight passes x through."""
+    sc = getattr(w, "x_scale", None)
+    if sc is None:
+        return x
+    x = np.asarray(x, np.float32)
+    sc = np.float32(sc)
+    if w.x_zero is not None:
+        z = np.float32(w.x_zero)
+        q = np.clip(np.rint((x - z) / sc), np.float32(0), np.float32(255))
+        return (q * sc + z).astype(np.float32)
+    q = np.clip(np.rint(x / sc), np.float32(-128), np.float32(127))
+    return (q * sc).astype(np.float32)
+
+
+def w8a8_state(state):
+    """INT8 runtime checkpoint -> a state dict the graphs below run as the reference's fake-quant execution
+    (``predequantize`` off): ``<layer>.weight`` = weight_int8 * scale in fp32 (W8*.forward), and for W8A8 layers the
+    returned weight carries x_scale / x_zero so that conv2d / linear quantise their input first."""
+    out = {}
+    for k, v in state.items():
+        a = np.asarray(v)
+        if k.endswith(".weight_int8"):
+            base = k[: -len(".weight_int8")]
+            w_scale = state.get(base + ".w_scale", state.get(base + ".scale"))
+            shape = (-1,) + (1,) * (a.ndim - 1)
+            w = (a.astype(np.float32) * np.asarray(w_scale, np.float32).reshape(shape)).astype(np.float32).view(QWeight)
+            if base + ".x_scale" in state:
+                w.x_scale = float(np.asarray(state[base + ".x_scale"], np.float32).reshape(-1)[0])
+                if base + ".x_zero" in state:
+                    w.x_zero = float(np.asarray(state[base + ".x_zero"], np.float32).reshape(-1)[0])
+            out[base + ".weight"] = w
+        elif k.endswith((".w_scale", ".scale", ".x_scale", ".x_zero")):
+            continue
+        else:
+            out[k] = a.astype(np.float32) if a.dtype.kind == "f" else a
+    return out
+
+
 # --------------------------------------------------------------------------- ops
 def conv2d(x, w, b=None, stride=1, pad=0):
-    x, xp = _f(x)
+    x, xp = _f(_fq(x, w))
     w, wp = _f(w)
     co, ci, k, _ = w.shape
     assert x.shape[0] == ci, (x.shape, w.shape)
@@ -71,7 +120,7 @@ def conv2d(x, w, b=None, stride=1, pad=0):
 
 
 def linear(v, w, b):
-    return (np.asarray(w, np.float32) @ np.asarray(v, np.float32) + np.asarray(b, np.float32)).astype(np.float32)
+    return (np.asarray(w, np.float32) @ np.asarray(_fq(v, w), np.float32) + np.asarray(b, np.float32)).astype(np.float32)
 
 
 def avgpool3s2p1(x):
@@ -149,6 +198,8 @@ def use_backend(name: str) -> None:
     elif name == "aten":
         from . import aten_backend
         globals().update(aten_backend.OPS)
+        aten_conv = aten_backend.OPS["conv2d"]
+        globals()["conv2d"] = lambda x, w, b=None, stride=1, pad=0: aten_conv(_fq(x, w), w, b, stride, pad)
     else:
         raise ValueError(name)
 

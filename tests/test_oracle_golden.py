@@ -155,3 +155,43 @@ def test_c_operators_agree_with_aten(hr_state, hg_state):
     for k in taps_c:
         if k in taps_a and isinstance(taps_c[k], np.ndarray) and taps_c[k].dtype == np.float32:
             assert np.abs(taps_c[k] - taps_a[k]).max() <= 2e-4, k
+
+
+@pytest.mark.parametrize("tag", ["full_qat", "mixed_qat"])
+def test_int8_fake_quant_execution(golden_dir, tag):
+    """BASELINE.json configs[4] semantics: the INT8 checkpoints executed as fake-quant W8A8 / W8 layers
+    (``predequantize`` off; W8A8Conv2d.forward etc., hdrtvnet_torch.py:233-410), which is what an int8-MFMA path has
+    to reproduce.  Goldens: tests/golden/gen_golden_w8a8.py ran the reference itself that way on CPU.
+    Fake-quant graphs amplify one-ulp differences (a rounding tie flips a whole activation step), so a
+    reimplementation can only be statistically close: with PyTorch's own conv kernels under the oracle's graph the
+    fully quantised model reproduces the reference to 1e-6 everywhere (the semantics are exact); with the plain-C
+    operators, and for the mixed model (whose fp layers already differ by an ulp), a few isolated steps flip."""
+    from hdrtv_mi355x import weights as W
+    st = W.load_pack(os.path.join(golden_dir, f"hr_int8_{tag}.hdrw"))
+    d = _load(golden_dir, f"int8_{tag}_w8a8_64x96_gradient_s6.npz")
+    kinds = dict(x.split("=") for x in d["layer_kinds"])
+    q = O.w8a8_state(st)
+    n_w8a8 = sum(1 for v in q.values() if getattr(v, "x_scale", None) is not None)
+    assert n_w8a8 == sum(1 for v in kinds.values() if v.startswith("W8A8")) == {"full_qat": 128, "mixed_qat": 29}[tag]
+    assert all(getattr(v, "x_zero", None) is not None for v in q.values() if getattr(v, "x_scale", None) is not None)
+
+    def run():
+        out, a = O.hr_forward(q, d["tensor"], d["cond"])
+        e = np.abs(out - d["out"])
+        u8 = O.postprocess_u8(out)
+        mae = np.abs(u8.astype(np.int32) - d["u8_bgr"].astype(np.int32)).mean()
+        return np.abs(a - d["agcm_out"]).max(), e.max(), e.mean(), mae
+
+    ea, emax, emean, mae = run()
+    print(f"  {tag} C operators: agcm {ea:.2e} out max {emax:.2e} mean {emean:.2e} u8 MAE {mae:.3f}")
+    assert ea <= 2e-3 and emax <= 3e-2 and emean <= 1.5e-3 and mae <= 0.5          # reference's own bound: u8 MAE <= 5
+    O.use_backend("aten")
+    try:
+        ea, emax, emean, mae = run()
+    finally:
+        O.use_backend("c")
+    print(f"  {tag} ATen operators: agcm {ea:.2e} out max {emax:.2e} mean {emean:.2e} u8 MAE {mae:.3f}")
+    if tag == "full_qat":
+        assert emax <= 1e-5 and mae == 0.0
+    else:
+        assert emax <= 3e-2 and emean <= 1.5e-3 and mae <= 0.5
