@@ -101,3 +101,11 @@ struct LetterboxParams {
     const float *xw, *yw;
     const int *xc, *yc;
 };
+
+// Objective metrics (metrics.hip): two unit-range images [3][H][W], per-workgroup partial sums {squared error, SSIM, dE-ITP}
+struct MetricsParams {
+    const void *a, *b;
+    int is_f32, H, W;
+    float peak_nits;
+    double *partials;   // [workgroups][3]
+};

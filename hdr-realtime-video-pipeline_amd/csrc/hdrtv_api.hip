@@ -152,6 +152,9 @@ struct hdrtv_ctx {
     LetterboxParams lb{};
     void *lb_dev = nullptr;
     size_t lb_cap = 0;
+    // objective metrics partial sums
+    double *mt_dev = nullptr;
+    size_t mt_cap = 0;
     // ring
     std::vector<RingSlot> ring;
     int ring_next = 0, ring_H = 0, ring_W = 0;
@@ -964,6 +967,7 @@ int hdrtv_destroy(hdrtv_ctx *c)
     hdrtv_ring_destroy(c);
     for (hipEvent_t ev : c->prof_ev) (void)hipEventDestroy(ev);
     if (c->lb_dev) (void)hipFree(c->lb_dev);
+    if (c->mt_dev) (void)hipFree(c->mt_dev);
     if (c->ws.dev) (void)hipFree(c->ws.dev);
     if (c->wts.dev) (void)hipFree(c->wts.dev);
     delete c;
@@ -1135,6 +1139,40 @@ int hdrtv_letterbox_u8(hdrtv_ctx *c, void *stream, const uint8_t *src_bgr, int s
     p.src = src_bgr; p.dst = dst_bgr;
     hipError_t e = letterbox_launch(p, (hipStream_t)stream);
     return e == hipSuccess ? HDRTV_OK : fail(c, HDRTV_EHIP, "letterbox: %s", hipGetErrorString(e));
+}
+
+// --------------------------------------------------------------------------------- metrics
+int hdrtv_metrics(hdrtv_ctx *c, void *stream, const void *a, const void *b, int dtype, int H, int W, float peak_nits,
+                  double *out3)
+{
+    if (!c || !a || !b || !out3 || H <= 0 || W <= 0 || !(peak_nits > 0.f)) return fail(c, HDRTV_EINVAL, "metrics: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nblk = (size_t)metrics_blocks(H, W);
+    if (nblk > c->mt_cap) {
+        if (c->mt_dev) (void)hipFree(c->mt_dev);
+        c->mt_dev = nullptr; c->mt_cap = 0;
+        if (hipMalloc((void **)&c->mt_dev, nblk * 3 * sizeof(double)) != hipSuccess) {
+            c->mt_dev = nullptr;
+            return fail(c, HDRTV_ENOMEM, "metrics: allocation failed");
+        }
+        c->mt_cap = nblk;
+    }
+    MetricsParams p;
+    p.a = a; p.b = b; p.is_f32 = dtype == HDRTV_F32; p.H = H; p.W = W; p.peak_nits = peak_nits; p.partials = c->mt_dev;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = metrics_launch(p, s);
+    if (e != hipSuccess) return fail(c, HDRTV_EHIP, "metrics: %s", hipGetErrorString(e));
+    std::vector<double> host(nblk * 3);
+    HIPCHK(c, hipMemcpyAsync(host.data(), c->mt_dev, host.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    double se = 0.0, ss = 0.0, de = 0.0;
+    for (size_t i = 0; i < nblk; ++i) { se += host[3 * i]; ss += host[3 * i + 1]; de += host[3 * i + 2]; }
+    const double npx = (double)H * W;
+    const double mse = se / (3.0 * npx);
+    out3[0] = mse <= 1e-12 ? 99.0 : 10.0 * std::log10(1.0 / mse);      // _psnr_bgr
+    out3[1] = ss / (3.0 * npx);                                         // _ssim_bgr
+    out3[2] = de / npx;                                                 // _delta_e_itp
+    return HDRTV_OK;
 }
 
 // ------------------------------------------------------------------------------------ ring

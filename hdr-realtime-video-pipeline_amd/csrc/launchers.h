@@ -44,3 +44,5 @@ struct HgFinalFusedArgs {
 };
 hipError_t hg_final_fused_launch(const HgFinalFusedArgs &a, int n_cu, hipStream_t s);
 hipError_t letterbox_launch(const LetterboxParams &p, hipStream_t s);
+hipError_t metrics_launch(const MetricsParams &p, hipStream_t s);
+int metrics_blocks(int H, int W);

@@ -29,6 +29,7 @@ SYMBOLS = [
     ("hdrtv_post_rgb48", _I, [_VP, _VP, _VP, _I, _I, _I, _VP]),
     ("hdrtv_post_pq_rgb48", _I, [_VP, _VP, _VP, _I, _I, _I, C.c_float, _VP]),
     ("hdrtv_letterbox_u8", _I, [_VP, _VP, _VP, _I, _I, _VP, _I, _I]),
+    ("hdrtv_metrics", _I, [_VP, _VP, _VP, _VP, _I, _I, _I, C.c_float, C.POINTER(C.c_double)]),
     ("hdrtv_ring_create", _I, [_VP, _I, _I, _I]),
     ("hdrtv_ring_acquire", _I, [_VP, _I, C.POINTER(_VP), C.POINTER(_VP)]),
     ("hdrtv_ring_commit", _I, [_VP, _I, _VP]),

@@ -173,7 +173,8 @@ class RealtimePlayback:
     ``_proc_w/_proc_h`` -- i.e. a ``HeadlessPipelineWorker`` (or a stand-in in tests)."""
 
     def __init__(self, worker, source, *, sink=True, frame_stride=1, realtime=True, metrics_cb=None, csv_path=None,
-                 metrics_interval_s=0.20, metrics_window=120, clock=time.perf_counter, sleep=None, status_cb=None):
+                 metrics_interval_s=0.20, metrics_window=120, clock=time.perf_counter, sleep=None, status_cb=None,
+                 gt_source=None, objective_every=10):
         self.w, self.source = worker, source
         self.sink = sink
         self.frame_stride = max(1, int(frame_stride))
@@ -184,6 +185,10 @@ class RealtimePlayback:
         self._window = int(metrics_window)
         self._clock = clock
         self._sleep = sleep or self._sleep_until_default
+        # optional ground-truth HDR frames ([3,H,W] or [1,3,H,W] unit-range tensors from ``gt_source.read()``): every
+        # ``objective_every``-th processed frame is scored on the device (gui_pipeline_worker_objective.py role)
+        self.gt_source, self.objective_every = gt_source, max(1, int(objective_every))
+        self._objective = {"psnr_db": None, "sssim": None, "delta_e_itp": None}
         self._pending_precision = None
         self._pending_resolution = None
         self._display_prebuffer_target = 0
@@ -292,8 +297,12 @@ class RealtimePlayback:
 
             present_t = max(next_frame_t, self._clock()) if self.realtime else None
             t0 = self._clock()
-            _, _, _, _, model_latency_ms = w._process_frame(frame=frame, frame_idx=frame_idx, present_t=present_t,
-                                                             proc_w=proc_w, proc_h=proc_h, mpv_w=self.sink)
+            _, _, prepared, _, model_latency_ms = w._process_frame(frame=frame, frame_idx=frame_idx, present_t=present_t,
+                                                                    proc_w=proc_w, proc_h=proc_h, mpv_w=self.sink)
+            if self.gt_source is not None:
+                ok_gt, gt = self.gt_source.read()
+                if ok_gt and prepared is not None and (self.frames_processed % self.objective_every) == 0:
+                    self._objective = w._processor.objective_metrics(prepared, gt)
             t1 = self._clock()
             next_frame_t += frame_interval_s
             frame_ms = (t1 - t0) * 1000.0
@@ -360,7 +369,8 @@ class RealtimePlayback:
             "is_live_capture": False, "frame": frame_idx, "cpu_mb": cpu_mb, "gpu_mb": gpu_mb,
             "model_mb": float(getattr(self.w, "_model_mb", 0.0) or 0.0), "model_size_label": "Checkpoint",
             "precision": self.w._precision_key, "proc_res": f"{proc_w}x{proc_h}",
-            "psnr_db": None, "sssim": None, "delta_e_itp": None, "hdr_vdp3": None, "objective_enabled": False,
+            "psnr_db": self._objective["psnr_db"], "sssim": self._objective["sssim"],
+            "delta_e_itp": self._objective["delta_e_itp"], "hdr_vdp3": None, "objective_enabled": self.gt_source is not None,
             "objective_note": "", "hdr_vdp3_note": "",
             # CSV-only columns (cli_playback_benchmark.py)
             "infer_ms": float(model_avg), "fps_1p_low": one_percent_low(fps_samples, fps),

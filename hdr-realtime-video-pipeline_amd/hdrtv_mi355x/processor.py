@@ -247,6 +247,25 @@ class HDRTVNetMI355X:
         return self._gpu_out, self._gpu_agcm
 
     @torch.inference_mode()
+    def objective_metrics(self, pred, ref, peak_nits=1000.0):
+        """PSNR / SSIM / dE-ITP between two ``[1,3,H,W]`` (or ``[3,H,W]``) CUDA tensors in unit range, as the reference's
+        ``_psnr_bgr`` / ``_ssim_bgr`` / ``_delta_e_itp_bgr`` compute them (gui_objective_metrics.py:438-528) -> a dict
+        with the reference's metric keys (``psnr_db``, ``sssim``, ``delta_e_itp``).  Parity unpinned (cv2 module)."""
+        a = pred[0] if isinstance(pred, (tuple, list)) else pred
+        b = ref[0] if isinstance(ref, (tuple, list)) else ref
+        if a.shape != b.shape or a.shape[-3] != 3:
+            raise ValueError("objective_metrics expects two tensors of the same [.., 3, H, W] shape")
+        dt = torch.float32 if (a.dtype == torch.float32 or b.dtype == torch.float32) else torch.float16
+        a = a.to(device=self.device, dtype=dt).contiguous()
+        b = b.to(device=self.device, dtype=dt).contiguous()
+        h, w = int(a.shape[-2]), int(a.shape[-1])
+        out = (C.c_double * 3)()
+        self._chk(self._lib.hdrtv_metrics(self._ctx, self._stream(), a.data_ptr(), b.data_ptr(),
+                                          _L.F32 if dt == torch.float32 else _L.F16, h, w, float(peak_nits), out),
+                  "hdrtv_metrics")
+        return {"psnr_db": float(out[0]), "sssim": float(out[1]), "delta_e_itp": float(out[2])}
+
+    @torch.inference_mode()
     def postprocess(self, output):
         """hdrtvnet_torch.py:2351-2368.  Returns a zero-copy view of processor-owned pinned memory."""
         if isinstance(output, (tuple, list)):

@@ -102,6 +102,14 @@ int hdrtv_post_pq_rgb48(hdrtv_ctx *ctx, void *stream, const void *dev_out, int d
 int hdrtv_letterbox_u8(hdrtv_ctx *ctx, void *stream, const uint8_t *dev_src_bgr, int sh, int sw,
                        uint8_t *dev_dst_bgr, int dh, int dw);
 
+/* Objective metrics of the reference's metrics dict between two device images [3][H][W]
+ * (R, G, B planes, unit range, f16 or f32): out3 = { PSNR dB, SSIM, dE-ITP } as _psnr_bgr / _ssim_bgr /
+ * _delta_e_itp_bgr compute them (src/gui_objective_metrics.py:438-528; peak_nits = HDRTVNET_OBJECTIVE_HDR_PEAK_NITS,
+ * 1000).  Synchronises `stream` (the three numbers come back to the host).  Parity UNPINNED: that module needs
+ * cv2; the arithmetic is oracle/metrics_oracle.py's restatement. */
+int hdrtv_metrics(hdrtv_ctx *ctx, void *stream, const void *dev_a, const void *dev_b, int dtype, int H, int W,
+                  float peak_nits, double *out3);
+
 /* ---- pinned host RGB48 ring: replaces _pinned_u16_host_ring / _acquire_pinned_u16_slot /
  * _PinnedMpvFrame (gui_pipeline_worker_feeders.py:38-70, 125-170).  `slots` in [2,8]
  * (HDRTVNET_FEEDER_GPU_RGB48_RING_FRAMES).  A slot cycles free -> acquired -> (kernel

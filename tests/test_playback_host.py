@@ -184,3 +184,29 @@ def test_rgb48le_sink_and_rawvideo_source(tmp_path):
     assert src.read() == (False, None)
     with pytest.raises(ValueError):
         P.RawVideoSource(str(path), 7, 6, 24.0)
+
+
+def test_objective_metrics_hook():
+    """With a ground-truth source attached every Nth processed frame is scored and the metrics dict carries it."""
+    clk = FakeClock()
+    w = FakeWorker(clk, 0.002)
+
+    class Proc:
+        calls = 0
+
+        def objective_metrics(self, pred, gt):
+            Proc.calls += 1
+            return {"psnr_db": 40.0 + Proc.calls, "sssim": 0.99, "delta_e_itp": 1.5}
+
+    w._processor = Proc()
+    w._process_frame = lambda **kw: (clk.__setattr__("t", clk.t + 0.002), (None, None, "pred", False, 1.8))[1]
+
+    class Gt:
+        def read(self):
+            return True, "gt"
+
+    src = P.SyntheticSource(96, 64, fps=60.0, n_frames=21, pool=1, kind="noise")
+    got = []
+    r = P.RealtimePlayback(w, src, clock=clk, sleep=clk.sleep_until, gt_source=Gt(), objective_every=10, metrics_cb=got.append).run()
+    assert Proc.calls == 3 and r["last_metrics"]["objective_enabled"] is True          # frames 0, 10, 20
+    assert r["last_metrics"]["psnr_db"] == 43.0 and r["last_metrics"]["delta_e_itp"] == 1.5
