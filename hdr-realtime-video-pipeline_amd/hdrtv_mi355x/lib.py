@@ -56,6 +56,9 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found: the MI355X HIP extension is not built and there is no "
             "fallback path (run __graft_entry__.build())")
+    # PyTorch ships its own HIP runtime (libamdhip64 with the system library's SONAME).  Whichever copy a process loads
+    # first serves both users, and torch on the system copy finds no device: make torch's the first.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)      # AttributeError here = header/library mismatch
