@@ -16,8 +16,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-AGCM_MAX = 4e-3
-OUT_MAX, OUT_MEAN = 1.5e-2, 2e-3
+AGCM_MAX = 2e-3
+OUT_MAX, OUT_MEAN = 6e-3, 5e-4      # ~3x the worst measured case (profiles/r01_final_layers.txt era)
 U8_MAX, U8_MEAN = 3, 0.6
 
 
@@ -151,10 +151,10 @@ def test_hr_golden(proc_hr, golden_dir, hr_state, name):
     # LE stage taps against the oracle evaluated on OUR agcm output (isolates LE from AGCM error)
     taps = {}
     O.le(hr_state, agcm_np, taps)
-    for ours, theirs, tol in (("le.cond", "LE.cond_first", 6e-3), ("le.cond1", "LE.CondNet1", 6e-3),
-                              ("le.cond2", "LE.CondNet2", 8e-3), ("le.cond3", "LE.CondNet3", 1e-2),
-                              ("le.cond4", "LE.CondNet4", 2e-2), ("le.fea0", None, 8e-3),
-                              ("le.fea1", "LE.recon_trunk1", 1e-2), ("le.fea2", "LE.recon_trunk2", 1.5e-2)):
+    for ours, theirs, tol in (("le.cond", "LE.cond_first", 3e-3), ("le.cond1", "LE.CondNet1", 3e-3),
+                              ("le.cond2", "LE.CondNet2", 4e-3), ("le.cond3", "LE.CondNet3", 6e-3),
+                              ("le.cond4", "LE.CondNet4", 1.5e-2), ("le.fea0", None, 4e-3),
+                              ("le.fea1", "LE.recon_trunk1", 5e-3), ("le.fea2", "LE.recon_trunk2", 1.2e-2)):
         got = proc_hr.tap(ours).numpy()
         if theirs is None:
             want = np.maximum(taps["LE.HR_conv1"], 0)
@@ -189,20 +189,20 @@ def test_hg_golden(proc_hg, golden_dir, hr_state, hg_state, name):
     ref = O.hg_generator(hg_state, np.pad(base, ((0, 0), (0, ph), (0, pw)), mode="reflect"),
                          np.pad(mask, ((0, 0), (0, ph), (0, pw)), mode="reflect"), taps)[:, :h, :w]
     assert np.array_equal(proc_hg.tap("hg.mask").numpy()[:, :h, :w], mask)
-    for ours, tol in (("hg.conv2", 2e-2), ("hg.conv3_2", 4e-2), ("hg.conv4_2", 5e-2), ("hg.conv5_2", 5e-2),
-                      ("hg.conv_code2", 8e-2), ("hg.conv6", 5e-2), ("hg.conv7", 5e-2), ("hg.conv8", 4e-2),
-                      ("hg.conv9", 3e-2)):
+    for ours, tol in (("hg.conv2", 1e-2), ("hg.conv3_2", 1.2e-2), ("hg.conv4_2", 2e-2), ("hg.conv5_2", 2.5e-2),
+                      ("hg.conv_code2", 2e-2), ("hg.conv6", 1e-2), ("hg.conv7", 1e-2), ("hg.conv8", 8e-3),
+                      ("hg.conv9", 6e-3)):
         mx, _ = _stats(ours, proc_hg.tap(ours).numpy(), taps[ours])
         assert mx <= tol, ours
     mx, mean = _stats("hg_out vs oracle(our base)", out_np, ref)
-    assert mx <= 3e-2 and mean <= 2e-3
+    assert mx <= 3e-3 and mean <= 1e-4
     # against the reference's golden output, away from pixels whose mask bit flipped under fp16
     same = (mask == d["mask"])[0]
     print(f"  mask flips vs golden: {int((~same).sum())} of {same.size}")
     assert (~same).mean() <= 0.002
     dd = np.abs(out_np - d["out"])[:, same]
     print(f"  hg_out vs golden: max_abs={dd.max():.3e} mean_abs={dd.mean():.3e}")
-    assert dd.max() <= 4e-2 and dd.mean() <= 3e-3
+    assert dd.max() <= 8e-3 and dd.mean() <= 6e-4
 
 
 def test_mid_size_vs_oracle(proc_hg, hr_state, hg_state):
@@ -222,7 +222,7 @@ def test_mid_size_vs_oracle(proc_hg, hr_state, hg_state):
     ref = O.hg_generator(hg_state, np.pad(base, ((0, 0), (0, ph), (0, pw)), mode="reflect"),
                          np.pad(mask, ((0, 0), (0, ph), (0, pw)), mode="reflect"))[:, :272, :480]
     mx, mean = _stats("hg 272x480", out.cpu().numpy()[0], ref)
-    assert mx <= 3e-2 and mean <= 2e-3
+    assert mx <= 3e-3 and mean <= 1e-4
 
 
 @pytest.mark.parametrize("hw", [(1080, 1920), (2160, 3840)])
@@ -339,4 +339,4 @@ def test_full_hd_hg_vs_oracle(proc_hg, hr_state, hg_state):
         mx, mean = _stats(name + " 1088x1920", proc_hg.tap(name).numpy(), taps[name])
         assert mx <= tol and mean <= tol / 20, name
     mx, mean = _stats("hg out 1080x1920", out.cpu().numpy()[0], ref)
-    assert mx <= 3e-2 and mean <= 2e-3
+    assert mx <= 3e-3 and mean <= 1e-4

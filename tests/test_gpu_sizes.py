@@ -45,11 +45,11 @@ def test_480p_vs_oracle(proc, hr_state, hg_state):
     rt, rc = O.preprocess(f)
     rbase, ragcm = O.hr_forward(hr_state, rt, rc)
     assert np.abs(agcm.float().cpu().numpy()[0] - ragcm).max() <= 2e-3
-    assert np.abs(base - rbase).max() <= 1.5e-2 and np.abs(base - rbase).mean() <= 1e-3
+    assert np.abs(base - rbase).max() <= 6e-3 and np.abs(base - rbase).mean() <= 5e-4
     mask = O.hg_mask(base)
     ph, pw = (32 - h % 32) % 32, (32 - w % 32) % 32
     ref = O.hg_generator(hg_state, np.pad(base, ((0, 0), (0, ph), (0, pw)), mode="reflect"),
                          np.pad(mask, ((0, 0), (0, ph), (0, pw)), mode="reflect"))[:, :h, :w]
     d = np.abs(out.cpu().numpy()[0] - ref)
     print(f"  480x854: hg max {d.max():.3e} mean {d.mean():.3e}")
-    assert d.max() <= 3e-2 and d.mean() <= 2e-3
+    assert d.max() <= 3e-3 and d.mean() <= 1e-4
