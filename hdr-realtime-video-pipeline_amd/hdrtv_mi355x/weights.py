@@ -186,3 +186,76 @@ def synthetic_frame(h: int, w: int, seed: int = 1234, kind: str = "noise") -> np
         img += (0.9 * np.exp(-d2))[:, :, None] * rng.uniform(0.7, 1.0, 3).astype(np.float32)
     img += rng.normal(0, 0.01, img.shape).astype(np.float32)
     return np.clip(img * 255.0 + 0.5, 0, 255).astype(np.uint8)
+
+
+# ------------------------------------------------------------------ W8A8 HG (BASELINE configs[4], int8 MFMA)
+# The HG layers that run on int8 MFMA, with the activation tensor(s) each one reads.  Tensors that are concatenated
+# (pixel-shuffled Up_conv output + encoder skip) or read by two layers share ONE quantiser, so that each activation
+# exists once in HBM as int8: in the reference's checkpoint format (per-layer x_scale / x_zero,
+# hdrtvnet_torch.py:296-364) this is simply equal values on the layers of a group.  conv1, conv2, conv9, Up_conv5,
+# conv10 and conv_last stay fp16, as the first and last layers do in the reference's mixed recipes
+# (configs/qat_layouts/original_hg_composite_mixed_w8a8.txt keeps 24 layers fp16).
+HG_W8A8_GROUPS = OrderedDict([
+    # group (= activation tensors)      layers reading it
+    ("conv2", ("conv3_1.0",)),
+    ("p3", ("conv3_2.0",)),
+    ("conv3_2+up3", ("conv4_1.0", "conv8")),
+    ("p4", ("conv4_2.0",)),
+    ("conv4_2+up2", ("conv5_1.0", "conv7")),
+    ("p5", ("conv5_2.0",)),
+    ("conv5_2+up1", ("conv_code1.0", "conv6")),
+    ("pc", ("conv_code2.0",)),
+    ("conv_code2", ("Up_conv1.0",)),
+    ("conv6", ("Up_conv2.0",)),
+    ("conv7", ("Up_conv3.0",)),
+    ("conv8", ("Up_conv4.0",)),
+])
+
+
+def activation_qparams(lo: float, hi: float):
+    """Range -> (x_scale, x_zero) of the reference's asymmetric u8 activation quantiser
+    (``x_q = round((x - x_zero) / x_scale).clamp(0, 255)``) with an INTEGER zero point: x_zero = -k * x_scale,
+    k in 0..255, x_scale fp16-representable so that k * x_scale is exact in fp32.  Zero padding (applied after
+    dequantisation in the reference) is then the code k exactly, which lets an integer kernel pad with a constant."""
+    lo, hi = min(float(lo), 0.0), max(float(hi), 0.0)
+    s = np.float32(np.float16(max(hi - lo, 1e-6) / 255.0 * 1.0005))       # never round the range down
+    k = int(np.clip(np.rint(-lo / float(s)), 0, 255))
+    return float(s), float(np.float32(-k) * s)
+
+
+def hg_w8a8_state(hg_state, act_ranges) -> "OrderedDict[str, np.ndarray]":
+    """fp HG state + ``{group: (lo, hi)}`` calibration ranges -> runtime W8A8 state in the reference's key layout
+    (``<layer>.weight_int8`` int8, ``.w_scale`` per output channel, ``.bias``, ``.x_scale``, ``.x_zero``;
+    W8A8Conv2d.__init__, hdrtvnet_torch.py:309-337: w_scale = max|w| / 127, round, clamp).  BatchNorm tensors and the
+    fp16 layers pass through unchanged."""
+    layer_q = {}
+    for group, layers in HG_W8A8_GROUPS.items():
+        qp = activation_qparams(*act_ranges[group])
+        for name in layers:
+            layer_q[name] = qp
+    out = OrderedDict()
+    for k, v in hg_state.items():
+        a = np.asarray(v)
+        base = k[: -len(".weight")] if k.endswith(".weight") else None
+        if base in layer_q:
+            w = a.astype(np.float32)
+            w_scale = np.maximum(np.abs(w.reshape(w.shape[0], -1)).max(axis=1), np.float32(1e-8)) / np.float32(127.0)
+            q = np.clip(np.rint(w / w_scale.reshape(-1, 1, 1, 1)), -128, 127).astype(np.int8)
+            out[base + ".weight_int8"] = q
+            out[base + ".w_scale"] = w_scale.astype(np.float32)
+            out[base + ".x_scale"] = np.array(layer_q[base][0], np.float32)
+            out[base + ".x_zero"] = np.array(layer_q[base][1], np.float32)
+        else:
+            out[k] = a
+    return out
+
+
+def seeded_hg_w8a8_state(seed: int = 1234) -> "OrderedDict[str, np.ndarray]":
+    """The seeded HG stand-in quantised with the calibration table shipped in ``data/`` (ranges measured with the fp32
+    network on the synthetic gradient frames; tests/golden/gen_golden_hg_w8a8.py writes it)."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", f"hg_w8a8_calib_seed{seed}.json")
+    with open(path) as f:
+        ranges = {k: tuple(v) for k, v in json.load(f)["ranges"].items()}
+    return hg_w8a8_state(seeded_hg_state(seed), ranges)

@@ -195,3 +195,42 @@ def test_int8_fake_quant_execution(golden_dir, tag):
         assert emax <= 1e-5 and mae == 0.0
     else:
         assert emax <= 3e-2 and emean <= 1.5e-3 and mae <= 0.5
+
+
+def test_hg_w8a8_fake_quant_execution(golden_dir):
+    """The W8A8 HG head (15 layers of weights.HG_W8A8_GROUPS on the reference's W8A8Conv2d, asymmetric u8 activations
+    with integer zero points; the recipe and the calibration table are the product's).  Golden:
+    tests/golden/gen_golden_hg_w8a8.py swapped the reference's own W8A8Conv2d into its HG_Composite and ran it on CPU.
+    With ATen's conv under the oracle's graph the restatement is bit-exact against that run; with the plain-C
+    operators isolated quantisation steps flip (see test_int8_fake_quant_execution)."""
+    from hdrtv_mi355x import weights as W
+    d = _load(golden_dir, "hg_w8a8_96x128_gradient_s3.npz")
+    hr = {k: np.asarray(v, np.float32) for k, v in W.load_pack(os.path.join(golden_dir, "hr_weights.hdrw")).items()}
+    qs = W.seeded_hg_w8a8_state(1234)
+    for layers in W.HG_W8A8_GROUPS.values():
+        for name in layers:
+            s, z = float(qs[name + ".x_scale"]), float(qs[name + ".x_zero"])
+            k = -z / s
+            assert k == round(k) and 0 <= k <= 255 and qs[name + ".weight_int8"].dtype == np.int8, name
+            assert all(float(qs[n + ".x_scale"]) == s and float(qs[n + ".x_zero"]) == z for n in layers)
+    q = O.w8a8_state(qs)
+    assert sum(1 for v in q.values() if getattr(v, "x_scale", None) is not None) == 15
+    steps = (("hg.conv2", 16), ("hg.conv3_2", 16), ("hg.conv5_2", 4), ("hg.conv_code2", 4), ("hg.conv6", 4),
+             ("hg.conv8", 16), ("hg.conv9", 16))
+
+    def run():
+        taps = {}
+        out, _ = O.hg_composite(hr, q, *O.preprocess(d["frame"]), taps)
+        e = np.abs(out - d["out"])
+        return e.max(), e.mean(), max(np.abs(taps[k][::s] - d["tap:" + k]).max() for k, s in steps)
+
+    emax, emean, tmax = run()
+    print(f"  C operators: out max {emax:.2e} mean {emean:.2e} taps max {tmax:.2e}")
+    assert emax <= 3e-2 and emean <= 2e-4 and tmax <= 0.3
+    O.use_backend("aten")
+    try:
+        emax, emean, tmax = run()
+    finally:
+        O.use_backend("c")
+    print(f"  ATen operators: out max {emax:.2e} mean {emean:.2e} taps max {tmax:.2e}")
+    assert emax <= 1e-6 and tmax <= 1e-6

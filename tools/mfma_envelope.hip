@@ -52,6 +52,28 @@ __global__ __launch_bounds__(512, 1) void mfma32(const f16x8 *__restrict__ src, 
     if (s[0] == 123.456f) dst[blockIdx.x * blockDim.x + threadIdx.x] = s[0];
 }
 
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+
+// int8: v_mfma_i32_16x16x64_i8, the same cycles as the f16 16x16x32 at twice the K
+__global__ __launch_bounds__(512, 1) void mfma16_i8(const f16x8 *__restrict__ src, float *__restrict__ dst, int iters) {
+    const int lane = threadIdx.x & 63;
+    i32x4v a[4], b[4];
+    const i32x4v *s4 = (const i32x4v *)src;
+    for (int i = 0; i < 4; ++i) { a[i] = s4[(lane + 64 * i) & 1023]; b[i] = s4[(lane + 64 * (i + 4)) & 1023]; }
+    i32x4 acc[4][4] = {};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    i32x4 s = {};
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) s += acc[i][j];
+    if (s[0] == 123456789) dst[blockIdx.x * blockDim.x + threadIdx.x] = (float)(s[0] + s[1] + s[2] + s[3]);
+}
+
 static double run(void (*k)(const f16x8 *, float *, int), int wg, int threads, const f16x8 *src, float *dst, int iters,
                   double flop_per_wave_iter, int reps, double *ms_out) {
     hipEvent_t e0, e1;
@@ -90,6 +112,8 @@ int main() {
             // 16 MFMAs of 16x16x32 per iteration: 2*16*16*32 flop each
             double tf16 = run(mfma16, wg, threads, src, dst, 20000, 16.0 * 2 * 16 * 16 * 32, 50, &ms);
             printf("%-12s 16x16x32  %2d waves/CU  %8.3f ms/launch  %7.1f TFLOP/s\n", mn, waves_per_cu, ms, tf16);
+            double ti8 = run(mfma16_i8, wg, threads, src, dst, 20000, 16.0 * 2 * 16 * 16 * 64, 50, &ms);
+            printf("%-12s i8 16x16x64 %2d waves/CU  %8.3f ms/launch  %7.1f TOP/s\n", mn, waves_per_cu, ms, ti8);
             double tf32 = run(mfma32, wg, threads, src, dst, 20000, 8.0 * 2 * 32 * 32 * 16, 50, &ms);
             printf("%-12s 32x32x16  %2d waves/CU  %8.3f ms/launch  %7.1f TFLOP/s\n", mn, waves_per_cu, ms, tf32);
         }
