@@ -68,6 +68,24 @@ struct ConvParams {
     void *trash;           // conv_pglds: >= 2 KiB scratch that out-of-image lanes store to (never read)
 };
 
+// Parameter block of the int8 HG convolutions (conv3x3_pglds_i8.hip, conv_i8_misc.hip).  Activations are int8 codes
+// c = q - 128 of the reference's u8 quantiser q = round((x - x_zero) / x_scale), NHWC, pixel stride = channel count.
+struct ConvI8Params {
+    const int8_t *src0, *src1;   // src1: channel concat after src0, or nullptr
+    int c0, c1;                  // multiples of 128
+    int Hi, Wi, Ho, Wo;
+    const int8_t *wpk;           // [KS*KS][Cin/128][Cout][128]
+    const float *scale, *shift;  // [Cout]: out = acc * scale + shift, in output codes (int8 dst) or real units (f16 dst)
+    int Cout;                    // multiple of 128
+    int mode;                    // ST_NHWC / ST_PS / ST_POOL
+    int out_f16;                 // dst holds ReLU'd f16 values instead of int8 codes
+    void *dst;
+    int dstC, Hd, Wd;
+    int tiles_x, tiles_y;
+    const int8_t *padline;       // 128 B of the input tensor's zero-point code (k - 128): out-of-image halo pixels
+    void *trash;                 // >= 2 KiB scratch that out-of-image lanes store to (never read)
+};
+
 // Parameter block of the persistent 32-channel conv (conv32p.hip): 3x3, stride 1, Cin = 32.
 struct Conv32Params {
     const f16 *src;        // NHWC 32

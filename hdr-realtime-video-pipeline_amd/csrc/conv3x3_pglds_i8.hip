@@ -1,0 +1,371 @@
+// conv3x3_pglds_i8.hip -- the persistent HG 3x3 convolution of conv3x3_pglds.hip on int8 MFMA (W8A8 layers of the HG head,
+// BASELINE.json configs[4]; semantics: W8A8Conv2d.forward, hdrtvnet_torch.py:351-364, asymmetric u8 activations).
+//
+// Activations live in HBM as int8 codes c = q - 128 (q = the reference's u8 code), NHWC; weights as the checkpoint's
+// int8.  With an integer zero point k (x_zero = -k * x_scale) the reference's zero padding after dequantisation is the
+// code k, so out-of-image halo pixels are filled from a constant line and
+//     conv = x_scale * w_scale[co] * (sum c * w + (128 - k) * sum w)
+// exactly, in integers; the second term, the bias, BatchNorm and the OUTPUT tensor's quantiser are folded on the host
+// into one per-channel {scale, shift}, so the epilogue is  code = clamp(rint(acc * scale + shift), -128, 127)
+// (ReLU is the lower clamp: post-ReLU tensors have k = 0).
+//
+// Byte geometry is the f16 kernel's: a 128-channel int8 chunk is the same 128 B per pixel as its 64-channel f16 chunk,
+// so tile sizes, LDS images, swizzles, LDS-DMA pieces, the weight ring and every counted wait are unchanged; one
+// v_mfma_i32_16x16x64_i8 consumes the 64 bytes of K that two f16 MFMAs did, at the same cycles.
+#include "launchers.h"
+
+namespace {
+
+constexpr int TH = 16, TW = 16, HW = 18, NPIX = HW * HW;
+constexpr int CT = 128, PIXB = CT;                       // 128-channel int8 chunk = 128 B per pixel
+constexpr int BN = 128;
+constexpr int A_PIECES_PER_WAVE = 6, A_BYTES = 8 * A_PIECES_PER_WAVE * 1024;   // 324 halo px -> 48 KiB
+constexpr int B_BYTES = BN * PIXB, B_PIECES_PER_WAVE = 2;                       // 16 KiB
+constexpr int SS_OFF = 2 * A_BYTES + 3 * B_BYTES;        // two 1-KiB {scale[128], shift[128]} slots
+constexpr int SMEM = SS_OFF + 2048;                      // 146 KiB
+
+// stores per wave and tile, by store mode (see the epilogues)
+template <int MODE, bool OUTF16> struct NStores { static constexpr int N = OUTF16 ? 8 : (MODE == ST_POOL ? 1 : 4); };
+
+__device__ __forceinline__ void glds16(const void *g, void *lds)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds, 16, 0, 0);
+}
+
+template <int N> __device__ __forceinline__ void wait_vm()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+struct Tile { int n0, oy0, ox0; };
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+template <int MODE, bool OUTF16>
+__global__ __launch_bounds__(512) void conv_pglds_i8_kernel(ConvI8Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *sA = smem;
+    char *sB = smem + 2 * A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kg = lane >> 4;
+
+    // ---- this block's run of tiles: XCD x owns a contiguous range, its blocks interleave in it --
+    const int ntn = p.Cout / BN;
+    const int total = p.tiles_x * p.tiles_y * ntn;
+    int t_first, t_step, ntile;
+    {
+        const int G = gridDim.x, b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+        const int nslots = (G - xcd + 7) >> 3;
+        const int q = total >> 3, r = total & 7;
+        const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        const int len = q + (xcd < r ? 1 : 0);
+        t_first = base + slot;
+        t_step = nslots;
+        ntile = slot < len ? (len - slot + nslots - 1) / nslots : 0;
+    }
+    if (ntile == 0) return;
+    auto decode = [&](int t) {
+        Tile o;
+        const int nt_i = t % ntn, sp = t / ntn;
+        const int ty = sp / p.tiles_x, tx = sp - ty * p.tiles_x;
+        o.n0 = nt_i * BN; o.oy0 = ty * TH; o.ox0 = tx * TW;
+        return o;
+    };
+
+    const int nchunk = (p.c0 + p.c1) / CT, nchunk0 = p.c0 / CT;
+    const int nit = nchunk * 9;
+
+    // ---- LDS-DMA issue helpers (wave-uniform LDS base, per-lane swizzled source) ------------
+    const int l_row = lane >> 3, l_slot = lane & 7;
+    auto issue_A = [&](int cc, int buf, const Tile &T) {
+        const int8_t *src;
+        int cs, coff;
+        if (cc < nchunk0) { src = p.src0; cs = p.c0; coff = cc * CT; }
+        else { src = p.src1; cs = p.c1; coff = (cc - nchunk0) * CT; }
+#pragma unroll
+        for (int it = 0; it < A_PIECES_PER_WAVE; ++it) {
+            const int piece = wave + it * 8;
+            const int hp = piece * 8 + l_row;
+            const int hy = hp / HW, hx = hp - hy * HW;
+            const int iy = T.oy0 - 1 + hy, ix = T.ox0 - 1 + hx;
+            const bool ok = hp < NPIX && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+            const int8_t *g = ok ? src + ((size_t)iy * p.Wi + ix) * cs + coff + ((l_slot ^ (hx & 7)) << 4)
+                                 : p.padline + (l_slot << 4);
+            glds16(g, sA + buf * A_BYTES + piece * 1024);
+        }
+    };
+    auto issue_B = [&](int it_i, int n0, int slot) {
+        const int cc = it_i / 9, tap = it_i - cc * 9;
+        const int8_t *base = p.wpk + ((size_t)(tap * nchunk + cc) * p.Cout + n0) * CT;
+#pragma unroll
+        for (int k = 0; k < B_PIECES_PER_WAVE; ++k) {
+            const int piece = wave * B_PIECES_PER_WAVE + k;
+            const int n = piece * 8 + l_row;
+            glds16(base + (size_t)n * CT + ((l_slot ^ (n & 7)) << 4), sB + slot * B_BYTES + piece * 1024);
+        }
+    };
+    auto issue_SS = [&](int n0, int slot) {      // every wave writes the same 1 KiB: {scale[128], shift[128]}
+        const float *g = (lane < 32 ? p.scale : p.shift - 128) + n0 + lane * 4;
+        glds16(g, smem + SS_OFF + slot * 1024);
+    };
+
+    // ---- wave tiling: 2 (channels) x 4 (pixel rows) waves, each 64 ch x 64 px = 4x4 tiles of 16x16
+    const int wc = wave & 1, wp = wave >> 1;
+    i32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = i32x4{0, 0, 0, 0};
+    const int kw = l15 & 7;
+    const int b_lane = (wc * 64 + l15) * PIXB;
+    const int a_lane = (wp * 4 * HW + l15) * PIXB;
+
+    // ---- prologue: first tile's halo, scale/shift and weights of taps 0 and 1 -----------------
+    Tile cur = decode(t_first), nxt = cur;
+    issue_A(0, 0, cur);
+    issue_SS(cur.n0, 0);
+    issue_B(0, cur.n0, 0);
+    issue_B(1, cur.n0, 1);
+    issue_B(2, cur.n0, 2);
+    wait_vm<4>();
+    __builtin_amdgcn_s_barrier();
+
+    int gch = 0;                                  // chunks done so far: halo buffer parity
+    for (int k = 0; k < ntile; ++k) {
+        const bool has_next = k + 1 < ntile;
+        if (has_next) nxt = decode(t_first + (k + 1) * t_step);
+        for (int cc = 0; cc < nchunk; ++cc, ++gch) {
+            const char *a = sA + (gch & 1) * A_BYTES;
+            const bool last_chunk = cc + 1 == nchunk;
+            const bool pfA = !last_chunk || has_next;    // a halo tile is staged during this chunk's tap 6
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int it_i = cc * 9 + tap;
+                // stream index = 9 * gch + tap, so the ring slot of this iteration is tap % 3
+                // (a tile's weights(2) are issued before the tile starts: prologue / end of the previous tile)
+                bool pfB = true;
+                if (tap == 0 && cc == 0) {}
+                else if (it_i + 2 < nit) issue_B(it_i + 2, cur.n0, (tap + 2) % 3);
+                else if (has_next) issue_B(it_i + 2 - nit, nxt.n0, (tap + 2) % 3);
+                else pfB = false;
+                if (tap == 6 && pfA) {
+                    if (!last_chunk) issue_A(cc + 1, (gch + 1) & 1, cur);
+                    else { issue_A(0, (gch + 1) & 1, nxt); issue_SS(nxt.n0, (k + 1) & 1); }
+                }
+
+                const char *bw = sB + (tap % 3) * B_BYTES + b_lane;
+                const char *ax = a + a_lane + ((tap / 3) * HW + tap % 3) * PIXB;
+                const int kx = (l15 + tap % 3) & 7;
+                i32x4 wf[2][4], xf[2][4];
+                auto ldw = [&](int ks, int i) {
+                    wf[ks][i] = *reinterpret_cast<const i32x4 *>(bw + i * 16 * PIXB + (((ks * 4 + kg) ^ kw) << 4));
+                };
+                auto ldx = [&](int ks, int j) {
+                    xf[ks][j] = *reinterpret_cast<const i32x4 *>(ax + j * HW * PIXB + (((ks * 4 + kg) ^ kx) << 4));
+                };
+                // program order IS the schedule: sched_barrier(0) lets nothing cross
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { ldw(0, i); ldx(0, i); }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    acc[g >> 2][g & 3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[0][g >> 2], xf[0][g & 3], acc[g >> 2][g & 3], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // k-step 1 fragments in the order its MFMAs want them: w0 x0 x1 x2 x3 w1 w2 w3
+                    if (g == 0) ldw(1, 0); else if (g < 5) ldx(1, g - 1); else ldw(1, g - 4);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int m = 8; m < 16; ++m)
+                    acc[m >> 2][m & 3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[0][m >> 2], xf[0][m & 3], acc[m >> 2][m & 3], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < 16; ++m)
+                    acc[m >> 2][m & 3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[1][m >> 2], xf[1][m & 3], acc[m >> 2][m & 3], 0, 0, 0);
+
+                // The next iteration reads weights(s+1), issued one iteration ago, and at a chunk boundary
+                // the halo staged at tap 6.  Allow exactly the DMAs (and, right after a tile boundary, the
+                // previous tile's stores) that are younger than those.
+                if (!pfB) {
+                    wait_vm<0>();
+                } else if ((tap == 6 || tap == 7) && pfA) {
+                    if (last_chunk) wait_vm<9>();        // halo (6) + scale/shift (1) + weights(s+2) (2)
+                    else wait_vm<8>();
+                } else if (tap <= 1 && cc == 0 && k > 0) {
+                    wait_vm<NStores<MODE, OUTF16>::N + 2>();     // weights(s+1) are older than the last tile's stores
+                } else {
+                    wait_vm<2>();
+                }
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+
+        // weights(2) of the next tile go out BEFORE this tile's stores: vmcnt retires in issue order, so the
+        // first DMA wait that has to see the stores complete is then three taps away instead of one
+        if (has_next) issue_B(2, nxt.n0, 2);
+        // ------------------------------------------------------------ epilogue, from registers
+        // lane: pixel (row wp*4 + j, column l15), channels wc*64 + i*16 + 4*kg + {0..3}
+        const float *ss = reinterpret_cast<const float *>(smem + SS_OFF + (k & 1) * 1024);
+        char *trash = reinterpret_cast<char *>(p.trash) + lane * 16;
+        const int cw = wc * 64 + 4 * kg;
+        // wave-private strip of the halo buffer this tile just finished with (free until the next tile's tap 6); LDS
+        // operations of one wave execute in order: no barrier
+        char *stg = sA + ((gch - 1) & 1) * A_BYTES + wave * 5120;
+        if constexpr (OUTF16) {
+            // dequantised f16 output (the layer in front of an fp16 consumer): the f16 kernel's ST_PS epilogue
+            static_assert(!OUTF16 || MODE == ST_PS, "f16 output is built for the pixel-shuffle store only");
+            f16x4 o[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 sc = *reinterpret_cast<const float4 *>(ss + cw + i * 16);
+                const float4 sh = *reinterpret_cast<const float4 *>(ss + 128 + cw + i * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[i][j][0] = (f16)fmaxf((float)acc[i][j][0] * sc.x + sh.x, 0.f);
+                    o[i][j][1] = (f16)fmaxf((float)acc[i][j][1] * sc.y + sh.y, 0.f);
+                    o[i][j][2] = (f16)fmaxf((float)acc[i][j][2] * sc.z + sh.z, 0.f);
+                    o[i][j][3] = (f16)fmaxf((float)acc[i][j][3] * sc.w + sh.w, 0.f);
+                    acc[i][j] = i32x4{0, 0, 0, 0};
+                }
+            }
+            constexpr int SP = 144;
+            char *stg16 = sA + ((gch - 1) & 1) * A_BYTES + wave * (32 * SP);
+            const int s_row = lane >> 3, s_chunk = lane & 7;
+            const int cps = p.dstC;
+            const int chw = cur.n0 + wc * 64;
+            const int sub = chw / cps;
+            const int cbase = chw - sub * cps + s_chunk * 8;
+            f16 *dst = reinterpret_cast<f16 *>(p.dst);
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        *reinterpret_cast<f16x4 *>(stg16 + (jj * 16 + l15) * SP + (i * 16 + 4 * kg) * 2) = o[i][2 * pass + jj];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const f16x8 v = *reinterpret_cast<const f16x8 *>(stg16 + (rr * 8 + s_row) * SP + s_chunk * 16);
+                    const int oy = cur.oy0 + wp * 4 + 2 * pass + (rr >> 1);
+                    const int oxx = cur.ox0 + (rr & 1) * 8 + s_row;
+                    const int Y = 2 * oy + (sub >> 1), X = 2 * oxx + (sub & 1);
+                    const bool ok = oy < p.Ho && oxx < p.Wo && Y < p.Hd && X < p.Wd;
+                    f16 *d = ok ? dst + ((size_t)Y * p.Wd + X) * cps + cbase : reinterpret_cast<f16 *>(trash);
+                    *reinterpret_cast<f16x8 *>(d) = v;
+                }
+            }
+        } else {
+            // int8 codes of the output tensor's quantiser: clamp(rint(acc * scale + shift), -128, 127)
+            float q[4][4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 sc = *reinterpret_cast<const float4 *>(ss + cw + i * 16);
+                const float4 sh = *reinterpret_cast<const float4 *>(ss + 128 + cw + i * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    q[i][j][0] = fminf(fmaxf(__builtin_rintf((float)acc[i][j][0] * sc.x + sh.x), -128.f), 127.f);
+                    q[i][j][1] = fminf(fmaxf(__builtin_rintf((float)acc[i][j][1] * sc.y + sh.y), -128.f), 127.f);
+                    q[i][j][2] = fminf(fmaxf(__builtin_rintf((float)acc[i][j][2] * sc.z + sh.z), -128.f), 127.f);
+                    q[i][j][3] = fminf(fmaxf(__builtin_rintf((float)acc[i][j][3] * sc.w + sh.w), -128.f), 127.f);
+                    acc[i][j] = i32x4{0, 0, 0, 0};
+                }
+            }
+            auto pack4 = [](const float *v) -> unsigned {
+                return ((unsigned)(int)v[0] & 0xffu) | (((unsigned)(int)v[1] & 0xffu) << 8) | (((unsigned)(int)v[2] & 0xffu) << 16) |
+                       ((unsigned)(int)v[3] << 24);
+            };
+            constexpr int SP = 80;                                   // strip row pitch: 64 ch x 1 B + 16
+            const int s_px = lane >> 2, s_chunk = lane & 3;
+            int8_t *dst = reinterpret_cast<int8_t *>(p.dst);
+            if constexpr (MODE == ST_NHWC || MODE == ST_PS) {
+                const int cps = p.dstC;
+                const int chw = cur.n0 + wc * 64;
+                const int sub = MODE == ST_PS ? chw / cps : 0;
+                const int cbase = (MODE == ST_PS ? chw - sub * cps : chw) + s_chunk * 16;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        *reinterpret_cast<unsigned *>(stg + (j * 16 + l15) * SP + i * 16 + 4 * kg) = pack4(q[i][j]);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {                     // strip row rr*16 + s_px = wave pixel row rr, column s_px
+                    const i32x4 v = *reinterpret_cast<const i32x4 *>(stg + (rr * 16 + s_px) * SP + s_chunk * 16);
+                    const int oy = cur.oy0 + wp * 4 + rr;
+                    const int oxx = cur.ox0 + s_px;
+                    int8_t *d;
+                    if constexpr (MODE == ST_NHWC) {
+                        const bool ok = oy < p.Ho && oxx < p.Wo;
+                        d = ok ? dst + ((size_t)oy * p.Wo + oxx) * p.dstC + cbase : reinterpret_cast<int8_t *>(trash);
+                    } else {
+                        // channels were permuted at pack time: ch = sub * dstC + c; the wave's 64 channels share one sub
+                        const int Y = 2 * oy + (sub >> 1), X = 2 * oxx + (sub & 1);
+                        const bool ok = oy < p.Ho && oxx < p.Wo && Y < p.Hd && X < p.Wd;
+                        d = ok ? dst + ((size_t)Y * p.Wd + X) * cps + cbase : reinterpret_cast<int8_t *>(trash);
+                    }
+                    *reinterpret_cast<i32x4 *>(d) = v;
+                }
+            } else {   // ST_POOL: 2x2 max of the codes (the quantiser is monotone): rows in-lane, columns by DPP (no LDS)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float m[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float a = fmaxf(q[i][2 * jj][r], q[i][2 * jj + 1][r]);
+                            const float b = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0xB1, 0xF, 0xF, false));
+                            m[r] = fmaxf(a, b);
+                        }
+                        if ((l15 & 1) == 0)
+                            *reinterpret_cast<unsigned *>(stg + (jj * 8 + (l15 >> 1)) * SP + i * 16 + 4 * kg) = pack4(m);
+                    }
+                const i32x4 v = *reinterpret_cast<const i32x4 *>(stg + s_px * SP + s_chunk * 16);
+                const int py = (cur.oy0 >> 1) + wp * 2 + (s_px >> 3), px = (cur.ox0 >> 1) + (s_px & 7);
+                const bool ok = py < p.Hd && px < p.Wd;
+                int8_t *d = ok ? dst + ((size_t)py * p.Wd + px) * p.dstC + cur.n0 + wc * 64 + s_chunk * 16 : reinterpret_cast<int8_t *>(trash);
+                *reinterpret_cast<i32x4 *>(d) = v;
+            }
+        }
+        cur = nxt;
+    }
+}
+
+template <int MODE, bool OUTF16>
+hipError_t launch_mode(const ConvI8Params &p, int grid, hipStream_t stream)
+{
+    static bool attr_set = false;
+    auto kern = conv_pglds_i8_kernel<MODE, OUTF16>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), SMEM, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// 3x3, stride 1, pad 1 on int8 codes: Cin (src0 [+ src1 concat]) multiple of 128, Cout multiple of 128; store modes
+// NHWC / PS / POOL to int8 codes, or PS to dequantised f16.  One block per CU, each walking tiles.
+hipError_t conv_pglds_i8_launch(ConvI8Params p, int n_cu, hipStream_t stream)
+{
+    if ((p.c0 % CT) || (p.c1 % CT) || p.c0 + p.c1 < CT || (p.Cout % BN) || !p.padline || !p.trash || n_cu < 8 ||
+        (p.mode != ST_NHWC && p.mode != ST_PS && p.mode != ST_POOL) || (p.out_f16 && p.mode != ST_PS) ||
+        (p.mode == ST_PS && (p.dstC % 64)))
+        return hipErrorInvalidValue;
+    p.tiles_x = (p.Wo + TW - 1) / TW;
+    p.tiles_y = (p.Ho + TH - 1) / TH;
+    const int total = p.tiles_x * p.tiles_y * (p.Cout / BN);
+    const int grid = total < n_cu ? total : n_cu;
+    if (p.out_f16) return launch_mode<ST_PS, true>(p, grid, stream);
+    switch (p.mode) {
+    case ST_NHWC: return launch_mode<ST_NHWC, false>(p, grid, stream);
+    case ST_PS: return launch_mode<ST_PS, false>(p, grid, stream);
+    default: return launch_mode<ST_POOL, false>(p, grid, stream);
+    }
+}

@@ -75,6 +75,16 @@ struct Pack {
         else { err = "unsupported dtype for " + name; return false; }
         return true;
     }
+    bool has(const std::string &name) const { return e.find(name) != e.end(); }
+    bool get_i8(const std::string &name, size_t numel, std::vector<int8_t> &out, std::string &err) const
+    {
+        auto it = e.find(name);
+        if (it == e.end()) { err = "tensor missing from weight pack: " + name; return false; }
+        const PackEntry &pe = it->second;
+        if (pe.numel() != numel || pe.dtype != 2) { err = "bad shape or dtype (want int8) for " + name; return false; }
+        out.assign((const int8_t *)pe.data, (const int8_t *)pe.data + numel);
+        return true;
+    }
 };
 
 // --------------------------------------------------------------------------- device arenas
@@ -101,16 +111,20 @@ struct ConvLayer {
     size_t wpk = 0, scale = 0, shift = 0;   // weight-arena offsets
     int cin = 0, cout = 0, coutPad = 0, ks = 0, stride = 1, cin_t = 0, bn = 0;
 };
+struct ConvI8Layer {                        // W8A8 HG layer on int8 MFMA
+    size_t wpk = 0, scale = 0, shift = 0, padline = 0;
+    int cin = 0, cout = 0, ks = 0, out_f16 = 0;
+};
 struct C3Layer { size_t wfrag = 0, scale = 0, shift = 0; int cout = 0; };
 struct SftLayer { size_t wfrag = 0, bias = 0; };
 
 struct Tensor {
     size_t off = 0;
-    int C = 0, H = 0, W = 0, layout = 0;   // 0 NHWC f16, 1 planar f16, 2 planar f32, 3 f32 vector, 4 u8 plane
+    int C = 0, H = 0, W = 0, layout = 0;   // 0 NHWC f16, 1 planar f16, 2 planar f32, 3 f32 vector, 4 u8 plane, 5 NHWC int8 codes
     size_t bytes() const
     {
         const size_t n = (size_t)C * H * W;
-        return layout == 2 || layout == 3 ? n * 4 : (layout == 4 ? n : n * 2);
+        return layout == 2 || layout == 3 ? n * 4 : (layout == 4 || layout == 5 ? n : n * 2);
     }
 };
 
@@ -130,6 +144,9 @@ struct hdrtv_ctx {
     Arena wts;
     std::map<std::string, ConvLayer> conv;
     std::map<std::string, C3Layer> c3;
+    std::map<std::string, ConvI8Layer> conv8;
+    bool hg_i8 = false;                   // the HG pack is a W8A8 checkpoint: 15 layers run on int8 MFMA
+    float hg_q0_inv = 0.f, hg_q0_zero = 0.f;   // quantiser of the fp16 -> int8 boundary (conv2's output)
     std::map<std::string, SftLayer> sft;
     std::map<std::string, size_t> f32v;   // raw fp32 vectors/matrices in the weight arena
     size_t zeros_off = 0;                 // 256 B of zeros in the weight arena
@@ -242,6 +259,79 @@ bool pack_conv(hdrtv_ctx *c, const Pack &pk, const std::string &key, const std::
     L.scale = c->wts.put(scale.data(), scale.size() * 4);
     L.shift = c->wts.put(shift.data(), shift.size() * 4);
     c->conv[key] = L;
+    return true;
+}
+
+// W8A8 layer (W8A8Conv2d, hdrtvnet_torch.py:296-364, asymmetric) for the int8 kernels: weight_int8 [Co][Ci][K][K] ->
+// wpk [K*K][Ci/128][Co][128]; activation codes are q - 128 with an integer zero point k = -x_zero / x_scale, so
+//     y = x_scale * w_scale[n] * (acc + (128 - k) * sum(w_int8[n])) + bias[n]      (then BatchNorm, folded)
+// and the epilogue's {scale, shift} map acc straight to the OUTPUT tensor's codes (out_scale, out_k) or, out_scale == 0,
+// to real units for an fp16 consumer.
+struct ActQ { float scale = 0.f; int k = 0; };
+bool read_actq(hdrtv_ctx *c, const Pack &pk, const std::string &layer, ActQ &q)
+{
+    std::vector<float> xs, xz;
+    if (!pk.get(layer + ".x_scale", 1, xs, c->err) || !pk.get(layer + ".x_zero", 1, xz, c->err)) return false;
+    const double k = -(double)xz[0] / (double)xs[0];
+    if (!(xs[0] > 0.f) || std::fabs(k - std::nearbyint(k)) > 1e-3 || k < -0.5 || k > 255.5) {
+        c->err = "W8A8 HG layer " + layer + ": the int8 path needs x_zero = -k * x_scale with an integer k in 0..255";
+        return false;
+    }
+    q.scale = xs[0];
+    q.k = (int)std::nearbyint(k);
+    return true;
+}
+bool pack_conv_i8(hdrtv_ctx *c, const Pack &pk, const std::string &key, const std::string &wname, int co, int ci, int ks,
+                  const std::string &bn_name, int ps_cps, const ActQ &out)
+{
+    std::vector<int8_t> w;
+    std::vector<float> ws, b;
+    ActQ in;
+    if (!pk.get_i8(wname + ".weight_int8", (size_t)co * ci * ks * ks, w, c->err) || !pk.get(wname + ".w_scale", co, ws, c->err) ||
+        !pk.get(wname + ".bias", co, b, c->err) || !read_actq(c, pk, wname, in))
+        return false;
+    if (ci % 128 || co % 128) { c->err = "unsupported W8A8 conv shape: " + wname; return false; }
+    std::vector<float> g, be, mu, var;
+    const bool has_bn = !bn_name.empty();
+    if (has_bn) {
+        if (!pk.get(bn_name + ".weight", co, g, c->err) || !pk.get(bn_name + ".bias", co, be, c->err) ||
+            !pk.get(bn_name + ".running_mean", co, mu, c->err) || !pk.get(bn_name + ".running_var", co, var, c->err))
+            return false;
+    }
+    const int nch = ci / 128, taps = ks * ks;
+    std::vector<int8_t> wp((size_t)taps * nch * co * 128);
+    std::vector<float> scale(co), shift(co);
+    for (int np = 0; np < co; ++np) {
+        const int n = ps_cps > 0 ? 4 * (np % ps_cps) + np / ps_cps : np;
+        long wsum = 0;
+        for (int k = 0; k < ci; ++k)
+            for (int tap = 0; tap < taps; ++tap) {
+                const int8_t v = w[((size_t)n * ci + k) * taps + tap];
+                wsum += v;
+                wp[(((size_t)tap * nch + k / 128) * co + np) * 128 + k % 128] = v;
+            }
+        const double a = (double)in.scale * (double)ws[n];
+        double sc = a, sh = a * (double)(128 - in.k) * (double)wsum + (double)b[n];
+        if (has_bn) {
+            const double gs = (double)g[n] / std::sqrt((double)var[n] + 1e-5);
+            sc *= gs;
+            sh = (sh - (double)mu[n]) * gs + (double)be[n];
+        }
+        if (out.scale > 0.f) {      // to the codes (q - 128) of the consumer's quantiser
+            sc /= (double)out.scale;
+            sh = sh / (double)out.scale + (double)out.k - 128.0;
+        }
+        scale[np] = (float)sc;
+        shift[np] = (float)sh;
+    }
+    std::vector<int8_t> pad(128, (int8_t)(in.k - 128));
+    ConvI8Layer L;
+    L.cin = ci; L.cout = co; L.ks = ks; L.out_f16 = out.scale > 0.f ? 0 : 1;
+    L.wpk = c->wts.put(wp.data(), wp.size());
+    L.scale = c->wts.put(scale.data(), scale.size() * 4);
+    L.shift = c->wts.put(shift.data(), shift.size() * 4);
+    L.padline = c->wts.put(pad.data(), pad.size());
+    c->conv8[key] = L;
     return true;
 }
 
@@ -441,21 +531,63 @@ bool build_weights(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
     // ---- HG
     if (hg) {
         if (!pack_c3(c, *hg, "hg.conv1", "conv1.0", 64, "conv1.1")) return false;
-        const Spec blocks[] = {{"conv2", 128, 64, 3, 1, 0}, {"conv3_1", 256, 128, 3, 1, 0}, {"conv3_2", 256, 256, 3, 1, 0},
-                               {"conv4_1", 512, 256, 3, 1, 0}, {"conv4_2", 512, 512, 3, 1, 0}, {"conv5_1", 512, 512, 3, 1, 0},
-                               {"conv5_2", 512, 512, 3, 1, 0}, {"conv_code1", 512, 512, 3, 1, 0}, {"conv_code2", 512, 512, 3, 1, 0}};
-        for (const Spec &s : blocks)
-            if (!pack_conv(c, *hg, std::string("hg.") + s.name, std::string(s.name) + ".0", s.co, s.ci, 3, 1,
-                           std::string(s.name) + ".1", 0))
+        c->hg_i8 = hg->has("conv3_1.0.weight_int8");
+        if (!c->hg_i8) {
+            const Spec blocks[] = {{"conv2", 128, 64, 3, 1, 0}, {"conv3_1", 256, 128, 3, 1, 0}, {"conv3_2", 256, 256, 3, 1, 0},
+                                   {"conv4_1", 512, 256, 3, 1, 0}, {"conv4_2", 512, 512, 3, 1, 0}, {"conv5_1", 512, 512, 3, 1, 0},
+                                   {"conv5_2", 512, 512, 3, 1, 0}, {"conv_code1", 512, 512, 3, 1, 0}, {"conv_code2", 512, 512, 3, 1, 0}};
+            for (const Spec &s : blocks)
+                if (!pack_conv(c, *hg, std::string("hg.") + s.name, std::string(s.name) + ".0", s.co, s.ci, 3, 1,
+                               std::string(s.name) + ".1", 0))
+                    return false;
+            const Spec ups[] = {{"Up_conv1", 2048, 512, 3, 1, 512}, {"Up_conv2", 2048, 512, 3, 1, 512}, {"Up_conv3", 1024, 256, 3, 1, 256},
+                                {"Up_conv4", 512, 128, 3, 1, 128}, {"Up_conv5", 256, 64, 3, 1, 64}};
+            for (const Spec &s : ups)
+                if (!pack_conv(c, *hg, std::string("hg.") + s.name, std::string(s.name) + ".0", s.co, s.ci, 3, 1, "", s.ps)) return false;
+            const Spec fuses[] = {{"conv6", 512, 1024, 1, 1, 0}, {"conv7", 256, 1024, 1, 1, 0}, {"conv8", 128, 512, 1, 1, 0},
+                                  {"conv9", 64, 256, 1, 1, 0}};
+            for (const Spec &s : fuses)
+                if (!pack_conv(c, *hg, std::string("hg.") + s.name, s.name, s.co, s.ci, 1, 1, "", 0)) return false;
+        } else {
+            // W8A8 checkpoint (weights.HG_W8A8_GROUPS): conv3_1 .. Up_conv4 and the fuse convs conv6..8 on int8 MFMA; conv1,
+            // conv2, conv9, Up_conv5, conv10, conv_last stay fp16.  A layer's epilogue writes the codes of the layer that
+            // reads its output; tensors read by two layers (encoder skip) or concatenated must share one quantiser.
+            if (!pack_conv(c, *hg, "hg.conv2", "conv2.0", 128, 64, 3, 1, "conv2.1", 0) ||
+                !pack_conv(c, *hg, "hg.Up_conv5", "Up_conv5.0", 256, 64, 3, 1, "", 64) ||
+                !pack_conv(c, *hg, "hg.conv9", "conv9", 64, 256, 1, 1, "", 0))
                 return false;
-        const Spec ups[] = {{"Up_conv1", 2048, 512, 3, 1, 512}, {"Up_conv2", 2048, 512, 3, 1, 512}, {"Up_conv3", 1024, 256, 3, 1, 256},
-                            {"Up_conv4", 512, 128, 3, 1, 128}, {"Up_conv5", 256, 64, 3, 1, 64}};
-        for (const Spec &s : ups)
-            if (!pack_conv(c, *hg, std::string("hg.") + s.name, std::string(s.name) + ".0", s.co, s.ci, 3, 1, "", s.ps)) return false;
-        const Spec fuses[] = {{"conv6", 512, 1024, 1, 1, 0}, {"conv7", 256, 1024, 1, 1, 0}, {"conv8", 128, 512, 1, 1, 0},
-                              {"conv9", 64, 256, 1, 1, 0}};
-        for (const Spec &s : fuses)
-            if (!pack_conv(c, *hg, std::string("hg.") + s.name, s.name, s.co, s.ci, 1, 1, "", 0)) return false;
+            struct Q8 { const char *name; int co, ci, ks, ps; const char *bn; const char *consumer; const char *shares; };
+            const Q8 q8[] = {
+                {"conv3_1", 256, 128, 3, 0, "conv3_1.1", "conv3_2.0", nullptr}, {"conv3_2", 256, 256, 3, 0, "conv3_2.1", "conv4_1.0", "conv8"},
+                {"conv4_1", 512, 256, 3, 0, "conv4_1.1", "conv4_2.0", nullptr}, {"conv4_2", 512, 512, 3, 0, "conv4_2.1", "conv5_1.0", "conv7"},
+                {"conv5_1", 512, 512, 3, 0, "conv5_1.1", "conv5_2.0", nullptr}, {"conv5_2", 512, 512, 3, 0, "conv5_2.1", "conv_code1.0", "conv6"},
+                {"conv_code1", 512, 512, 3, 0, "conv_code1.1", "conv_code2.0", nullptr},
+                {"conv_code2", 512, 512, 3, 0, "conv_code2.1", "Up_conv1.0", nullptr},
+                {"Up_conv1", 2048, 512, 3, 512, "", "conv6", nullptr}, {"conv6", 512, 1024, 1, 0, "", "Up_conv2.0", nullptr},
+                {"Up_conv2", 2048, 512, 3, 512, "", "conv7", nullptr}, {"conv7", 256, 1024, 1, 0, "", "Up_conv3.0", nullptr},
+                {"Up_conv3", 1024, 256, 3, 256, "", "conv8", nullptr}, {"conv8", 128, 512, 1, 0, "", "Up_conv4.0", nullptr},
+                {"Up_conv4", 512, 128, 3, 128, "", nullptr, nullptr}};
+            for (const Q8 &L : q8) {
+                ActQ out;
+                if (L.consumer && !read_actq(c, *hg, L.consumer, out)) return false;
+                if (L.shares) {
+                    ActQ o2;
+                    if (!read_actq(c, *hg, L.shares, o2)) return false;
+                    if (o2.scale != out.scale || o2.k != out.k) {
+                        c->err = std::string("W8A8 HG: ") + L.consumer + " and " + L.shares + " read one tensor and must share x_scale / x_zero";
+                        return false;
+                    }
+                }
+                const bool relu = L.ks == 3;       // conv blocks and Up blocks end in ReLU: their output codes start at k = 0
+                if (relu && L.consumer && out.k != 0) { c->err = std::string("W8A8 HG: post-ReLU tensor in front of ") + L.consumer + " needs x_zero = 0"; return false; }
+                const std::string wname = L.ks == 3 ? std::string(L.name) + ".0" : std::string(L.name);
+                if (!pack_conv_i8(c, *hg, std::string("hg.") + L.name, wname, L.co, L.ci, L.ks, L.bn, L.ps, out)) return false;
+            }
+            ActQ q0;
+            if (!read_actq(c, *hg, "conv3_1.0", q0)) return false;
+            c->hg_q0_inv = 1.f / q0.scale;
+            c->hg_q0_zero = (float)(q0.k - 128);
+        }
         if (!put_f32(c, *hg, "hg.w10", "conv10.weight", 3 * 128) || !put_f32(c, *hg, "hg.b10", "conv10.bias", 3) ||
             !put_f32(c, *hg, "hg.wl", "conv_last.weight", 18) || !put_f32(c, *hg, "hg.bl", "conv_last.bias", 3))
             return false;
@@ -616,13 +748,24 @@ int do_reserve(hdrtv_ctx *c, int H, int W)
         ws_add(c, "hg.img", 3, Hp, Wp, 1); ws_add(c, "hg.mask", 1, Hp, Wp, 4);
         ws_add(c, "hg.p1", 64, Hp / 2, Wp / 2, 0); ws_add(c, "hg.part", 4, Hp, Wp, 3);
         ws_add(c, "hg.conv2", 128, Hp / 2, Wp / 2, 0);
-        ws_add(c, "hg.p3", 256, Hp / 4, Wp / 4, 0); ws_add(c, "hg.conv3_2", 256, Hp / 4, Wp / 4, 0);
-        ws_add(c, "hg.p4", 512, Hp / 8, Wp / 8, 0); ws_add(c, "hg.conv4_2", 512, Hp / 8, Wp / 8, 0);
-        ws_add(c, "hg.p5", 512, Hp / 16, Wp / 16, 0); ws_add(c, "hg.conv5_2", 512, Hp / 16, Wp / 16, 0);
-        ws_add(c, "hg.pc", 512, Hp / 32, Wp / 32, 0); ws_add(c, "hg.conv_code2", 512, Hp / 32, Wp / 32, 0);
-        ws_add(c, "hg.up1", 512, Hp / 16, Wp / 16, 0); ws_add(c, "hg.conv6", 512, Hp / 16, Wp / 16, 0);
-        ws_add(c, "hg.up2", 512, Hp / 8, Wp / 8, 0); ws_add(c, "hg.conv7", 256, Hp / 8, Wp / 8, 0);
-        ws_add(c, "hg.up3", 256, Hp / 4, Wp / 4, 0); ws_add(c, "hg.conv8", 128, Hp / 4, Wp / 4, 0);
+        if (!c->hg_i8) {
+            ws_add(c, "hg.p3", 256, Hp / 4, Wp / 4, 0); ws_add(c, "hg.conv3_2", 256, Hp / 4, Wp / 4, 0);
+            ws_add(c, "hg.p4", 512, Hp / 8, Wp / 8, 0); ws_add(c, "hg.conv4_2", 512, Hp / 8, Wp / 8, 0);
+            ws_add(c, "hg.p5", 512, Hp / 16, Wp / 16, 0); ws_add(c, "hg.conv5_2", 512, Hp / 16, Wp / 16, 0);
+            ws_add(c, "hg.pc", 512, Hp / 32, Wp / 32, 0); ws_add(c, "hg.conv_code2", 512, Hp / 32, Wp / 32, 0);
+            ws_add(c, "hg.up1", 512, Hp / 16, Wp / 16, 0); ws_add(c, "hg.conv6", 512, Hp / 16, Wp / 16, 0);
+            ws_add(c, "hg.up2", 512, Hp / 8, Wp / 8, 0); ws_add(c, "hg.conv7", 256, Hp / 8, Wp / 8, 0);
+            ws_add(c, "hg.up3", 256, Hp / 4, Wp / 4, 0); ws_add(c, "hg.conv8", 128, Hp / 4, Wp / 4, 0);
+        } else {            // W8A8: the same tensors as int8 codes (q - 128), each once
+            ws_add(c, "hg8.conv2", 128, Hp / 2, Wp / 2, 5);
+            ws_add(c, "hg8.p3", 256, Hp / 4, Wp / 4, 5); ws_add(c, "hg8.conv3_2", 256, Hp / 4, Wp / 4, 5);
+            ws_add(c, "hg8.p4", 512, Hp / 8, Wp / 8, 5); ws_add(c, "hg8.conv4_2", 512, Hp / 8, Wp / 8, 5);
+            ws_add(c, "hg8.p5", 512, Hp / 16, Wp / 16, 5); ws_add(c, "hg8.conv5_2", 512, Hp / 16, Wp / 16, 5);
+            ws_add(c, "hg8.pc", 512, Hp / 32, Wp / 32, 5); ws_add(c, "hg8.conv_code2", 512, Hp / 32, Wp / 32, 5);
+            ws_add(c, "hg8.up1", 512, Hp / 16, Wp / 16, 5); ws_add(c, "hg8.conv6", 512, Hp / 16, Wp / 16, 5);
+            ws_add(c, "hg8.up2", 512, Hp / 8, Wp / 8, 5); ws_add(c, "hg8.conv7", 256, Hp / 8, Wp / 8, 5);
+            ws_add(c, "hg8.up3", 256, Hp / 4, Wp / 4, 5); ws_add(c, "hg8.conv8", 128, Hp / 4, Wp / 4, 5);
+        }
         ws_add(c, "hg.up4", 128, Hp / 2, Wp / 2, 0); ws_add(c, "hg.conv9", 64, Hp / 2, Wp / 2, 0);
     }
     if (hipMalloc((void **)&c->ws.dev, c->ws.size + 4096) != hipSuccess) {
@@ -714,6 +857,35 @@ struct Seq {
                 : (pglds ? conv_pglds_launch(p, c->n_cu, s)
                          : (glds1 ? conv_glds1_launch(p, s) : conv_igemm_launch(p, L.cin_t, L.bn, L.ks, L.stride, s))),
             key.c_str(), tag, macs, bytes);
+    }
+    // W8A8 HG layer on int8 MFMA: 3x3 (conv3x3_pglds_i8.hip) or 1x1 (conv_i8_misc.hip)
+    void conv8(const std::string &key, const int8_t *src0, int c0, const int8_t *src1, int c1, int Hi, int Wi, int mode, void *dst,
+               int dstC, int Hd, int Wd)
+    {
+        if (!ok()) return;
+        auto it = c->conv8.find(key);
+        if (it == c->conv8.end()) { rc = fail(c, HDRTV_ESTATE, "no packed int8 conv %s", key.c_str()); return; }
+        const ConvI8Layer &L = it->second;
+        if (c0 + c1 != L.cin) { rc = fail(c, HDRTV_ESTATE, "conv %s: channel mismatch", key.c_str()); return; }
+        ConvI8Params p;
+        memset(&p, 0, sizeof p);
+        p.src0 = src0; p.src1 = src1; p.c0 = c0; p.c1 = c1; p.Hi = Hi; p.Wi = Wi; p.Ho = Hi; p.Wo = Wi;
+        p.wpk = wtp<int8_t>(c, L.wpk); p.scale = wtp<float>(c, L.scale); p.shift = wtp<float>(c, L.shift);
+        p.Cout = L.cout; p.mode = mode; p.out_f16 = L.out_f16; p.dst = dst; p.dstC = dstC; p.Hd = Hd; p.Wd = Wd;
+        p.padline = wtp<int8_t>(c, L.padline);
+        p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
+        char tag[64];
+        if (L.ks == 3) snprintf(tag, sizeof tag, "conv_pglds_i8<%s%s>", mode == ST_POOL ? "pool" : (mode == ST_PS ? "ps" : "nhwc"), L.out_f16 ? ",f16" : "");
+        else snprintf(tag, sizeof tag, "conv1x1_i8");
+        const double macs = (double)Hi * Wi * L.cin * L.ks * L.ks * L.cout;
+        const double outel = mode == ST_POOL ? (double)Hd * Wd * L.cout : (double)Hi * Wi * L.cout;
+        const double bytes = (double)Hi * Wi * L.cin + (double)L.ks * L.ks * L.cin * L.cout + outel * (L.out_f16 ? 2.0 : 1.0);
+        chk(L.ks == 3 ? conv_pglds_i8_launch(p, c->n_cu, s) : conv1x1_i8_launch(p, s), key.c_str(), tag, macs, bytes);
+    }
+    void quant8(const char *what, const f16 *src, int8_t *dst, size_t n, float inv_scale, float zero_code)
+    {
+        if (!ok()) return;
+        chk(quant_i8_launch(src, dst, n, inv_scale, zero_code, s), what, "quant_i8", 0.0, 3.0 * (double)n);
     }
     void c3(const std::string &key, const f16 *in, int H, int W, int act, f16 *out, f16 *out_pool)
     {
@@ -877,29 +1049,54 @@ int run_hg(hdrtv_ctx *c, Seq &q, const f16 *base, void *out, int out_f32)
     f16 *img = wsp<f16>(c, "hg.img");
     uint8_t *mask = wsp<uint8_t>(c, "hg.mask");
     q.chk(hg_prep_launch(base, s.H, s.W, Hp, Wp, img, mask, 0.75f, 0.1f, q.s), "hg_prep", "hg_prep", 0.0, 13.0 * Hp * Wp);
-    f16 *p1 = wsp<f16>(c, "hg.p1"), *c2 = wsp<f16>(c, "hg.conv2"), *p3 = wsp<f16>(c, "hg.p3"),
-        *c3 = wsp<f16>(c, "hg.conv3_2"), *p4 = wsp<f16>(c, "hg.p4"), *c4 = wsp<f16>(c, "hg.conv4_2"), *p5 = wsp<f16>(c, "hg.p5"),
-        *c5 = wsp<f16>(c, "hg.conv5_2"), *pc = wsp<f16>(c, "hg.pc"), *code = wsp<f16>(c, "hg.conv_code2");
+    f16 *p1 = wsp<f16>(c, "hg.p1"), *c2 = wsp<f16>(c, "hg.conv2"), *u4 = wsp<f16>(c, "hg.up4"), *c9 = wsp<f16>(c, "hg.conv9");
+    float *part = wsp<float>(c, "hg.part");
     q.c3("hg.conv1", img, Hp, Wp, ACT_RELU, nullptr, p1);      // only the pooled map is kept; conv1_out is recomputed in hg_final_fused
     q.conv("hg.conv2", p1, 64, nullptr, 0, Hp / 2, Wp / 2, ACT_RELU, ST_NHWC, c2, 128, Hp / 2, Wp / 2);
-    q.conv("hg.conv3_1", c2, 128, nullptr, 0, Hp / 2, Wp / 2, ACT_RELU, ST_POOL, p3, 256, Hp / 4, Wp / 4);
-    q.conv("hg.conv3_2", p3, 256, nullptr, 0, Hp / 4, Wp / 4, ACT_RELU, ST_NHWC, c3, 256, Hp / 4, Wp / 4);
-    q.conv("hg.conv4_1", c3, 256, nullptr, 0, Hp / 4, Wp / 4, ACT_RELU, ST_POOL, p4, 512, Hp / 8, Wp / 8);
-    q.conv("hg.conv4_2", p4, 512, nullptr, 0, Hp / 8, Wp / 8, ACT_RELU, ST_NHWC, c4, 512, Hp / 8, Wp / 8);
-    q.conv("hg.conv5_1", c4, 512, nullptr, 0, Hp / 8, Wp / 8, ACT_RELU, ST_POOL, p5, 512, Hp / 16, Wp / 16);
-    q.conv("hg.conv5_2", p5, 512, nullptr, 0, Hp / 16, Wp / 16, ACT_RELU, ST_NHWC, c5, 512, Hp / 16, Wp / 16);
-    q.conv("hg.conv_code1", c5, 512, nullptr, 0, Hp / 16, Wp / 16, ACT_RELU, ST_POOL, pc, 512, Hp / 32, Wp / 32);
-    q.conv("hg.conv_code2", pc, 512, nullptr, 0, Hp / 32, Wp / 32, ACT_RELU, ST_NHWC, code, 512, Hp / 32, Wp / 32);
-    f16 *u1 = wsp<f16>(c, "hg.up1"), *c6 = wsp<f16>(c, "hg.conv6"), *u2 = wsp<f16>(c, "hg.up2"), *c7 = wsp<f16>(c, "hg.conv7"),
-        *u3 = wsp<f16>(c, "hg.up3"), *c8 = wsp<f16>(c, "hg.conv8"), *u4 = wsp<f16>(c, "hg.up4"), *c9 = wsp<f16>(c, "hg.conv9");
-    float *part = wsp<float>(c, "hg.part");
-    q.conv("hg.Up_conv1", code, 512, nullptr, 0, Hp / 32, Wp / 32, ACT_RELU, ST_PS, u1, 512, Hp / 16, Wp / 16);
-    q.conv("hg.conv6", u1, 512, c5, 512, Hp / 16, Wp / 16, ACT_NONE, ST_NHWC, c6, 512, Hp / 16, Wp / 16);
-    q.conv("hg.Up_conv2", c6, 512, nullptr, 0, Hp / 16, Wp / 16, ACT_RELU, ST_PS, u2, 512, Hp / 8, Wp / 8);
-    q.conv("hg.conv7", u2, 512, c4, 512, Hp / 8, Wp / 8, ACT_NONE, ST_NHWC, c7, 256, Hp / 8, Wp / 8);
-    q.conv("hg.Up_conv3", c7, 256, nullptr, 0, Hp / 8, Wp / 8, ACT_RELU, ST_PS, u3, 256, Hp / 4, Wp / 4);
-    q.conv("hg.conv8", u3, 256, c3, 256, Hp / 4, Wp / 4, ACT_NONE, ST_NHWC, c8, 128, Hp / 4, Wp / 4);
-    q.conv("hg.Up_conv4", c8, 128, nullptr, 0, Hp / 4, Wp / 4, ACT_RELU, ST_PS, u4, 128, Hp / 2, Wp / 2);
+    if (c->hg_i8) {
+        // W8A8 checkpoint: conv3_1 .. Up_conv4 on int8 MFMA, every activation between them one int8 tensor
+        int8_t *c2q = wsp<int8_t>(c, "hg8.conv2"), *p3 = wsp<int8_t>(c, "hg8.p3"), *c3 = wsp<int8_t>(c, "hg8.conv3_2"),
+               *p4 = wsp<int8_t>(c, "hg8.p4"), *c4 = wsp<int8_t>(c, "hg8.conv4_2"), *p5 = wsp<int8_t>(c, "hg8.p5"),
+               *c5 = wsp<int8_t>(c, "hg8.conv5_2"), *pc = wsp<int8_t>(c, "hg8.pc"), *code = wsp<int8_t>(c, "hg8.conv_code2"),
+               *u1 = wsp<int8_t>(c, "hg8.up1"), *c6 = wsp<int8_t>(c, "hg8.conv6"), *u2 = wsp<int8_t>(c, "hg8.up2"),
+               *c7 = wsp<int8_t>(c, "hg8.conv7"), *u3 = wsp<int8_t>(c, "hg8.up3"), *c8 = wsp<int8_t>(c, "hg8.conv8");
+        q.quant8("hg.quant(conv2)", c2, c2q, (size_t)128 * (Hp / 2) * (Wp / 2), c->hg_q0_inv, c->hg_q0_zero);
+        q.conv8("hg.conv3_1", c2q, 128, nullptr, 0, Hp / 2, Wp / 2, ST_POOL, p3, 256, Hp / 4, Wp / 4);
+        q.conv8("hg.conv3_2", p3, 256, nullptr, 0, Hp / 4, Wp / 4, ST_NHWC, c3, 256, Hp / 4, Wp / 4);
+        q.conv8("hg.conv4_1", c3, 256, nullptr, 0, Hp / 4, Wp / 4, ST_POOL, p4, 512, Hp / 8, Wp / 8);
+        q.conv8("hg.conv4_2", p4, 512, nullptr, 0, Hp / 8, Wp / 8, ST_NHWC, c4, 512, Hp / 8, Wp / 8);
+        q.conv8("hg.conv5_1", c4, 512, nullptr, 0, Hp / 8, Wp / 8, ST_POOL, p5, 512, Hp / 16, Wp / 16);
+        q.conv8("hg.conv5_2", p5, 512, nullptr, 0, Hp / 16, Wp / 16, ST_NHWC, c5, 512, Hp / 16, Wp / 16);
+        q.conv8("hg.conv_code1", c5, 512, nullptr, 0, Hp / 16, Wp / 16, ST_POOL, pc, 512, Hp / 32, Wp / 32);
+        q.conv8("hg.conv_code2", pc, 512, nullptr, 0, Hp / 32, Wp / 32, ST_NHWC, code, 512, Hp / 32, Wp / 32);
+        q.conv8("hg.Up_conv1", code, 512, nullptr, 0, Hp / 32, Wp / 32, ST_PS, u1, 512, Hp / 16, Wp / 16);
+        q.conv8("hg.conv6", u1, 512, c5, 512, Hp / 16, Wp / 16, ST_NHWC, c6, 512, Hp / 16, Wp / 16);
+        q.conv8("hg.Up_conv2", c6, 512, nullptr, 0, Hp / 16, Wp / 16, ST_PS, u2, 512, Hp / 8, Wp / 8);
+        q.conv8("hg.conv7", u2, 512, c4, 512, Hp / 8, Wp / 8, ST_NHWC, c7, 256, Hp / 8, Wp / 8);
+        q.conv8("hg.Up_conv3", c7, 256, nullptr, 0, Hp / 8, Wp / 8, ST_PS, u3, 256, Hp / 4, Wp / 4);
+        q.conv8("hg.conv8", u3, 256, c3, 256, Hp / 4, Wp / 4, ST_NHWC, c8, 128, Hp / 4, Wp / 4);
+        q.conv8("hg.Up_conv4", c8, 128, nullptr, 0, Hp / 4, Wp / 4, ST_PS, u4, 128, Hp / 2, Wp / 2);     // -> f16
+    } else {
+        f16 *p3 = wsp<f16>(c, "hg.p3"), *c3 = wsp<f16>(c, "hg.conv3_2"), *p4 = wsp<f16>(c, "hg.p4"), *c4 = wsp<f16>(c, "hg.conv4_2"),
+            *p5 = wsp<f16>(c, "hg.p5"), *c5 = wsp<f16>(c, "hg.conv5_2"), *pc = wsp<f16>(c, "hg.pc"), *code = wsp<f16>(c, "hg.conv_code2");
+        f16 *u1 = wsp<f16>(c, "hg.up1"), *c6 = wsp<f16>(c, "hg.conv6"), *u2 = wsp<f16>(c, "hg.up2"), *c7 = wsp<f16>(c, "hg.conv7"),
+            *u3 = wsp<f16>(c, "hg.up3"), *c8 = wsp<f16>(c, "hg.conv8");
+        q.conv("hg.conv3_1", c2, 128, nullptr, 0, Hp / 2, Wp / 2, ACT_RELU, ST_POOL, p3, 256, Hp / 4, Wp / 4);
+        q.conv("hg.conv3_2", p3, 256, nullptr, 0, Hp / 4, Wp / 4, ACT_RELU, ST_NHWC, c3, 256, Hp / 4, Wp / 4);
+        q.conv("hg.conv4_1", c3, 256, nullptr, 0, Hp / 4, Wp / 4, ACT_RELU, ST_POOL, p4, 512, Hp / 8, Wp / 8);
+        q.conv("hg.conv4_2", p4, 512, nullptr, 0, Hp / 8, Wp / 8, ACT_RELU, ST_NHWC, c4, 512, Hp / 8, Wp / 8);
+        q.conv("hg.conv5_1", c4, 512, nullptr, 0, Hp / 8, Wp / 8, ACT_RELU, ST_POOL, p5, 512, Hp / 16, Wp / 16);
+        q.conv("hg.conv5_2", p5, 512, nullptr, 0, Hp / 16, Wp / 16, ACT_RELU, ST_NHWC, c5, 512, Hp / 16, Wp / 16);
+        q.conv("hg.conv_code1", c5, 512, nullptr, 0, Hp / 16, Wp / 16, ACT_RELU, ST_POOL, pc, 512, Hp / 32, Wp / 32);
+        q.conv("hg.conv_code2", pc, 512, nullptr, 0, Hp / 32, Wp / 32, ACT_RELU, ST_NHWC, code, 512, Hp / 32, Wp / 32);
+        q.conv("hg.Up_conv1", code, 512, nullptr, 0, Hp / 32, Wp / 32, ACT_RELU, ST_PS, u1, 512, Hp / 16, Wp / 16);
+        q.conv("hg.conv6", u1, 512, c5, 512, Hp / 16, Wp / 16, ACT_NONE, ST_NHWC, c6, 512, Hp / 16, Wp / 16);
+        q.conv("hg.Up_conv2", c6, 512, nullptr, 0, Hp / 16, Wp / 16, ACT_RELU, ST_PS, u2, 512, Hp / 8, Wp / 8);
+        q.conv("hg.conv7", u2, 512, c4, 512, Hp / 8, Wp / 8, ACT_NONE, ST_NHWC, c7, 256, Hp / 8, Wp / 8);
+        q.conv("hg.Up_conv3", c7, 256, nullptr, 0, Hp / 8, Wp / 8, ACT_RELU, ST_PS, u3, 256, Hp / 4, Wp / 4);
+        q.conv("hg.conv8", u3, 256, c3, 256, Hp / 4, Wp / 4, ACT_NONE, ST_NHWC, c8, 128, Hp / 4, Wp / 4);
+        q.conv("hg.Up_conv4", c8, 128, nullptr, 0, Hp / 4, Wp / 4, ACT_RELU, ST_PS, u4, 128, Hp / 2, Wp / 2);
+    }
     q.conv("hg.conv9", u4, 128, c2, 128, Hp / 2, Wp / 2, ACT_NONE, ST_NHWC, c9, 64, Hp / 2, Wp / 2);
     // Up_conv5 -> pixel shuffle -> ReLU -> first half of conv10, fused: 3 partial sums per pixel leave the kernel
     q.conv("hg.Up_conv5", c9, 64, nullptr, 0, Hp / 2, Wp / 2, ACT_RELU, ST_PS_DOT3, nullptr, 64, Hp, Wp, nullptr, nullptr, nullptr,

@@ -48,7 +48,10 @@ class HDRTVNetMI355X:
 
     ``model_path``: HR checkpoint (``HR.pt``, an ``.hdrw`` pack, or a state mapping).
     ``hg_weights``: HG checkpoint path / mapping, or ``"seeded:<int>"`` for the deterministic
-    stand-in of the un-shipped ``HG.pt`` (weights.seeded_hg_state).  As in the reference
+    stand-in of the un-shipped ``HG.pt`` (weights.seeded_hg_state); ``"seeded-w8a8:<int>"`` is that
+    stand-in as a W8A8 checkpoint (weights.seeded_hg_w8a8_state).  An HG checkpoint that carries
+    ``weight_int8`` / ``x_scale`` / ``x_zero`` tensors in the layout of weights.HG_W8A8_GROUPS runs its
+    15 quantised layers on int8 MFMA (BASELINE configs[4]); any other layout is rejected.  As in the reference
     (hdrtvnet_torch.py:2065-2086): an explicit but missing path raises ``FileNotFoundError``;
     with no path given and ``use_hg=True`` the model silently continues without HG.
     ``compile_*``, ``use_cuda_graphs``, ``force_channels_last``, ``predequantize`` are accepted
@@ -101,12 +104,15 @@ class HDRTVNetMI355X:
         if self._use_hg:
             if isinstance(hg_weights, str) and hg_weights.startswith("seeded:"):
                 hg_state = _W.seeded_hg_state(int(hg_weights.split(":", 1)[1]))
+            elif isinstance(hg_weights, str) and hg_weights.startswith("seeded-w8a8:"):
+                hg_state = _W.seeded_hg_w8a8_state(int(hg_weights.split(":", 1)[1]))
             elif hg_weights is not None:
                 hg_state = _load_state(hg_weights, "HG weights")     # FileNotFoundError if missing
             else:
                 print("WARNING: HG weights not given; continuing with no-HG model.")
                 self._use_hg = False
         self._hg_weights = hg_weights if self._use_hg else None
+        self._hg_int8 = hg_state is not None and _W.is_int8_state(hg_state)
         hr_blob = _W.pack_state({k: hr_state[k] for k, _ in _arch_hr()})
         hg_blob = _W.pack_state({k: v for k, v in hg_state.items()
                                  if not k.endswith("num_batches_tracked")}) if hg_state is not None else b""
@@ -125,7 +131,7 @@ class HDRTVNetMI355X:
         self._pin_input = self._pin_output = None
         self._gpu_out = self._gpu_agcm = self._gpu_u8 = None
         print(f"MI355X device : {self.device}")
-        print(f"MI355X precision: {self.precision}  (HG {'on' if self._use_hg else 'off'})")
+        print(f"MI355X precision: {self.precision}  (HG {('W8A8 on int8 MFMA' if self._hg_int8 else 'on') if self._use_hg else 'off'})")
         if self._warmup_passes > 0:
             self._warmup()
 
@@ -321,11 +327,13 @@ class HDRTVNetMI355X:
             buf = torch.empty(n, dtype=torch.float16, device=self.device)
         elif lay.value == 4:
             buf = torch.empty(n, dtype=torch.uint8, device=self.device)
+        elif lay.value == 5:
+            buf = torch.empty(n, dtype=torch.int8, device=self.device)
         else:
             buf = torch.empty(n, dtype=torch.float32, device=self.device)
         _hip_memcpy_d2d(buf.data_ptr(), p.value, buf.numel() * buf.element_size())
         torch.cuda.synchronize(self.device)
-        if lay.value == 0:
+        if lay.value in (0, 5):          # NHWC; int8 taps are codes q - 128 of the reading layer's quantiser
             return buf.view(h.value, w.value, c.value).permute(2, 0, 1).float().cpu()
         return buf.view(c.value, h.value, w.value).float().cpu()
 
