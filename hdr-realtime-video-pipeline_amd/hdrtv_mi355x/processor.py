@@ -113,6 +113,7 @@ class HDRTVNetMI355X:
                 self._use_hg = False
         self._hg_weights = hg_weights if self._use_hg else None
         self._hg_int8 = hg_state is not None and _W.is_int8_state(hg_state)
+        self._hg_state_fp = hg_state if (hg_state is not None and not self._hg_int8) else None
         hr_blob = _W.pack_state({k: hr_state[k] for k, _ in _arch_hr()})
         hg_blob = _W.pack_state({k: v for k, v in hg_state.items()
                                  if not k.endswith("num_batches_tracked")}) if hg_state is not None else b""
@@ -336,6 +337,47 @@ class HDRTVNetMI355X:
         if lay.value in (0, 5):          # NHWC; int8 taps are codes q - 128 of the reading layer's quantiser
             return buf.view(h.value, w.value, c.value).permute(2, 0, 1).float().cpu()
         return buf.view(c.value, h.value, w.value).float().cpu()
+
+    def _tap_device(self, name):
+        """Flat device copy of an internal activation (no layout conversion)."""
+        p, c, h, w, lay = C.c_void_p(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self._chk(self._lib.hdrtv_get_tap(self._ctx, name.encode(), C.byref(p), C.byref(c), C.byref(h), C.byref(w),
+                                          C.byref(lay)), "hdrtv_get_tap")
+        dt = {0: torch.float16, 1: torch.float16, 4: torch.uint8, 5: torch.int8}.get(lay.value, torch.float32)
+        buf = torch.empty(c.value * h.value * w.value, dtype=dt, device=self.device)
+        torch.cuda.synchronize(self.device)
+        _hip_memcpy_d2d(buf.data_ptr(), p.value, buf.numel() * buf.element_size())
+        torch.cuda.synchronize(self.device)
+        return buf
+
+    @torch.inference_mode()
+    def calibrate_hg_w8a8(self, frames):
+        """Activation ranges for a W8A8 HG checkpoint, the reference's ``calibrate_w8a8(method="max")``
+        (hdrtvnet_torch.py:1001-1099: running min / max of every quantised layer's input over the calibration set),
+        taken from this fp16 model's own activations on ``frames`` (u8 BGR).  Returns ``{group: (lo, hi)}`` for
+        ``weights.hg_w8a8_state`` / ``hg_w8a8_checkpoint``; layers that read one tensor or a concatenation share a range."""
+        if self._hg_state_fp is None:
+            raise RuntimeError("calibrate_hg_w8a8 needs a model loaded with floating-point HG weights")
+        members = {"conv2": ("hg.conv2",), "p3": ("hg.p3",), "conv3_2+up3": ("hg.conv3_2", "hg.up3"), "p4": ("hg.p4",),
+                   "conv4_2+up2": ("hg.conv4_2", "hg.up2"), "p5": ("hg.p5",), "conv5_2+up1": ("hg.conv5_2", "hg.up1"),
+                   "pc": ("hg.pc",), "conv_code2": ("hg.conv_code2",), "conv6": ("hg.conv6",), "conv7": ("hg.conv7",),
+                   "conv8": ("hg.conv8",)}
+        assert list(members) == list(_W.HG_W8A8_GROUPS)
+        ranges = {g: [0.0, 0.0] for g in members}
+        for f in frames:
+            self.infer(self.preprocess(f))
+            for g, taps in members.items():
+                for t in taps:
+                    v = self._tap_device(t)
+                    ranges[g][0] = min(ranges[g][0], float(v.amin()))
+                    ranges[g][1] = max(ranges[g][1], float(v.amax()))
+        return {g: (lo, hi) for g, (lo, hi) in ranges.items()}
+
+    def hg_w8a8_checkpoint(self, ranges):
+        """This model's HG weights as a W8A8 state (reference key layout) for ``hg_weights=``; see calibrate_hg_w8a8."""
+        if self._hg_state_fp is None:
+            raise RuntimeError("hg_w8a8_checkpoint needs a model loaded with floating-point HG weights")
+        return _W.hg_w8a8_state(self._hg_state_fp, ranges)
 
     def profile_enable(self, on=True):
         """Per-launch HIP-event timing of subsequent infer() calls (bench.py roofline)."""

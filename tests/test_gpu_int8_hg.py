@@ -166,3 +166,35 @@ def test_w8a8_schedules_do_not_change_results(golden_dir):
         p.close()
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+
+
+def test_calibrate_and_requantise_on_device(golden_dir):
+    """calibrate_hg_w8a8 (the reference's calibrate_w8a8, method "max") on the fp16 model's own activations, then the
+    resulting W8A8 checkpoint loaded back: ranges agree with the shipped table (same weights, similar frames) and the
+    int8 model stays close to the fp16 one."""
+    import json
+    from hdrtv_mi355x import weights as W
+    from hdrtv_mi355x.processor import HDRTVNetMI355X
+    hr = os.path.join(golden_dir, "hr_weights.hdrw")
+    frames = [W.synthetic_frame(288, 480, seed=s, kind="gradient") for s in (11, 12, 3)]
+    p = HDRTVNetMI355X(hr, use_hg=True, hg_weights="seeded:1234", warmup_passes=0)
+    ranges = p.calibrate_hg_w8a8(frames)
+    ckpt = p.hg_w8a8_checkpoint(ranges)
+    test = W.synthetic_frame(272, 480, seed=21, kind="gradient")
+    ref, _ = p.infer(p.preprocess(test))
+    ref = ref.cpu().numpy()[0]
+    with pytest.raises(RuntimeError):
+        HDRTVNetMI355X.calibrate_hg_w8a8(type("X", (), {"_hg_state_fp": None})(), frames)
+    p.close()
+    table = json.load(open(os.path.join(os.path.dirname(W.__file__), "data", "hg_w8a8_calib_seed1234.json")))["ranges"]
+    for g, (lo, hi) in ranges.items():
+        tlo, thi = table[g]
+        print(f"  {g:14s} device [{lo:8.4f}, {hi:8.4f}]  table [{tlo:8.4f}, {thi:8.4f}]")
+        assert abs(hi - thi) <= 0.03 * thi + 0.02 and abs(lo - tlo) <= 0.03 * abs(tlo) + 0.02
+    pq = HDRTVNetMI355X(hr, use_hg=True, hg_weights=ckpt, warmup_passes=0)
+    assert pq._hg_int8
+    out, _ = pq.infer(pq.preprocess(test))
+    e = np.abs(out.cpu().numpy()[0] - ref)
+    print(f"  W8A8 vs fp16 HG output: max {e.max():.3e} mean {e.mean():.3e}")
+    assert e.max() <= 5e-2 and e.mean() <= 5e-4
+    pq.close()
