@@ -256,7 +256,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "p50_ms": round(p50, 3), "p99_ms": round(p99, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i8+f16" if args.int8 else "f16",
             "data": "synthetic (seeded u8 noise + gradient/highlight frames; HR.pt weights, seeded HG weights)",
-            "config": {"workload": (f"configs[4]: INT8-QAT HDRTVNet++ {Wd}x{H}: HG head W8A8 on int8 MFMA (15 layers, 81 % of the MACs), AGCM+LE int8 weights dequantised to fp16 (the reference's ROCm behaviour)"
+            "config": {"workload": (f"configs[4]: INT8-QAT HDRTVNet++ {Wd}x{H}: HG head W8A8 on int8 MFMA (16 layers, 80 % of the MACs), AGCM+LE int8 weights dequantised to fp16 (the reference's ROCm behaviour)"
                                     if args.int8 else
                                     f"configs[2]: full HDRTVNet++ fp16 {Wd}x{H} + fused RGB48 post, 1 frame per GPU per step")
                        if use_hg else f"DEBUG no-HG {Wd}x{H}",

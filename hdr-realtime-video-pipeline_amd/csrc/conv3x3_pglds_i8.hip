@@ -25,7 +25,7 @@ constexpr int SS_OFF = 2 * A_BYTES + 3 * B_BYTES;        // two 1-KiB {scale[128
 constexpr int SMEM = SS_OFF + 2048;                      // 146 KiB
 
 // stores per wave and tile, by store mode (see the epilogues)
-template <int MODE, bool OUTF16> struct NStores { static constexpr int N = OUTF16 ? 8 : (MODE == ST_POOL ? 1 : 4); };
+template <int MODE> struct NStores { static constexpr int N = MODE == ST_POOL ? 1 : 4; };
 
 __device__ __forceinline__ void glds16(const void *g, void *lds)
 {
@@ -42,7 +42,7 @@ struct Tile { int n0, oy0, ox0; };
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-template <int MODE, bool OUTF16>
+template <int MODE>
 __global__ __launch_bounds__(512) void conv_pglds_i8_kernel(ConvI8Params p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(512) void conv_pglds_i8_kernel(ConvI8Params p)
                     if (last_chunk) wait_vm<9>();        // halo (6) + scale/shift (1) + weights(s+2) (2)
                     else wait_vm<8>();
                 } else if (tap <= 1 && cc == 0 && k > 0) {
-                    wait_vm<NStores<MODE, OUTF16>::N + 2>();     // weights(s+1) are older than the last tile's stores
+                    wait_vm<NStores<MODE>::N + 2>();     // weights(s+1) are older than the last tile's stores
                 } else {
                     wait_vm<2>();
                 }
@@ -215,50 +215,7 @@ __global__ __launch_bounds__(512) void conv_pglds_i8_kernel(ConvI8Params p)
         // wave-private strip of the halo buffer this tile just finished with (free until the next tile's tap 6); LDS
         // operations of one wave execute in order: no barrier
         char *stg = sA + ((gch - 1) & 1) * A_BYTES + wave * 5120;
-        if constexpr (OUTF16) {
-            // dequantised f16 output (the layer in front of an fp16 consumer): the f16 kernel's ST_PS epilogue
-            static_assert(!OUTF16 || MODE == ST_PS, "f16 output is built for the pixel-shuffle store only");
-            f16x4 o[4][4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float4 sc = *reinterpret_cast<const float4 *>(ss + cw + i * 16);
-                const float4 sh = *reinterpret_cast<const float4 *>(ss + 128 + cw + i * 16);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    o[i][j][0] = (f16)fmaxf((float)acc[i][j][0] * sc.x + sh.x, 0.f);
-                    o[i][j][1] = (f16)fmaxf((float)acc[i][j][1] * sc.y + sh.y, 0.f);
-                    o[i][j][2] = (f16)fmaxf((float)acc[i][j][2] * sc.z + sh.z, 0.f);
-                    o[i][j][3] = (f16)fmaxf((float)acc[i][j][3] * sc.w + sh.w, 0.f);
-                    acc[i][j] = i32x4{0, 0, 0, 0};
-                }
-            }
-            constexpr int SP = 144;
-            char *stg16 = sA + ((gch - 1) & 1) * A_BYTES + wave * (32 * SP);
-            const int s_row = lane >> 3, s_chunk = lane & 7;
-            const int cps = p.dstC;
-            const int chw = cur.n0 + wc * 64;
-            const int sub = chw / cps;
-            const int cbase = chw - sub * cps + s_chunk * 8;
-            f16 *dst = reinterpret_cast<f16 *>(p.dst);
-#pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        *reinterpret_cast<f16x4 *>(stg16 + (jj * 16 + l15) * SP + (i * 16 + 4 * kg) * 2) = o[i][2 * pass + jj];
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const f16x8 v = *reinterpret_cast<const f16x8 *>(stg16 + (rr * 8 + s_row) * SP + s_chunk * 16);
-                    const int oy = cur.oy0 + wp * 4 + 2 * pass + (rr >> 1);
-                    const int oxx = cur.ox0 + (rr & 1) * 8 + s_row;
-                    const int Y = 2 * oy + (sub >> 1), X = 2 * oxx + (sub & 1);
-                    const bool ok = oy < p.Ho && oxx < p.Wo && Y < p.Hd && X < p.Wd;
-                    f16 *d = ok ? dst + ((size_t)Y * p.Wd + X) * cps + cbase : reinterpret_cast<f16 *>(trash);
-                    *reinterpret_cast<f16x8 *>(d) = v;
-                }
-            }
-        } else {
+        {
             // int8 codes of the output tensor's quantiser: clamp(rint(acc * scale + shift), -128, 127)
             float q[4][4][4];
 #pragma unroll
@@ -334,11 +291,11 @@ __global__ __launch_bounds__(512) void conv_pglds_i8_kernel(ConvI8Params p)
     }
 }
 
-template <int MODE, bool OUTF16>
+template <int MODE>
 hipError_t launch_mode(const ConvI8Params &p, int grid, hipStream_t stream)
 {
     static bool attr_set = false;
-    auto kern = conv_pglds_i8_kernel<MODE, OUTF16>;
+    auto kern = conv_pglds_i8_kernel<MODE>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return e;
@@ -351,21 +308,20 @@ hipError_t launch_mode(const ConvI8Params &p, int grid, hipStream_t stream)
 }  // namespace
 
 // 3x3, stride 1, pad 1 on int8 codes: Cin (src0 [+ src1 concat]) multiple of 128, Cout multiple of 128; store modes
-// NHWC / PS / POOL to int8 codes, or PS to dequantised f16.  One block per CU, each walking tiles.
+// NHWC / PS / POOL to int8 codes.  One block per CU, each walking tiles.
 hipError_t conv_pglds_i8_launch(ConvI8Params p, int n_cu, hipStream_t stream)
 {
     if ((p.c0 % CT) || (p.c1 % CT) || p.c0 + p.c1 < CT || (p.Cout % BN) || !p.padline || !p.trash || n_cu < 8 ||
-        (p.mode != ST_NHWC && p.mode != ST_PS && p.mode != ST_POOL) || (p.out_f16 && p.mode != ST_PS) ||
+        (p.mode != ST_NHWC && p.mode != ST_PS && p.mode != ST_POOL) || p.out_f16 ||
         (p.mode == ST_PS && (p.dstC % 64)))
         return hipErrorInvalidValue;
     p.tiles_x = (p.Wo + TW - 1) / TW;
     p.tiles_y = (p.Ho + TH - 1) / TH;
     const int total = p.tiles_x * p.tiles_y * (p.Cout / BN);
     const int grid = total < n_cu ? total : n_cu;
-    if (p.out_f16) return launch_mode<ST_PS, true>(p, grid, stream);
     switch (p.mode) {
-    case ST_NHWC: return launch_mode<ST_NHWC, false>(p, grid, stream);
-    case ST_PS: return launch_mode<ST_PS, false>(p, grid, stream);
-    default: return launch_mode<ST_POOL, false>(p, grid, stream);
+    case ST_NHWC: return launch_mode<ST_NHWC>(p, grid, stream);
+    case ST_PS: return launch_mode<ST_PS>(p, grid, stream);
+    default: return launch_mode<ST_POOL>(p, grid, stream);
     }
 }

@@ -1,32 +1,14 @@
-// conv_i8_misc.hip -- the two small kernels beside conv3x3_pglds_i8.hip on the W8A8 HG path:
-//   * quant_i8: f16 tensor -> int8 codes of a consumer's activation quantiser (the one fp16 -> int8 boundary, conv2's
-//     output; W8A8Conv2d.forward, hdrtvnet_torch.py:351-356: round((x - x_zero) / x_scale).clamp(0, 255), stored - 128);
-//   * conv1x1_i8: the decoder's 1x1 fuse convolutions conv6 / conv7 / conv8 (Hallucination_arch.py:118-131) on
-//     v_mfma_i32_16x16x64_i8: K = the concatenation of two int8 tensors that share one quantiser, no activation, output
-//     re-quantised to the next layer's (signed-range) codes.  HBM-bound: 256 pixels x 128 output channels per block,
-//     128-channel K chunks staged by LDS-DMA into a 3-deep ring, one barrier per chunk.
+// conv_i8_misc.hip -- conv1x1_i8, the small kernel beside conv3x3_pglds_i8.hip on the W8A8 HG path: the decoder's 1x1
+// fuse convolutions conv6 .. conv9 (Hallucination_arch.py:118-133) on v_mfma_i32_16x16x64_i8.  K = the concatenation of
+// two int8 tensors that share one quantiser, no activation; the output is re-quantised to the next layer's (signed-range)
+// codes, or -- conv9, whose reader Up_conv5 is an fp16 layer -- written as f16 values.  HBM-bound: 256 pixels x 128
+// output channels per block, 128-channel K chunks staged by LDS-DMA into a 3-deep ring, one barrier per chunk.
+// (The fp16 -> int8 boundary at the other end is conv2's store mode ST_NHWC_Q8, conv3x3_pglds.hip.)
 #include "launchers.h"
 
 namespace {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-
-__global__ __launch_bounds__(256) void quant_i8_kernel(const f16 *__restrict__ src, int8_t *__restrict__ dst, size_t n8,
-                                                        float inv_scale, float zero_code)
-{
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
-        const f16x8 v = reinterpret_cast<const f16x8 *>(src)[i];
-        unsigned lo = 0, hi = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float q = fminf(fmaxf(__builtin_rintf((float)v[k] * inv_scale + zero_code), -128.f), 127.f);
-            const unsigned b = (unsigned)(int)q & 0xffu;
-            if (k < 4) lo |= b << (8 * k); else hi |= b << (8 * (k - 4));
-        }
-        reinterpret_cast<uint2 *>(dst)[i] = make_uint2(lo, hi);
-    }
-}
 
 constexpr int TP = 256, BN = 128, CT = 128;           // pixels x output channels per block, K chunk (bytes per row)
 constexpr int A_BYTES = TP * CT, B_BYTES = BN * CT;   // 32 KiB + 16 KiB per stage
@@ -40,6 +22,7 @@ __device__ __forceinline__ void glds16(const void *g, void *lds)
 }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+template <bool OUTF16>
 __global__ __launch_bounds__(512) void conv1x1_i8_kernel(ConvI8Params p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -85,6 +68,8 @@ __global__ __launch_bounds__(512) void conv1x1_i8_kernel(ConvI8Params p)
         for (int j = 0; j < 4; ++j) acc[i][j] = i32x4{0, 0, 0, 0};
     const int kw = l15 & 7;
     const int b_lane = (wc * 64 + l15) * CT, a_lane = (wp * 64 + l15) * CT;
+    // f16 output (conv9: 64 real channels in a 128-wide tile): waves whose 64 channels are padding only stage data
+    const bool live = !OUTF16 || n0 + wc * 64 < p.dstC;
 
     issue(0, 0);
     if (nchunk > 1) issue(1, 1);
@@ -93,6 +78,7 @@ __global__ __launch_bounds__(512) void conv1x1_i8_kernel(ConvI8Params p)
         __builtin_amdgcn_s_barrier();                 // chunk cc is in LDS for everyone; stage (cc+2)%3 is no longer read
         if (cc + 2 < nchunk) issue(cc + 2, (cc + 2) % NSTAGE);
         const char *a = smem + (cc % NSTAGE) * STAGE + a_lane, *b = smem + (cc % NSTAGE) * STAGE + A_BYTES + b_lane;
+        if (!live) continue;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             i32x4 wf[4], xf[4];
@@ -109,9 +95,38 @@ __global__ __launch_bounds__(512) void conv1x1_i8_kernel(ConvI8Params p)
     __syncthreads();                                   // LDS is free: wave-private strips for the 16-byte stores
 
     // lane: pixel wp*64 + j*16 + l15, channels wc*64 + i*16 + 4*kg + {0..3}
+    const int cw = n0 + wc * 64 + 4 * kg;
+    if constexpr (OUTF16) {
+        // real-valued f16 output for an fp16 consumer: no activation, no re-quantisation
+        if (!live) return;
+        constexpr int SPH = 144;
+        char *sth = smem + wave * (64 * SPH);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 sc = *reinterpret_cast<const float4 *>(p.scale + cw + i * 16);
+            const float4 sh = *reinterpret_cast<const float4 *>(p.shift + cw + i * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f16x4 o;
+                o[0] = (f16)((float)acc[i][j][0] * sc.x + sh.x);
+                o[1] = (f16)((float)acc[i][j][1] * sc.y + sh.y);
+                o[2] = (f16)((float)acc[i][j][2] * sc.z + sh.z);
+                o[3] = (f16)((float)acc[i][j][3] * sc.w + sh.w);
+                *reinterpret_cast<f16x4 *>(sth + (j * 16 + l15) * SPH + (i * 16 + 4 * kg) * 2) = o;
+            }
+        }
+        const int h_px = lane >> 3, h_chunk = lane & 7;
+        f16 *dsth = reinterpret_cast<f16 *>(p.dst);
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const f16x8 v = *reinterpret_cast<const f16x8 *>(sth + (rr * 8 + h_px) * SPH + h_chunk * 16);
+            const size_t px = px0 + wp * 64 + rr * 8 + h_px;
+            if (px < npx) *reinterpret_cast<f16x8 *>(dsth + px * p.dstC + n0 + wc * 64 + h_chunk * 8) = v;
+        }
+        return;
+    }
     constexpr int SP = 80;
     char *stg = smem + wave * 5120;
-    const int cw = n0 + wc * 64 + 4 * kg;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float4 sc = *reinterpret_cast<const float4 *>(p.scale + cw + i * 16);
@@ -139,30 +154,26 @@ __global__ __launch_bounds__(512) void conv1x1_i8_kernel(ConvI8Params p)
 
 }  // namespace
 
-hipError_t quant_i8_launch(const f16 *src, int8_t *dst, size_t n, float inv_scale, float zero_code, hipStream_t stream)
-{
-    if (n % 8) return hipErrorInvalidValue;
-    const size_t n8 = n / 8;
-    const int grid = (int)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096);
-    hipLaunchKernelGGL(quant_i8_kernel, dim3(grid ? grid : 1), dim3(256), 0, stream, src, dst, n8, inv_scale, zero_code);
-    return hipGetLastError();
-}
-
-// 1x1 on int8 codes, NHWC, src0 [+ src1] channels multiples of 128, Cout multiple of 128, dst int8 [Hi*Wi][dstC].
+// 1x1 on int8 codes, NHWC, src0 [+ src1] channels multiples of 128, Cout multiple of 128; dst int8 codes [Hi*Wi][dstC], or
+// (out_f16) real values as f16 with dstC = the real channel count (Cout - 64 or Cout: the tile's upper half may be padding).
 hipError_t conv1x1_i8_launch(ConvI8Params p, hipStream_t stream)
 {
-    if ((p.c0 % CT) || (p.c1 % CT) || p.c0 + p.c1 < CT || (p.Cout % BN) || !p.padline || p.out_f16 || p.mode != ST_NHWC ||
-        p.dstC < p.Cout)
+    if ((p.c0 % CT) || (p.c1 % CT) || p.c0 + p.c1 < CT || (p.Cout % BN) || !p.padline || p.mode != ST_NHWC ||
+        (!p.out_f16 && p.dstC < p.Cout) || (p.out_f16 && (p.dstC % 64 || p.dstC > p.Cout || p.dstC + 64 < p.Cout)))
         return hipErrorInvalidValue;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_i8_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_i8_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_i8_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const size_t npx = (size_t)p.Hi * p.Wi;
     const int grid = (int)((npx + TP - 1) / TP) * (p.Cout / BN);
-    hipLaunchKernelGGL(conv1x1_i8_kernel, dim3(grid), dim3(512), SMEM, stream, p);
+    if (p.out_f16) hipLaunchKernelGGL(conv1x1_i8_kernel<true>, dim3(grid), dim3(512), SMEM, stream, p);
+    else hipLaunchKernelGGL(conv1x1_i8_kernel<false>, dim3(grid), dim3(512), SMEM, stream, p);
     return hipGetLastError();
 }

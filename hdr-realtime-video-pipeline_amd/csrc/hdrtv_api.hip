@@ -113,7 +113,7 @@ struct ConvLayer {
 };
 struct ConvI8Layer {                        // W8A8 HG layer on int8 MFMA
     size_t wpk = 0, scale = 0, shift = 0, padline = 0;
-    int cin = 0, cout = 0, ks = 0, out_f16 = 0;
+    int cin = 0, cout = 0, cout_real = 0, ks = 0, out_f16 = 0;   // cout: padded to a multiple of 128
 };
 struct C3Layer { size_t wfrag = 0, scale = 0, shift = 0; int cout = 0; };
 struct SftLayer { size_t wfrag = 0, bias = 0; };
@@ -290,7 +290,8 @@ bool pack_conv_i8(hdrtv_ctx *c, const Pack &pk, const std::string &key, const st
     if (!pk.get_i8(wname + ".weight_int8", (size_t)co * ci * ks * ks, w, c->err) || !pk.get(wname + ".w_scale", co, ws, c->err) ||
         !pk.get(wname + ".bias", co, b, c->err) || !read_actq(c, pk, wname, in))
         return false;
-    if (ci % 128 || co % 128) { c->err = "unsupported W8A8 conv shape: " + wname; return false; }
+    const int coP = (co + 127) / 128 * 128;          // conv9: 64 real output channels in a 128-wide tile
+    if (ci % 128 || (co % 128 && (ks != 1 || out.scale > 0.f))) { c->err = "unsupported W8A8 conv shape: " + wname; return false; }
     std::vector<float> g, be, mu, var;
     const bool has_bn = !bn_name.empty();
     if (has_bn) {
@@ -299,8 +300,8 @@ bool pack_conv_i8(hdrtv_ctx *c, const Pack &pk, const std::string &key, const st
             return false;
     }
     const int nch = ci / 128, taps = ks * ks;
-    std::vector<int8_t> wp((size_t)taps * nch * co * 128);
-    std::vector<float> scale(co), shift(co);
+    std::vector<int8_t> wp((size_t)taps * nch * coP * 128, (int8_t)0);
+    std::vector<float> scale(coP, 0.f), shift(coP, 0.f);
     for (int np = 0; np < co; ++np) {
         const int n = ps_cps > 0 ? 4 * (np % ps_cps) + np / ps_cps : np;
         long wsum = 0;
@@ -308,7 +309,7 @@ bool pack_conv_i8(hdrtv_ctx *c, const Pack &pk, const std::string &key, const st
             for (int tap = 0; tap < taps; ++tap) {
                 const int8_t v = w[((size_t)n * ci + k) * taps + tap];
                 wsum += v;
-                wp[(((size_t)tap * nch + k / 128) * co + np) * 128 + k % 128] = v;
+                wp[(((size_t)tap * nch + k / 128) * coP + np) * 128 + k % 128] = v;
             }
         const double a = (double)in.scale * (double)ws[n];
         double sc = a, sh = a * (double)(128 - in.k) * (double)wsum + (double)b[n];
@@ -326,7 +327,7 @@ bool pack_conv_i8(hdrtv_ctx *c, const Pack &pk, const std::string &key, const st
     }
     std::vector<int8_t> pad(128, (int8_t)(in.k - 128));
     ConvI8Layer L;
-    L.cin = ci; L.cout = co; L.ks = ks; L.out_f16 = out.scale > 0.f ? 0 : 1;
+    L.cin = ci; L.cout = coP; L.cout_real = co; L.ks = ks; L.out_f16 = out.scale > 0.f ? 0 : 1;
     L.wpk = c->wts.put(wp.data(), wp.size());
     L.scale = c->wts.put(scale.data(), scale.size() * 4);
     L.shift = c->wts.put(shift.data(), shift.size() * 4);
@@ -549,12 +550,11 @@ bool build_weights(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
             for (const Spec &s : fuses)
                 if (!pack_conv(c, *hg, std::string("hg.") + s.name, s.name, s.co, s.ci, 1, 1, "", 0)) return false;
         } else {
-            // W8A8 checkpoint (weights.HG_W8A8_GROUPS): conv3_1 .. Up_conv4 and the fuse convs conv6..8 on int8 MFMA; conv1,
-            // conv2, conv9, Up_conv5, conv10, conv_last stay fp16.  A layer's epilogue writes the codes of the layer that
+            // W8A8 checkpoint (weights.HG_W8A8_GROUPS): conv3_1 .. Up_conv4 and the fuse convs conv6..9 on int8 MFMA; conv1,
+            // conv2, Up_conv5, conv10, conv_last stay fp16 (conv2 writes int8 codes, conv9 f16 values).  A layer's epilogue writes the codes of the layer that
             // reads its output; tensors read by two layers (encoder skip) or concatenated must share one quantiser.
             if (!pack_conv(c, *hg, "hg.conv2", "conv2.0", 128, 64, 3, 1, "conv2.1", 0) ||
-                !pack_conv(c, *hg, "hg.Up_conv5", "Up_conv5.0", 256, 64, 3, 1, "", 64) ||
-                !pack_conv(c, *hg, "hg.conv9", "conv9", 64, 256, 1, 1, "", 0))
+                !pack_conv(c, *hg, "hg.Up_conv5", "Up_conv5.0", 256, 64, 3, 1, "", 64))
                 return false;
             struct Q8 { const char *name; int co, ci, ks, ps; const char *bn; const char *consumer; const char *shares; };
             const Q8 q8[] = {
@@ -566,7 +566,7 @@ bool build_weights(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
                 {"Up_conv1", 2048, 512, 3, 512, "", "conv6", nullptr}, {"conv6", 512, 1024, 1, 0, "", "Up_conv2.0", nullptr},
                 {"Up_conv2", 2048, 512, 3, 512, "", "conv7", nullptr}, {"conv7", 256, 1024, 1, 0, "", "Up_conv3.0", nullptr},
                 {"Up_conv3", 1024, 256, 3, 256, "", "conv8", nullptr}, {"conv8", 128, 512, 1, 0, "", "Up_conv4.0", nullptr},
-                {"Up_conv4", 512, 128, 3, 128, "", nullptr, nullptr}};
+                {"Up_conv4", 512, 128, 3, 128, "", "conv9", "conv3_1.0"}, {"conv9", 64, 256, 1, 0, "", nullptr, nullptr}};
             for (const Q8 &L : q8) {
                 ActQ out;
                 if (L.consumer && !read_actq(c, *hg, L.consumer, out)) return false;
@@ -747,8 +747,8 @@ int do_reserve(hdrtv_ctx *c, int H, int W)
         const int Hp = s.Hp, Wp = s.Wp;
         ws_add(c, "hg.img", 3, Hp, Wp, 1); ws_add(c, "hg.mask", 1, Hp, Wp, 4);
         ws_add(c, "hg.p1", 64, Hp / 2, Wp / 2, 0); ws_add(c, "hg.part", 4, Hp, Wp, 3);
-        ws_add(c, "hg.conv2", 128, Hp / 2, Wp / 2, 0);
         if (!c->hg_i8) {
+            ws_add(c, "hg.conv2", 128, Hp / 2, Wp / 2, 0); ws_add(c, "hg.up4", 128, Hp / 2, Wp / 2, 0);
             ws_add(c, "hg.p3", 256, Hp / 4, Wp / 4, 0); ws_add(c, "hg.conv3_2", 256, Hp / 4, Wp / 4, 0);
             ws_add(c, "hg.p4", 512, Hp / 8, Wp / 8, 0); ws_add(c, "hg.conv4_2", 512, Hp / 8, Wp / 8, 0);
             ws_add(c, "hg.p5", 512, Hp / 16, Wp / 16, 0); ws_add(c, "hg.conv5_2", 512, Hp / 16, Wp / 16, 0);
@@ -757,7 +757,7 @@ int do_reserve(hdrtv_ctx *c, int H, int W)
             ws_add(c, "hg.up2", 512, Hp / 8, Wp / 8, 0); ws_add(c, "hg.conv7", 256, Hp / 8, Wp / 8, 0);
             ws_add(c, "hg.up3", 256, Hp / 4, Wp / 4, 0); ws_add(c, "hg.conv8", 128, Hp / 4, Wp / 4, 0);
         } else {            // W8A8: the same tensors as int8 codes (q - 128), each once
-            ws_add(c, "hg8.conv2", 128, Hp / 2, Wp / 2, 5);
+            ws_add(c, "hg8.conv2", 128, Hp / 2, Wp / 2, 5); ws_add(c, "hg8.up4", 128, Hp / 2, Wp / 2, 5);
             ws_add(c, "hg8.p3", 256, Hp / 4, Wp / 4, 5); ws_add(c, "hg8.conv3_2", 256, Hp / 4, Wp / 4, 5);
             ws_add(c, "hg8.p4", 512, Hp / 8, Wp / 8, 5); ws_add(c, "hg8.conv4_2", 512, Hp / 8, Wp / 8, 5);
             ws_add(c, "hg8.p5", 512, Hp / 16, Wp / 16, 5); ws_add(c, "hg8.conv5_2", 512, Hp / 16, Wp / 16, 5);
@@ -766,7 +766,7 @@ int do_reserve(hdrtv_ctx *c, int H, int W)
             ws_add(c, "hg8.up2", 512, Hp / 8, Wp / 8, 5); ws_add(c, "hg8.conv7", 256, Hp / 8, Wp / 8, 5);
             ws_add(c, "hg8.up3", 256, Hp / 4, Wp / 4, 5); ws_add(c, "hg8.conv8", 128, Hp / 4, Wp / 4, 5);
         }
-        ws_add(c, "hg.up4", 128, Hp / 2, Wp / 2, 0); ws_add(c, "hg.conv9", 64, Hp / 2, Wp / 2, 0);
+        ws_add(c, "hg.conv9", 64, Hp / 2, Wp / 2, 0);
     }
     if (hipMalloc((void **)&c->ws.dev, c->ws.size + 4096) != hipSuccess) {
         c->ws.dev = nullptr;
@@ -835,16 +835,18 @@ struct Seq {
         p.dst = dst; p.dst_full = dst_full; p.dstC = dstC; p.Hd = Hd; p.Wd = Wd;
         p.res1 = res1; p.res2 = res2; p.dst_planar = dst_planar; p.res_planar = res_planar;
         p.dotw = dotw; p.dst_dot = dst_dot;
+        p.q_inv = c->hg_q0_inv; p.q_zero = c->hg_q0_zero;
         if (c0 + c1 != L.cin) { rc = fail(c, HDRTV_ESTATE, "conv %s: channel mismatch", key.c_str()); return; }
         p.zeros = wtp<f16>(c, c->zeros_off);
         const bool g64 = L.stride == 1 && L.cin_t == 64 && L.bn == 128 && !res1 && !res2 && !dst_full && mode != ST_PLANAR3;
         const bool pglds = g64 && L.ks == 3 && L.cout == L.coutPad;      // HG 3x3 convs: persistent LDS-DMA kernel
         const bool glds1 = g64 && L.ks == 1 && mode == ST_NHWC;          // HG 1x1 fuse convs
+        if (mode == ST_NHWC_Q8 && !pglds) { rc = fail(c, HDRTV_ESTATE, "conv %s: int8-code store needs the pglds kernel", key.c_str()); return; }
         p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
         const bool s2g = L.ks == 3 && L.stride == 2 && L.cin_t == 64 && L.bn == L.coutPad && (L.coutPad == 64 || L.coutPad == 192);
         char tag[64];
         if (s2g) snprintf(tag, sizeof tag, "conv3x3s2_preg<%d>", L.coutPad);
-        else if (pglds) snprintf(tag, sizeof tag, "conv_pglds<%s>", mode == ST_POOL ? "pool" : (mode == ST_PS ? "ps" : (mode == ST_PS_DOT3 ? "ps_dot3" : "nhwc")));
+        else if (pglds) snprintf(tag, sizeof tag, "conv_pglds<%s>", mode == ST_POOL ? "pool" : (mode == ST_PS ? "ps" : (mode == ST_PS_DOT3 ? "ps_dot3" : (mode == ST_NHWC_Q8 ? "nhwc_q8" : "nhwc"))));
         else if (glds1) snprintf(tag, sizeof tag, "conv_glds1");
         else snprintf(tag, sizeof tag, "conv_igemm<%d,%d,%d,%d>", L.cin_t, L.bn, L.ks, L.stride);
         const double macs = (double)p.Ho * p.Wo * L.cin * L.ks * L.ks * L.cout;
@@ -876,16 +878,11 @@ struct Seq {
         p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
         char tag[64];
         if (L.ks == 3) snprintf(tag, sizeof tag, "conv_pglds_i8<%s%s>", mode == ST_POOL ? "pool" : (mode == ST_PS ? "ps" : "nhwc"), L.out_f16 ? ",f16" : "");
-        else snprintf(tag, sizeof tag, "conv1x1_i8");
-        const double macs = (double)Hi * Wi * L.cin * L.ks * L.ks * L.cout;
-        const double outel = mode == ST_POOL ? (double)Hd * Wd * L.cout : (double)Hi * Wi * L.cout;
+        else snprintf(tag, sizeof tag, "conv1x1_i8%s", L.out_f16 ? "<f16>" : "");
+        const double macs = (double)Hi * Wi * L.cin * L.ks * L.ks * L.cout_real;
+        const double outel = mode == ST_POOL ? (double)Hd * Wd * L.cout_real : (double)Hi * Wi * L.cout_real;
         const double bytes = (double)Hi * Wi * L.cin + (double)L.ks * L.ks * L.cin * L.cout + outel * (L.out_f16 ? 2.0 : 1.0);
         chk(L.ks == 3 ? conv_pglds_i8_launch(p, c->n_cu, s) : conv1x1_i8_launch(p, s), key.c_str(), tag, macs, bytes);
-    }
-    void quant8(const char *what, const f16 *src, int8_t *dst, size_t n, float inv_scale, float zero_code)
-    {
-        if (!ok()) return;
-        chk(quant_i8_launch(src, dst, n, inv_scale, zero_code, s), what, "quant_i8", 0.0, 3.0 * (double)n);
     }
     void c3(const std::string &key, const f16 *in, int H, int W, int act, f16 *out, f16 *out_pool)
     {
@@ -1049,18 +1046,19 @@ int run_hg(hdrtv_ctx *c, Seq &q, const f16 *base, void *out, int out_f32)
     f16 *img = wsp<f16>(c, "hg.img");
     uint8_t *mask = wsp<uint8_t>(c, "hg.mask");
     q.chk(hg_prep_launch(base, s.H, s.W, Hp, Wp, img, mask, 0.75f, 0.1f, q.s), "hg_prep", "hg_prep", 0.0, 13.0 * Hp * Wp);
-    f16 *p1 = wsp<f16>(c, "hg.p1"), *c2 = wsp<f16>(c, "hg.conv2"), *u4 = wsp<f16>(c, "hg.up4"), *c9 = wsp<f16>(c, "hg.conv9");
+    f16 *p1 = wsp<f16>(c, "hg.p1"), *c9 = wsp<f16>(c, "hg.conv9");
     float *part = wsp<float>(c, "hg.part");
     q.c3("hg.conv1", img, Hp, Wp, ACT_RELU, nullptr, p1);      // only the pooled map is kept; conv1_out is recomputed in hg_final_fused
-    q.conv("hg.conv2", p1, 64, nullptr, 0, Hp / 2, Wp / 2, ACT_RELU, ST_NHWC, c2, 128, Hp / 2, Wp / 2);
     if (c->hg_i8) {
-        // W8A8 checkpoint: conv3_1 .. Up_conv4 on int8 MFMA, every activation between them one int8 tensor
+        // W8A8 checkpoint: conv3_1 .. conv9 on int8 MFMA, every activation between conv2 and conv9 one int8 tensor
         int8_t *c2q = wsp<int8_t>(c, "hg8.conv2"), *p3 = wsp<int8_t>(c, "hg8.p3"), *c3 = wsp<int8_t>(c, "hg8.conv3_2"),
                *p4 = wsp<int8_t>(c, "hg8.p4"), *c4 = wsp<int8_t>(c, "hg8.conv4_2"), *p5 = wsp<int8_t>(c, "hg8.p5"),
                *c5 = wsp<int8_t>(c, "hg8.conv5_2"), *pc = wsp<int8_t>(c, "hg8.pc"), *code = wsp<int8_t>(c, "hg8.conv_code2"),
                *u1 = wsp<int8_t>(c, "hg8.up1"), *c6 = wsp<int8_t>(c, "hg8.conv6"), *u2 = wsp<int8_t>(c, "hg8.up2"),
-               *c7 = wsp<int8_t>(c, "hg8.conv7"), *u3 = wsp<int8_t>(c, "hg8.up3"), *c8 = wsp<int8_t>(c, "hg8.conv8");
-        q.quant8("hg.quant(conv2)", c2, c2q, (size_t)128 * (Hp / 2) * (Wp / 2), c->hg_q0_inv, c->hg_q0_zero);
+               *c7 = wsp<int8_t>(c, "hg8.conv7"), *u3 = wsp<int8_t>(c, "hg8.up3"), *c8 = wsp<int8_t>(c, "hg8.conv8"),
+               *u4q = wsp<int8_t>(c, "hg8.up4");
+        // conv2 (fp16 MFMA) writes the codes its reader conv3_1 wants: the fp16 -> int8 boundary costs no pass of its own
+        q.conv("hg.conv2", p1, 64, nullptr, 0, Hp / 2, Wp / 2, ACT_RELU, ST_NHWC_Q8, reinterpret_cast<f16 *>(c2q), 128, Hp / 2, Wp / 2);
         q.conv8("hg.conv3_1", c2q, 128, nullptr, 0, Hp / 2, Wp / 2, ST_POOL, p3, 256, Hp / 4, Wp / 4);
         q.conv8("hg.conv3_2", p3, 256, nullptr, 0, Hp / 4, Wp / 4, ST_NHWC, c3, 256, Hp / 4, Wp / 4);
         q.conv8("hg.conv4_1", c3, 256, nullptr, 0, Hp / 4, Wp / 4, ST_POOL, p4, 512, Hp / 8, Wp / 8);
@@ -1075,8 +1073,11 @@ int run_hg(hdrtv_ctx *c, Seq &q, const f16 *base, void *out, int out_f32)
         q.conv8("hg.conv7", u2, 512, c4, 512, Hp / 8, Wp / 8, ST_NHWC, c7, 256, Hp / 8, Wp / 8);
         q.conv8("hg.Up_conv3", c7, 256, nullptr, 0, Hp / 8, Wp / 8, ST_PS, u3, 256, Hp / 4, Wp / 4);
         q.conv8("hg.conv8", u3, 256, c3, 256, Hp / 4, Wp / 4, ST_NHWC, c8, 128, Hp / 4, Wp / 4);
-        q.conv8("hg.Up_conv4", c8, 128, nullptr, 0, Hp / 4, Wp / 4, ST_PS, u4, 128, Hp / 2, Wp / 2);     // -> f16
+        q.conv8("hg.Up_conv4", c8, 128, nullptr, 0, Hp / 4, Wp / 4, ST_PS, u4q, 128, Hp / 2, Wp / 2);
+        q.conv8("hg.conv9", u4q, 128, c2q, 128, Hp / 2, Wp / 2, ST_NHWC, c9, 64, Hp / 2, Wp / 2);           // -> f16 values
     } else {
+        f16 *c2 = wsp<f16>(c, "hg.conv2"), *u4 = wsp<f16>(c, "hg.up4");
+        q.conv("hg.conv2", p1, 64, nullptr, 0, Hp / 2, Wp / 2, ACT_RELU, ST_NHWC, c2, 128, Hp / 2, Wp / 2);
         f16 *p3 = wsp<f16>(c, "hg.p3"), *c3 = wsp<f16>(c, "hg.conv3_2"), *p4 = wsp<f16>(c, "hg.p4"), *c4 = wsp<f16>(c, "hg.conv4_2"),
             *p5 = wsp<f16>(c, "hg.p5"), *c5 = wsp<f16>(c, "hg.conv5_2"), *pc = wsp<f16>(c, "hg.pc"), *code = wsp<f16>(c, "hg.conv_code2");
         f16 *u1 = wsp<f16>(c, "hg.up1"), *c6 = wsp<f16>(c, "hg.conv6"), *u2 = wsp<f16>(c, "hg.up2"), *c7 = wsp<f16>(c, "hg.conv7"),
@@ -1096,8 +1097,8 @@ int run_hg(hdrtv_ctx *c, Seq &q, const f16 *base, void *out, int out_f32)
         q.conv("hg.Up_conv3", c7, 256, nullptr, 0, Hp / 8, Wp / 8, ACT_RELU, ST_PS, u3, 256, Hp / 4, Wp / 4);
         q.conv("hg.conv8", u3, 256, c3, 256, Hp / 4, Wp / 4, ACT_NONE, ST_NHWC, c8, 128, Hp / 4, Wp / 4);
         q.conv("hg.Up_conv4", c8, 128, nullptr, 0, Hp / 4, Wp / 4, ACT_RELU, ST_PS, u4, 128, Hp / 2, Wp / 2);
+        q.conv("hg.conv9", u4, 128, c2, 128, Hp / 2, Wp / 2, ACT_NONE, ST_NHWC, c9, 64, Hp / 2, Wp / 2);
     }
-    q.conv("hg.conv9", u4, 128, c2, 128, Hp / 2, Wp / 2, ACT_NONE, ST_NHWC, c9, 64, Hp / 2, Wp / 2);
     // Up_conv5 -> pixel shuffle -> ReLU -> first half of conv10, fused: 3 partial sums per pixel leave the kernel
     q.conv("hg.Up_conv5", c9, 64, nullptr, 0, Hp / 2, Wp / 2, ACT_RELU, ST_PS_DOT3, nullptr, 64, Hp, Wp, nullptr, nullptr, nullptr,
            nullptr, nullptr, wtp<float>(c, c->hg_w10a), part);

@@ -7,7 +7,6 @@ hipError_t conv_glds1_launch(ConvParams p, hipStream_t stream);
 hipError_t conv_pglds_launch(ConvParams p, int n_cu, hipStream_t stream);
 hipError_t conv_pglds_i8_launch(ConvI8Params p, int n_cu, hipStream_t stream);
 hipError_t conv1x1_i8_launch(ConvI8Params p, hipStream_t stream);
-hipError_t quant_i8_launch(const f16 *src, int8_t *dst, size_t n, float inv_scale, float zero_code, hipStream_t stream);
 hipError_t conv32p_launch(Conv32Params p, int n_cu, hipStream_t stream);
 hipError_t conv3x3s2_preg_launch(ConvParams p, int n_cu, hipStream_t stream);
 

@@ -84,11 +84,11 @@ LAYERS = (("conv3_1", ("hg8.conv2",), "hg8.p3", "pool"), ("conv3_2", ("hg8.p3",)
           ("Up_conv1", ("hg8.conv_code2",), "hg8.up1", "up"), ("conv6", ("hg8.up1", "hg8.conv5_2"), "hg8.conv6", "fuse"),
           ("Up_conv2", ("hg8.conv6",), "hg8.up2", "up"), ("conv7", ("hg8.up2", "hg8.conv4_2"), "hg8.conv7", "fuse"),
           ("Up_conv3", ("hg8.conv7",), "hg8.up3", "up"), ("conv8", ("hg8.up3", "hg8.conv3_2"), "hg8.conv8", "fuse"),
-          ("Up_conv4", ("hg8.conv8",), "hg.up4", "up"))
+          ("Up_conv4", ("hg8.conv8",), "hg8.up4", "up"), ("conv9", ("hg8.up4", "hg8.conv2"), "hg.conv9", "fuse"))
 READER = {"hg8.p3": "conv3_2.0", "hg8.conv3_2": "conv4_1.0", "hg8.p4": "conv4_2.0", "hg8.conv4_2": "conv5_1.0",
           "hg8.p5": "conv5_2.0", "hg8.conv5_2": "conv_code1.0", "hg8.pc": "conv_code2.0", "hg8.conv_code2": "Up_conv1.0",
           "hg8.up1": "conv6", "hg8.conv6": "Up_conv2.0", "hg8.up2": "conv7", "hg8.conv7": "Up_conv3.0", "hg8.up3": "conv8",
-          "hg8.conv8": "Up_conv4.0", "hg8.conv2": "conv3_1.0"}
+          "hg8.conv8": "Up_conv4.0", "hg8.conv2": "conv3_1.0", "hg8.up4": "conv9"}
 
 
 @pytest.mark.parametrize("hw,seed", [((96, 128), 3), ((272, 480), 11)])
