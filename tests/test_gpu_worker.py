@@ -88,3 +88,21 @@ def test_realtime_playback_into_rgb48le_sink(golden_dir, tmp_path):
     assert got and got[-1]["precision"] == "FP16" and got[-1]["proc_res"] == "96x64" and got[-1]["model_latency_ms"] > 0
     w.close()
     torch.cuda.synchronize()
+
+
+def test_worker_with_w8a8_hg(golden_dir, tmp_path):
+    """The drop-in worker with a W8A8 HG checkpoint (int8 MFMA path) and the INT8-QAT HR checkpoint: configs[4] through
+    the reference's _load_model / _process_frame surface."""
+    from hdrtv_mi355x import weights as W
+    from hdrtv_mi355x.worker import HeadlessPipelineWorker
+    wdir = tmp_path / "weights" / "original"
+    wdir.mkdir(parents=True)
+    os.symlink(os.path.join(golden_dir, "hr_weights.hdrw"), wdir / "HR.hdrw")
+    w = HeadlessPipelineWorker(str(tmp_path / "weights"), use_hg=True, proc_w=128, proc_h=96, hg_weights="seeded-w8a8:1234")
+    assert w._load_model("FP16") is True
+    assert w._processor._hg_int8
+    d = np.load(os.path.join(golden_dir, "hg_w8a8_96x128_gradient_s3.npz"))
+    _, out, prepared, need_cpu, ms = w._process_frame(frame=d["frame"], frame_idx=0, mpv_w=None)
+    assert need_cpu and ms > 0
+    assert np.abs(out.astype(int) - d["u8_bgr"].astype(int)).mean() <= 0.2      # the reference's own W8A8 run
+    w.close()
