@@ -223,22 +223,34 @@ def main():
         # --pmc passes of this same command (tools/pmc_pass.sh, tools/pmc_to_json.py) and committed
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))["kernels"]
+            pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic_int8.json" if args.int8 else "pmc_traffic.json")))["kernels"]
             # profile tag -> kernel name in the rocprofv3 counter CSV (template argument = store mode, common.h)
             key = {"conv_pglds<nhwc>": "conv_pglds_kernel<0>", "conv_pglds<ps>": "conv_pglds_kernel<1>",
                    "conv_pglds<pool>": "conv_pglds_kernel<2>", "conv_pglds<ps_dot3>": "conv_pglds_kernel<4>",
-                   "conv_glds1": "conv_glds1_kernel"}.get(kern, kern)
+                   "conv_pglds<nhwc_q8>": "conv_pglds_kernel<5>", "conv_glds1": "conv_glds1_kernel",
+                   "conv_pglds_i8<nhwc>": "conv_pglds_i8_kernel<0>", "conv_pglds_i8<ps>": "conv_pglds_i8_kernel<1>",
+                   "conv_pglds_i8<pool>": "conv_pglds_i8_kernel<2>", "conv1x1_i8": "conv1x1_i8_kernel<false>",
+                   "conv1x1_i8<f16>": "conv1x1_i8_kernel<true>", "conv32p<1,sft>": "conv32p_kernel<1, true, 8>",
+                   "conv32p<4,plain>": "conv32p_kernel<4, false, 8>", "conv32p<1,plain>": "conv32p_kernel<1, false, 4>",
+                   "conv3x3s2_preg<192>": "conv3x3s2_preg_kernel<12>", "conv3x3s2_preg<64>": "conv3x3s2_preg_kernel<4>"}.get(kern, kern)
             if (H, Wd) == (2160, 3840) and use_hg and key in pmc:
                 traffic = pmc[key]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             traffic = None
         peak = MFMA_F16_DENSE_PEAK_TFLOPS * (2.0 if "_i8" in kern else 1.0)       # int8 MFMA: twice the K per instruction
-        roof = {"kernel": kern, "bound": "mfma", "achieved": round(tflops, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(tflops / peak, 4), "traffic": traffic,
+        # which roof bounds this kernel: its algorithmic intensity against the machine balance (peak FLOP/s / 8 TB/s)
+        if 2.0 * macs / max(nbytes, 1.0) >= peak * 1e12 / (HBM_PEAK_GBS * 1e9):
+            roof = {"kernel": kern, "bound": "mfma", "achieved": round(tflops, 2), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(tflops / peak, 4), "traffic": traffic}
+        else:
+            gbs = nbytes / n / (avg_ms * 1e-3) / 1e9
+            roof = {"kernel": kern, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic}
+        roof.update({
                 "algorithmic_bytes_per_launch": round(nbytes / n),
                 "launches_per_frame": n // nprof, "avg_launch_ms": round(avg_ms, 4),
                 "flop_per_launch": 2.0 * macs / n, "share_of_infer_time": round(ms / nprof / infer_ms, 3),
-                "infer_ms_profiled": round(infer_ms, 3)}
+                "infer_ms_profiled": round(infer_ms, 3)})
         if args.layers:
             for kname, (kms, kmacs, kb, kn) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
                 print(f"[kernel] {kname:28s} n/frame={kn // nprof:3d} ms/frame={kms / nprof:8.3f} "
