@@ -371,9 +371,10 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
                     if (ooff[pass][it] >= 0) {
                         const int qq = (tid + it * NT) >> 2;
                         f16x8 v = *reinterpret_cast<const f16x8 *>(sO + qq * OUT_ROWB + c8 * 16);
-                        const f16x8 r1 = rs1[pass][it], r2 = rs2[pass][it];
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) v[k] = (f16)(((float)v[k] + (float)r1[k]) + (float)r2[k]);
+                        // residual adds in packed f16, one rounding per add as the reference's fp16 model does
+                        // (x + conv2(..) then + skip, arch_util.py:95, HDRUNet3T1_arch.py:186-198); 6 VALU per 8
+                        // values instead of ~40 through fp32 -- this kernel is instruction-issue-bound
+                        v = (v + rs1[pass][it]) + rs2[pass][it];
                         *reinterpret_cast<f16x8 *>(p.dst + ooff[pass][it]) = v;
                     }
                 }
