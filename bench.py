@@ -283,6 +283,7 @@ def main():
         print(json.dumps(line), flush=True)
     proc.close()
     if world > 1:
+        dist.barrier()                     # rank 0 is still profiling while the others are done: leave together
         dist.destroy_process_group()
 
 
