@@ -15,7 +15,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // Epilogue activation codes
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU01 = 2 };
 // Conv store modes
-enum { ST_NHWC = 0, ST_PS = 1, ST_POOL = 2, ST_PLANAR3 = 3, ST_PS_DOT3 = 4, ST_NHWC_Q8 = 5 };   // Q8: int8 codes of a W8A8 consumer
+enum { ST_NHWC = 0, ST_PS = 1, ST_POOL = 2, ST_PLANAR3 = 3, ST_PS_DOT3 = 4 };
 
 __device__ __forceinline__ float act_apply(float v, int act)
 {
@@ -66,7 +66,6 @@ struct ConvParams {
     const float *dotw;     // ST_PS_DOT3: [3][dstC] weights of the 1x1 conv fused behind the pixel shuffle
     float *dst_dot;        // ST_PS_DOT3: f32 [Hd][Wd][4] partial sums (x,y,z used)
     void *trash;           // conv_pglds: >= 2 KiB scratch that out-of-image lanes store to (never read)
-    float q_inv, q_zero;   // ST_NHWC_Q8: dst holds int8 codes clamp(rint(f16(y) * q_inv + q_zero), -128, 127), dstC bytes per pixel
 };
 
 // Parameter block of the int8 HG convolutions (conv3x3_pglds_i8.hip, conv_i8_misc.hip).  Activations are int8 codes

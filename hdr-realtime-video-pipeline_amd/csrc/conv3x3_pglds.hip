@@ -30,7 +30,7 @@ constexpr int DOTW_OFF = SS_OFF + 2048;                  // ST_PS_DOT3: 3 x 64 f
 constexpr int SMEM = DOTW_OFF + 1024;                    // 147 KiB
 
 // stores per wave and tile, by store mode (see the epilogues)
-template <int MODE> struct NStores { static constexpr int N = MODE == ST_POOL ? 2 : (MODE == ST_PS_DOT3 ? 1 : (MODE == ST_NHWC_Q8 ? 4 : 8)); };
+template <int MODE> struct NStores { static constexpr int N = MODE == ST_POOL ? 2 : (MODE == ST_PS_DOT3 ? 1 : 8); };
 
 __device__ __forceinline__ void glds16(const void *g, void *lds)
 {
@@ -274,34 +274,6 @@ __global__ __launch_bounds__(512) void conv_pglds_kernel(ConvParams p)
                     *reinterpret_cast<f16x8 *>(d) = v;
                 }
             }
-        } else if constexpr (MODE == ST_NHWC_Q8) {
-            // the fp16 -> int8 boundary in front of a W8A8 layer (W8A8Conv2d.forward, hdrtvnet_torch.py:351-356): the codes
-            // q - 128 of the f16-rounded outputs; 64 bytes per pixel and wave, 4 lanes x 16 B cover it
-            constexpr int SQ = 80;
-            char *stq = sA + ((gch - 1) & 1) * A_BYTES + wave * (64 * SQ);
-            const float qi = p.q_inv, qz = p.q_zero;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    unsigned pk = 0;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float q = fminf(fmaxf(__builtin_rintf((float)o[i][j][r] * qi + qz), -128.f), 127.f);
-                        pk |= ((unsigned)(int)q & 0xffu) << (8 * r);
-                    }
-                    *reinterpret_cast<unsigned *>(stq + (j * 16 + l15) * SQ + i * 16 + 4 * kg) = pk;
-                }
-            const int q_px = lane >> 2, q_chunk = lane & 3;
-            int8_t *dst8 = reinterpret_cast<int8_t *>(p.dst);
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(stq + (rr * 16 + q_px) * SQ + q_chunk * 16);
-                const int oy = cur.oy0 + wp * 4 + rr, oxx = cur.ox0 + q_px;
-                const bool ok = oy < p.Ho && oxx < p.Wo;
-                int8_t *d = ok ? dst8 + ((size_t)oy * p.Wo + oxx) * p.dstC + cur.n0 + wc * 64 + q_chunk * 16 : reinterpret_cast<int8_t *>(trash);
-                *reinterpret_cast<uint4 *>(d) = v;
-            }
         } else if constexpr (MODE == ST_POOL) {
             // 2x2 max: rows j, j+1 are in this lane; columns 2c, 2c+1 meet in the strip
 #pragma unroll
@@ -384,12 +356,12 @@ hipError_t launch_mode(const ConvParams &p, int grid, hipStream_t stream)
 }  // namespace
 
 // 3x3, stride 1, pad 1, Cin (src0 [+ src1 concat]) multiple of 64, Cout == CoutPad multiple of 128, no residuals;
-// store modes NHWC / PS / POOL / PS_DOT3 / NHWC_Q8.  One block per CU (n_cu), each walking tiles.  hipErrorInvalidValue otherwise.
+// store modes NHWC / PS / POOL / PS_DOT3.  One block per CU (n_cu), each walking tiles.  hipErrorInvalidValue otherwise.
 hipError_t conv_pglds_launch(ConvParams p, int n_cu, hipStream_t stream)
 {
     if ((p.c0 % CT) || (p.c1 % CT) || p.c0 + p.c1 < CT || (p.CoutPad % BN) || p.Cout != p.CoutPad || p.res1 || p.res2 ||
         p.dst_full || !p.zeros || !p.trash || n_cu < 8 ||
-        (p.mode != ST_NHWC && p.mode != ST_PS && p.mode != ST_POOL && p.mode != ST_PS_DOT3 && p.mode != ST_NHWC_Q8) ||
+        (p.mode != ST_NHWC && p.mode != ST_PS && p.mode != ST_POOL && p.mode != ST_PS_DOT3) ||
         (p.mode == ST_PS && (p.dstC % 64)) || (p.mode == ST_PS_DOT3 && (p.dstC != 64 || !p.dotw || !p.dst_dot)))
         return hipErrorInvalidValue;
     p.tiles_x = (p.Wo + TW - 1) / TW;
@@ -400,7 +372,6 @@ hipError_t conv_pglds_launch(ConvParams p, int n_cu, hipStream_t stream)
     case ST_NHWC: return launch_mode<ST_NHWC>(p, grid, stream);
     case ST_PS: return launch_mode<ST_PS>(p, grid, stream);
     case ST_POOL: return launch_mode<ST_POOL>(p, grid, stream);
-    case ST_NHWC_Q8: return launch_mode<ST_NHWC_Q8>(p, grid, stream);
     default: return launch_mode<ST_PS_DOT3>(p, grid, stream);
     }
 }

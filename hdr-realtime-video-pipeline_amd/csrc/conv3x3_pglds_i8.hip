@@ -42,7 +42,12 @@ struct Tile { int n0, oy0, ox0; };
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-template <int MODE>
+// C64: a 64-channel input (conv2, Up_conv5).  One LDS row is then a PAIR of horizontally adjacent pixels (pixel hx in
+// bytes 0..63, pixel hx+1 in bytes 64..127; each halo pixel is DMA'd twice), and the 3x3 filter becomes 3 rows x 2
+// row-taps at columns {0, 2}: tap (ky, 0) multiplies [w(ky,0) | w(ky,1)], tap (ky, 2) multiplies [w(ky,2) | 0].  Everything
+// else -- tile, ring, waits, epilogues -- is the 128-channel kernel with 6 taps and one chunk; a quarter of the MFMA
+// work multiplies zeros, which is still 1.5x the fp16 kernel's rate on these layers.
+template <int MODE, bool C64>
 __global__ __launch_bounds__(512) void conv_pglds_i8_kernel(ConvI8Params p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -76,8 +81,9 @@ __global__ __launch_bounds__(512) void conv_pglds_i8_kernel(ConvI8Params p)
         return o;
     };
 
-    const int nchunk = (p.c0 + p.c1) / CT, nchunk0 = p.c0 / CT;
-    const int nit = nchunk * 9;
+    constexpr int NT = C64 ? 6 : 9;                    // taps per chunk
+    const int nchunk = C64 ? 1 : (p.c0 + p.c1) / CT, nchunk0 = C64 ? 1 : p.c0 / CT;
+    const int nit = nchunk * NT;
 
     // ---- LDS-DMA issue helpers (wave-uniform LDS base, per-lane swizzled source) ------------
     const int l_row = lane >> 3, l_slot = lane & 7;
@@ -93,13 +99,20 @@ __global__ __launch_bounds__(512) void conv_pglds_i8_kernel(ConvI8Params p)
             const int hy = hp / HW, hx = hp - hy * HW;
             const int iy = T.oy0 - 1 + hy, ix = T.ox0 - 1 + hx;
             const bool ok = hp < NPIX && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
-            const int8_t *g = ok ? src + ((size_t)iy * p.Wi + ix) * cs + coff + ((l_slot ^ (hx & 7)) << 4)
-                                 : p.padline + (l_slot << 4);
+            const int8_t *g;
+            if constexpr (C64) {
+                const int sc = l_slot ^ (hx & 7);            // source chunk 0..3: this pixel, 4..7: its right neighbour
+                const int ixx = ix + (sc >> 2);
+                const bool ok2 = hp < NPIX && iy >= 0 && iy < p.Hi && ixx >= 0 && ixx < p.Wi;
+                g = ok2 ? src + ((size_t)iy * p.Wi + ixx) * 64 + ((sc & 3) << 4) : p.padline + (l_slot << 4);
+            } else {
+                g = ok ? src + ((size_t)iy * p.Wi + ix) * cs + coff + ((l_slot ^ (hx & 7)) << 4) : p.padline + (l_slot << 4);
+            }
             glds16(g, sA + buf * A_BYTES + piece * 1024);
         }
     };
     auto issue_B = [&](int it_i, int n0, int slot) {
-        const int cc = it_i / 9, tap = it_i - cc * 9;
+        const int cc = it_i / NT, tap = it_i - cc * NT;
         const int8_t *base = p.wpk + ((size_t)(tap * nchunk + cc) * p.Cout + n0) * CT;
 #pragma unroll
         for (int k = 0; k < B_PIECES_PER_WAVE; ++k) {
@@ -143,23 +156,24 @@ __global__ __launch_bounds__(512) void conv_pglds_i8_kernel(ConvI8Params p)
             const bool last_chunk = cc + 1 == nchunk;
             const bool pfA = !last_chunk || has_next;    // a halo tile is staged during this chunk's tap 6
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int it_i = cc * 9 + tap;
-                // stream index = 9 * gch + tap, so the ring slot of this iteration is tap % 3
+            for (int tap = 0; tap < NT; ++tap) {
+                const int it_i = cc * NT + tap;
+                // stream index = NT * gch + tap (NT = 9 or 6), so the ring slot of this iteration is tap % 3
                 // (a tile's weights(2) are issued before the tile starts: prologue / end of the previous tile)
                 bool pfB = true;
                 if (tap == 0 && cc == 0) {}
                 else if (it_i + 2 < nit) issue_B(it_i + 2, cur.n0, (tap + 2) % 3);
                 else if (has_next) issue_B(it_i + 2 - nit, nxt.n0, (tap + 2) % 3);
                 else pfB = false;
-                if (tap == 6 && pfA) {
+                if (tap == NT - 3 && pfA) {
                     if (!last_chunk) issue_A(cc + 1, (gch + 1) & 1, cur);
                     else { issue_A(0, (gch + 1) & 1, nxt); issue_SS(nxt.n0, (k + 1) & 1); }
                 }
 
                 const char *bw = sB + (tap % 3) * B_BYTES + b_lane;
-                const char *ax = a + a_lane + ((tap / 3) * HW + tap % 3) * PIXB;
-                const int kx = (l15 + tap % 3) & 7;
+                const int t_ky = C64 ? tap / 2 : tap / 3, t_kx = C64 ? 2 * (tap % 2) : tap % 3;
+                const char *ax = a + a_lane + (t_ky * HW + t_kx) * PIXB;
+                const int kx = (l15 + t_kx) & 7;
                 i32x4 wf[2][4], xf[2][4];
                 auto ldw = [&](int ks, int i) {
                     wf[ks][i] = *reinterpret_cast<const i32x4 *>(bw + i * 16 * PIXB + (((ks * 4 + kg) ^ kw) << 4));
@@ -192,7 +206,7 @@ __global__ __launch_bounds__(512) void conv_pglds_i8_kernel(ConvI8Params p)
                 // previous tile's stores) that are younger than those.
                 if (!pfB) {
                     wait_vm<0>();
-                } else if ((tap == 6 || tap == 7) && pfA) {
+                } else if ((tap == NT - 3 || tap == NT - 2) && pfA) {
                     if (last_chunk) wait_vm<9>();        // halo (6) + scale/shift (1) + weights(s+2) (2)
                     else wait_vm<8>();
                 } else if (tap <= 1 && cc == 0 && k > 0) {
@@ -291,11 +305,11 @@ __global__ __launch_bounds__(512) void conv_pglds_i8_kernel(ConvI8Params p)
     }
 }
 
-template <int MODE>
+template <int MODE, bool C64>
 hipError_t launch_mode(const ConvI8Params &p, int grid, hipStream_t stream)
 {
     static bool attr_set = false;
-    auto kern = conv_pglds_i8_kernel<MODE>;
+    auto kern = conv_pglds_i8_kernel<MODE, C64>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return e;
@@ -307,11 +321,13 @@ hipError_t launch_mode(const ConvI8Params &p, int grid, hipStream_t stream)
 
 }  // namespace
 
-// 3x3, stride 1, pad 1 on int8 codes: Cin (src0 [+ src1 concat]) multiple of 128, Cout multiple of 128; store modes
+// 3x3, stride 1, pad 1 on int8 codes: Cin (src0 [+ src1 concat]) multiple of 128, or exactly 64 (pixel-pair rows, NHWC
+// store only; weights packed as 6 row-taps); Cout multiple of 128; store modes
 // NHWC / PS / POOL to int8 codes.  One block per CU, each walking tiles.
 hipError_t conv_pglds_i8_launch(ConvI8Params p, int n_cu, hipStream_t stream)
 {
-    if ((p.c0 % CT) || (p.c1 % CT) || p.c0 + p.c1 < CT || (p.Cout % BN) || !p.padline || !p.trash || n_cu < 8 ||
+    const bool c64 = p.c0 == 64 && p.c1 == 0;
+    if ((!c64 && ((p.c0 % CT) || (p.c1 % CT) || p.c0 + p.c1 < CT)) || (p.Cout % BN) || !p.padline || !p.trash || n_cu < 8 ||
         (p.mode != ST_NHWC && p.mode != ST_PS && p.mode != ST_POOL) || p.out_f16 ||
         (p.mode == ST_PS && (p.dstC % 64)))
         return hipErrorInvalidValue;
@@ -319,9 +335,10 @@ hipError_t conv_pglds_i8_launch(ConvI8Params p, int n_cu, hipStream_t stream)
     p.tiles_y = (p.Ho + TH - 1) / TH;
     const int total = p.tiles_x * p.tiles_y * (p.Cout / BN);
     const int grid = total < n_cu ? total : n_cu;
+    if (c64) return p.mode == ST_NHWC ? launch_mode<ST_NHWC, true>(p, grid, stream) : hipErrorInvalidValue;
     switch (p.mode) {
-    case ST_NHWC: return launch_mode<ST_NHWC>(p, grid, stream);
-    case ST_PS: return launch_mode<ST_PS>(p, grid, stream);
-    default: return launch_mode<ST_POOL>(p, grid, stream);
+    case ST_NHWC: return launch_mode<ST_NHWC, false>(p, grid, stream);
+    case ST_PS: return launch_mode<ST_PS, false>(p, grid, stream);
+    default: return launch_mode<ST_POOL, false>(p, grid, stream);
     }
 }

@@ -291,7 +291,8 @@ bool pack_conv_i8(hdrtv_ctx *c, const Pack &pk, const std::string &key, const st
         !pk.get(wname + ".bias", co, b, c->err) || !read_actq(c, pk, wname, in))
         return false;
     const int coP = (co + 127) / 128 * 128;          // conv9: 64 real output channels in a 128-wide tile
-    if (ci % 128 || (co % 128 && (ks != 1 || out.scale > 0.f))) { c->err = "unsupported W8A8 conv shape: " + wname; return false; }
+    const bool c64 = ci == 64 && ks == 3;             // pixel-pair rows: 6 row-taps of 128 bytes (conv3x3_pglds_i8.hip, C64)
+    if ((ci % 128 && !c64) || (co % 128 && (ks != 1 || out.scale > 0.f))) { c->err = "unsupported W8A8 conv shape: " + wname; return false; }
     std::vector<float> g, be, mu, var;
     const bool has_bn = !bn_name.empty();
     if (has_bn) {
@@ -299,8 +300,8 @@ bool pack_conv_i8(hdrtv_ctx *c, const Pack &pk, const std::string &key, const st
             !pk.get(bn_name + ".running_mean", co, mu, c->err) || !pk.get(bn_name + ".running_var", co, var, c->err))
             return false;
     }
-    const int nch = ci / 128, taps = ks * ks;
-    std::vector<int8_t> wp((size_t)taps * nch * coP * 128, (int8_t)0);
+    const int nch = c64 ? 1 : ci / 128, taps = ks * ks;
+    std::vector<int8_t> wp((size_t)(c64 ? 6 : taps) * nch * coP * 128, (int8_t)0);
     std::vector<float> scale(coP, 0.f), shift(coP, 0.f);
     for (int np = 0; np < co; ++np) {
         const int n = ps_cps > 0 ? 4 * (np % ps_cps) + np / ps_cps : np;
@@ -309,7 +310,12 @@ bool pack_conv_i8(hdrtv_ctx *c, const Pack &pk, const std::string &key, const st
             for (int tap = 0; tap < taps; ++tap) {
                 const int8_t v = w[((size_t)n * ci + k) * taps + tap];
                 wsum += v;
-                wp[(((size_t)tap * nch + k / 128) * coP + np) * 128 + k % 128] = v;
+                if (c64) {      // row-tap (ky, 0) = [w(ky,0) | w(ky,1)], row-tap (ky, 2) = [w(ky,2) | 0]
+                    const int ky = tap / 3, kx = tap % 3;
+                    wp[((size_t)(ky * 2 + (kx == 2)) * coP + np) * 128 + (kx == 1 ? 64 : 0) + k] = v;
+                } else {
+                    wp[(((size_t)tap * nch + k / 128) * coP + np) * 128 + k % 128] = v;
+                }
             }
         const double a = (double)in.scale * (double)ws[n];
         double sc = a, sh = a * (double)(128 - in.k) * (double)wsum + (double)b[n];
@@ -550,14 +556,13 @@ bool build_weights(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
             for (const Spec &s : fuses)
                 if (!pack_conv(c, *hg, std::string("hg.") + s.name, s.name, s.co, s.ci, 1, 1, "", 0)) return false;
         } else {
-            // W8A8 checkpoint (weights.HG_W8A8_GROUPS): conv3_1 .. Up_conv4 and the fuse convs conv6..9 on int8 MFMA; conv1,
-            // conv2, Up_conv5, conv10, conv_last stay fp16 (conv2 writes int8 codes, conv9 f16 values).  A layer's epilogue writes the codes of the layer that
+            // W8A8 checkpoint (weights.HG_W8A8_GROUPS): conv2 .. Up_conv4 and the fuse convs conv6..9 on int8 MFMA; conv1,
+            // Up_conv5, conv10, conv_last stay fp16 (conv1 writes int8 codes of its pooled output, conv9 f16 values).  A layer's epilogue writes the codes of the layer that
             // reads its output; tensors read by two layers (encoder skip) or concatenated must share one quantiser.
-            if (!pack_conv(c, *hg, "hg.conv2", "conv2.0", 128, 64, 3, 1, "conv2.1", 0) ||
-                !pack_conv(c, *hg, "hg.Up_conv5", "Up_conv5.0", 256, 64, 3, 1, "", 64))
-                return false;
+            if (!pack_conv(c, *hg, "hg.Up_conv5", "Up_conv5.0", 256, 64, 3, 1, "", 64)) return false;
             struct Q8 { const char *name; int co, ci, ks, ps; const char *bn; const char *consumer; const char *shares; };
             const Q8 q8[] = {
+                {"conv2", 128, 64, 3, 0, "conv2.1", "conv3_1.0", "conv9"},
                 {"conv3_1", 256, 128, 3, 0, "conv3_1.1", "conv3_2.0", nullptr}, {"conv3_2", 256, 256, 3, 0, "conv3_2.1", "conv4_1.0", "conv8"},
                 {"conv4_1", 512, 256, 3, 0, "conv4_1.1", "conv4_2.0", nullptr}, {"conv4_2", 512, 512, 3, 0, "conv4_2.1", "conv5_1.0", "conv7"},
                 {"conv5_1", 512, 512, 3, 0, "conv5_1.1", "conv5_2.0", nullptr}, {"conv5_2", 512, 512, 3, 0, "conv5_2.1", "conv_code1.0", "conv6"},
@@ -566,7 +571,7 @@ bool build_weights(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
                 {"Up_conv1", 2048, 512, 3, 512, "", "conv6", nullptr}, {"conv6", 512, 1024, 1, 0, "", "Up_conv2.0", nullptr},
                 {"Up_conv2", 2048, 512, 3, 512, "", "conv7", nullptr}, {"conv7", 256, 1024, 1, 0, "", "Up_conv3.0", nullptr},
                 {"Up_conv3", 1024, 256, 3, 256, "", "conv8", nullptr}, {"conv8", 128, 512, 1, 0, "", "Up_conv4.0", nullptr},
-                {"Up_conv4", 512, 128, 3, 128, "", "conv9", "conv3_1.0"}, {"conv9", 64, 256, 1, 0, "", nullptr, nullptr}};
+                {"Up_conv4", 512, 128, 3, 128, "", "conv9", nullptr}, {"conv9", 64, 256, 1, 0, "", nullptr, nullptr}};
             for (const Q8 &L : q8) {
                 ActQ out;
                 if (L.consumer && !read_actq(c, *hg, L.consumer, out)) return false;
@@ -583,8 +588,9 @@ bool build_weights(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
                 const std::string wname = L.ks == 3 ? std::string(L.name) + ".0" : std::string(L.name);
                 if (!pack_conv_i8(c, *hg, std::string("hg.") + L.name, wname, L.co, L.ci, L.ks, L.bn, L.ps, out)) return false;
             }
-            ActQ q0;
-            if (!read_actq(c, *hg, "conv3_1.0", q0)) return false;
+            ActQ q0;                       // the fp16 -> int8 boundary: conv1's pooled output, read by conv2
+            if (!read_actq(c, *hg, "conv2.0", q0)) return false;
+            if (q0.k != 0) { c->err = "W8A8 HG: post-ReLU tensor in front of conv2.0 needs x_zero = 0"; return false; }
             c->hg_q0_inv = 1.f / q0.scale;
             c->hg_q0_zero = (float)(q0.k - 128);
         }
@@ -746,8 +752,9 @@ int do_reserve(hdrtv_ctx *c, int H, int W)
     if (c->has_hg) {
         const int Hp = s.Hp, Wp = s.Wp;
         ws_add(c, "hg.img", 3, Hp, Wp, 1); ws_add(c, "hg.mask", 1, Hp, Wp, 4);
-        ws_add(c, "hg.p1", 64, Hp / 2, Wp / 2, 0); ws_add(c, "hg.part", 4, Hp, Wp, 3);
+        ws_add(c, "hg.part", 4, Hp, Wp, 3);
         if (!c->hg_i8) {
+            ws_add(c, "hg.p1", 64, Hp / 2, Wp / 2, 0);
             ws_add(c, "hg.conv2", 128, Hp / 2, Wp / 2, 0); ws_add(c, "hg.up4", 128, Hp / 2, Wp / 2, 0);
             ws_add(c, "hg.p3", 256, Hp / 4, Wp / 4, 0); ws_add(c, "hg.conv3_2", 256, Hp / 4, Wp / 4, 0);
             ws_add(c, "hg.p4", 512, Hp / 8, Wp / 8, 0); ws_add(c, "hg.conv4_2", 512, Hp / 8, Wp / 8, 0);
@@ -757,6 +764,7 @@ int do_reserve(hdrtv_ctx *c, int H, int W)
             ws_add(c, "hg.up2", 512, Hp / 8, Wp / 8, 0); ws_add(c, "hg.conv7", 256, Hp / 8, Wp / 8, 0);
             ws_add(c, "hg.up3", 256, Hp / 4, Wp / 4, 0); ws_add(c, "hg.conv8", 128, Hp / 4, Wp / 4, 0);
         } else {            // W8A8: the same tensors as int8 codes (q - 128), each once
+            ws_add(c, "hg8.p1", 64, Hp / 2, Wp / 2, 5);
             ws_add(c, "hg8.conv2", 128, Hp / 2, Wp / 2, 5); ws_add(c, "hg8.up4", 128, Hp / 2, Wp / 2, 5);
             ws_add(c, "hg8.p3", 256, Hp / 4, Wp / 4, 5); ws_add(c, "hg8.conv3_2", 256, Hp / 4, Wp / 4, 5);
             ws_add(c, "hg8.p4", 512, Hp / 8, Wp / 8, 5); ws_add(c, "hg8.conv4_2", 512, Hp / 8, Wp / 8, 5);
@@ -835,18 +843,16 @@ struct Seq {
         p.dst = dst; p.dst_full = dst_full; p.dstC = dstC; p.Hd = Hd; p.Wd = Wd;
         p.res1 = res1; p.res2 = res2; p.dst_planar = dst_planar; p.res_planar = res_planar;
         p.dotw = dotw; p.dst_dot = dst_dot;
-        p.q_inv = c->hg_q0_inv; p.q_zero = c->hg_q0_zero;
         if (c0 + c1 != L.cin) { rc = fail(c, HDRTV_ESTATE, "conv %s: channel mismatch", key.c_str()); return; }
         p.zeros = wtp<f16>(c, c->zeros_off);
         const bool g64 = L.stride == 1 && L.cin_t == 64 && L.bn == 128 && !res1 && !res2 && !dst_full && mode != ST_PLANAR3;
         const bool pglds = g64 && L.ks == 3 && L.cout == L.coutPad;      // HG 3x3 convs: persistent LDS-DMA kernel
         const bool glds1 = g64 && L.ks == 1 && mode == ST_NHWC;          // HG 1x1 fuse convs
-        if (mode == ST_NHWC_Q8 && !pglds) { rc = fail(c, HDRTV_ESTATE, "conv %s: int8-code store needs the pglds kernel", key.c_str()); return; }
         p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
         const bool s2g = L.ks == 3 && L.stride == 2 && L.cin_t == 64 && L.bn == L.coutPad && (L.coutPad == 64 || L.coutPad == 192);
         char tag[64];
         if (s2g) snprintf(tag, sizeof tag, "conv3x3s2_preg<%d>", L.coutPad);
-        else if (pglds) snprintf(tag, sizeof tag, "conv_pglds<%s>", mode == ST_POOL ? "pool" : (mode == ST_PS ? "ps" : (mode == ST_PS_DOT3 ? "ps_dot3" : (mode == ST_NHWC_Q8 ? "nhwc_q8" : "nhwc"))));
+        else if (pglds) snprintf(tag, sizeof tag, "conv_pglds<%s>", mode == ST_POOL ? "pool" : (mode == ST_PS ? "ps" : (mode == ST_PS_DOT3 ? "ps_dot3" : "nhwc")));
         else if (glds1) snprintf(tag, sizeof tag, "conv_glds1");
         else snprintf(tag, sizeof tag, "conv_igemm<%d,%d,%d,%d>", L.cin_t, L.bn, L.ks, L.stride);
         const double macs = (double)p.Ho * p.Wo * L.cin * L.ks * L.ks * L.cout;
@@ -884,12 +890,13 @@ struct Seq {
         const double bytes = (double)Hi * Wi * L.cin + (double)L.ks * L.ks * L.cin * L.cout + outel * (L.out_f16 ? 2.0 : 1.0);
         chk(L.ks == 3 ? conv_pglds_i8_launch(p, c->n_cu, s) : conv1x1_i8_launch(p, s), key.c_str(), tag, macs, bytes);
     }
-    void c3(const std::string &key, const f16 *in, int H, int W, int act, f16 *out, f16 *out_pool)
+    void c3(const std::string &key, const f16 *in, int H, int W, int act, f16 *out, f16 *out_pool, float pool_q_inv = 0.f,
+            float pool_q_zero = 0.f)
     {
         if (!ok()) return;
         const C3Layer &L = c->c3.at(key);
         chk(conv_c3_launch(in, H, W, wtp<f16>(c, L.wfrag), wtp<float>(c, L.scale), wtp<float>(c, L.shift), L.cout, act, out,
-                           out_pool, c->n_cu, s), key.c_str(), L.cout == 64 ? "conv_c3<64>" : "conv_c3<32>", (double)H * W * 27 * L.cout,
+                           out_pool, c->n_cu, s, pool_q_inv, pool_q_zero), key.c_str(), L.cout == 64 ? "conv_c3<64>" : "conv_c3<32>", (double)H * W * 27 * L.cout,
             (double)H * W * (6.0 + 2.0 * L.cout * (out_pool ? 1.25 : 1.0)));
     }
     // persistent 32-channel 3x3 conv, optionally with the SFT layer `sft_key` fused in front (conv32p.hip)
@@ -1046,19 +1053,21 @@ int run_hg(hdrtv_ctx *c, Seq &q, const f16 *base, void *out, int out_f32)
     f16 *img = wsp<f16>(c, "hg.img");
     uint8_t *mask = wsp<uint8_t>(c, "hg.mask");
     q.chk(hg_prep_launch(base, s.H, s.W, Hp, Wp, img, mask, 0.75f, 0.1f, q.s), "hg_prep", "hg_prep", 0.0, 13.0 * Hp * Wp);
-    f16 *p1 = wsp<f16>(c, "hg.p1"), *c9 = wsp<f16>(c, "hg.conv9");
+    f16 *c9 = wsp<f16>(c, "hg.conv9");
     float *part = wsp<float>(c, "hg.part");
-    q.c3("hg.conv1", img, Hp, Wp, ACT_RELU, nullptr, p1);      // only the pooled map is kept; conv1_out is recomputed in hg_final_fused
+    // conv1: only the pooled map is kept (conv1_out is recomputed in hg_final_fused)
     if (c->hg_i8) {
-        // W8A8 checkpoint: conv3_1 .. conv9 on int8 MFMA, every activation between conv2 and conv9 one int8 tensor
+        int8_t *p1q = wsp<int8_t>(c, "hg8.p1");
+        // the fp16 -> int8 boundary costs no pass of its own: conv1 stores the codes its reader conv2 wants
+        q.c3("hg.conv1", img, Hp, Wp, ACT_RELU, nullptr, reinterpret_cast<f16 *>(p1q), c->hg_q0_inv, c->hg_q0_zero);
+        // W8A8 checkpoint: conv2 .. conv9 on int8 MFMA, every activation between conv1 and conv9 one int8 tensor
         int8_t *c2q = wsp<int8_t>(c, "hg8.conv2"), *p3 = wsp<int8_t>(c, "hg8.p3"), *c3 = wsp<int8_t>(c, "hg8.conv3_2"),
                *p4 = wsp<int8_t>(c, "hg8.p4"), *c4 = wsp<int8_t>(c, "hg8.conv4_2"), *p5 = wsp<int8_t>(c, "hg8.p5"),
                *c5 = wsp<int8_t>(c, "hg8.conv5_2"), *pc = wsp<int8_t>(c, "hg8.pc"), *code = wsp<int8_t>(c, "hg8.conv_code2"),
                *u1 = wsp<int8_t>(c, "hg8.up1"), *c6 = wsp<int8_t>(c, "hg8.conv6"), *u2 = wsp<int8_t>(c, "hg8.up2"),
                *c7 = wsp<int8_t>(c, "hg8.conv7"), *u3 = wsp<int8_t>(c, "hg8.up3"), *c8 = wsp<int8_t>(c, "hg8.conv8"),
                *u4q = wsp<int8_t>(c, "hg8.up4");
-        // conv2 (fp16 MFMA) writes the codes its reader conv3_1 wants: the fp16 -> int8 boundary costs no pass of its own
-        q.conv("hg.conv2", p1, 64, nullptr, 0, Hp / 2, Wp / 2, ACT_RELU, ST_NHWC_Q8, reinterpret_cast<f16 *>(c2q), 128, Hp / 2, Wp / 2);
+        q.conv8("hg.conv2", p1q, 64, nullptr, 0, Hp / 2, Wp / 2, ST_NHWC, c2q, 128, Hp / 2, Wp / 2);
         q.conv8("hg.conv3_1", c2q, 128, nullptr, 0, Hp / 2, Wp / 2, ST_POOL, p3, 256, Hp / 4, Wp / 4);
         q.conv8("hg.conv3_2", p3, 256, nullptr, 0, Hp / 4, Wp / 4, ST_NHWC, c3, 256, Hp / 4, Wp / 4);
         q.conv8("hg.conv4_1", c3, 256, nullptr, 0, Hp / 4, Wp / 4, ST_POOL, p4, 512, Hp / 8, Wp / 8);
@@ -1076,7 +1085,8 @@ int run_hg(hdrtv_ctx *c, Seq &q, const f16 *base, void *out, int out_f32)
         q.conv8("hg.Up_conv4", c8, 128, nullptr, 0, Hp / 4, Wp / 4, ST_PS, u4q, 128, Hp / 2, Wp / 2);
         q.conv8("hg.conv9", u4q, 128, c2q, 128, Hp / 2, Wp / 2, ST_NHWC, c9, 64, Hp / 2, Wp / 2);           // -> f16 values
     } else {
-        f16 *c2 = wsp<f16>(c, "hg.conv2"), *u4 = wsp<f16>(c, "hg.up4");
+        f16 *p1 = wsp<f16>(c, "hg.p1"), *c2 = wsp<f16>(c, "hg.conv2"), *u4 = wsp<f16>(c, "hg.up4");
+        q.c3("hg.conv1", img, Hp, Wp, ACT_RELU, nullptr, p1);
         q.conv("hg.conv2", p1, 64, nullptr, 0, Hp / 2, Wp / 2, ACT_RELU, ST_NHWC, c2, 128, Hp / 2, Wp / 2);
         f16 *p3 = wsp<f16>(c, "hg.p3"), *c3 = wsp<f16>(c, "hg.conv3_2"), *p4 = wsp<f16>(c, "hg.p4"), *c4 = wsp<f16>(c, "hg.conv4_2"),
             *p5 = wsp<f16>(c, "hg.p5"), *c5 = wsp<f16>(c, "hg.conv5_2"), *pc = wsp<f16>(c, "hg.pc"), *code = wsp<f16>(c, "hg.conv_code2");

@@ -30,7 +30,8 @@ hipError_t agcm_fold_launch(const AgcmFoldArgs &a, f16 *frags, float *biasbuf, h
 hipError_t agcm_mlp_launch(const f16 *in, f16 *out, size_t npix, const f16 *frags, const float *biasbuf, hipStream_t s);
 
 hipError_t conv_c3_launch(const f16 *in, int H, int W, const f16 *wfrag, const float *scale, const float *shift, int cout,
-                          int act, f16 *out, f16 *out_pool, int n_cu, hipStream_t s);
+                          int act, f16 *out, f16 *out_pool, int n_cu, hipStream_t s, float pool_q_inv = 0.f, float pool_q_zero = 0.f);
+// pool_q_inv > 0: out_pool holds int8 codes clamp(rint(v * pool_q_inv + pool_q_zero), -128, 127), COUT bytes per pixel
 hipError_t le_cond_trunk_launch(const f16 *img, int H, int W, const f16 *wfrag, const float *bias, f16 *cond, f16 *cond1,
                                 int n_cu, hipStream_t s);
 hipError_t hg_prep_launch(const f16 *base, int H, int W, int Hp, int Wp, f16 *img_pad, uint8_t *mask, float r, float thresh,

@@ -19,7 +19,8 @@ constexpr int C3_HH = C3_TH + 2, C3_HW = C3_TW + 2;
 template <int COUT>
 __global__ __launch_bounds__(256) void conv_c3_kernel(const f16 *__restrict__ in, int H, int W, const f16 *__restrict__ wfrag,
                                                       const float *__restrict__ scale, const float *__restrict__ shift,
-                                                      int act, f16 *__restrict__ out, f16 *__restrict__ out_pool)
+                                                      int act, f16 *__restrict__ out, f16 *__restrict__ out_pool, float pool_q_inv,
+                                                      float pool_q_zero)
 {
     constexpr int MT = COUT / 32;
     constexpr int ROWB = COUT * 2 + 16;
@@ -137,7 +138,19 @@ __global__ __launch_bounds__(256) void conv_c3_kernel(const f16 *__restrict__ in
                     const f16 m2 = v2[k] > v3[k] ? v2[k] : v3[k];
                     v[k] = m > m2 ? m : m2;
                 }
-                *reinterpret_cast<f16x8 *>(out_pool + ((size_t)oy * Wp + ox) * COUT + c8 * 8) = v;
+                if (pool_q_inv > 0.f) {
+                    // the pooled map as int8 codes q - 128 of a W8A8 reader (W8A8Conv2d.forward, hdrtvnet_torch.py:351-356)
+                    unsigned lo = 0, hi = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float q = fminf(fmaxf(__builtin_rintf((float)v[k] * pool_q_inv + pool_q_zero), -128.f), 127.f);
+                        const unsigned b = (unsigned)(int)q & 0xffu;
+                        if (k < 4) lo |= b << (8 * k); else hi |= b << (8 * (k - 4));
+                    }
+                    *reinterpret_cast<uint2 *>(reinterpret_cast<int8_t *>(out_pool) + ((size_t)oy * Wp + ox) * COUT + c8 * 8) = make_uint2(lo, hi);
+                } else {
+                    *reinterpret_cast<f16x8 *>(out_pool + ((size_t)oy * Wp + ox) * COUT + c8 * 8) = v;
+                }
             }
         }
     }
@@ -315,15 +328,15 @@ inline int grid_for(size_t n, int per_block)
 }  // namespace
 
 hipError_t conv_c3_launch(const f16 *in, int H, int W, const f16 *wfrag, const float *scale, const float *shift, int cout,
-                          int act, f16 *out, f16 *out_pool, int n_cu, hipStream_t s)
+                          int act, f16 *out, f16 *out_pool, int n_cu, hipStream_t s, float pool_q_inv, float pool_q_zero)
 {
     const int ntiles = ((W + C3_TW - 1) / C3_TW) * ((H + C3_TH - 1) / C3_TH);
     const int per_cu = cout == 32 ? 6 : 4;                        // LDS: 22 KiB / 39 KiB per workgroup
     const dim3 grid(ntiles < per_cu * n_cu ? ntiles : per_cu * n_cu);
     if (cout == 32)
-        hipLaunchKernelGGL(conv_c3_kernel<32>, grid, dim3(256), 0, s, in, H, W, wfrag, scale, shift, act, out, out_pool);
+        hipLaunchKernelGGL(conv_c3_kernel<32>, grid, dim3(256), 0, s, in, H, W, wfrag, scale, shift, act, out, out_pool, pool_q_inv, pool_q_zero);
     else if (cout == 64)
-        hipLaunchKernelGGL(conv_c3_kernel<64>, grid, dim3(256), 0, s, in, H, W, wfrag, scale, shift, act, out, out_pool);
+        hipLaunchKernelGGL(conv_c3_kernel<64>, grid, dim3(256), 0, s, in, H, W, wfrag, scale, shift, act, out, out_pool, pool_q_inv, pool_q_zero);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();

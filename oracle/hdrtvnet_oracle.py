@@ -429,7 +429,7 @@ def hg_generator(hg, img, mask, taps=None):
         return v
 
     c1 = tap("hg.conv1", _hg_block(hg, "conv1", img))
-    c2 = tap("hg.conv2", _hg_block(hg, "conv2", maxpool2(c1)))
+    c2 = tap("hg.conv2", _hg_block(hg, "conv2", tap("hg.p1", maxpool2(c1))))
     c3 = tap("hg.conv3_2", _hg_block(hg, "conv3_2", maxpool2(_hg_block(hg, "conv3_1", c2))))
     c4 = tap("hg.conv4_2", _hg_block(hg, "conv4_2", maxpool2(_hg_block(hg, "conv4_1", c3))))
     c5 = tap("hg.conv5_2", _hg_block(hg, "conv5_2", maxpool2(_hg_block(hg, "conv5_1", c4))))

@@ -46,7 +46,7 @@ def _oracle_on_base(qstate, base):
 
 
 # device int8 tensor -> (oracle tap holding the same tensor before quantisation, a layer that reads it)
-CODE_TAPS = (("hg8.conv2", "hg.conv2", "conv3_1.0"), ("hg8.conv3_2", "hg.conv3_2", "conv4_1.0"),
+CODE_TAPS = (("hg8.p1", "hg.p1", "conv2.0"), ("hg8.conv2", "hg.conv2", "conv3_1.0"), ("hg8.conv3_2", "hg.conv3_2", "conv4_1.0"),
              ("hg8.conv4_2", "hg.conv4_2", "conv5_1.0"), ("hg8.conv5_2", "hg.conv5_2", "conv_code1.0"),
              ("hg8.conv_code2", "hg.conv_code2", "Up_conv1.0"), ("hg8.conv6", "hg.conv6", "Up_conv2.0"),
              ("hg8.conv7", "hg.conv7", "Up_conv3.0"), ("hg8.conv8", "hg.conv8", "Up_conv4.0"))
@@ -69,7 +69,7 @@ def test_w8a8_hg_vs_oracle(proc_q, qstate, hw, seed):
         d = np.abs(codes - want)
         print(f"  {dev_name}: codes differ at {np.mean(d > 0):.4%}, by more than one at {np.mean(d > 1):.4%}, max {d.max():.0f} "
               f"(k={k}, used range {want.min():.0f}..{want.max():.0f})")
-        if dev_name == "hg8.conv2":          # the fp16 -> int8 boundary: only conv1/conv2's fp16 rounding separates the two
+        if dev_name == "hg8.p1":             # the fp16 -> int8 boundary: only conv1's fp16 rounding separates the two
             assert np.mean(d > 0) <= 0.03 and d.max() <= 1
     e = np.abs(out - ref)
     print(f"  {hw} out vs oracle (same base): max {e.max():.3e} mean {e.mean():.3e}; mask fraction {mask.mean():.4f}")
@@ -77,7 +77,7 @@ def test_w8a8_hg_vs_oracle(proc_q, qstate, hw, seed):
 
 
 # (layer, input code tensors, output tensor, store): each layer alone, fed the DEVICE's own input codes
-LAYERS = (("conv3_1", ("hg8.conv2",), "hg8.p3", "pool"), ("conv3_2", ("hg8.p3",), "hg8.conv3_2", "block"),
+LAYERS = (("conv2", ("hg8.p1",), "hg8.conv2", "block"), ("conv3_1", ("hg8.conv2",), "hg8.p3", "pool"), ("conv3_2", ("hg8.p3",), "hg8.conv3_2", "block"),
           ("conv4_1", ("hg8.conv3_2",), "hg8.p4", "pool"), ("conv4_2", ("hg8.p4",), "hg8.conv4_2", "block"),
           ("conv5_1", ("hg8.conv4_2",), "hg8.p5", "pool"), ("conv5_2", ("hg8.p5",), "hg8.conv5_2", "block"),
           ("conv_code1", ("hg8.conv5_2",), "hg8.pc", "pool"), ("conv_code2", ("hg8.pc",), "hg8.conv_code2", "block"),
@@ -88,7 +88,7 @@ LAYERS = (("conv3_1", ("hg8.conv2",), "hg8.p3", "pool"), ("conv3_2", ("hg8.p3",)
 READER = {"hg8.p3": "conv3_2.0", "hg8.conv3_2": "conv4_1.0", "hg8.p4": "conv4_2.0", "hg8.conv4_2": "conv5_1.0",
           "hg8.p5": "conv5_2.0", "hg8.conv5_2": "conv_code1.0", "hg8.pc": "conv_code2.0", "hg8.conv_code2": "Up_conv1.0",
           "hg8.up1": "conv6", "hg8.conv6": "Up_conv2.0", "hg8.up2": "conv7", "hg8.conv7": "Up_conv3.0", "hg8.up3": "conv8",
-          "hg8.conv8": "Up_conv4.0", "hg8.conv2": "conv3_1.0", "hg8.up4": "conv9"}
+          "hg8.conv8": "Up_conv4.0", "hg8.conv2": "conv3_1.0", "hg8.up4": "conv9", "hg8.p1": "conv2.0"}
 
 
 @pytest.mark.parametrize("hw,seed", [((96, 128), 3), ((272, 480), 11)])

@@ -33,9 +33,9 @@ def _asm(src, tmp_path):
 def test_pglds_store_counts_match_the_counted_waits(tmp_path):
     kernels = _asm("conv3x3_pglds.hip", tmp_path)
     src = open(os.path.join(CSRC, "conv3x3_pglds.hip")).read()
-    m = re.search(r"MODE == ST_POOL \? (\d+) : \(MODE == ST_PS_DOT3 \? (\d+) : \(MODE == ST_NHWC_Q8 \? (\d+) : (\d+)\)\)", src)
-    n_pool, n_dot3, n_q8, n_other = (int(v) for v in m.groups())
-    expect = {0: n_other, 1: n_other, 2: n_pool, 4: n_dot3, 5: n_q8}   # ST_NHWC, ST_PS, ST_POOL, ST_PS_DOT3, ST_NHWC_Q8 (common.h)
+    m = re.search(r"MODE == ST_POOL \? (\d+) : \(MODE == ST_PS_DOT3 \? (\d+) : (\d+)\)", src)
+    n_pool, n_dot3, n_other = (int(v) for v in m.groups())
+    expect = {0: n_other, 1: n_other, 2: n_pool, 4: n_dot3}          # ST_NHWC, ST_PS, ST_POOL, ST_PS_DOT3 (common.h)
     seen = 0
     for name, body in kernels.items():
         km = re.search(r"conv_pglds_kernelILi(\d+)E", name)
@@ -47,7 +47,7 @@ def test_pglds_store_counts_match_the_counted_waits(tmp_path):
         waits = set(int(v) for v in re.findall(r"s_waitcnt vmcnt\((\d+)\)", body))
         assert expect[mode] + 2 in waits, (name, sorted(waits))
         seen += 1
-    assert seen == 5
+    assert seen == 4
 
 
 def test_pglds_i8_store_counts_match_the_counted_waits(tmp_path):
@@ -58,7 +58,7 @@ def test_pglds_i8_store_counts_match_the_counted_waits(tmp_path):
     n_pool, n_other = (int(v) for v in m.groups())
     seen = 0
     for name, body in kernels.items():
-        km = re.search(r"conv_pglds_i8_kernelILi(\d+)E", name)
+        km = re.search(r"conv_pglds_i8_kernelILi(\d+)ELb\d", name)
         if not km:
             continue
         want = n_pool if int(km.group(1)) == 2 else n_other
@@ -68,7 +68,7 @@ def test_pglds_i8_store_counts_match_the_counted_waits(tmp_path):
         assert want + 2 in waits, (name, sorted(waits))
         assert "v_mfma_i32_16x16x64_i8" in body and "scratch_" not in body
         seen += 1
-    assert seen == 3
+    assert seen == 4
 
 
 def test_conv32p_asm_loads_are_read_only_after_the_wait(tmp_path):
