@@ -78,7 +78,9 @@ struct ConvI8Params {
     const float *scale, *shift;  // [Cout]: out = acc * scale + shift, in output codes (int8 dst) or real units (f16 dst)
     int Cout;                    // multiple of 128
     int mode;                    // ST_NHWC / ST_PS / ST_POOL
-    int out_f16;                 // dst holds f16 values instead of int8 codes (3x3: ReLU'd; 1x1: Cout_real = dstC <= Cout)
+    int out_f16;                 // real-valued output instead of int8 codes: 1x1 -> f16 dst; 3x3 ST_PS_DOT3 -> dst_dot
+    const float *dotw;           // ST_PS_DOT3: [3][dstC] weights of the 1x1 conv fused behind the pixel shuffle
+    float *dst_dot;              // ST_PS_DOT3: f32 [Hd][Wd][4] partial sums (x,y,z used)
     void *dst;
     int dstC, Hd, Wd;
     int tiles_x, tiles_y;

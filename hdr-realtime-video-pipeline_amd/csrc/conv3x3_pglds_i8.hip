@@ -22,10 +22,11 @@ constexpr int BN = 128;
 constexpr int A_PIECES_PER_WAVE = 6, A_BYTES = 8 * A_PIECES_PER_WAVE * 1024;   // 324 halo px -> 48 KiB
 constexpr int B_BYTES = BN * PIXB, B_PIECES_PER_WAVE = 2;                       // 16 KiB
 constexpr int SS_OFF = 2 * A_BYTES + 3 * B_BYTES;        // two 1-KiB {scale[128], shift[128]} slots
-constexpr int SMEM = SS_OFF + 2048;                      // 146 KiB
+constexpr int DOTW_OFF = SS_OFF + 2048;                  // ST_PS_DOT3: 3 x 64 floats
+constexpr int SMEM = DOTW_OFF + 1024;                    // 147 KiB
 
 // stores per wave and tile, by store mode (see the epilogues)
-template <int MODE> struct NStores { static constexpr int N = MODE == ST_POOL ? 1 : 4; };
+template <int MODE> struct NStores { static constexpr int N = (MODE == ST_POOL || MODE == ST_PS_DOT3) ? 1 : 4; };
 
 __device__ __forceinline__ void glds16(const void *g, void *lds)
 {
@@ -125,6 +126,12 @@ __global__ __launch_bounds__(512) void conv_pglds_i8_kernel(ConvI8Params p)
         const float *g = (lane < 32 ? p.scale : p.shift - 128) + n0 + lane * 4;
         glds16(g, smem + SS_OFF + slot * 1024);
     };
+
+    if constexpr (MODE == ST_PS_DOT3) {          // before any DMA is in flight (ordinary loads drain the queue)
+        float *s_w = reinterpret_cast<float *>(smem + DOTW_OFF);
+        for (int e = tid; e < 3 * 64; e += 512) s_w[e] = p.dotw[e];
+        __syncthreads();
+    }
 
     // ---- wave tiling: 2 (channels) x 4 (pixel rows) waves, each 64 ch x 64 px = 4x4 tiles of 16x16
     const int wc = wave & 1, wp = wave >> 1;
@@ -229,7 +236,49 @@ __global__ __launch_bounds__(512) void conv_pglds_i8_kernel(ConvI8Params p)
         // wave-private strip of the halo buffer this tile just finished with (free until the next tile's tap 6); LDS
         // operations of one wave execute in order: no barrier
         char *stg = sA + ((gch - 1) & 1) * A_BYTES + wave * 5120;
-        {
+        if constexpr (MODE == ST_PS_DOT3) {
+            // Up_conv5: {scale, shift} give real values; ReLU, f16 rounding (the tensor the reference's fp16 conv10 reads),
+            // pixel shuffle, then the first half of conv10 as 3 dot products per pixel (conv3x3_pglds.hip, same epilogue)
+            const float *s_w = reinterpret_cast<const float *>(smem + DOTW_OFF);
+            float a0[4], a1[4], a2[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a0[j] = a1[j] = a2[j] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 sc = *reinterpret_cast<const float4 *>(ss + cw + i * 16);
+                const float4 sh = *reinterpret_cast<const float4 *>(ss + 128 + cw + i * 16);
+                const float4 w0 = *reinterpret_cast<const float4 *>(s_w + i * 16 + 4 * kg);
+                const float4 w1 = *reinterpret_cast<const float4 *>(s_w + 64 + i * 16 + 4 * kg);
+                const float4 w2 = *reinterpret_cast<const float4 *>(s_w + 128 + i * 16 + 4 * kg);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x0 = (float)(f16)fmaxf((float)acc[i][j][0] * sc.x + sh.x, 0.f);
+                    const float x1 = (float)(f16)fmaxf((float)acc[i][j][1] * sc.y + sh.y, 0.f);
+                    const float x2 = (float)(f16)fmaxf((float)acc[i][j][2] * sc.z + sh.z, 0.f);
+                    const float x3 = (float)(f16)fmaxf((float)acc[i][j][3] * sc.w + sh.w, 0.f);
+                    acc[i][j] = i32x4{0, 0, 0, 0};
+                    a0[j] += w0.x * x0 + w0.y * x1 + w0.z * x2 + w0.w * x3;
+                    a1[j] += w1.x * x0 + w1.y * x1 + w1.z * x2 + w1.w * x3;
+                    a2[j] += w2.x * x0 + w2.y * x1 + w2.z * x2 + w2.w * x3;
+                }
+            }
+            // k-groups of a pixel are summed through the wave-private strip, not ds_bpermute (see conv3x3_pglds.hip)
+            const int sub = cur.n0 / 64 + wc;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<float4 *>(stg + j * 1024 + kg * 256 + l15 * 16) = make_float4(a0[j], a1[j], a2[j], 0.f);
+            float4 r = *reinterpret_cast<const float4 *>(stg + kg * 1024 + l15 * 16);
+#pragma unroll
+            for (int kk = 1; kk < 4; ++kk) {
+                const float4 v = *reinterpret_cast<const float4 *>(stg + kg * 1024 + kk * 256 + l15 * 16);
+                r.x += v.x; r.y += v.y; r.z += v.z;
+            }
+            const int oy = cur.oy0 + wp * 4 + kg, ox = cur.ox0 + l15;
+            const int Y = 2 * oy + (sub >> 1), X = 2 * ox + (sub & 1);
+            const bool ok = oy < p.Ho && ox < p.Wo && Y < p.Hd && X < p.Wd;
+            float4 *d = ok ? reinterpret_cast<float4 *>(p.dst_dot + ((size_t)Y * p.Wd + X) * 4) : reinterpret_cast<float4 *>(trash);
+            *d = make_float4(r.x, r.y, r.z, 0.f);
+        } else {
             // int8 codes of the output tensor's quantiser: clamp(rint(acc * scale + shift), -128, 127)
             float q[4][4][4];
 #pragma unroll
@@ -321,21 +370,24 @@ hipError_t launch_mode(const ConvI8Params &p, int grid, hipStream_t stream)
 
 }  // namespace
 
-// 3x3, stride 1, pad 1 on int8 codes: Cin (src0 [+ src1 concat]) multiple of 128, or exactly 64 (pixel-pair rows, NHWC
-// store only; weights packed as 6 row-taps); Cout multiple of 128; store modes
+// 3x3, stride 1, pad 1 on int8 codes: Cin (src0 [+ src1 concat]) multiple of 128, or exactly 64 (pixel-pair rows; NHWC
+// store, or PS_DOT3 = pixel shuffle + ReLU + fused 64->3 dot products; weights packed as 6 row-taps); Cout multiple of 128; store modes
 // NHWC / PS / POOL to int8 codes.  One block per CU, each walking tiles.
 hipError_t conv_pglds_i8_launch(ConvI8Params p, int n_cu, hipStream_t stream)
 {
     const bool c64 = p.c0 == 64 && p.c1 == 0;
     if ((!c64 && ((p.c0 % CT) || (p.c1 % CT) || p.c0 + p.c1 < CT)) || (p.Cout % BN) || !p.padline || !p.trash || n_cu < 8 ||
-        (p.mode != ST_NHWC && p.mode != ST_PS && p.mode != ST_POOL) || p.out_f16 ||
-        (p.mode == ST_PS && (p.dstC % 64)))
+        (p.mode != ST_NHWC && p.mode != ST_PS && p.mode != ST_POOL && p.mode != ST_PS_DOT3) ||
+        (p.out_f16 != (p.mode == ST_PS_DOT3)) || (p.mode == ST_PS && (p.dstC % 64)) ||
+        (p.mode == ST_PS_DOT3 && (!c64 || p.dstC != 64 || !p.dotw || !p.dst_dot)))
         return hipErrorInvalidValue;
     p.tiles_x = (p.Wo + TW - 1) / TW;
     p.tiles_y = (p.Ho + TH - 1) / TH;
     const int total = p.tiles_x * p.tiles_y * (p.Cout / BN);
     const int grid = total < n_cu ? total : n_cu;
-    if (c64) return p.mode == ST_NHWC ? launch_mode<ST_NHWC, true>(p, grid, stream) : hipErrorInvalidValue;
+    if (c64)
+        return p.mode == ST_NHWC ? launch_mode<ST_NHWC, true>(p, grid, stream)
+                                 : (p.mode == ST_PS_DOT3 ? launch_mode<ST_PS_DOT3, true>(p, grid, stream) : hipErrorInvalidValue);
     switch (p.mode) {
     case ST_NHWC: return launch_mode<ST_NHWC, false>(p, grid, stream);
     case ST_PS: return launch_mode<ST_PS, false>(p, grid, stream);

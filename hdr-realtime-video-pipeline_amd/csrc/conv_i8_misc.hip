@@ -69,7 +69,7 @@ __global__ __launch_bounds__(512) void conv1x1_i8_kernel(ConvI8Params p)
     const int kw = l15 & 7;
     const int b_lane = (wc * 64 + l15) * CT, a_lane = (wp * 64 + l15) * CT;
     // f16 output (conv9: 64 real channels in a 128-wide tile): waves whose 64 channels are padding only stage data
-    const bool live = !OUTF16 || n0 + wc * 64 < p.dstC;
+    const bool live = n0 + wc * 64 < p.dstC;
 
     issue(0, 0);
     if (nchunk > 1) issue(1, 1);
@@ -125,6 +125,7 @@ __global__ __launch_bounds__(512) void conv1x1_i8_kernel(ConvI8Params p)
         }
         return;
     }
+    if (!live) return;
     constexpr int SP = 80;
     char *stg = smem + wave * 5120;
 #pragma unroll
@@ -155,11 +156,11 @@ __global__ __launch_bounds__(512) void conv1x1_i8_kernel(ConvI8Params p)
 }  // namespace
 
 // 1x1 on int8 codes, NHWC, src0 [+ src1] channels multiples of 128, Cout multiple of 128; dst int8 codes [Hi*Wi][dstC], or
-// (out_f16) real values as f16 with dstC = the real channel count (Cout - 64 or Cout: the tile's upper half may be padding).
+// (out_f16) real values as f16; dstC = the real channel count (Cout, or Cout - 64: the last tile's upper half is padding).
 hipError_t conv1x1_i8_launch(ConvI8Params p, hipStream_t stream)
 {
     if ((p.c0 % CT) || (p.c1 % CT) || p.c0 + p.c1 < CT || (p.Cout % BN) || !p.padline || p.mode != ST_NHWC ||
-        (!p.out_f16 && p.dstC < p.Cout) || (p.out_f16 && (p.dstC % 64 || p.dstC > p.Cout || p.dstC + 64 < p.Cout)))
+        (p.dstC % 64) || (p.dstC < p.Cout && p.dstC + 64 != p.Cout))
         return hipErrorInvalidValue;
     static bool attr_set = false;
     if (!attr_set) {

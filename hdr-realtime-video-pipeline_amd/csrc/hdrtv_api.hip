@@ -292,7 +292,7 @@ bool pack_conv_i8(hdrtv_ctx *c, const Pack &pk, const std::string &key, const st
         return false;
     const int coP = (co + 127) / 128 * 128;          // conv9: 64 real output channels in a 128-wide tile
     const bool c64 = ci == 64 && ks == 3;             // pixel-pair rows: 6 row-taps of 128 bytes (conv3x3_pglds_i8.hip, C64)
-    if ((ci % 128 && !c64) || (co % 128 && (ks != 1 || out.scale > 0.f))) { c->err = "unsupported W8A8 conv shape: " + wname; return false; }
+    if ((ci % 128 && !c64) || (co % 128 && ks != 1)) { c->err = "unsupported W8A8 conv shape: " + wname; return false; }
     std::vector<float> g, be, mu, var;
     const bool has_bn = !bn_name.empty();
     if (has_bn) {
@@ -556,10 +556,9 @@ bool build_weights(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
             for (const Spec &s : fuses)
                 if (!pack_conv(c, *hg, std::string("hg.") + s.name, s.name, s.co, s.ci, 1, 1, "", 0)) return false;
         } else {
-            // W8A8 checkpoint (weights.HG_W8A8_GROUPS): conv2 .. Up_conv4 and the fuse convs conv6..9 on int8 MFMA; conv1,
-            // Up_conv5, conv10, conv_last stay fp16 (conv1 writes int8 codes of its pooled output, conv9 f16 values).  A layer's epilogue writes the codes of the layer that
+            // W8A8 checkpoint (weights.HG_W8A8_GROUPS): conv2 .. Up_conv5 and the fuse convs conv6..9 on int8 MFMA; conv1,
+            // conv10, conv_last stay fp16 (conv1 writes int8 codes of its pooled output, Up_conv5 real-valued partial sums).  A layer's epilogue writes the codes of the layer that
             // reads its output; tensors read by two layers (encoder skip) or concatenated must share one quantiser.
-            if (!pack_conv(c, *hg, "hg.Up_conv5", "Up_conv5.0", 256, 64, 3, 1, "", 64)) return false;
             struct Q8 { const char *name; int co, ci, ks, ps; const char *bn; const char *consumer; const char *shares; };
             const Q8 q8[] = {
                 {"conv2", 128, 64, 3, 0, "conv2.1", "conv3_1.0", "conv9"},
@@ -571,7 +570,8 @@ bool build_weights(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
                 {"Up_conv1", 2048, 512, 3, 512, "", "conv6", nullptr}, {"conv6", 512, 1024, 1, 0, "", "Up_conv2.0", nullptr},
                 {"Up_conv2", 2048, 512, 3, 512, "", "conv7", nullptr}, {"conv7", 256, 1024, 1, 0, "", "Up_conv3.0", nullptr},
                 {"Up_conv3", 1024, 256, 3, 256, "", "conv8", nullptr}, {"conv8", 128, 512, 1, 0, "", "Up_conv4.0", nullptr},
-                {"Up_conv4", 512, 128, 3, 128, "", "conv9", nullptr}, {"conv9", 64, 256, 1, 0, "", nullptr, nullptr}};
+                {"Up_conv4", 512, 128, 3, 128, "", "conv9", nullptr}, {"conv9", 64, 256, 1, 0, "", "Up_conv5.0", nullptr},
+                {"Up_conv5", 256, 64, 3, 64, "", nullptr, nullptr}};
             for (const Q8 &L : q8) {
                 ActQ out;
                 if (L.consumer && !read_actq(c, *hg, L.consumer, out)) return false;
@@ -766,6 +766,7 @@ int do_reserve(hdrtv_ctx *c, int H, int W)
         } else {            // W8A8: the same tensors as int8 codes (q - 128), each once
             ws_add(c, "hg8.p1", 64, Hp / 2, Wp / 2, 5);
             ws_add(c, "hg8.conv2", 128, Hp / 2, Wp / 2, 5); ws_add(c, "hg8.up4", 128, Hp / 2, Wp / 2, 5);
+            ws_add(c, "hg8.conv9", 64, Hp / 2, Wp / 2, 5);
             ws_add(c, "hg8.p3", 256, Hp / 4, Wp / 4, 5); ws_add(c, "hg8.conv3_2", 256, Hp / 4, Wp / 4, 5);
             ws_add(c, "hg8.p4", 512, Hp / 8, Wp / 8, 5); ws_add(c, "hg8.conv4_2", 512, Hp / 8, Wp / 8, 5);
             ws_add(c, "hg8.p5", 512, Hp / 16, Wp / 16, 5); ws_add(c, "hg8.conv5_2", 512, Hp / 16, Wp / 16, 5);
@@ -774,7 +775,7 @@ int do_reserve(hdrtv_ctx *c, int H, int W)
             ws_add(c, "hg8.up2", 512, Hp / 8, Wp / 8, 5); ws_add(c, "hg8.conv7", 256, Hp / 8, Wp / 8, 5);
             ws_add(c, "hg8.up3", 256, Hp / 4, Wp / 4, 5); ws_add(c, "hg8.conv8", 128, Hp / 4, Wp / 4, 5);
         }
-        ws_add(c, "hg.conv9", 64, Hp / 2, Wp / 2, 0);
+        if (!c->hg_i8) ws_add(c, "hg.conv9", 64, Hp / 2, Wp / 2, 0);
     }
     if (hipMalloc((void **)&c->ws.dev, c->ws.size + 4096) != hipSuccess) {
         c->ws.dev = nullptr;
@@ -868,7 +869,7 @@ struct Seq {
     }
     // W8A8 HG layer on int8 MFMA: 3x3 (conv3x3_pglds_i8.hip) or 1x1 (conv_i8_misc.hip)
     void conv8(const std::string &key, const int8_t *src0, int c0, const int8_t *src1, int c1, int Hi, int Wi, int mode, void *dst,
-               int dstC, int Hd, int Wd)
+               int dstC, int Hd, int Wd, const float *dotw = nullptr, float *dst_dot = nullptr)
     {
         if (!ok()) return;
         auto it = c->conv8.find(key);
@@ -882,12 +883,14 @@ struct Seq {
         p.Cout = L.cout; p.mode = mode; p.out_f16 = L.out_f16; p.dst = dst; p.dstC = dstC; p.Hd = Hd; p.Wd = Wd;
         p.padline = wtp<int8_t>(c, L.padline);
         p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
+        p.dotw = dotw; p.dst_dot = dst_dot;
         char tag[64];
-        if (L.ks == 3) snprintf(tag, sizeof tag, "conv_pglds_i8<%s%s>", mode == ST_POOL ? "pool" : (mode == ST_PS ? "ps" : "nhwc"), L.out_f16 ? ",f16" : "");
+        if (L.ks == 3) snprintf(tag, sizeof tag, "conv_pglds_i8<%s%s>", mode == ST_POOL ? "pool" : (mode == ST_PS ? "ps" : (mode == ST_PS_DOT3 ? "ps_dot3" : "nhwc")), c0 == 64 ? ",c64" : "");
         else snprintf(tag, sizeof tag, "conv1x1_i8%s", L.out_f16 ? "<f16>" : "");
         const double macs = (double)Hi * Wi * L.cin * L.ks * L.ks * L.cout_real;
         const double outel = mode == ST_POOL ? (double)Hd * Wd * L.cout_real : (double)Hi * Wi * L.cout_real;
-        const double bytes = (double)Hi * Wi * L.cin + (double)L.ks * L.ks * L.cin * L.cout + outel * (L.out_f16 ? 2.0 : 1.0);
+        const double bytes = (double)Hi * Wi * L.cin + (double)L.ks * L.ks * L.cin * L.cout +
+                             (mode == ST_PS_DOT3 ? 16.0 * Hd * Wd : outel * (L.out_f16 ? 2.0 : 1.0));
         chk(L.ks == 3 ? conv_pglds_i8_launch(p, c->n_cu, s) : conv1x1_i8_launch(p, s), key.c_str(), tag, macs, bytes);
     }
     void c3(const std::string &key, const f16 *in, int H, int W, int act, f16 *out, f16 *out_pool, float pool_q_inv = 0.f,
@@ -1053,7 +1056,6 @@ int run_hg(hdrtv_ctx *c, Seq &q, const f16 *base, void *out, int out_f32)
     f16 *img = wsp<f16>(c, "hg.img");
     uint8_t *mask = wsp<uint8_t>(c, "hg.mask");
     q.chk(hg_prep_launch(base, s.H, s.W, Hp, Wp, img, mask, 0.75f, 0.1f, q.s), "hg_prep", "hg_prep", 0.0, 13.0 * Hp * Wp);
-    f16 *c9 = wsp<f16>(c, "hg.conv9");
     float *part = wsp<float>(c, "hg.part");
     // conv1: only the pooled map is kept (conv1_out is recomputed in hg_final_fused)
     if (c->hg_i8) {
@@ -1066,7 +1068,7 @@ int run_hg(hdrtv_ctx *c, Seq &q, const f16 *base, void *out, int out_f32)
                *c5 = wsp<int8_t>(c, "hg8.conv5_2"), *pc = wsp<int8_t>(c, "hg8.pc"), *code = wsp<int8_t>(c, "hg8.conv_code2"),
                *u1 = wsp<int8_t>(c, "hg8.up1"), *c6 = wsp<int8_t>(c, "hg8.conv6"), *u2 = wsp<int8_t>(c, "hg8.up2"),
                *c7 = wsp<int8_t>(c, "hg8.conv7"), *u3 = wsp<int8_t>(c, "hg8.up3"), *c8 = wsp<int8_t>(c, "hg8.conv8"),
-               *u4q = wsp<int8_t>(c, "hg8.up4");
+               *u4q = wsp<int8_t>(c, "hg8.up4"), *c9q = wsp<int8_t>(c, "hg8.conv9");
         q.conv8("hg.conv2", p1q, 64, nullptr, 0, Hp / 2, Wp / 2, ST_NHWC, c2q, 128, Hp / 2, Wp / 2);
         q.conv8("hg.conv3_1", c2q, 128, nullptr, 0, Hp / 2, Wp / 2, ST_POOL, p3, 256, Hp / 4, Wp / 4);
         q.conv8("hg.conv3_2", p3, 256, nullptr, 0, Hp / 4, Wp / 4, ST_NHWC, c3, 256, Hp / 4, Wp / 4);
@@ -1083,9 +1085,11 @@ int run_hg(hdrtv_ctx *c, Seq &q, const f16 *base, void *out, int out_f32)
         q.conv8("hg.Up_conv3", c7, 256, nullptr, 0, Hp / 8, Wp / 8, ST_PS, u3, 256, Hp / 4, Wp / 4);
         q.conv8("hg.conv8", u3, 256, c3, 256, Hp / 4, Wp / 4, ST_NHWC, c8, 128, Hp / 4, Wp / 4);
         q.conv8("hg.Up_conv4", c8, 128, nullptr, 0, Hp / 4, Wp / 4, ST_PS, u4q, 128, Hp / 2, Wp / 2);
-        q.conv8("hg.conv9", u4q, 128, c2q, 128, Hp / 2, Wp / 2, ST_NHWC, c9, 64, Hp / 2, Wp / 2);           // -> f16 values
+        q.conv8("hg.conv9", u4q, 128, c2q, 128, Hp / 2, Wp / 2, ST_NHWC, c9q, 64, Hp / 2, Wp / 2);
+        // Up_conv5 -> pixel shuffle -> ReLU -> first half of conv10, fused: 3 partial sums per pixel leave the kernel
+        q.conv8("hg.Up_conv5", c9q, 64, nullptr, 0, Hp / 2, Wp / 2, ST_PS_DOT3, nullptr, 64, Hp, Wp, wtp<float>(c, c->hg_w10a), part);
     } else {
-        f16 *p1 = wsp<f16>(c, "hg.p1"), *c2 = wsp<f16>(c, "hg.conv2"), *u4 = wsp<f16>(c, "hg.up4");
+        f16 *p1 = wsp<f16>(c, "hg.p1"), *c2 = wsp<f16>(c, "hg.conv2"), *u4 = wsp<f16>(c, "hg.up4"), *c9 = wsp<f16>(c, "hg.conv9");
         q.c3("hg.conv1", img, Hp, Wp, ACT_RELU, nullptr, p1);
         q.conv("hg.conv2", p1, 64, nullptr, 0, Hp / 2, Wp / 2, ACT_RELU, ST_NHWC, c2, 128, Hp / 2, Wp / 2);
         f16 *p3 = wsp<f16>(c, "hg.p3"), *c3 = wsp<f16>(c, "hg.conv3_2"), *p4 = wsp<f16>(c, "hg.p4"), *c4 = wsp<f16>(c, "hg.conv4_2"),
@@ -1108,10 +1112,10 @@ int run_hg(hdrtv_ctx *c, Seq &q, const f16 *base, void *out, int out_f32)
         q.conv("hg.conv8", u3, 256, c3, 256, Hp / 4, Wp / 4, ACT_NONE, ST_NHWC, c8, 128, Hp / 4, Wp / 4);
         q.conv("hg.Up_conv4", c8, 128, nullptr, 0, Hp / 4, Wp / 4, ACT_RELU, ST_PS, u4, 128, Hp / 2, Wp / 2);
         q.conv("hg.conv9", u4, 128, c2, 128, Hp / 2, Wp / 2, ACT_NONE, ST_NHWC, c9, 64, Hp / 2, Wp / 2);
+        // Up_conv5 -> pixel shuffle -> ReLU -> first half of conv10, fused: 3 partial sums per pixel leave the kernel
+        q.conv("hg.Up_conv5", c9, 64, nullptr, 0, Hp / 2, Wp / 2, ACT_RELU, ST_PS_DOT3, nullptr, 64, Hp, Wp, nullptr, nullptr, nullptr,
+               nullptr, nullptr, wtp<float>(c, c->hg_w10a), part);
     }
-    // Up_conv5 -> pixel shuffle -> ReLU -> first half of conv10, fused: 3 partial sums per pixel leave the kernel
-    q.conv("hg.Up_conv5", c9, 64, nullptr, 0, Hp / 2, Wp / 2, ACT_RELU, ST_PS_DOT3, nullptr, 64, Hp, Wp, nullptr, nullptr, nullptr,
-           nullptr, nullptr, wtp<float>(c, c->hg_w10a), part);
     if (!q.ok()) return q.rc;
     const C3Layer &L1 = c->c3.at("hg.conv1");
     HgFinalFusedArgs fa;

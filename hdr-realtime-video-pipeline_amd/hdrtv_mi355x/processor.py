@@ -51,7 +51,7 @@ class HDRTVNetMI355X:
     stand-in of the un-shipped ``HG.pt`` (weights.seeded_hg_state); ``"seeded-w8a8:<int>"`` is that
     stand-in as a W8A8 checkpoint (weights.seeded_hg_w8a8_state).  An HG checkpoint that carries
     ``weight_int8`` / ``x_scale`` / ``x_zero`` tensors in the layout of weights.HG_W8A8_GROUPS runs its
-    17 quantised layers on int8 MFMA (BASELINE configs[4]); any other layout is rejected.  As in the reference
+    18 quantised layers on int8 MFMA (BASELINE configs[4]); any other layout is rejected.  As in the reference
     (hdrtvnet_torch.py:2065-2086): an explicit but missing path raises ``FileNotFoundError``;
     with no path given and ``use_hg=True`` the model silently continues without HG.
     ``compile_*``, ``use_cuda_graphs``, ``force_channels_last``, ``predequantize`` are accepted
@@ -361,7 +361,7 @@ class HDRTVNetMI355X:
         members = {"p1": ("hg.p1",), "conv2+up4": ("hg.conv2", "hg.up4"), "p3": ("hg.p3",), "conv3_2+up3": ("hg.conv3_2", "hg.up3"), "p4": ("hg.p4",),
                    "conv4_2+up2": ("hg.conv4_2", "hg.up2"), "p5": ("hg.p5",), "conv5_2+up1": ("hg.conv5_2", "hg.up1"),
                    "pc": ("hg.pc",), "conv_code2": ("hg.conv_code2",), "conv6": ("hg.conv6",), "conv7": ("hg.conv7",),
-                   "conv8": ("hg.conv8",)}
+                   "conv8": ("hg.conv8",), "conv9": ("hg.conv9",)}
         assert list(members) == list(_W.HG_W8A8_GROUPS)
         ranges = {g: [0.0, 0.0] for g in members}
         for f in frames:

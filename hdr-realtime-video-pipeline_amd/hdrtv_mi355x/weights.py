@@ -192,8 +192,8 @@ def synthetic_frame(h: int, w: int, seed: int = 1234, kind: str = "noise") -> np
 # The HG layers that run on int8 MFMA, with the activation tensor(s) each one reads.  Tensors that are concatenated
 # (pixel-shuffled Up_conv output + encoder skip) or read by two layers share ONE quantiser, so that each activation
 # exists once in HBM as int8: in the reference's checkpoint format (per-layer x_scale / x_zero,
-# hdrtvnet_torch.py:296-364) this is simply equal values on the layers of a group.  conv1, Up_conv5, conv10
-# and conv_last stay fp16, as the first and last layers do in the reference's mixed recipes
+# hdrtvnet_torch.py:296-364) this is simply equal values on the layers of a group.  conv1, conv10 and conv_last
+# (3-channel input / output) stay fp16, as the first and last layers do in the reference's mixed recipes
 # (configs/qat_layouts/original_hg_composite_mixed_w8a8.txt keeps 24 layers fp16).
 HG_W8A8_GROUPS = OrderedDict([
     # group (= activation tensors)      layers reading it
@@ -210,6 +210,7 @@ HG_W8A8_GROUPS = OrderedDict([
     ("conv6", ("Up_conv2.0",)),
     ("conv7", ("Up_conv3.0",)),
     ("conv8", ("Up_conv4.0",)),
+    ("conv9", ("Up_conv5.0",)),
 ])
 
 

@@ -3,7 +3,7 @@
 
 1. calibrate: activation ranges of the seeded fp32 HG head on synthetic gradient frames (the oracle evaluates the
    network; ranges go to hdrtv_mi355x/data/hg_w8a8_calib_seed1234.json, the recipe the product quantises with);
-2. golden: RUN THE REFERENCE -- its own HG_Composite with the 17 layers of weights.HG_W8A8_GROUPS replaced by its own
+2. golden: RUN THE REFERENCE -- its own HG_Composite with the 18 layers of weights.HG_W8A8_GROUPS replaced by its own
    W8A8Conv2d (hdrtvnet_torch.py:296-364, asymmetric, fp32 compute on CPU) carrying those quantiser values -- on one
    frame, and keep inputs, outputs and a few taps.
 
@@ -66,9 +66,10 @@ def calibrate():
         u3 = O._hg_up(hg, "Up_conv3", c7)
         c8 = fuse("conv8", u3, c3)
         u4 = O._hg_up(hg, "Up_conv4", c8)
+        c9 = fuse("conv9", u4, c2)
         see("p1", p1); see("conv2+up4", c2, u4); see("p3", p3); see("conv3_2+up3", c3, u3); see("p4", p4); see("conv4_2+up2", c4, u2)
         see("p5", p5); see("conv5_2+up1", c5, u1); see("pc", pc); see("conv_code2", code)
-        see("conv6", c6); see("conv7", c7); see("conv8", c8)
+        see("conv6", c6); see("conv7", c7); see("conv8", c8); see("conv9", c9)
     ranges = {g: (round(lo[g], 6), round(hi[g], 6)) for g in W.HG_W8A8_GROUPS}
     path = os.path.join(G.REPO, "hdr-realtime-video-pipeline_amd", "hdrtv_mi355x", "data", f"hg_w8a8_calib_seed{SEED}.json")
     with open(path, "w") as fjs:

@@ -49,7 +49,8 @@ def _oracle_on_base(qstate, base):
 CODE_TAPS = (("hg8.p1", "hg.p1", "conv2.0"), ("hg8.conv2", "hg.conv2", "conv3_1.0"), ("hg8.conv3_2", "hg.conv3_2", "conv4_1.0"),
              ("hg8.conv4_2", "hg.conv4_2", "conv5_1.0"), ("hg8.conv5_2", "hg.conv5_2", "conv_code1.0"),
              ("hg8.conv_code2", "hg.conv_code2", "Up_conv1.0"), ("hg8.conv6", "hg.conv6", "Up_conv2.0"),
-             ("hg8.conv7", "hg.conv7", "Up_conv3.0"), ("hg8.conv8", "hg.conv8", "Up_conv4.0"))
+             ("hg8.conv7", "hg.conv7", "Up_conv3.0"), ("hg8.conv8", "hg.conv8", "Up_conv4.0"),
+             ("hg8.conv9", "hg.conv9", "Up_conv5.0"))
 
 
 @pytest.mark.parametrize("hw,seed", [((96, 128), 3), ((80, 112), 4), ((272, 480), 11)])
@@ -84,11 +85,11 @@ LAYERS = (("conv2", ("hg8.p1",), "hg8.conv2", "block"), ("conv3_1", ("hg8.conv2"
           ("Up_conv1", ("hg8.conv_code2",), "hg8.up1", "up"), ("conv6", ("hg8.up1", "hg8.conv5_2"), "hg8.conv6", "fuse"),
           ("Up_conv2", ("hg8.conv6",), "hg8.up2", "up"), ("conv7", ("hg8.up2", "hg8.conv4_2"), "hg8.conv7", "fuse"),
           ("Up_conv3", ("hg8.conv7",), "hg8.up3", "up"), ("conv8", ("hg8.up3", "hg8.conv3_2"), "hg8.conv8", "fuse"),
-          ("Up_conv4", ("hg8.conv8",), "hg8.up4", "up"), ("conv9", ("hg8.up4", "hg8.conv2"), "hg.conv9", "fuse"))
+          ("Up_conv4", ("hg8.conv8",), "hg8.up4", "up"), ("conv9", ("hg8.up4", "hg8.conv2"), "hg8.conv9", "fuse"), ("Up_conv5", ("hg8.conv9",), "hg.part", "dot3"))
 READER = {"hg8.p3": "conv3_2.0", "hg8.conv3_2": "conv4_1.0", "hg8.p4": "conv4_2.0", "hg8.conv4_2": "conv5_1.0",
           "hg8.p5": "conv5_2.0", "hg8.conv5_2": "conv_code1.0", "hg8.pc": "conv_code2.0", "hg8.conv_code2": "Up_conv1.0",
           "hg8.up1": "conv6", "hg8.conv6": "Up_conv2.0", "hg8.up2": "conv7", "hg8.conv7": "Up_conv3.0", "hg8.up3": "conv8",
-          "hg8.conv8": "Up_conv4.0", "hg8.conv2": "conv3_1.0", "hg8.up4": "conv9", "hg8.p1": "conv2.0"}
+          "hg8.conv8": "Up_conv4.0", "hg8.conv2": "conv3_1.0", "hg8.up4": "conv9", "hg8.p1": "conv2.0", "hg8.conv9": "Up_conv5.0"}
 
 
 @pytest.mark.parametrize("hw,seed", [((96, 128), 3), ((272, 480), 11)])
@@ -115,6 +116,18 @@ def test_w8a8_layers_exact_given_device_inputs(proc_q, qstate, hw, seed):
         x = np.concatenate(xs, axis=0)
         if kind == "fuse":
             y = O.conv2d(x, q[name + ".weight"], q[name + ".bias"])
+        elif kind == "dot3":
+            # Up_conv5 + pixel shuffle + ReLU, then the first 64 input channels of conv10 (the fused epilogue): the device
+            # keeps only these three partial sums per pixel, f32 [H][W][4]
+            u5 = O._hg_up(q, name, x).astype(np.float16).astype(np.float32)
+            w10 = np.asarray(qstate["conv10.weight"], np.float32).reshape(3, 128)[:, :64]
+            y = np.tensordot(w10, u5, axes=(1, 0))
+            hp, wp = y.shape[1:]
+            got = proc_q.tap(dst).numpy().reshape(hp, wp, 4)[:, :, :3].transpose(2, 0, 1)
+            d = np.abs(got - y)
+            print(f"  {name:10s} -> {dst} (f32 partial sums): max {d.max():.3e} mean {d.mean():.3e} |ref| {np.abs(y).mean():.3e}")
+            assert d.max() <= 2e-3
+            continue
         elif kind == "up":
             y = O._hg_up(q, name, x)
         else:

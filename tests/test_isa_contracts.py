@@ -54,21 +54,21 @@ def test_pglds_i8_store_counts_match_the_counted_waits(tmp_path):
     """The int8 twin (conv3x3_pglds_i8.hip) keeps the same hand-counted scheme with its own store counts."""
     kernels = _asm("conv3x3_pglds_i8.hip", tmp_path)
     src = open(os.path.join(CSRC, "conv3x3_pglds_i8.hip")).read()
-    m = re.search(r"N = MODE == ST_POOL \? (\d+) : (\d+);", src)
+    m = re.search(r"N = \(MODE == ST_POOL \|\| MODE == ST_PS_DOT3\) \? (\d+) : (\d+);", src)
     n_pool, n_other = (int(v) for v in m.groups())
     seen = 0
     for name, body in kernels.items():
         km = re.search(r"conv_pglds_i8_kernelILi(\d+)ELb\d", name)
         if not km:
             continue
-        want = n_pool if int(km.group(1)) == 2 else n_other
+        want = n_pool if int(km.group(1)) in (2, 4) else n_other
         stores = len(re.findall(r"^\s*(?:global|buffer|flat)_store", body, re.M))
         assert stores == want, (name, stores, want)
         waits = set(int(v) for v in re.findall(r"s_waitcnt vmcnt\((\d+)\)", body))
         assert want + 2 in waits, (name, sorted(waits))
         assert "v_mfma_i32_16x16x64_i8" in body and "scratch_" not in body
         seen += 1
-    assert seen == 4
+    assert seen == 5
 
 
 def test_conv32p_asm_loads_are_read_only_after_the_wait(tmp_path):

@@ -198,7 +198,7 @@ def test_int8_fake_quant_execution(golden_dir, tag):
 
 
 def test_hg_w8a8_fake_quant_execution(golden_dir):
-    """The W8A8 HG head (17 layers of weights.HG_W8A8_GROUPS on the reference's W8A8Conv2d, asymmetric u8 activations
+    """The W8A8 HG head (18 layers of weights.HG_W8A8_GROUPS on the reference's W8A8Conv2d, asymmetric u8 activations
     with integer zero points; the recipe and the calibration table are the product's).  Golden:
     tests/golden/gen_golden_hg_w8a8.py swapped the reference's own W8A8Conv2d into its HG_Composite and ran it on CPU.
     With ATen's conv under the oracle's graph the restatement is bit-exact against that run; with the plain-C
@@ -214,7 +214,7 @@ def test_hg_w8a8_fake_quant_execution(golden_dir):
             assert k == round(k) and 0 <= k <= 255 and qs[name + ".weight_int8"].dtype == np.int8, name
             assert all(float(qs[n + ".x_scale"]) == s and float(qs[n + ".x_zero"]) == z for n in layers)
     q = O.w8a8_state(qs)
-    assert sum(1 for v in q.values() if getattr(v, "x_scale", None) is not None) == 17
+    assert sum(1 for v in q.values() if getattr(v, "x_scale", None) is not None) == 18
     steps = (("hg.conv2", 16), ("hg.conv3_2", 16), ("hg.conv5_2", 4), ("hg.conv_code2", 4), ("hg.conv6", 4),
              ("hg.conv8", 16), ("hg.conv9", 16))
 

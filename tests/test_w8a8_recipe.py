@@ -27,7 +27,7 @@ def test_hg_w8a8_state_layout_and_sharing():
     q = W.seeded_hg_w8a8_state(1234)
     assert W.is_int8_state(q) and not W.is_int8_state(fp)
     quantised = [n for layers in W.HG_W8A8_GROUPS.values() for n in layers]
-    assert len(quantised) == 17 and len(set(quantised)) == 17
+    assert len(quantised) == 18 and len(set(quantised)) == 18
     for layers in W.HG_W8A8_GROUPS.values():
         assert len({(float(q[n + ".x_scale"]), float(q[n + ".x_zero"])) for n in layers}) == 1
     for n in quantised:
