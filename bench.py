@@ -227,9 +227,10 @@ def main():
             # profile tag -> kernel name in the rocprofv3 counter CSV (template argument = store mode, common.h)
             key = {"conv_pglds<nhwc>": "conv_pglds_kernel<0>", "conv_pglds<ps>": "conv_pglds_kernel<1>",
                    "conv_pglds<pool>": "conv_pglds_kernel<2>", "conv_pglds<ps_dot3>": "conv_pglds_kernel<4>",
-                   "conv_pglds<nhwc_q8>": "conv_pglds_kernel<5>", "conv_glds1": "conv_glds1_kernel",
-                   "conv_pglds_i8<nhwc>": "conv_pglds_i8_kernel<0>", "conv_pglds_i8<ps>": "conv_pglds_i8_kernel<1>",
-                   "conv_pglds_i8<pool>": "conv_pglds_i8_kernel<2>", "conv1x1_i8": "conv1x1_i8_kernel<false>",
+                   "conv_glds1": "conv_glds1_kernel",
+                   "conv_pglds_i8<nhwc>": "conv_pglds_i8_kernel<0, false>", "conv_pglds_i8<ps>": "conv_pglds_i8_kernel<1, false>",
+                   "conv_pglds_i8<pool>": "conv_pglds_i8_kernel<2, false>", "conv_pglds_i8<nhwc,c64>": "conv_pglds_i8_kernel<0, true>",
+                   "conv_pglds_i8<ps_dot3,c64>": "conv_pglds_i8_kernel<4, true>", "conv1x1_i8": "conv1x1_i8_kernel<false>",
                    "conv1x1_i8<f16>": "conv1x1_i8_kernel<true>", "conv32p<1,sft>": "conv32p_kernel<1, true, 8>",
                    "conv32p<4,plain>": "conv32p_kernel<4, false, 8>", "conv32p<1,plain>": "conv32p_kernel<1, false, 4>",
                    "conv3x3s2_preg<192>": "conv3x3s2_preg_kernel<12>", "conv3x3s2_preg<64>": "conv3x3s2_preg_kernel<4>"}.get(kern, kern)
@@ -268,7 +269,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "p50_ms": round(p50, 3), "p99_ms": round(p99, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i8+f16" if args.int8 else "f16",
             "data": "synthetic (seeded u8 noise + gradient/highlight frames; HR.pt weights, seeded HG weights)",
-            "config": {"workload": (f"configs[4]: INT8-QAT HDRTVNet++ {Wd}x{H}: HG head W8A8 on int8 MFMA (16 layers, 80 % of the MACs), AGCM+LE int8 weights dequantised to fp16 (the reference's ROCm behaviour)"
+            "config": {"workload": (f"configs[4]: INT8-QAT HDRTVNet++ {Wd}x{H}: HG head W8A8 on int8 MFMA (18 layers, 81 % of the MACs), AGCM+LE int8 weights dequantised to fp16 (the reference's ROCm behaviour)"
                                     if args.int8 else
                                     f"configs[2]: full HDRTVNet++ fp16 {Wd}x{H} + fused RGB48 post, 1 frame per GPU per step")
                        if use_hg else f"DEBUG no-HG {Wd}x{H}",
