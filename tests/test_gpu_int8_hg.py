@@ -211,3 +211,40 @@ def test_calibrate_and_requantise_on_device(golden_dir):
     print(f"  W8A8 vs fp16 HG output: max {e.max():.3e} mean {e.mean():.3e}")
     assert e.max() <= 5e-2 and e.mean() <= 5e-4
     pq.close()
+
+
+def test_w8a8_checkpoint_file_and_loader_errors(golden_dir, tmp_path, qstate):
+    """A W8A8 HG checkpoint from a torch file in the reference's wrapper layout ({"state_dict": ...}, hdrtvnet_torch.py:1491)
+    loads through ``hg_weights=<path>``; layouts the int8 path cannot represent exactly are rejected with the layer named."""
+    import torch
+    from hdrtv_mi355x import weights as W
+    from hdrtv_mi355x.processor import HDRTVNetMI355X
+    hr = os.path.join(golden_dir, "hr_weights.hdrw")
+    path = str(tmp_path / "HG_w8a8.pt")
+    torch.save({"state_dict": {k: torch.from_numpy(np.array(v)) for k, v in qstate.items()}, "quantization": "w8a8"}, path)
+    p = HDRTVNetMI355X(hr, use_hg=True, hg_weights=path, warmup_passes=0)
+    assert p._hg_int8
+    f = W.synthetic_frame(96, 128, seed=3, kind="gradient")
+    a, _ = p.infer(p.preprocess(f))
+    a = a.clone()
+    p.close()
+    p2 = HDRTVNetMI355X(hr, use_hg=True, hg_weights="seeded-w8a8:1234", warmup_passes=0)
+    b, _ = p2.infer(p2.preprocess(f))
+    assert torch.equal(a, b)
+    p2.close()
+    # a non-integer zero point
+    bad = dict(qstate)
+    bad["Up_conv2.0.x_zero"] = np.array(float(qstate["Up_conv2.0.x_zero"]) + 0.4 * float(qstate["Up_conv2.0.x_scale"]), np.float32)
+    with pytest.raises(ValueError, match="Up_conv2.0"):
+        HDRTVNetMI355X(hr, use_hg=True, hg_weights=bad, warmup_passes=0)
+    # two readers of one tensor with different quantisers
+    bad = dict(qstate)
+    bad["conv8.x_scale"] = np.array(float(qstate["conv8.x_scale"]) * 2, np.float32)
+    with pytest.raises(ValueError, match="share"):
+        HDRTVNetMI355X(hr, use_hg=True, hg_weights=bad, warmup_passes=0)
+    # a partially quantised head (one layer left in floating point)
+    bad = {k: v for k, v in qstate.items() if not k.startswith("conv5_2.0.")}
+    bad["conv5_2.0.weight"] = W.seeded_hg_state(1234)["conv5_2.0.weight"]
+    bad["conv5_2.0.bias"] = qstate["conv5_2.0.bias"]
+    with pytest.raises(ValueError, match="conv5_2.0"):
+        HDRTVNetMI355X(hr, use_hg=True, hg_weights=bad, warmup_passes=0)
