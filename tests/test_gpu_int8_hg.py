@@ -92,7 +92,7 @@ READER = {"hg8.p3": "conv3_2.0", "hg8.conv3_2": "conv4_1.0", "hg8.p4": "conv4_2.
           "hg8.conv8": "Up_conv4.0", "hg8.conv2": "conv3_1.0", "hg8.up4": "conv9", "hg8.p1": "conv2.0", "hg8.conv9": "Up_conv5.0"}
 
 
-@pytest.mark.parametrize("hw,seed", [((96, 128), 3), ((272, 480), 11)])
+@pytest.mark.parametrize("hw,seed", [((96, 128), 3), ((272, 480), 11), ((480, 854), 99)])
 def test_w8a8_layers_exact_given_device_inputs(proc_q, qstate, hw, seed):
     """Each int8 layer in isolation: the oracle's layer (fp32 convolution of the dequantised DEVICE input codes, then
     BatchNorm / ReLU / pool / pixel shuffle and the output quantiser) against the device's output codes.  The integer
