@@ -331,7 +331,15 @@ hipError_t conv_c3_launch(const f16 *in, int H, int W, const f16 *wfrag, const f
                           int act, f16 *out, f16 *out_pool, int n_cu, hipStream_t s, float pool_q_inv, float pool_q_zero)
 {
     const int ntiles = ((W + C3_TW - 1) / C3_TW) * ((H + C3_TH - 1) / C3_TH);
-    const int per_cu = cout == 32 ? 6 : 4;                        // LDS: 22 KiB / 39 KiB per workgroup
+    // persistent: as many workgroups as are resident at once (registers: 3 / 2 per CU today), one round
+    static int occ[2] = {0, 0};
+    int &per_cu = occ[cout == 64];
+    if (per_cu == 0) {
+        int nb = 0;
+        const hipError_t e = cout == 32 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_c3_kernel<32>, 256, 0)
+                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_c3_kernel<64>, 256, 0);
+        per_cu = (e == hipSuccess && nb >= 1) ? nb : 2;
+    }
     const dim3 grid(ntiles < per_cu * n_cu ? ntiles : per_cu * n_cu);
     if (cout == 32)
         hipLaunchKernelGGL(conv_c3_kernel<32>, grid, dim3(256), 0, s, in, H, W, wfrag, scale, shift, act, out, out_pool, pool_q_inv, pool_q_zero);
@@ -356,7 +364,15 @@ hipError_t hg_final_fused_launch(const HgFinalFusedArgs &a, int n_cu, hipStream_
     p.img = a.img; p.mask = a.mask; p.part = a.part; p.wfrag = a.wfrag; p.scale = a.scale; p.shift = a.shift;
     p.b10 = a.b10; p.wl = a.wl; p.bl = a.bl; p.out = a.out; p.out_f32 = a.out_f32; p.H = a.H; p.W = a.W; p.Hp = a.Hp; p.Wp = a.Wp;
     const int ntiles = ((a.W + C3_TW - 1) / C3_TW) * ((a.H + C3_TH - 1) / C3_TH);
-    const int grid = ntiles < 4 * n_cu ? ntiles : 4 * n_cu;
+    // persistent: exactly as many workgroups as are resident at once (registers allow 3 per CU today; a 4th per CU would
+    // start when the first ones finish and run a second, mostly empty round)
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hg_final_fused_kernel, 256, 0) != hipSuccess || nb < 1) nb = 3;
+        per_cu = nb;
+    }
+    const int grid = ntiles < per_cu * n_cu ? ntiles : per_cu * n_cu;
     hipLaunchKernelGGL(hg_final_fused_kernel, dim3(grid), dim3(256), 0, s, p);
     return hipGetLastError();
 }
