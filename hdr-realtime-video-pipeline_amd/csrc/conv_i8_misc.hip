@@ -1,8 +1,8 @@
 // conv_i8_misc.hip -- conv1x1_i8, the small kernel beside conv3x3_pglds_i8.hip on the W8A8 HG path: the decoder's 1x1
 // fuse convolutions conv6 .. conv9 (Hallucination_arch.py:118-133) on v_mfma_i32_16x16x64_i8.  K = the concatenation of
 // two int8 tensors that share one quantiser, no activation; the output is re-quantised to the next layer's (signed-range)
-// codes, or -- conv9, whose reader Up_conv5 is an fp16 layer -- written as f16 values.  HBM-bound: 256 pixels x 128
-// output channels per block, 128-channel K chunks staged by LDS-DMA into a 3-deep ring, one barrier per chunk.
+// codes (or real values as f16 for an fp16 reader).  HBM-bound: 128 pixels x 128 output channels per block, 128-channel
+// K chunks staged by LDS-DMA into two stages, one barrier per chunk, two blocks per CU.
 // (The fp16 -> int8 boundary at the other end is conv2's store mode ST_NHWC_Q8, conv3x3_pglds.hip.)
 #include "launchers.h"
 
@@ -10,10 +10,12 @@ namespace {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TP = 256, BN = 128, CT = 128;           // pixels x output channels per block, K chunk (bytes per row)
-constexpr int A_BYTES = TP * CT, B_BYTES = BN * CT;   // 32 KiB + 16 KiB per stage
-constexpr int STAGE = A_BYTES + B_BYTES, NSTAGE = 3;
-constexpr int SMEM = NSTAGE * STAGE;                  // 144 KiB
+// 128 pixels x 128 output channels per block, two stages of {A 16 KiB, B 16 KiB}: 64 KiB, so TWO blocks share a CU and
+// one block's loads and stores overlap the other's MFMAs (with one 144-KiB block per CU the phases ran back to back)
+constexpr int TP = 128, BN = 128, CT = 128;           // pixels x output channels per block, K chunk (bytes per row)
+constexpr int A_BYTES = TP * CT, B_BYTES = BN * CT;   // 16 KiB + 16 KiB per stage
+constexpr int STAGE = A_BYTES + B_BYTES, NSTAGE = 2;
+constexpr int SMEM = NSTAGE * STAGE;                  // 64 KiB
 
 __device__ __forceinline__ void glds16(const void *g, void *lds)
 {
@@ -43,8 +45,8 @@ __global__ __launch_bounds__(512) void conv1x1_i8_kernel(ConvI8Params p)
         else { src = p.src1; cs = p.c1; coff = (cc - nchunk0) * CT; }
         char *sa = smem + stage * STAGE, *sb = sa + A_BYTES;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {              // 32 pieces of 8 pixel rows
-            const int piece = wave * 4 + it;
+        for (int it = 0; it < 2; ++it) {              // 16 pieces of 8 pixel rows
+            const int piece = wave * 2 + it;
             const int r = piece * 8 + l_row;
             const size_t px = px0 + r;
             const int8_t *g = px < npx ? src + px * cs + coff + ((l_slot ^ (r & 7)) << 4) : p.padline + (l_slot << 4);
@@ -59,54 +61,52 @@ __global__ __launch_bounds__(512) void conv1x1_i8_kernel(ConvI8Params p)
         }
     };
 
-    // wave tiling as in conv3x3_pglds_i8: 2 (channels) x 4 (pixel groups of 64), 4x4 tiles of 16x16 each
+    // wave tiling: 2 (channels) x 4 (pixel groups of 32), 4x2 tiles of 16x16 each
     const int wc = wave & 1, wp = wave >> 1;
-    i32x4 acc[4][4];
+    i32x4 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = i32x4{0, 0, 0, 0};
+        for (int j = 0; j < 2; ++j) acc[i][j] = i32x4{0, 0, 0, 0};
     const int kw = l15 & 7;
-    const int b_lane = (wc * 64 + l15) * CT, a_lane = (wp * 64 + l15) * CT;
+    const int b_lane = (wc * 64 + l15) * CT, a_lane = (wp * 32 + l15) * CT;
     // f16 output (conv9: 64 real channels in a 128-wide tile): waves whose 64 channels are padding only stage data
     const bool live = n0 + wc * 64 < p.dstC;
 
     issue(0, 0);
-    if (nchunk > 1) issue(1, 1);
     for (int cc = 0; cc < nchunk; ++cc) {
-        if (cc + 1 < nchunk) wait_vm<6>(); else wait_vm<0>();
-        __builtin_amdgcn_s_barrier();                 // chunk cc is in LDS for everyone; stage (cc+2)%3 is no longer read
-        if (cc + 2 < nchunk) issue(cc + 2, (cc + 2) % NSTAGE);
-        const char *a = smem + (cc % NSTAGE) * STAGE + a_lane, *b = smem + (cc % NSTAGE) * STAGE + A_BYTES + b_lane;
+        wait_vm<0>();
+        __builtin_amdgcn_s_barrier();                 // chunk cc is in LDS for everyone; the other stage is no longer read
+        if (cc + 1 < nchunk) issue(cc + 1, (cc + 1) & 1);
+        const char *a = smem + (cc & 1) * STAGE + a_lane, *b = smem + (cc & 1) * STAGE + A_BYTES + b_lane;
         if (!live) continue;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            i32x4 wf[4], xf[4];
+            i32x4 wf[4], xf[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                wf[i] = *reinterpret_cast<const i32x4 *>(b + i * 16 * CT + (((ks * 4 + kg) ^ kw) << 4));
-                xf[i] = *reinterpret_cast<const i32x4 *>(a + i * 16 * CT + (((ks * 4 + kg) ^ kw) << 4));
-            }
+            for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const i32x4 *>(b + i * 16 * CT + (((ks * 4 + kg) ^ kw) << 4));
 #pragma unroll
-            for (int m = 0; m < 16; ++m)
-                acc[m >> 2][m & 3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[m >> 2], xf[m & 3], acc[m >> 2][m & 3], 0, 0, 0);
+            for (int j = 0; j < 2; ++j) xf[j] = *reinterpret_cast<const i32x4 *>(a + j * 16 * CT + (((ks * 4 + kg) ^ kw) << 4));
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+                acc[m >> 1][m & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[m >> 1], xf[m & 1], acc[m >> 1][m & 1], 0, 0, 0);
         }
     }
     __syncthreads();                                   // LDS is free: wave-private strips for the 16-byte stores
 
-    // lane: pixel wp*64 + j*16 + l15, channels wc*64 + i*16 + 4*kg + {0..3}
+    // lane: pixel wp*32 + j*16 + l15, channels wc*64 + i*16 + 4*kg + {0..3}
     const int cw = n0 + wc * 64 + 4 * kg;
     if constexpr (OUTF16) {
         // real-valued f16 output for an fp16 consumer: no activation, no re-quantisation
         if (!live) return;
         constexpr int SPH = 144;
-        char *sth = smem + wave * (64 * SPH);
+        char *sth = smem + wave * (32 * SPH);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float4 sc = *reinterpret_cast<const float4 *>(p.scale + cw + i * 16);
             const float4 sh = *reinterpret_cast<const float4 *>(p.shift + cw + i * 16);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 2; ++j) {
                 f16x4 o;
                 o[0] = (f16)((float)acc[i][j][0] * sc.x + sh.x);
                 o[1] = (f16)((float)acc[i][j][1] * sc.y + sh.y);
@@ -118,22 +118,22 @@ __global__ __launch_bounds__(512) void conv1x1_i8_kernel(ConvI8Params p)
         const int h_px = lane >> 3, h_chunk = lane & 7;
         f16 *dsth = reinterpret_cast<f16 *>(p.dst);
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
+        for (int rr = 0; rr < 4; ++rr) {
             const f16x8 v = *reinterpret_cast<const f16x8 *>(sth + (rr * 8 + h_px) * SPH + h_chunk * 16);
-            const size_t px = px0 + wp * 64 + rr * 8 + h_px;
+            const size_t px = px0 + wp * 32 + rr * 8 + h_px;
             if (px < npx) *reinterpret_cast<f16x8 *>(dsth + px * p.dstC + n0 + wc * 64 + h_chunk * 8) = v;
         }
         return;
     }
     if (!live) return;
     constexpr int SP = 80;
-    char *stg = smem + wave * 5120;
+    char *stg = smem + wave * 2560;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float4 sc = *reinterpret_cast<const float4 *>(p.scale + cw + i * 16);
         const float4 sh = *reinterpret_cast<const float4 *>(p.shift + cw + i * 16);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 2; ++j) {
             const float q0 = fminf(fmaxf(__builtin_rintf((float)acc[i][j][0] * sc.x + sh.x), -128.f), 127.f);
             const float q1 = fminf(fmaxf(__builtin_rintf((float)acc[i][j][1] * sc.y + sh.y), -128.f), 127.f);
             const float q2 = fminf(fmaxf(__builtin_rintf((float)acc[i][j][2] * sc.z + sh.z), -128.f), 127.f);
@@ -146,9 +146,9 @@ __global__ __launch_bounds__(512) void conv1x1_i8_kernel(ConvI8Params p)
     const int s_px = lane >> 2, s_chunk = lane & 3;
     int8_t *dst = reinterpret_cast<int8_t *>(p.dst);
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
+    for (int rr = 0; rr < 2; ++rr) {
         const i32x4 v = *reinterpret_cast<const i32x4 *>(stg + (rr * 16 + s_px) * SP + s_chunk * 16);
-        const size_t px = px0 + wp * 64 + rr * 16 + s_px;
+        const size_t px = px0 + wp * 32 + rr * 16 + s_px;
         if (px < npx) *reinterpret_cast<i32x4 *>(dst + px * p.dstC + n0 + wc * 64 + s_chunk * 16) = v;
     }
 }
