@@ -74,6 +74,27 @@ __global__ __launch_bounds__(512, 1) void mfma16_i8(const f16x8 *__restrict__ sr
     if (s[0] == 123456789) dst[blockIdx.x * blockDim.x + threadIdx.x] = (float)(s[0] + s[1] + s[2] + s[3]);
 }
 
+// LDS read rate alone: every wave streams conflict-free ds_read_b128 from a 16-KiB image (the conv kernels' fragment
+// reads); calibrates SQ_LDS_IDX_ACTIVE and gives the ceiling the MFMA kernels' operand traffic is priced against
+__global__ __launch_bounds__(512, 1) void lds_read(const f16x8 *__restrict__ src, float *__restrict__ dst, int iters) {
+    __shared__ f16x8 img[1024];
+    for (int e = threadIdx.x; e < 1024; e += blockDim.x) img[e] = src[e];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 acc = {};
+    const unsigned base = (unsigned)(size_t)(&img[0]) + (unsigned)lane * 16u;      // LDS byte address of this lane's slot
+    for (int it = 0; it < iters; ++it) {
+        f32x4 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k)     // volatile asm: the compiler may neither hoist nor drop the reads
+            asm volatile("ds_read_b128 %0, %1" : "=v"(v[k]) : "v"(base + (unsigned)(((wave + k) & 15) * 1024)));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += v[k];
+    }
+    if (acc[0] == 123.456f) dst[blockIdx.x * blockDim.x + threadIdx.x] = acc[1];
+}
+
 static double run(void (*k)(const f16x8 *, float *, int), int wg, int threads, const f16x8 *src, float *dst, int iters,
                   double flop_per_wave_iter, int reps, double *ms_out) {
     hipEvent_t e0, e1;
@@ -97,6 +118,21 @@ int main() {
     f16x8 *src; float *dst;
     CK(hipMalloc(&src, 1024 * sizeof(f16x8))); CK(hipMalloc(&dst, 1 << 24));
     std::vector<_Float16> h(8192);
+    {
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int wpc : {8, 16}) {
+            const int wg = ncu * wpc / 8, iters = 20000;
+            hipLaunchKernelGGL(lds_read, dim3(wg), dim3(512), 0, 0, src, dst, iters);
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0));
+            for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(lds_read, dim3(wg), dim3(512), 0, 0, src, dst, iters);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+            const double bytes = (double)wg * 8 * iters * 16 * 1024 * 5;
+            printf("lds_read ds_read_b128 %2d waves/CU  %8.3f ms/launch  %7.1f TB/s  (%.0f B/clk/CU at 2.4 GHz)\n", wpc, ms / 5,
+                   bytes / (ms * 1e-3) / 1e12, bytes / (ms * 1e-3) / ncu / 2.4e9);
+        }
+    }
     for (int mode = 0; mode < 3; ++mode) {           // operand data: zeros / small-range activations / full random bits
         srand(7);
         for (auto &v : h) {
