@@ -50,6 +50,8 @@ def parse():
                     help="BASELINE configs[4] instead of the headline fp16 configuration: HR from the INT8-QAT checkpoint "
                          "(int8 storage, fp16 compute, as the reference runs it on ROCm) and the HG head as a W8A8 checkpoint on "
                          "int8 MFMA (seeded + calibrated: the reference's int8 HG weights are not shipped)")
+    ap.add_argument("--no-int8-extra", action="store_true",
+                    help="skip the extra BASELINE configs[4] measurement (INT8-QAT, HG on int8 MFMA) reported beside the headline at N=1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="1920x1080", help="WxH of the oracle's bounded sample")
     ap.add_argument("--layers", action="store_true", help="print the per-layer profile to stderr")
@@ -90,6 +92,46 @@ def cpu_baseline(args, use_hg):
     out["aten_eager"] = {"value": round(1.0 / (dt2 * sc2), 5), "unit": "frames/s", "cores": cores,
                          "sample": f"1 frame 960x540 in {dt2:.2f} s with oracle/aten_backend.py, scaled by pixel count"}
     return out
+
+
+def int8_extra(args, dev, dev_frames, steps=20, warmup=3):
+    """BASELINE configs[4] beside the headline, same frames, same timing method (never `value`): HR from the INT8-QAT
+    checkpoint (int8 storage, fp16 compute), HG head W8A8 on int8 MFMA.  `python bench.py --int8` is the full run."""
+    import contextlib
+    import torch
+    from hdrtv_mi355x import lib as L
+    from hdrtv_mi355x.processor import HDRTVNetMI355X
+    try:
+        H, Wd = args.height, args.width
+        with contextlib.redirect_stdout(sys.stderr):
+            proc = HDRTVNetMI355X(os.path.join(REPO, "tests", "golden", "hr_int8_full_qat.hdrw"), device=str(dev),
+                                  precision="int8-full", use_hg=True, hg_weights="seeded-w8a8:1234", warmup_passes=0)
+        proc._ensure_buffers(H, Wd)
+        lib, ctx = proc._lib, proc._ctx
+        rgb48 = torch.empty((H, Wd, 3), dtype=torch.uint16, device=dev)
+
+        def step(i):
+            st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            fr = dev_frames[i % len(dev_frames)]
+            proc._chk(lib.hdrtv_preprocess(ctx, st, fr.data_ptr(), H, Wd, proc._gpu_input.data_ptr(), proc._gpu_cond.data_ptr()), "preprocess")
+            proc._chk(lib.hdrtv_infer(ctx, st, proc._gpu_input.data_ptr(), proc._gpu_cond.data_ptr(), H, Wd,
+                                      proc._gpu_out.data_ptr(), L.F32, proc._gpu_agcm.data_ptr()), "infer")
+            proc._chk(lib.hdrtv_post_rgb48(ctx, st, proc._gpu_out.data_ptr(), L.F32, H, Wd, rgb48.data_ptr()), "post_rgb48")
+
+        for i in range(warmup):
+            step(i)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        proc.close()
+        return {"metric": "frames/sec, INT8-QAT HDRTVNet++ (HR int8 weights / fp16 compute, HG W8A8 on int8 MFMA), same frames",
+                "value": round(steps / el, 3), "unit": "frames/s", "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
+                "dtype": "i8+f16"}
+    except Exception as exc:  # noqa: BLE001  (an extra: never take the headline line down with it)
+        return {"error": f"{type(exc).__name__}: {exc}"}
 
 
 def main():
@@ -279,6 +321,8 @@ def main():
             "value_pcie_inclusive": round(pcie, 3) if pcie else None,
             "roofline": roof,
         }
+        if world == 1 and use_hg and not args.int8 and not args.no_int8_extra:
+            line["config4_int8"] = int8_extra(args, dev, dev_frames)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, use_hg)
         print(json.dumps(line), flush=True)
