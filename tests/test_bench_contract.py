@@ -1,0 +1,38 @@
+"""The bench.py output contract, checked on the lines committed under profiles/ (produced by the same bench.py on an
+MI355X; no GPU needed here): every key the driver and the judge read is present and well-formed."""
+import json
+import os
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name", ["r01_final_bench_default.json", "r01_int8_bench.json"])
+def test_committed_bench_lines_follow_the_contract(name):
+    d = json.load(open(os.path.join(REPO, "profiles", name)))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["n_gpus"] == 1 and d["value"] > 0 and abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 0.02
+    assert "workload" in d["config"] and "model" not in d["config"] and d["data"].startswith("synthetic")
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == ("GB/s" if r["bound"] == "hbm" else "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] < 1
+    assert r["traffic"] is None or r["traffic"] >= 0.9 * r["algorithmic_bytes_per_launch"]
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and 0 < c["value"] < d["value"]
+
+
+def test_bench_defaults_are_the_headline_configuration():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(REPO, "bench.py"))
+    src = open(os.path.join(REPO, "bench.py")).read()
+    assert spec is not None
+    for needle in ('"--gpus", type=int, default=1', '"--height", type=int, default=2160', '"--width", type=int, default=3840'):
+        assert needle in src, needle
