@@ -15,6 +15,8 @@ from __future__ import annotations
 
 import csv
 import os
+import queue
+import threading
 import time
 
 import numpy as np
@@ -54,6 +56,104 @@ class SyntheticSource:
 
     def release(self):
         pass
+
+
+class PinnedFrame(np.ndarray):
+    """A u8 BGR frame that lives in page-locked memory; ``pinned_tensor`` is the torch tensor sharing it
+    (HDRTVNetMI355X.preprocess uploads such a frame without the host-side copy into its own pinned slot).  When the
+    prefetcher has already uploaded it, ``device_tensor`` is the device copy and ``ready_event`` the event recorded
+    behind that upload on the prefetcher's stream."""
+    pinned_tensor = None
+    device_tensor = None
+    ready_event = None
+
+
+class PinnedPrefetch:
+    """Source wrapper: a reader thread pulls frames from ``source`` and copies them into a small pool of page-locked
+    buffers while the previous frame is on the GPU, so the 25 MB host copy of a 4K frame (2-3 ms) leaves the
+    per-frame critical path.  The reference copies into its pinned slot inside preprocess, on the caller's thread
+    (hdrtvnet_torch.py:2262-2266); here the HIP path hands the buffer over by hipMemcpyAsync + the stream order.
+    At most one frame is queued and one is being filled, so a pool of three is never overwritten while in use
+    (``_process_frame`` returns only after the frame's work has completed)."""
+
+    def __init__(self, source, pool=3, upload=True):
+        self._src = source
+        self._upload = bool(upload)       # also hipMemcpyAsync the frame to the device on a side stream (+ hipEvent)
+        self._dev = {}
+        self._stream = None
+        self.width, self.height, self.fps = source.width, source.height, source.fps
+        self.frame_count = getattr(source, "frame_count", 0)
+        self._pool_n = max(3, int(pool))
+        self._bufs = {}
+        self._q = queue.Queue(maxsize=1)
+        self._stop = threading.Event()
+        self._t = threading.Thread(target=self._run, name="hdrtv-pinned-prefetch", daemon=True)
+        self._t.start()
+
+    def _stage(self, frame, i):
+        import ctypes
+        import torch
+        key = frame.shape
+        pool = self._bufs.get(key)
+        if pool is None:
+            try:
+                pool = [torch.empty(key, dtype=torch.uint8, pin_memory=True) for _ in range(self._pool_n)]
+            except RuntimeError:          # no HIP runtime in this process (CPU-only host): frames pass through unstaged
+                pool = []
+            self._bufs[key] = pool
+        if not pool:
+            return frame
+        t = pool[i % self._pool_n]
+        src = np.ascontiguousarray(frame)
+        ctypes.memmove(t.data_ptr(), src.ctypes.data, src.nbytes)      # plain memcpy, GIL released
+        out = t.numpy().view(PinnedFrame)
+        out.pinned_tensor = t
+        if self._upload and torch.cuda.is_available():
+            dpool = self._dev.get(key)
+            if dpool is None:
+                dpool = self._dev[key] = [torch.empty(key, dtype=torch.uint8, device="cuda") for _ in range(self._pool_n)]
+                self._stream = self._stream or torch.cuda.Stream()
+            d = dpool[i % self._pool_n]
+            with torch.cuda.stream(self._stream):
+                d.copy_(t, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._stream)
+            out.device_tensor, out.ready_event = d, ev
+        return out
+
+    def _run(self):
+        i = 0
+        while not self._stop.is_set():
+            ret, frame = self._src.read()
+            item = (False, None)
+            if ret and frame is not None and frame.dtype == np.uint8 and frame.ndim == 3:
+                item = (True, self._stage(frame, i))
+                i += 1
+            elif ret:
+                item = (ret, frame)
+            while not self._stop.is_set():
+                try:
+                    self._q.put(item, timeout=0.1)
+                    break
+                except queue.Full:
+                    continue
+            if not item[0]:
+                return
+
+    def read(self):
+        if not self._t.is_alive() and self._q.empty():
+            return False, None
+        while True:
+            try:
+                return self._q.get(timeout=0.5)
+            except queue.Empty:
+                if not self._t.is_alive() and self._q.empty():
+                    return False, None
+
+    def release(self):
+        self._stop.set()
+        self._t.join(timeout=2.0)
+        self._src.release()
 
 
 class RawVideoSource:
@@ -404,11 +504,14 @@ def main(argv=None):
     ap.add_argument("--no-hg", action="store_true")
     ap.add_argument("--hg-weights", default=None, help="HG weight file, or seeded:<n>")
     ap.add_argument("--max-throughput", action="store_true", help="do not pace to the source clock")
+    ap.add_argument("--no-prefetch", action="store_true", help="copy each frame into pinned memory on the processing thread, as the reference does")
     ap.add_argument("--stride", type=int, default=1)
     ap.add_argument("--csv")
     a = ap.parse_args(argv)
     wd, ht = (int(v) for v in a.size.lower().split("x", 1))
     src = RawVideoSource(a.input, wd, ht, a.fps) if a.input else SyntheticSource(wd, ht, a.fps, a.frames)
+    if not a.no_prefetch:
+        src = PinnedPrefetch(src)
     worker = HeadlessPipelineWorker(a.weights_dir, use_hg=not a.no_hg, proc_w=wd, proc_h=ht, hg_weights=a.hg_weights,
                                     status_cb=lambda m: print(m, flush=True))
     if not worker._load_model(a.precision):

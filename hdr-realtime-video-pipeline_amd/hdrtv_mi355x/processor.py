@@ -202,9 +202,23 @@ class HDRTVNetMI355X:
         # plain memcpy into the pinned slot (GIL released).  Not tensor.copy_: ATen parallelises a 25 MB copy
         # over every OpenMP thread, whose spin-wait afterwards starves the HIP runtime's completion handling
         # (measured on the GPU box: every third 4K frame stalled ~55 ms behind a 128-thread copy).
-        src = np.ascontiguousarray(frame_bgr)
-        C.memmove(self._pin_input.data_ptr(), src.ctypes.data, src.nbytes)
-        self._gpu_raw.copy_(self._pin_input, non_blocking=True)
+        staged = getattr(frame_bgr, "pinned_tensor", None)
+        dev_copy, ready = getattr(frame_bgr, "device_tensor", None), getattr(frame_bgr, "ready_event", None)
+        if dev_copy is not None and ready is not None and dev_copy.device == self.device and tuple(dev_copy.shape) == (h, w, 3):
+            # already uploaded by the prefetcher on its own stream (hipMemcpyAsync + hipEvent handoff): wait for that
+            # event in stream order and unpack straight from its buffer
+            torch.cuda.current_stream(self.device).wait_event(ready)
+            self._chk(self._lib.hdrtv_preprocess(self._ctx, self._stream(), dev_copy.data_ptr(), h, w,
+                                                 self._gpu_input.data_ptr(), self._gpu_cond.data_ptr()), "hdrtv_preprocess")
+            return self._gpu_input, self._gpu_cond
+        if staged is not None and staged.is_pinned() and tuple(staged.shape) == (h, w, 3):
+            # the frame already lives in page-locked memory (playback.PinnedPrefetch filled it on its own thread while
+            # the previous frame was on the GPU): upload it as it is
+            self._gpu_raw.copy_(staged, non_blocking=True)
+        else:
+            src = np.ascontiguousarray(frame_bgr)
+            C.memmove(self._pin_input.data_ptr(), src.ctypes.data, src.nbytes)
+            self._gpu_raw.copy_(self._pin_input, non_blocking=True)
         self._chk(self._lib.hdrtv_preprocess(self._ctx, self._stream(), self._gpu_raw.data_ptr(), h, w,
                                              self._gpu_input.data_ptr(), self._gpu_cond.data_ptr()), "hdrtv_preprocess")
         return self._gpu_input, self._gpu_cond

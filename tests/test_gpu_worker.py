@@ -49,7 +49,8 @@ def test_worker_load_process_feed(golden_dir, tmp_path):
     w.close()
 
 
-def test_realtime_playback_into_rgb48le_sink(golden_dir, tmp_path):
+@pytest.mark.parametrize("prefetch", [False, True])
+def test_realtime_playback_into_rgb48le_sink(golden_dir, tmp_path, prefetch):
     """SURVEY 8f rows 1 + 3: source -> pacing loop -> worker -> feeder -> rgb48le byte stream, in order."""
     import io
     import time
@@ -72,7 +73,9 @@ def test_realtime_playback_into_rgb48le_sink(golden_dir, tmp_path):
     sink = P.Rgb48leSink(buf, 96, 64, 120.0)
     w._start_hdr_feeder(sink)
     got = []
-    pb = P.RealtimePlayback(w, src, sink=True, realtime=True, metrics_cb=got.append, csv_path=str(tmp_path / "m.csv"))
+    # prefetch: frames arrive page-locked and already uploaded on the prefetcher's stream (event handoff): same bytes out
+    feed = P.PinnedPrefetch(src) if prefetch else src
+    pb = P.RealtimePlayback(w, feed, sink=True, realtime=True, metrics_cb=got.append, csv_path=str(tmp_path / "m.csv"))
     t0 = time.perf_counter()
     res = pb.run()
     elapsed = time.perf_counter() - t0
@@ -86,6 +89,7 @@ def test_realtime_playback_into_rgb48le_sink(golden_dir, tmp_path):
     for i in range(12):
         assert np.array_equal(data[i], expect[i % 2]), i
     assert got and got[-1]["precision"] == "FP16" and got[-1]["proc_res"] == "96x64" and got[-1]["model_latency_ms"] > 0
+    feed.release()
     w.close()
     torch.cuda.synchronize()
 

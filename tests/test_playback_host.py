@@ -210,3 +210,28 @@ def test_objective_metrics_hook():
     r = P.RealtimePlayback(w, src, clock=clk, sleep=clk.sleep_until, gt_source=Gt(), objective_every=10, metrics_cb=got.append).run()
     assert Proc.calls == 3 and r["last_metrics"]["objective_enabled"] is True          # frames 0, 10, 20
     assert r["last_metrics"]["psnr_db"] == 43.0 and r["last_metrics"]["delta_e_itp"] == 1.5
+
+
+def test_pinned_prefetch_source_preserves_order_and_marks_frames():
+    """PinnedPrefetch: frames come back in order, as page-locked arrays that carry their tensor, and EOF is sticky."""
+    import torch
+    from hdrtv_mi355x import playback as P
+    src = P.SyntheticSource(96, 64, fps=30.0, n_frames=7, pool=4, kind="noise")
+    ref = P.SyntheticSource(96, 64, fps=30.0, n_frames=7, pool=4, kind="noise")
+    pf = P.PinnedPrefetch(src)
+    assert (pf.width, pf.height, pf.frame_count) == (96, 64, 7)
+    got = []
+    while True:
+        ok, f = pf.read()
+        if not ok:
+            break
+        if torch.cuda.is_available():               # page-locked staging needs a HIP runtime; without one frames pass through
+            assert isinstance(f, P.PinnedFrame) and isinstance(f.pinned_tensor, torch.Tensor) and f.pinned_tensor.shape == (64, 96, 3)
+            assert f.ctypes.data == f.pinned_tensor.data_ptr()
+        got.append(np.array(f))
+    assert pf.read() == (False, None)
+    pf.release()
+    assert len(got) == 7
+    for g in got:
+        ok, r = ref.read()
+        assert ok and np.array_equal(g, r)
