@@ -225,12 +225,47 @@ def main():
         n2 = max(4, min(args.steps, 12))
         t1 = time.perf_counter()
         pending = []
+        # uploads run one frame ahead on their own stream (hipMemcpyAsync + hipEvent handoff, as playback.PinnedPrefetch)
+        up_stream = torch.cuda.Stream(dev)
+        up_ev = [torch.cuda.Event() for _ in range(nfr)]
+        done_ev = [None] * nfr
+
+        def upload(i):
+            with torch.cuda.stream(up_stream):
+                if done_ev[i % nfr] is not None:
+                    up_stream.wait_event(done_ev[i % nfr])          # the slot's previous frame has been unpacked
+                dev_frames[i % nfr].copy_(pin[i % nfr], non_blocking=True)
+                up_ev[i % nfr].record(up_stream)
+
+        dn_stream = torch.cuda.Stream(dev)
+        out_dev = [torch.empty((H, Wd, 3), dtype=torch.uint16, device=dev) for _ in range(2)]
+        d2h_ev = [None, None]
+        hip = C.CDLL("libamdhip64.so")                              # torch's runtime, already loaded
+        hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        hip.hipMemcpyAsync.restype = C.c_int
+        upload(0)
         for i in range(n2):
             hp, dp = C.c_void_p(), C.c_void_p()
             slot = proc._chk(lib.hdrtv_ring_acquire(ctx, 250, C.byref(hp), C.byref(dp)), "ring_acquire")
-            dev_frames[i % nfr].copy_(pin[i % nfr], non_blocking=True)
-            step(i, dp.value)
-            proc._chk(lib.hdrtv_ring_commit(ctx, slot, stream()), "ring_commit")
+            if i + 1 < n2:
+                upload(i + 1)
+            main = torch.cuda.current_stream(dev)
+            main.wait_event(up_ev[i % nfr])
+            if d2h_ev[i % 2] is not None:
+                main.wait_event(d2h_ev[i % 2])                      # the frame that used this RGB48 buffer has left
+            step(i, out_dev[i % 2].data_ptr())
+            done_ev[i % nfr] = torch.cuda.Event()
+            done_ev[i % nfr].record(main)
+            # RGB48 leaves on the copy engine while the next frame computes (a kernel storing straight into mapped host
+            # memory holds the compute stream for ~2 ms per 4K frame)
+            dn_stream.wait_event(done_ev[i % nfr])
+            rc_cp = hip.hipMemcpyAsync(C.c_void_p(hp.value), C.c_void_p(out_dev[i % 2].data_ptr()), C.c_size_t(out_dev[i % 2].numel() * 2),
+                                       4, C.c_void_p(dn_stream.cuda_stream))
+            if rc_cp != 0:
+                raise RuntimeError(f"hipMemcpyAsync failed: {rc_cp}")
+            d2h_ev[i % 2] = torch.cuda.Event()
+            d2h_ev[i % 2].record(dn_stream)
+            proc._chk(lib.hdrtv_ring_commit(ctx, slot, C.c_void_p(dn_stream.cuda_stream)), "ring_commit")
             pending.append(slot)
             if len(pending) == 2:                      # consumer side: wait + release one frame behind
                 s0 = pending.pop(0)
