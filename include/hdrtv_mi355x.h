@@ -82,8 +82,8 @@ int hdrtv_post_u8(hdrtv_ctx *ctx, void *stream, const void *dev_out, int dtype, 
 
 /* Replaces _tensor_to_rgb48_bytes' GPU branch (gui_pipeline_worker_feeders.py:223-227):
  * fp32(x) -> clamp(0,1) -> *65535 -> +0.5 (two fp32 roundings) -> trunc u16, planar ->
- * [H][W][3] RGB little-endian (mpv "rgb48le").  dst may be device memory or a device-visible
- * pointer to pinned host memory (hdrtv_ring_* slots), making the D2H copy part of the kernel. */
+ * [H][W][3] RGB little-endian (mpv "rgb48le").  dst is device memory (e.g. a ring slot's dev_ptr;
+ * hdrtv_ring_commit then moves it to the slot's pinned host buffer as the reference's host.copy_ does, :228). */
 int hdrtv_post_rgb48(hdrtv_ctx *ctx, void *stream, const void *dev_out, int dtype, int H, int W,
                      uint16_t *dst);
 
@@ -112,13 +112,14 @@ int hdrtv_metrics(hdrtv_ctx *ctx, void *stream, const void *dev_a, const void *d
 
 /* ---- pinned host RGB48 ring: replaces _pinned_u16_host_ring / _acquire_pinned_u16_slot /
  * _PinnedMpvFrame (gui_pipeline_worker_feeders.py:38-70, 125-170).  `slots` in [2,8]
- * (HDRTVNET_FEEDER_GPU_RGB48_RING_FRAMES).  A slot cycles free -> acquired -> (kernel
- * writes, event recorded) -> waited -> released. */
+ * (HDRTVNET_FEEDER_GPU_RGB48_RING_FRAMES).  A slot cycles free -> acquired -> (kernel writes its device
+ * buffer; commit = hipMemcpyAsync to the pinned host buffer + event) -> waited -> released. */
 int hdrtv_ring_create(hdrtv_ctx *ctx, int slots, int H, int W);
-/* Returns the slot index (>=0) and its host / device-visible pointers, or HDRTV_ESTATE when no
+/* Returns the slot index (>=0), its pinned host buffer and its device staging buffer, or HDRTV_ESTATE when no
  * slot frees up within timeout_ms (reference: 250 ms, feeders.py:166). */
 int hdrtv_ring_acquire(hdrtv_ctx *ctx, int timeout_ms, uint16_t **host_ptr, uint16_t **dev_ptr);
-/* Records the slot's ready event on `stream` (after hdrtv_post_rgb48 into it). */
+/* After hdrtv_post_rgb48 into the slot's dev_ptr: enqueues the device -> pinned-host copy on `stream` and records
+ * the slot's ready event behind it. */
 int hdrtv_ring_commit(hdrtv_ctx *ctx, int slot, void *stream);
 /* Blocks the calling host thread until the slot's contents are complete (wait_ready). */
 int hdrtv_ring_wait(hdrtv_ctx *ctx, int slot);
