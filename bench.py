@@ -216,17 +216,17 @@ def main():
         p50 = float(pp.item())
     value = world * args.steps / elapsed
 
-    # ---- PCIe-inclusive variant (pinned H2D in, RGB48 straight into the pinned host ring): reported, never `value`
+    # ---- PCIe-inclusive variant (pinned H2D in, RGB48 out through the pinned host ring): reported, never `value`
     pcie = None
     if rank == 0:
         proc._chk(lib.hdrtv_ring_create(ctx, 3, H, Wd), "ring_create")
         pin = [torch.from_numpy(f).pin_memory() for f in frames]
         torch.cuda.synchronize(dev)
-        n2 = max(4, min(args.steps, 12))
-        t1 = time.perf_counter()
+        n2, nwarm = max(20, args.steps), 3
         pending = []
-        # uploads run one frame ahead on their own stream (hipMemcpyAsync + hipEvent handoff, as playback.PinnedPrefetch)
-        up_stream = torch.cuda.Stream(dev)
+        # uploads run one frame ahead on their own stream and RGB48 leaves through the ring on a copy stream
+        # (hipMemcpyAsync + hipEvent handoffs, as playback.PinnedPrefetch and the worker's feeder do)
+        up_stream, dn_stream = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
         up_ev = [torch.cuda.Event() for _ in range(nfr)]
         done_ev = [None] * nfr
 
@@ -237,19 +237,21 @@ def main():
                 dev_frames[i % nfr].copy_(pin[i % nfr], non_blocking=True)
                 up_ev[i % nfr].record(up_stream)
 
-        dn_stream = torch.cuda.Stream(dev)
         upload(0)
-        for i in range(n2):
+        t1 = None
+        for i in range(n2 + nwarm):
+            if i == nwarm:
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
             hp, dp = C.c_void_p(), C.c_void_p()
             slot = proc._chk(lib.hdrtv_ring_acquire(ctx, 250, C.byref(hp), C.byref(dp)), "ring_acquire")
-            if i + 1 < n2:
+            if i + 1 < n2 + nwarm:
                 upload(i + 1)
             main = torch.cuda.current_stream(dev)
             main.wait_event(up_ev[i % nfr])
             step(i, dp.value)                                       # RGB48 into the slot's device buffer
             done_ev[i % nfr] = torch.cuda.Event()
             done_ev[i % nfr].record(main)
-            # the slot's device -> pinned-host copy (hdrtv_ring_commit) rides a copy stream while the next frame computes
             dn_stream.wait_event(done_ev[i % nfr])
             proc._chk(lib.hdrtv_ring_commit(ctx, slot, C.c_void_p(dn_stream.cuda_stream)), "ring_commit")
             pending.append(slot)
