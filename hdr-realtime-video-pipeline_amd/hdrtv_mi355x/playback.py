@@ -81,6 +81,7 @@ class PinnedPrefetch:
         self._upload = bool(upload)       # also hipMemcpyAsync the frame to the device on a side stream (+ hipEvent)
         self._dev = {}
         self._stream = None
+        self._error = None
         self.width, self.height, self.fps = source.width, source.height, source.fps
         self.frame_count = getattr(source, "frame_count", 0)
         self._pool_n = max(3, int(pool))
@@ -122,6 +123,12 @@ class PinnedPrefetch:
         return out
 
     def _run(self):
+        try:
+            self._loop()
+        except BaseException as exc:  # noqa: BLE001  (handed to the consumer: read() re-raises it)
+            self._error = exc
+
+    def _loop(self):
         i = 0
         while not self._stop.is_set():
             ret, frame = self._src.read()
@@ -141,13 +148,14 @@ class PinnedPrefetch:
                 return
 
     def read(self):
-        if not self._t.is_alive() and self._q.empty():
-            return False, None
         while True:
             try:
-                return self._q.get(timeout=0.5)
+                return self._q.get(timeout=0.05 if not self._t.is_alive() else 0.5)
             except queue.Empty:
                 if not self._t.is_alive() and self._q.empty():
+                    if self._error is not None:
+                        err, self._error = self._error, None
+                        raise RuntimeError("frame source failed in the prefetch thread") from err
                     return False, None
 
     def release(self):

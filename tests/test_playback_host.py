@@ -235,3 +235,32 @@ def test_pinned_prefetch_source_preserves_order_and_marks_frames():
     for g in got:
         ok, r = ref.read()
         assert ok and np.array_equal(g, r)
+
+
+def test_pinned_prefetch_surfaces_source_errors():
+    """An exception in the wrapped source is not swallowed by the reader thread: read() raises."""
+    import pytest
+    from hdrtv_mi355x import playback as P
+
+    class Bad:
+        width, height, fps, frame_count = 8, 8, 30.0, 3
+
+        def __init__(self):
+            self.n = 0
+
+        def read(self):
+            self.n += 1
+            if self.n == 2:
+                raise OSError("decoder died")
+            return True, np.zeros((8, 8, 3), np.uint8)
+
+        def release(self):
+            pass
+
+    pf = P.PinnedPrefetch(Bad())
+    ok, f = pf.read()
+    assert ok and f.shape == (8, 8, 3)
+    with pytest.raises(RuntimeError, match="prefetch thread"):
+        pf.read()
+    assert pf.read() == (False, None)
+    pf.release()
