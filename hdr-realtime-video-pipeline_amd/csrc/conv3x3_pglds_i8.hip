@@ -7,7 +7,8 @@
 //     conv = x_scale * w_scale[co] * (sum c * w + (128 - k) * sum w)
 // exactly, in integers; the second term, the bias, BatchNorm and the OUTPUT tensor's quantiser are folded on the host
 // into one per-channel {scale, shift}, so the epilogue is  code = clamp(rint(acc * scale + shift), -128, 127)
-// (ReLU is the lower clamp: post-ReLU tensors have k = 0).
+// (ReLU is the lower clamp: post-ReLU tensors have k = 0).  The last quantised layer, Up_conv5, has an fp16 reader: its
+// {scale, shift} give real values and its epilogue is the f16 kernel's ST_PS_DOT3 (pixel shuffle, ReLU, 64 -> 3 dot products).
 //
 // Byte geometry is the f16 kernel's: a 128-channel int8 chunk is the same 128 B per pixel as its 64-channel f16 chunk,
 // so tile sizes, LDS images, swizzles, LDS-DMA pieces, the weight ring and every counted wait are unchanged; one
