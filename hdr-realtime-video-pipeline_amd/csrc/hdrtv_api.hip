@@ -153,6 +153,7 @@ struct hdrtv_ctx {
     size_t zeros_off = 0;                 // 256 B of zeros in the weight arena
     size_t dump_off = 0;                  // 8 KiB write-only scratch (conv32p masked lanes)
     size_t trunk_wfrag = 0, trunk_bias = 0;   // fused LE condition trunk (le_fused.hip)
+    size_t tail_wfrag = 0, tail_bias = 0;     // fused CondNet2 tail (le_fused.hip, cond_tail_kernel)
     size_t hgf_wfrag = 0, hg_w10a = 0;        // fused HG tail: conv1 + conv10(second half) fragments, conv10 first half
     // workspace
     int H = 0, W = 0;
@@ -454,6 +455,32 @@ bool pack_cond_trunk(hdrtv_ctx *c, const Pack &pk)
     return true;
 }
 
+// CondNet2's tail (1x1 64->64, LeakyReLU, 1x1 64->16) for cond_tail_kernel: 12 A fragments + 96 biases
+bool pack_cond_tail(hdrtv_ctx *c, const Pack &pk, const std::string &l1, const std::string &l2)
+{
+    std::vector<float> w1, b1, w2, b2;
+    if (!pk.get(l1 + ".weight", 64 * 64, w1, c->err) || !pk.get(l1 + ".bias", 64, b1, c->err) ||
+        !pk.get(l2 + ".weight", 16 * 64, w2, c->err) || !pk.get(l2 + ".bias", 16, b2, c->err))
+        return false;
+    std::vector<f16> fr((size_t)12 * 64 * 8, (f16)0.f);
+    std::vector<float> bias(96, 0.f);
+    for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+            const int m = lane & 31, p = 8 * (lane >> 5) + j;
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                for (int mt = 0; mt < 2; ++mt)       // layer 1 reads its operand from memory: natural k
+                    fr[((size_t)(mt * 4 + sidx) * 64 + lane) * 8 + j] = (f16)w1[(size_t)(mt * 32 + m) * 64 + 16 * sidx + p];
+                if (m < 16)                          // layer 2 reads layer 1's accumulator tiles: K-permuted
+                    fr[((size_t)(8 + sidx) * 64 + lane) * 8 + j] = (f16)w2[(size_t)m * 64 + 16 * sidx + acc_kperm16(p)];
+            }
+        }
+    for (int i = 0; i < 64; ++i) bias[i] = b1[i];
+    for (int i = 0; i < 16; ++i) bias[64 + i] = b2[i];
+    c->tail_wfrag = c->wts.put(fr.data(), fr.size() * sizeof(f16));
+    c->tail_bias = c->wts.put(bias.data(), bias.size() * 4);
+    return true;
+}
+
 bool put_f32(hdrtv_ctx *c, const Pack &pk, const std::string &key, const std::string &name, size_t numel)
 {
     std::vector<float> v;
@@ -507,10 +534,11 @@ bool build_weights(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
         return false;
 
     // ---- LE
-    if (!pack_cond_trunk(c, hr) || !pack_c3(c, hr, "le.conv_first", "LE.conv_first", 32, "")) return false;
+    if (!pack_cond_trunk(c, hr) || !pack_cond_tail(c, hr, "LE.CondNet2.2", "LE.CondNet2.4") ||
+        !pack_c3(c, hr, "le.conv_first", "LE.conv_first", 32, ""))
+        return false;
     struct Spec { const char *name; int co, ci, ks, stride, ps; };
     const Spec le_convs[] = {
-        {"LE.CondNet2.2", 64, 64, 1, 1, 0}, {"LE.CondNet2.4", 16, 64, 1, 1, 0},
         {"LE.CondNet3.4", 16, 64, 1, 1, 0}, {"LE.CondNet4.4", 16, 64, 3, 2, 0},
         {"LE.HR_conv1", 32, 32, 3, 1, 0}, {"LE.HR_conv2", 32, 32, 3, 1, 0}, {"LE.conv_last", 3, 32, 3, 1, 0},
         {"LE.down_conv1", 32, 32, 3, 2, 0}, {"LE.down_conv2", 32, 32, 3, 2, 0}, {"LE.down_conv3", 32, 32, 3, 2, 0},
@@ -738,7 +766,7 @@ int do_reserve(hdrtv_ctx *c, int H, int W)
     ws_add(c, "dbg.stamps", 8 * 8 * 512 * 2, 1, 1, 3);     // diagnostic builds only: [workgroup*NW + wave][8] u64 cycle sums
     ws_add(c, "le.cond", 64, H, W, 0);
     ws_add(c, "le.cond1", 16, H, W, 0);
-    ws_add(c, "le.x192", 192, s.H1, s.W1, 0); ws_add(c, "le.h1b", 64, s.H1, s.W1, 0);
+    ws_add(c, "le.x192", 192, s.H1, s.W1, 0);
     ws_add(c, "le.h2a", 64, s.H2, s.W2, 0); ws_add(c, "le.h2b", 64, s.H2, s.W2, 0);
     ws_add(c, "le.cond2", 16, s.H1, s.W1, 0); ws_add(c, "le.cond3", 16, s.H2, s.W2, 0); ws_add(c, "le.cond4", 16, s.H3, s.W3, 0);
     ws_add(c, "le.f0a", 32, H, W, 0); ws_add(c, "le.f0b", 32, H, W, 0); ws_add(c, "le.fea0", 32, H, W, 0);
@@ -1002,7 +1030,7 @@ int run_le(hdrtv_ctx *c, Seq &q, const f16 *img, f16 *out_planar)
     f16 *cond = wsp<f16>(c, "le.cond");
     f16 *cond1 = wsp<f16>(c, "le.cond1"), *cond2 = wsp<f16>(c, "le.cond2"), *cond3 = wsp<f16>(c, "le.cond3"),
         *cond4 = wsp<f16>(c, "le.cond4");
-    f16 *h1b = wsp<f16>(c, "le.h1b"), *h2a = wsp<f16>(c, "le.h2a");
+    f16 *h2a = wsp<f16>(c, "le.h2a");
     // condition trunk
     // cond_first (3 layers) + CondNet1 (3 layers) in one launch: img -> cond (64 ch) and cond1 (16 ch)
     if (q.ok())
@@ -1011,9 +1039,10 @@ int run_le(hdrtv_ctx *c, Seq &q, const f16 *img, f16 *out_planar)
     // CondNet2/3/4: the three 3x3/s2 first layers read `cond` once (one launch, 192 channels)
     f16 *x192 = wsp<f16>(c, "le.x192"), *h2b = wsp<f16>(c, "le.h2b");
     q.conv("LE.CondNet234.0", cond, 64, nullptr, 0, H, W, ACT_LRELU01, ST_NHWC, x192, 192, s.H1, s.W1);
-    q.conv("LE.CondNet2.2", x192, 64, nullptr, 0, s.H1, s.W1, ACT_LRELU01, ST_NHWC, h1b, 64, s.H1, s.W1, nullptr, nullptr, nullptr,
-           nullptr, nullptr, nullptr, nullptr, 192);
-    q.conv("LE.CondNet2.4", h1b, 64, nullptr, 0, s.H1, s.W1, ACT_NONE, ST_NHWC, cond2, 16, s.H1, s.W1);
+    // CondNet2.2 + .4 (1x1 64->64, LeakyReLU, 1x1 64->16) in one pass over x192's first 64 channels
+    if (q.ok())
+        q.chk(cond_tail_launch(x192, 192, (size_t)s.H1 * s.W1, wtp<f16>(c, c->tail_wfrag), wtp<float>(c, c->tail_bias), cond2, c->n_cu, q.s),
+              "LE.CondNet2.2+4", "cond_tail", (double)s.H1 * s.W1 * (64 * 64 + 64 * 16), (double)s.H1 * s.W1 * (128 + 32));
     q.conv("LE.CondNet3.2", x192 + 64, 64, nullptr, 0, s.H1, s.W1, ACT_LRELU01, ST_NHWC, h2a, 64, s.H2, s.W2, nullptr, nullptr,
            nullptr, nullptr, nullptr, nullptr, nullptr, 192);
     q.conv("LE.CondNet3.4", h2a, 64, nullptr, 0, s.H2, s.W2, ACT_NONE, ST_NHWC, cond3, 16, s.H2, s.W2);

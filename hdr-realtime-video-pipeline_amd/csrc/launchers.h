@@ -34,6 +34,8 @@ hipError_t conv_c3_launch(const f16 *in, int H, int W, const f16 *wfrag, const f
 // pool_q_inv > 0: out_pool holds int8 codes clamp(rint(v * pool_q_inv + pool_q_zero), -128, 127), COUT bytes per pixel
 hipError_t le_cond_trunk_launch(const f16 *img, int H, int W, const f16 *wfrag, const float *bias, f16 *cond, f16 *cond1,
                                 int n_cu, hipStream_t s);
+hipError_t cond_tail_launch(const f16 *x, int x_stride, size_t npx, const f16 *wfrag, const float *bias, f16 *out, int n_cu,
+                            hipStream_t s);
 hipError_t hg_prep_launch(const f16 *base, int H, int W, int Hp, int Wp, f16 *img_pad, uint8_t *mask, float r, float thresh,
                           hipStream_t s);
 struct HgFinalFusedArgs {

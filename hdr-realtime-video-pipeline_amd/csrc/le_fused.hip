@@ -194,6 +194,66 @@ __global__ __launch_bounds__(256, 2) void le_cond_trunk_kernel(const f16 *__rest
     }   // tile loop
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// CondNet2's tail (HDRUNet3T1_arch.py:47-52: 1x1 64->64, LeakyReLU(0.1), 1x1 64->16) as one pass: the 64-channel
+// intermediate never exists in HBM (two launches streamed 384 B per pixel; this one 128 B in, 32 B out).  A wave owns
+// 32-pixel groups; both weight sets live in its registers; layer 1 reads its B fragments straight from the NHWC input
+// (16 bytes per lane and k-step), layer 2 takes layer 1's accumulator tiles as operands (weights K-permuted at pack
+// time, common.h acc_kperm16), exactly as the trunk above chains its layers.
+__global__ __launch_bounds__(256) void cond_tail_kernel(const f16 *__restrict__ x, int x_stride, size_t npx,
+                                                        const f16 *__restrict__ wfrag, const float *__restrict__ bias,
+                                                        f16 *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
+    const f16x8 *fr = reinterpret_cast<const f16x8 *>(wfrag);
+    f16x8 w1[2][4], w2[4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) w1[mt][s] = fr[(mt * 4 + s) * 64 + lane];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) w2[s] = fr[(8 + s) * 64 + lane];
+    const f32x16 b1a = bias_tile_l(bias, lh), b1b = bias_tile_l(bias + 32, lh), b2 = bias_tile_l(bias + 64, lh);
+
+    const size_t ngroups = (npx + 31) / 32;
+    const size_t gstep = (size_t)gridDim.x * 4;
+    size_t g = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    auto load = [&](size_t grp, f16x8 *xf) {
+        size_t px = grp * 32 + l31;
+        if (px >= npx) px = npx - 1;                       // tail group: duplicate the last pixel, stores are masked
+        const f16 *p = x + px * x_stride + 8 * lh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) xf[s] = *reinterpret_cast<const f16x8 *>(p + 16 * s);
+    };
+    f16x8 cur[4], nxt[4];
+    if (g < ngroups) load(g, cur);
+    for (; g < ngroups; g += gstep) {
+        if (g + gstep < ngroups) load(g + gstep, nxt);
+        f32x16 h0 = b1a, h1 = b1b;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            h0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[0][s], cur[s], h0, 0, 0, 0);
+            h1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[1][s], cur[s], h1, 0, 0, 0);
+        }
+        const f16x8 bf[4] = {lrelu_pack(h0, 0), lrelu_pack(h0, 1), lrelu_pack(h1, 0), lrelu_pack(h1, 1)};
+        f32x16 o = b2;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) o = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[s], bf[s], o, 0, 0, 0);
+        // rows 0..15 live in registers 0..3 (rows 4*lh + k) and 4..7 (rows 8 + 4*lh + k)
+        const size_t px = g * 32 + l31;
+        if (px < npx) {
+            f16x4 lo, hi;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { lo[k] = (f16)o[k]; hi[k] = (f16)o[4 + k]; }
+            *reinterpret_cast<f16x4 *>(out + px * 16 + 4 * lh) = lo;
+            *reinterpret_cast<f16x4 *>(out + px * 16 + 8 + 4 * lh) = hi;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) cur[s] = nxt[s];
+    }
+}
+
 constexpr int TRUNK_SMEM = NFRAG * 64 * 16 + ((NBIAS * 4 + 15) / 16) * 16 + ((3 * T_HH * (T_HW + 2) * 2 + 15) / 16) * 16 +
                            4 * 32 * STG_ROWB;
 
@@ -212,5 +272,18 @@ hipError_t le_cond_trunk_launch(const f16 *img, int H, int W, const f16 *wfrag, 
     const int ntiles = ((W + T_TW - 1) / T_TW) * ((H + T_TH - 1) / T_TH);
     const int grid = ntiles < 2 * n_cu ? ntiles : 2 * n_cu;          // two workgroups per CU (LDS: ~60 KiB each)
     hipLaunchKernelGGL(le_cond_trunk_kernel, dim3(grid), dim3(256), TRUNK_SMEM, s, img, H, W, wfrag, bias, cond, cond1);
+    return hipGetLastError();
+}
+
+// x: NHWC with x_stride elements per pixel (the first 64 channels are read), out: NHWC 16.  wfrag: 12 fragments
+// (layer 1: 2 x 4 natural-k, layer 2: 4 K-permuted, rows 16..31 zero), bias: [64] + [32, upper half zero].
+hipError_t cond_tail_launch(const f16 *x, int x_stride, size_t npx, const f16 *wfrag, const float *bias, f16 *out, int n_cu,
+                            hipStream_t s)
+{
+    if (!npx || x_stride < 64 || (x_stride % 8)) return hipErrorInvalidValue;
+    const size_t ngroups = (npx + 31) / 32;
+    size_t grid = (ngroups + 3) / 4;
+    if (grid > (size_t)8 * n_cu) grid = (size_t)8 * n_cu;
+    hipLaunchKernelGGL(cond_tail_kernel, dim3((unsigned)grid), dim3(256), 0, s, x, x_stride, npx, wfrag, bias, out);
     return hipGetLastError();
 }
