@@ -66,6 +66,7 @@ struct ConvParams {
     const float *dotw;     // ST_PS_DOT3: [3][dstC] weights of the 1x1 conv fused behind the pixel shuffle
     float *dst_dot;        // ST_PS_DOT3: f32 [Hd][Wd][4] partial sums (x,y,z used)
     void *trash;           // conv_pglds: >= 2 KiB scratch that out-of-image lanes store to (never read)
+    int nt_slow;           // conv_pglds tile order: 0 = Cout-tile fastest (an XCD shares halos), 1 = Cout-tile slowest (shares a weight slab)
 };
 
 // Parameter block of the int8 HG convolutions (conv3x3_pglds_i8.hip, conv_i8_misc.hip).  Activations are int8 codes

@@ -185,12 +185,12 @@ hipError_t conv_glds1_launch(ConvParams p, hipStream_t stream)
     if ((p.c0 % CT) || (p.c1 % CT) || p.c0 + p.c1 < CT || (p.CoutPad % BN) || p.res1 || p.res2 || p.dst_full ||
         p.mode != ST_NHWC || !p.zeros)
         return hipErrorInvalidValue;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DevOnce attr_once;   // hipFuncSetAttribute is per (function, device)
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_glds1_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_once.done();
     }
     p.tiles_x = (p.Wo + TW - 1) / TW;
     p.tiles_y = (p.Ho + TH - 1) / TH;

@@ -26,6 +26,15 @@
 //     fragment addresses are base ^ (k-step << 5) plus immediates for kernel row and tap;
 //   * epilogue through LDS: fp32 scale/shift/activation, residual adds, PixelShuffle (one pass
 //     per sub-position for the 128-channel up-convs) or the planar 3-channel head.
+// W8A8 layers (template I8; W8A8Conv2d.forward, hdrtvnet_torch.py:351-364): the tile the conv reads is not the f16
+// halo tile but its int8 codes c = clamp(rint((x - x_zero) / x_scale), 0, 255) - 128, written by the same per-tile
+// pass that applies the SFT modulation (or, for a layer without SFT, by a pass that only quantises) into a second,
+// 32-byte-per-pixel LDS tile; the conv is 9 v_mfma_i32_32x32x32_i8 (one tap = 32 input channels = one K step) and
+// its integer sum is exact.  The reference pads with zeros AFTER dequantisation and x_zero is a float, so no code
+// means "0.0": out-of-image halo pixels hold code 0 (they add nothing to the sum) and the epilogue adds
+//     x_scale * w_scale[n] * acc + w_scale[n] * (128 * x_scale + x_zero) * sum(w_int8[n] over the IN-IMAGE taps) + b[n],
+// the second term being a per-channel constant for each of the 16 border classes (top / bottom row missing x left /
+// right column missing) that the host tabulates (hdrtv_api.hip pack_conv32_i8).
 // Out-of-image DMA lanes read the zeroed guard that the workspace keeps behind every tensor
 // (hdrtv_api.hip ws_add), so one scalar base + a 32-bit lane offset addresses every piece.
 #include <cstdlib>
@@ -43,6 +52,9 @@ namespace {
 #define STAMP_DECL
 #define STAMP(i)
 #endif
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int TW = 16, HC = TW + 2, HW = 20;
 constexpr int OUT_ROWB = 64 + 16;
@@ -88,23 +100,27 @@ __device__ __forceinline__ f16x8 lrelu_pack16(const f32x16 &a, int s)
     return __builtin_elementwise_max(o, o * (f16)0.1f);
 }
 
-template <int NPASS, bool SFT, int NW>
+template <int NPASS, bool SFT, int NW, bool I8>
 struct Lay {
     static constexpr int A_BYTES = Til<NW>::A_BYTES, C_BYTES = Til<NW>::C_BYTES, OUT_BYTES = Til<NW>::OUT_BYTES;
     static constexpr int COUTP = 32 * NPASS;
-    static constexpr int W_BYTES = 9 * COUTP * 64;
-    static constexpr int SS_BYTES = COUTP * 8;
+    static constexpr int W_BYTES = 9 * COUTP * (I8 ? 32 : 64);
+    static constexpr int SS_BYTES = I8 ? COUTP * 4 * 17 : COUTP * 8;    // I8: scale[COUTP] + shift[16 border classes][COUTP]
+    static constexpr int Q_BYTES = I8 ? Til<NW>::NG * 32 * 32 : 0;      // int8 code tile: 32 B per halo slot, whole 32-pixel groups
     static constexpr int OFF_SS = W_BYTES;
     static constexpr int OFF_A = OFF_SS + SS_BYTES;
     static constexpr int OFF_C = OFF_A + 2 * A_BYTES;
-    static constexpr int OFF_OUT = OFF_C + (SFT ? 2 * C_BYTES : 0);
+    static constexpr int OFF_Q = OFF_C + (SFT ? 2 * C_BYTES : 0);
+    static constexpr int OFF_OUT = OFF_Q + 2 * Q_BYTES;
     static constexpr int SMEM = OFF_OUT + OUT_BYTES;
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
 };
 
-template <int NPASS, bool SFT, int NW>
+template <int NPASS, bool SFT, int NW, bool I8>
 __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
 {
-    using L = Lay<NPASS, SFT, NW>;
+    using L = Lay<NPASS, SFT, NW, I8>;
+    constexpr bool PREP = SFT || I8;          // a per-tile pass over the landed halo tile exists
     using T = Til<NW>;
     constexpr int TH = T::TH, NT = T::NT, NPIX = T::NPIX, A_BYTES = T::A_BYTES, C_BYTES = T::C_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -112,6 +128,7 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
     float *sSS = reinterpret_cast<float *>(smem + L::OFF_SS);
     char *sA = smem + L::OFF_A;
     char *sC = smem + L::OFF_C;
+    char *sQ = smem + L::OFF_Q;
     char *sO = smem + L::OFF_OUT;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -161,26 +178,39 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
     };
 
     // ---- once per workgroup: the whole weight set and the per-channel scale/shift into LDS
-    for (int piece = wave; piece < 9 * L::COUTP / 16; piece += NW) {
-        const int r = piece * 16 + (lane >> 2), slot = lane & 3;     // r = tap*COUTP + n
-        const int n = r % L::COUTP;
-        glds16(p.wpk + (size_t)r * 32 + ((slot ^ swz32(n)) << 3), sW + piece * 1024);
-    }
-    for (int e = tid; e < L::COUTP; e += NT) {
-        sSS[e] = p.scale[e];
-        sSS[L::COUTP + e] = p.shift[e];
+    if constexpr (I8) {
+        // int8 weights [tap][COUTP][32 bytes, K order of the code tile]: rows of 32 B, the two 16-byte halves of row n
+        // swapped when (n >> 3) & 1 so that a 16-lane ds_read_b128 group never meets two rows 8 apart in the same half
+        for (int piece = wave; piece < 9 * L::COUTP / 32; piece += NW) {
+            const int r = piece * 32 + (lane >> 1), half = lane & 1;
+            const int n = r % L::COUTP;
+            glds16(p.wpk8 + (size_t)r * 32 + ((half ^ ((n >> 3) & 1)) << 4), sW + piece * 1024);
+        }
+        for (int e = tid; e < 17 * L::COUTP; e += NT) sSS[e] = e < L::COUTP ? p.scale[e] : p.shift[e - L::COUTP];
+    } else {
+        for (int piece = wave; piece < 9 * L::COUTP / 16; piece += NW) {
+            const int r = piece * 16 + (lane >> 2), slot = lane & 3;     // r = tap*COUTP + n
+            const int n = r % L::COUTP;
+            glds16(p.wpk + (size_t)r * 32 + ((slot ^ swz32(n)) << 3), sW + piece * 1024);
+        }
+        for (int e = tid; e < L::COUTP; e += NT) {
+            sSS[e] = p.scale[e];
+            sSS[L::COUTP + e] = p.shift[e];
+        }
     }
 
     // ---- SFT: lane constants of this wave's 32-pixel groups, fragments and biases
     f16x8 sa0, sa1s, sa1t;
     f32x16 sbh, sbs, sbt;
-    int g_pos[T::G_PW], g_c[T::G_PW], g_x[T::G_PW];
+    int g_pos[T::G_PW], g_c[T::G_PW], g_x[T::G_PW], g_q[T::G_PW];
     if (SFT) {
         const f16x8 *fr = reinterpret_cast<const f16x8 *>(p.sft_wfrag);
         sa0 = fr[lane]; sa1s = fr[64 + lane]; sa1t = fr[128 + lane];
         sbh = tile16(p.sft_bias, lh); sbs = tile16(p.sft_bias + 32, lh); sbt = tile16(p.sft_bias + 64, lh);
 #pragma unroll
         for (int k = 0; k < 16; ++k) sbs[k] += 1.f;            // (scale + 1) enters through the accumulator init
+    }
+    if (PREP) {
 #pragma unroll
         for (int gi = 0; gi < T::G_PW; ++gi) {
             const int hp = (wave + gi * NW) * 32 + l31;
@@ -188,6 +218,9 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
             g_pos[gi] = (hp < NPIX && hx < HC) ? (hy | (hx << 8)) : -1;
             g_c[gi] = hp * 32 + lh * 16;
             g_x[gi] = hp * 64 + (swz32(hx) << 4) + 8 * lh;      // channel quad qd lives at g_x ^ (qd << 4)
+            // code tile: this lane's 16 channels {8qd + 4lh + k} are ONE 16-byte half of the pixel's 32-byte row (the
+            // weights' K axis is packed in the same order); the halves swap on odd halo rows (bank conflicts, see ldfrag)
+            g_q[gi] = hp * 32 + ((lh ^ (hy & 1)) << 4);
         }
     }
     // y = x*(scale+1)+shift in place on a landed halo tile (arch_util.py:68-72)
@@ -201,23 +234,41 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
             if (wave + gi * NW < T::NG) {                      // wave-uniform
                 const bool inimg = g_pos[gi] >= 0 && (unsigned)(iy0 + (g_pos[gi] & 255)) < uH &&
                                    (unsigned)(ix0 + (g_pos[gi] >> 8)) < uW;
-                const f16x8 cf = *reinterpret_cast<const f16x8 *>(cbuf + g_c[gi]);
-                const f32x16 h = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa0, cf, sbh, 0, 0, 0);
-                const f16x8 hs = lrelu_pack16(h, 0), ht = lrelu_pack16(h, 1);
-                const f32x16 sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa1s, hs, sbs, 0, 0, 0);
-                const f32x16 sh = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa1t, ht, sbt, 0, 0, 0);
+                f32x16 sc, sh;
+                if constexpr (SFT) {
+                    const f16x8 cf = *reinterpret_cast<const f16x8 *>(cbuf + g_c[gi]);
+                    const f32x16 h = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa0, cf, sbh, 0, 0, 0);
+                    const f16x8 hs = lrelu_pack16(h, 0), ht = lrelu_pack16(h, 1);
+                    sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa1s, hs, sbs, 0, 0, 0);
+                    sh = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa1t, ht, sbt, 0, 0, 0);
+                }
                 if (g_pos[gi] >= 0) {
+                    i32x4 codes;
 #pragma unroll
                     for (int qd = 0; qd < 4; ++qd) {
                         char *addr = a + (g_x[gi] ^ (qd << 4));
-                        const f16x4 xv = *reinterpret_cast<const f16x4 *>(addr);
-                        f16x4 s1, s0;
+                        f16x4 y = *reinterpret_cast<const f16x4 *>(addr);
+                        if constexpr (SFT) {
+                            f16x4 s1, s0;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) { s1[k] = (f16)sc[4 * qd + k]; s0[k] = (f16)sh[4 * qd + k]; }
-                        f16x4 y = xv * s1 + s0;
-                        if (!inimg) { y[0] = (f16)0.f; y[1] = (f16)0.f; y[2] = (f16)0.f; y[3] = (f16)0.f; }
-                        *reinterpret_cast<f16x4 *>(addr) = y;
+                            for (int k = 0; k < 4; ++k) { s1[k] = (f16)sc[4 * qd + k]; s0[k] = (f16)sh[4 * qd + k]; }
+                            y = y * s1 + s0;
+                        }
+                        if constexpr (I8) {
+                            // u8 code q = clamp(rint((y - x_zero) / x_scale), 0, 255) as one FMA + rint + saturating pack
+                            unsigned w = 0;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float tq = __builtin_rintf(__builtin_fmaf((float)y[k], p.q_inv, p.q_zoff));
+                                w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(tq, 0.f, 255.f), k, w);
+                            }
+                            codes[qd] = inimg ? (int)(w ^ p.q_flip) : 0;     // q - 128 (asymmetric) / two's complement byte (symmetric)
+                        } else {
+                            if (!inimg) { y[0] = (f16)0.f; y[1] = (f16)0.f; y[2] = (f16)0.f; y[3] = (f16)0.f; }
+                            *reinterpret_cast<f16x4 *>(addr) = y;
+                        }
                     }
+                    if constexpr (I8) *reinterpret_cast<i32x4 *>(sQ + buf * L::Q_BYTES + g_q[gi]) = codes;
                 }
             }
         }
@@ -229,7 +280,7 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
     if (t < ntiles) issue_tile(t, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (SFT && t < ntiles) sft_tile(t, 0);
+    if (PREP && t < ntiles) sft_tile(t, 0);
     if (t + step < ntiles) issue_tile(t + step, 1);
     __syncthreads();
 
@@ -387,7 +438,7 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
         // prefetched residuals -- which would park the store phase on the DMA) and BEFORE the SFT of
         // tile t+1, so it has a whole tile period to land
         if (t + 2 * step < ntiles) issue_tile(t + 2 * step, buf);
-        if (SFT && t + step < ntiles) sft_tile(t + step, buf ^ 1);
+        if (PREP && t + step < ntiles) sft_tile(t + step, buf ^ 1);
         STAMP(6);      // SFT of the next tile
         __syncthreads();
     }
@@ -401,12 +452,12 @@ template <int NPASS, bool SFT, int NW>
 hipError_t launch_t(const Conv32Params &p, int n_cu, hipStream_t s)
 {
     using L = Lay<NPASS, SFT, NW>;
-    static bool attr_set = false;
+    static DevOnce attr_once;   // hipFuncSetAttribute is per (function, device)
     auto kern = conv32p_kernel<NPASS, SFT, NW>;
-    if (!attr_set) {
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L::SMEM);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_once.done();
     }
     const int ntiles = p.tiles_x * p.tiles_y;
     const long cap = (long)n_cu * (160 * 1024 / L::SMEM);  // persistent: as many workgroups as fit the chip

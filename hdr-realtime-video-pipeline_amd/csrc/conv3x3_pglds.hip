@@ -73,7 +73,8 @@ __global__ __launch_bounds__(512) void conv_pglds_kernel(ConvParams p)
     if (ntile == 0) return;
     auto decode = [&](int t) {
         Tile o;
-        const int nt_i = t % ntn, sp = t / ntn;
+        const int nsp = p.tiles_x * p.tiles_y;
+        const int nt_i = p.nt_slow ? t / nsp : t % ntn, sp = p.nt_slow ? t - nt_i * nsp : t / ntn;
         const int ty = sp / p.tiles_x, tx = sp - ty * p.tiles_x;
         o.n0 = nt_i * BN; o.oy0 = ty * TH; o.ox0 = tx * TW;
         return o;
@@ -342,12 +343,12 @@ __global__ __launch_bounds__(512) void conv_pglds_kernel(ConvParams p)
 template <int MODE>
 hipError_t launch_mode(const ConvParams &p, int grid, hipStream_t stream)
 {
-    static bool attr_set = false;
+    static DevOnce attr_once;   // hipFuncSetAttribute is per (function, device)
     auto kern = conv_pglds_kernel<MODE>;
-    if (!attr_set) {
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_once.done();
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), SMEM, stream, p);
     return hipGetLastError();

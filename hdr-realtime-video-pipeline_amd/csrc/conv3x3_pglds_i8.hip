@@ -358,12 +358,12 @@ __global__ __launch_bounds__(512) void conv_pglds_i8_kernel(ConvI8Params p)
 template <int MODE, bool C64>
 hipError_t launch_mode(const ConvI8Params &p, int grid, hipStream_t stream)
 {
-    static bool attr_set = false;
+    static DevOnce attr_once;   // hipFuncSetAttribute is per (function, device)
     auto kern = conv_pglds_i8_kernel<MODE, C64>;
-    if (!attr_set) {
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_once.done();
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), SMEM, stream, p);
     return hipGetLastError();

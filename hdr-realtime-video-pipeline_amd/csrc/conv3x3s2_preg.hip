@@ -148,12 +148,12 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3s2_preg_kernel(ConvParams p
 template <int NW>
 hipError_t launch_s2(ConvParams p, int n_cu, hipStream_t s)
 {
-    static bool attr_set = false;
+    static DevOnce attr_once;   // hipFuncSetAttribute is per (function, device)
     auto kern = conv3x3s2_preg_kernel<NW>;
-    if (!attr_set) {
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_once.done();
     }
     const int ntiles = p.tiles_x * p.tiles_y;
     hipLaunchKernelGGL(kern, dim3(ntiles < n_cu ? ntiles : n_cu), dim3(64 * NW), SMEM, s, p);

@@ -162,15 +162,15 @@ hipError_t conv1x1_i8_launch(ConvI8Params p, hipStream_t stream)
     if ((p.c0 % CT) || (p.c1 % CT) || p.c0 + p.c1 < CT || (p.Cout % BN) || !p.padline || p.mode != ST_NHWC ||
         (p.dstC % 64) || (p.dstC < p.Cout && p.dstC + 64 != p.Cout))
         return hipErrorInvalidValue;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DevOnce attr_once;   // hipFuncSetAttribute is per (function, device)
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_i8_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_i8_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_once.done();
     }
     const size_t npx = (size_t)p.Hi * p.Wi;
     const int grid = (int)((npx + TP - 1) / TP) * (p.Cout / BN);

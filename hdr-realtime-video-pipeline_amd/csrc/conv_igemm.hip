@@ -326,13 +326,13 @@ template <int CIN_T, int BN, int KS, int S>
 hipError_t launch_cfg(const ConvParams &p, hipStream_t stream)
 {
     using C = Cfg<CIN_T, BN, KS, S>;
-    static bool attr_set = false;
+    static DevOnce attr_once;   // hipFuncSetAttribute is per (function, device)
     auto kern = conv_igemm_kernel<CIN_T, BN, KS, S>;
-    if (!attr_set) {
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_once.done();
     }
     const int grid = p.tiles_x * p.tiles_y * (p.CoutPad / BN);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::SMEM, stream, p);

@@ -54,7 +54,16 @@ struct Pack {
             uint64_t off, nb;
             memcpy(&dt, r + 96, 4); memcpy(&nd, r + 100, 4); memcpy(d, r + 104, 16);
             memcpy(&off, r + 120, 8); memcpy(&nb, r + 128, 8);
-            if (off + nb > bytes || nd > 4) { err = std::string("weight pack truncated: ") + name; return false; }
+            // the blob crosses the C ABI: every table field is checked before anything is read through it
+            if (off > bytes || nb > bytes - off || nd > 4) { err = std::string("weight pack truncated: ") + name; return false; }
+            if (dt > 3) { err = std::string("weight pack: bad dtype for ") + name; return false; }
+            static const size_t esz[4] = {4, 2, 1, 8};
+            uint64_t numel = 1;
+            for (uint32_t k = 0; k < nd; ++k) {
+                if (d[k] == 0 || d[k] > (1u << 28) || numel > (1ull << 40) / d[k]) { err = std::string("weight pack: bad shape for ") + name; return false; }
+                numel *= d[k];
+            }
+            if (nb != numel * esz[dt]) { err = std::string("weight pack: size does not match shape for ") + name; return false; }
             pe.dtype = (int)dt; pe.ndim = (int)nd;
             for (int k = 0; k < 4; ++k) pe.dims[k] = (int)d[k];
             pe.data = b + off; pe.nbytes = nb;
@@ -146,6 +155,7 @@ struct hdrtv_ctx {
     std::map<std::string, ConvLayer> conv;
     std::map<std::string, C3Layer> c3;
     std::map<std::string, ConvI8Layer> conv8;
+    float mask_r = 0.75f;                 // HG_Composite(mask_r=0.75), HG_Composite_arch.py:21
     bool hg_i8 = false;                   // the HG pack is a W8A8 checkpoint: 15 layers run on int8 MFMA
     float hg_q0_inv = 0.f, hg_q0_zero = 0.f;   // quantiser of the fp16 -> int8 boundary (conv2's output)
     std::map<std::string, SftLayer> sft;
@@ -734,8 +744,12 @@ int do_reserve(hdrtv_ctx *c, int H, int W)
     // InstanceNorm2d needs more than one spatial element at the 4th classifier block (the reference raises
     // ValueError there too: torch/nn/functional.py _verify_spatial_size)
     if (s.ch[4] * s.cw[4] < 2) return fail(c, HDRTV_EINVAL, "frame %dx%d too small for the AGCM classifier", W, H);
+    // F.pad(mode="reflect") (HG_Composite_arch.py:97-103) needs the padding to be smaller than the dimension; torch raises
+    if (c->has_hg && (s.Hp - H >= H || s.Wp - W >= W))
+        return fail(c, HDRTV_EINVAL, "frame %dx%d too small for the HG head's reflect padding to a multiple of 32", W, H);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipDeviceSynchronize());
+    c->H = c->W = 0;                       // no valid workspace until every step below has succeeded
     if (c->ws.dev) { (void)hipFree(c->ws.dev); c->ws.dev = nullptr; }
     c->ws = Arena();
     c->t.clear();
@@ -811,13 +825,18 @@ int do_reserve(hdrtv_ctx *c, int H, int W)
         c->H = c->W = 0;
         return fail(c, HDRTV_ENOMEM, "workspace allocation of %zu bytes failed", c->ws.size);
     }
-    HIPCHK(c, hipMemset(c->ws.dev, 0, c->ws.size + 4096));
-    HIPCHK(c, hipMemcpy(wsp<float>(c, "aa.wx"), wx.data(), wx.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(wsp<float>(c, "aa.wy"), wy.data(), wy.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(wsp<int>(c, "aa.xmn"), xmn.data(), xmn.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(wsp<int>(c, "aa.xns"), xns.data(), xns.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(wsp<int>(c, "aa.ymn"), ymn.data(), ymn.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(wsp<int>(c, "aa.yns"), yns.data(), yns.size() * 4, hipMemcpyHostToDevice));
+    hipError_t e = hipMemset(c->ws.dev, 0, c->ws.size + 4096);
+    auto up = [&](const char *name, const void *src, size_t bytes) {
+        if (e == hipSuccess) e = hipMemcpy(wsp<char>(c, name), src, bytes, hipMemcpyHostToDevice);
+    };
+    up("aa.wx", wx.data(), wx.size() * 4); up("aa.wy", wy.data(), wy.size() * 4);
+    up("aa.xmn", xmn.data(), xmn.size() * 4); up("aa.xns", xns.data(), xns.size() * 4);
+    up("aa.ymn", ymn.data(), ymn.size() * 4); up("aa.yns", yns.data(), yns.size() * 4);
+    if (e != hipSuccess) {                 // leave no half-initialised workspace behind a size that looks reserved
+        (void)hipFree(c->ws.dev);
+        c->ws.dev = nullptr;
+        return fail(c, HDRTV_EHIP, "workspace initialisation failed: %s", hipGetErrorString(e));
+    }
     c->H = H; c->W = W;
     return HDRTV_OK;
 }
@@ -879,6 +898,8 @@ struct Seq {
         const bool pglds = g64 && L.ks == 3 && L.cout == L.coutPad;      // HG 3x3 convs: persistent LDS-DMA kernel
         const bool glds1 = g64 && L.ks == 1 && mode == ST_NHWC;          // HG 1x1 fuse convs
         p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
+        static const int nt_slow = [] { const char *e = getenv("HDRTV_PGLDS_NT_SLOW"); return e ? atoi(e) : 0; }();
+        p.nt_slow = nt_slow == 2 ? (L.coutPad >= 512) : nt_slow;
         const bool s2g = L.ks == 3 && L.stride == 2 && L.cin_t == 64 && L.bn == L.coutPad && (L.coutPad == 64 || L.coutPad == 192);
         char tag[64];
         if (s2g) snprintf(tag, sizeof tag, "conv3x3s2_preg<%d>", L.coutPad);
@@ -1085,7 +1106,7 @@ int run_hg(hdrtv_ctx *c, Seq &q, const f16 *base, void *out, int out_f32)
     const int Hp = s.Hp, Wp = s.Wp;
     f16 *img = wsp<f16>(c, "hg.img");
     uint8_t *mask = wsp<uint8_t>(c, "hg.mask");
-    q.chk(hg_prep_launch(base, s.H, s.W, Hp, Wp, img, mask, 0.75f, 0.1f, q.s), "hg_prep", "hg_prep", 0.0, 13.0 * Hp * Wp);
+    q.chk(hg_prep_launch(base, s.H, s.W, Hp, Wp, img, mask, c->mask_r, 0.1f, q.s), "hg_prep", "hg_prep", 0.0, 13.0 * Hp * Wp);
     float *part = wsp<float>(c, "hg.part");
     // conv1: only the pooled map is kept (conv1_out is recomputed in hg_final_fused)
     if (c->hg_i8) {
@@ -1218,6 +1239,14 @@ int hdrtv_destroy(hdrtv_ctx *c)
 
 int hdrtv_has_hg(const hdrtv_ctx *c) { return c && c->has_hg ? 1 : 0; }
 
+int hdrtv_set_hg_mask_r(hdrtv_ctx *c, float r)
+{
+    if (!c) return HDRTV_EINVAL;
+    if (!(r >= 0.f && r < 1.f)) return fail(c, HDRTV_EINVAL, "mask_r must be in [0, 1)");
+    c->mask_r = r;
+    return HDRTV_OK;
+}
+
 int hdrtv_reserve(hdrtv_ctx *c, int H, int W)
 {
     if (!c) return HDRTV_EINVAL;
@@ -1229,6 +1258,7 @@ int hdrtv_preprocess(hdrtv_ctx *c, void *stream, const uint8_t *bgr, int H, int 
 {
     if (!c || !bgr || !rgb || !cond) return fail(c, HDRTV_EINVAL, "null argument");
     if (c->H != H || c->W != W || !c->ws.dev) return fail(c, HDRTV_ESTATE, "call hdrtv_reserve(%d,%d) first", H, W);
+    HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     Seq q{c, s};
     q.chk(pre_unpack_launch(bgr, (f16 *)rgb, H, W, s), "pre_unpack");
@@ -1246,6 +1276,7 @@ int hdrtv_infer(hdrtv_ctx *c, void *stream, const void *rgb, const void *cond, i
     if (c->H != H || c->W != W || !c->ws.dev) return fail(c, HDRTV_ESTATE, "call hdrtv_reserve(%d,%d) first", H, W);
     if (out_dtype != HDRTV_F16 && out_dtype != HDRTV_F32) return fail(c, HDRTV_EINVAL, "bad out_dtype");
     if (!c->has_hg && out_dtype != HDRTV_F16) return fail(c, HDRTV_EINVAL, "the no-HG model returns f16");
+    HIPCHK(c, hipSetDevice(c->device));
     Seq q{c, (hipStream_t)stream};
     c->launches = 0;
     c->macs = 0.0;
@@ -1262,6 +1293,7 @@ int hdrtv_infer(hdrtv_ctx *c, void *stream, const void *rgb, const void *cond, i
 int hdrtv_post_u8(hdrtv_ctx *c, void *stream, const void *in, int dtype, int H, int W, uint8_t *bgr)
 {
     if (!c || !in || !bgr || H <= 0 || W <= 0) return fail(c, HDRTV_EINVAL, "bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
     hipError_t e = post_u8_launch(in, dtype == HDRTV_F32, H, W, bgr, (hipStream_t)stream);
     return e == hipSuccess ? HDRTV_OK : fail(c, HDRTV_EHIP, "post_u8: %s", hipGetErrorString(e));
 }
@@ -1269,6 +1301,7 @@ int hdrtv_post_u8(hdrtv_ctx *c, void *stream, const void *in, int dtype, int H, 
 int hdrtv_post_rgb48(hdrtv_ctx *c, void *stream, const void *in, int dtype, int H, int W, uint16_t *dst)
 {
     if (!c || !in || !dst || H <= 0 || W <= 0) return fail(c, HDRTV_EINVAL, "bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
     hipError_t e = post_rgb48_launch(in, dtype == HDRTV_F32, H, W, dst, 0, 0.f, (hipStream_t)stream);
     return e == hipSuccess ? HDRTV_OK : fail(c, HDRTV_EHIP, "post_rgb48: %s", hipGetErrorString(e));
 }
@@ -1276,6 +1309,7 @@ int hdrtv_post_rgb48(hdrtv_ctx *c, void *stream, const void *in, int dtype, int 
 int hdrtv_post_pq_rgb48(hdrtv_ctx *c, void *stream, const void *in, int dtype, int H, int W, float peak_nits, uint16_t *dst)
 {
     if (!c || !in || !dst || H <= 0 || W <= 0 || !(peak_nits > 0.f)) return fail(c, HDRTV_EINVAL, "bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
     hipError_t e = post_rgb48_launch(in, dtype == HDRTV_F32, H, W, dst, 1, peak_nits, (hipStream_t)stream);
     return e == hipSuccess ? HDRTV_OK : fail(c, HDRTV_EHIP, "post_pq_rgb48: %s", hipGetErrorString(e));
 }
@@ -1426,14 +1460,24 @@ int hdrtv_ring_create(hdrtv_ctx *c, int slots, int H, int W)
     std::lock_guard<std::mutex> lk(c->ring_mu);
     const size_t bytes = (size_t)H * W * 3 * 2;
     c->ring.resize(slots);
+    hipError_t e = hipSuccess;
     for (auto &sl : c->ring) {
         // The post kernel writes device memory and hdrtv_ring_commit moves it with hipMemcpyAsync: a kernel storing
         // straight into mapped host memory holds CUs for ~2 ms per 4K frame at PCIe speed, which the persistent
         // one-workgroup-per-CU convolutions of the next frame then wait for (measured: 75 -> 82 frames/s end to end)
-        HIPCHK(c, hipHostMalloc((void **)&sl.host, bytes, hipHostMallocPortable));
-        HIPCHK(c, hipMalloc((void **)&sl.dev, bytes));
-        HIPCHK(c, hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+        if (e == hipSuccess) e = hipHostMalloc((void **)&sl.host, bytes, hipHostMallocPortable);
+        if (e == hipSuccess) e = hipMalloc((void **)&sl.dev, bytes);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming);
         sl.state = 0;
+    }
+    if (e != hipSuccess) {                 // free the slots that were created before the failure
+        for (auto &sl : c->ring) {
+            if (sl.ev) (void)hipEventDestroy(sl.ev);
+            if (sl.host) (void)hipHostFree(sl.host);
+            if (sl.dev) (void)hipFree(sl.dev);
+        }
+        c->ring.clear();
+        return fail(c, HDRTV_EHIP, "ring: allocation failed: %s", hipGetErrorString(e));
     }
     c->ring_next = 0; c->ring_H = H; c->ring_W = W;
     return HDRTV_OK;

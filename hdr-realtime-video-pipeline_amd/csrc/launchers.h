@@ -2,6 +2,15 @@
 #pragma once
 #include "common.h"
 
+// One-time per-kernel setup (hipFuncSetAttribute) is a property of (function, device), not of the process: a process
+// that holds contexts on several devices must repeat it on each.  Races are benign (the setup is idempotent).
+struct DevOnce {
+    unsigned char set[64] = {};
+    static int cur() { int d = 0; return hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64 ? d : 0; }
+    bool need() const { return !set[cur()]; }
+    void done() { set[cur()] = 1; }
+};
+
 hipError_t conv_igemm_launch(ConvParams p, int cin_t, int bn, int ks, int stride, hipStream_t stream);
 hipError_t conv_glds1_launch(ConvParams p, hipStream_t stream);
 hipError_t conv_pglds_launch(ConvParams p, int n_cu, hipStream_t stream);

@@ -262,12 +262,12 @@ constexpr int TRUNK_SMEM = NFRAG * 64 * 16 + ((NBIAS * 4 + 15) / 16) * 16 + ((3 
 hipError_t le_cond_trunk_launch(const f16 *img, int H, int W, const f16 *wfrag, const float *bias, f16 *cond, f16 *cond1,
                                 int n_cu, hipStream_t s)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DevOnce attr_once;   // hipFuncSetAttribute is per (function, device)
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(le_cond_trunk_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, TRUNK_SMEM);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_once.done();
     }
     const int ntiles = ((W + T_TW - 1) / T_TW) * ((H + T_TH - 1) / T_TH);
     const int grid = ntiles < 2 * n_cu ? ntiles : 2 * n_cu;          // two workgroups per CU (LDS: ~60 KiB each)

@@ -393,6 +393,10 @@ class HDRTVNetMI355X:
             raise RuntimeError("hg_w8a8_checkpoint needs a model loaded with floating-point HG weights")
         return _W.hg_w8a8_state(self._hg_state_fp, ranges)
 
+    def set_hg_mask_r(self, r=0.75):
+        """``HG_Composite(mask_r=...)`` (HG_Composite_arch.py:21): threshold base of the highlight mask."""
+        self._chk(self._lib.hdrtv_set_hg_mask_r(self._ctx, float(r)), "hdrtv_set_hg_mask_r")
+
     def profile_enable(self, on=True):
         """Per-launch HIP-event timing of subsequent infer() calls (bench.py roofline)."""
         self._chk(self._lib.hdrtv_profile_enable(self._ctx, 1 if on else 0), "hdrtv_profile_enable")

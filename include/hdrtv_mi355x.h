@@ -53,6 +53,10 @@ int hdrtv_destroy(hdrtv_ctx *ctx);
 /* 1 if the context was created with HG weights. */
 int hdrtv_has_hg(const hdrtv_ctx *ctx);
 
+/* HG_Composite(mask_r=0.75) (HG_Composite_arch.py:21, 78-84): the highlight mask is max_c(base) > r + 0.1 * (1 - r).
+ * The reference fixes r at construction; 0 <= r < 1.  Takes effect at the next hdrtv_infer. */
+int hdrtv_set_hg_mask_r(hdrtv_ctx *ctx, float r);
+
 /* Replaces HDRTVNetTorch._ensure_buffers (hdrtvnet_torch.py:2198-2233): (re)allocates the
  * internal activation workspace for H x W frames.  No-op when the size is unchanged.
  * Synchronises the device when it reallocates. */

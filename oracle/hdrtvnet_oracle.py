@@ -400,7 +400,7 @@ def hr_forward(sd, tensor, cond, taps=None):
 
 
 # --------------------------------------------------------------------------- HG
-def hg_mask(base, r=0.75, thresh=0.1):
+def hg_mask(base, r=0.75, thresh=0.1):  # noqa: D401  (r = HG_Composite(mask_r))
     """HG_Composite._make_mask, HG_Composite_arch.py:78-84."""
     m = base.max(axis=0, keepdims=True)
     m = ((m - np.float32(r)) / np.float32(1.0 - r)).astype(np.float32)
@@ -442,7 +442,8 @@ def hg_generator(hg, img, mask, taps=None):
     c7 = tap("hg.conv7", fuse("conv7", _hg_up(hg, "Up_conv2", c6), c4))
     c8 = tap("hg.conv8", fuse("conv8", _hg_up(hg, "Up_conv3", c7), c3))
     c9 = tap("hg.conv9", fuse("conv9", _hg_up(hg, "Up_conv4", c8), c2))
-    c10 = tap("hg.conv10", fuse("conv10", _hg_up(hg, "Up_conv5", c9), c1))
+    up5 = tap("hg.up5", _hg_up(hg, "Up_conv5", c9))
+    c10 = tap("hg.conv10", fuse("conv10", up5, c1))
     out = fuse("conv_last", c10, img)
     return (mask * out + img).astype(np.float32)
 

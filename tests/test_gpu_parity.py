@@ -81,7 +81,7 @@ def test_pre_exact_and_cond(proc_hr, golden_dir, torch_cuda):
     assert np.abs(c.cpu().numpy()[0].astype(np.float32) - ref.astype(np.float32)).max() <= 1e-3
 
 
-@pytest.mark.parametrize("hw", [(64, 96), (61, 103), (1080, 1920)])
+@pytest.mark.parametrize("hw", [(64, 96), (61, 103), (1080, 1920), (2160, 3840)])
 def test_post_quantisers_exact(proc_hr, torch_cuda, golden_dir, hw):
     """fp32 and fp16 inputs through post_u8 / post_rgb48 vs the oracle: exact integers."""
     import ctypes as C
@@ -340,3 +340,66 @@ def test_full_hd_hg_vs_oracle(proc_hg, hr_state, hg_state):
         assert mx <= tol and mean <= tol / 20, name
     mx, mean = _stats("hg out 1080x1920", out.cpu().numpy()[0], ref)
     assert mx <= 3e-3 and mean <= 1e-4
+    # LE itself at this size (multi-tile persistent schedule of every LE kernel) against the oracle's whole HR forward
+    rt, rc = O.preprocess(f)
+    rbase, ragcm = O.hr_forward(hr_state, rt, rc)
+    mx, mean = _stats("le.out 1080x1920 vs O.hr_forward", base, rbase)
+    assert mx <= OUT_MAX and mean <= OUT_MEAN
+    mx, _ = _stats("agcm 1080x1920", agcm.float().cpu().numpy()[0], ragcm)
+    assert mx <= AGCM_MAX
+
+
+def test_full_hd_hg_tail_dense_mask(proc_hg, hr_state, hg_state):
+    """The HG tail -- Up_conv5's fused pixel-shuffle + 64->3 dot-product epilogue (conv_pglds<ps_dot3>) and
+    hg_final_fused -- reaches the output only through the highlight mask, which is on for ~0.02 % of the pixels of a
+    synthetic frame at the reference's mask_r = 0.75.  HG_Composite takes mask_r as a constructor argument
+    (HG_Composite_arch.py:21): with mask_r = 0.3 more than half of the 1080x1920 frame is masked in, so the whole tail is
+    compared with the oracle over the whole frame, and its partial sums (hg.part) over all 1088x1920 padded pixels."""
+    from hdrtv_mi355x import weights as W
+    from oracle import hdrtvnet_oracle as O
+    h, w = 1080, 1920
+    f = W.synthetic_frame(h, w, seed=32, kind="gradient")
+    proc_hg.set_hg_mask_r(0.3)
+    try:
+        out, agcm = proc_hg.infer(proc_hg.preprocess(f))
+        out_np = out.cpu().numpy()[0]
+        base = proc_hg.tap("le.out").numpy()
+        part = proc_hg.tap("hg.part").numpy().reshape(-1).reshape(1088, w, 4)[:, :, :3].transpose(2, 0, 1)
+        dev_mask = proc_hg.tap("hg.mask").numpy()[:, :h, :w]
+    finally:
+        proc_hg.set_hg_mask_r(0.75)
+    mask = O.hg_mask(base, r=0.3)
+    frac = float(mask.mean())
+    print(f"  highlight mask fraction at mask_r=0.3: {frac:.3f}")
+    assert frac >= 0.2
+    assert np.array_equal(dev_mask, mask)
+    ph = (32 - h % 32) % 32
+    taps = {}
+    ref = O.hg_generator(hg_state, np.pad(base, ((0, 0), (0, ph), (0, 0)), mode="reflect"),
+                         np.pad(mask, ((0, 0), (0, ph), (0, 0)), mode="reflect"), taps)[:, :h, :w]
+    # first half of conv10 (Hallucination_arch.py:131-133) over Up_conv5's 64 channels, bias excluded
+    w10 = np.asarray(hg_state["conv10.weight"], np.float32).reshape(3, 128)[:, :64]
+    want_part = np.einsum("ok,khw->ohw", w10, taps["hg.up5"]).astype(np.float32)
+    mx, mean = _stats("hg.part (ps_dot3 epilogue) 1088x1920", part, want_part)
+    assert mx <= 6e-3 and mean <= 4e-4
+    mx, mean = _stats("hg out, dense mask", out_np, ref)
+    assert mx <= 3e-3 and mean <= 2e-4
+    inside = mask[0] > 0
+    dd = np.abs(out_np - ref)[:, inside]
+    print(f"  masked-in pixels only ({int(inside.sum())}): max_abs={dd.max():.3e} mean_abs={dd.mean():.3e}")
+    assert dd.max() <= 3e-3
+
+
+def test_uhd_le_vs_oracle(proc_hr, hr_state):
+    """BASELINE.json configs[2] size: AGCM + LE at 3840x2160 against the oracle's HR forward (~40 s of CPU)."""
+    from hdrtv_mi355x import weights as W
+    from oracle import hdrtvnet_oracle as O
+    O.set_threads(min(16, os.cpu_count() or 1))
+    f = W.synthetic_frame(2160, 3840, seed=41, kind="gradient")
+    out, agcm = proc_hr.infer(proc_hr.preprocess(f))
+    rt, rc = O.preprocess(f)
+    rbase, ragcm = O.hr_forward(hr_state, rt, rc)
+    mx, mean = _stats("le.out 2160x3840 vs O.hr_forward", out.float().cpu().numpy()[0], rbase)
+    assert mx <= OUT_MAX and mean <= OUT_MEAN
+    mx, _ = _stats("agcm 2160x3840", agcm.float().cpu().numpy()[0], ragcm)
+    assert mx <= AGCM_MAX
