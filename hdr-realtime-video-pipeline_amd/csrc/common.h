@@ -28,6 +28,21 @@ __device__ __forceinline__ float act_apply(float v, int act)
 __host__ __device__ __forceinline__ float act_slope(int act) { return act == ACT_RELU ? 0.f : (act == ACT_LRELU01 ? 0.1f : 1.f); }
 __device__ __forceinline__ float act_fast(float v, float slope) { return fmaxf(v, slope * v); }
 
+// Four activations -> four int8 codes of the reference's u8 activation quantiser (W8A8Conv2d.forward,
+// hdrtvnet_torch.py:353-356): q = clamp(rint((x - x_zero) / x_scale), 0, 255) evaluated as one FMA (inv = 1 / x_scale,
+// zoff = -x_zero / x_scale; symmetric layers: zoff = 128), code = q - 128, byte k of the result = value k.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ unsigned quant4(float a, float b, float c, float d, float inv, float zoff)
+{
+    unsigned w = 0;
+    w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(__builtin_rintf(__builtin_fmaf(a, inv, zoff)), 0.f, 255.f), 0, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(__builtin_rintf(__builtin_fmaf(b, inv, zoff)), 0.f, 255.f), 1, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(__builtin_rintf(__builtin_fmaf(c, inv, zoff)), 0.f, 255.f), 2, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(__builtin_rintf(__builtin_fmaf(d, inv, zoff)), 0.f, 255.f), 3, w);
+    return w ^ 0x80808080u;                       // u8 code q -> int8 code q - 128
+}
+
 // K-dimension permutation that lets a 32x32 MFMA accumulator tile be re-used, packed to f16,
 // as the B operand of the next MFMA (cdna_hip_programming.md section 3, "An accumulator tile as
 // the next MFMA's operand"): operand slot p (0..15) of a 16-wide k-step holds logical k
@@ -107,6 +122,29 @@ struct Conv32Params {
     const f16 *zeros;
     f16 *dump;             // >= 8 KiB scratch that masked-off lanes store to (keeps store counts exact)
     int tiles_x, tiles_y;
+    // W8A8 layer (wpk8 != nullptr): int8 weights [9][CoutPad][32] with the K axis in code-tile order
+    // (byte 16h + 4qd + k = input channel 8qd + 4h + k), scale[CoutPad], shift[16 border classes][CoutPad], and the
+    // input quantiser as u8 code = clamp(rint(x * q_inv + q_zoff), 0, 255), int8 code = u8 ^ q_flip per byte
+    const int8_t *wpk8;
+    float q_inv, q_zoff;
+};
+
+// Parameter block of the W8A8 LE convolutions outside conv32p (conv_q8.hip).
+struct ConvQ8Params {
+    const void *src;       // NHWC: f16 (quantised while it is staged) or int8 codes q - 128 of THIS layer's quantiser
+    int src_i8;
+    int Cin;               // 32 or 64
+    int src_stride;        // elements per pixel of src (>= Cin: a channel slice of a wider tensor)
+    int Hi, Wi, Ho, Wo, ks, stride;
+    const int8_t *wpk8;    // [ks*ks][CoutPad][Cin], natural channel order
+    const float *scale;    // [CoutPad]: x_scale * w_scale[n]
+    const float *shift;    // [16 border classes][CoutPad]: bias + w_scale[n] * (128 x_scale + x_zero) * sum of in-image taps
+    int CoutPad, Cout, act;
+    float q_inv, q_zoff;   // input quantiser: u8 code = clamp(rint(x * q_inv + q_zoff), 0, 255)
+    void *dst;             // NHWC f16, or int8 codes of the READING layer's quantiser (oq_inv, oq_zoff)
+    int dst_i8;
+    float oq_inv, oq_zoff;
+    int dstC;
 };
 
 // Letterbox (letterbox.hip): u8 BGR [sh][sw][3] -> u8 BGR [dh][dw][3], resized region [y0, y0+new_h) x [x0, x0+new_w)

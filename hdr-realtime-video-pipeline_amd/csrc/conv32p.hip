@@ -53,8 +53,6 @@ namespace {
 #define STAMP(i)
 #endif
 
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int TW = 16, HC = TW + 2, HW = 20;
 constexpr int OUT_ROWB = 64 + 16;
@@ -256,13 +254,8 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
                         }
                         if constexpr (I8) {
                             // u8 code q = clamp(rint((y - x_zero) / x_scale), 0, 255) as one FMA + rint + saturating pack
-                            unsigned w = 0;
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                const float tq = __builtin_rintf(__builtin_fmaf((float)y[k], p.q_inv, p.q_zoff));
-                                w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(tq, 0.f, 255.f), k, w);
-                            }
-                            codes[qd] = inimg ? (int)(w ^ p.q_flip) : 0;     // q - 128 (asymmetric) / two's complement byte (symmetric)
+                            const unsigned w = quant4((float)y[0], (float)y[1], (float)y[2], (float)y[3], p.q_inv, p.q_zoff);
+                            codes[qd] = inimg ? (int)w : 0;
                         } else {
                             if (!inimg) { y[0] = (f16)0.f; y[1] = (f16)0.f; y[2] = (f16)0.f; y[3] = (f16)0.f; }
                             *reinterpret_cast<f16x4 *>(addr) = y;
@@ -290,7 +283,12 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
     int xoff[3];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) xoff[kx] = (qy * HW + qx + kx) * 64 + ((lh ^ swz32(qx + kx)) << 4);
-    const int woff = l31 * 64 + ((lh ^ swz32(l31)) << 4);
+    const int woff = I8 ? l31 * 32 + ((lh ^ ((l31 >> 3) & 1)) << 4) : l31 * 64 + ((lh ^ swz32(l31)) << 4);
+    // I8: code-tile fragment of kernel column kx; the 16-byte half is lh on even halo rows, swapped on odd ones, so the
+    // address for kernel row ky is (qoff[kx] + ky * HW * 32) ^ ((ky & 1) << 4)
+    int qoff[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) qoff[kx] = (qy * HW + qx + kx) * 32 + ((lh ^ (qy & 1)) << 4);
     // this thread's two 16-byte output chunks: pixel (q2y[it], q2x) of the tile, channel chunk c8
     const int c8 = tid & 3;
     int q2y[2];
@@ -308,6 +306,8 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
         const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
         const int oy0 = ty * TH, ox0 = tx * TW;
         const char *a = sA + buf * A_BYTES;
+        // I8: border class of this lane's output pixel = which kernel rows / columns fall outside the image there
+        const int bcls = I8 ? ((((oy0 + qy == 0) | ((oy0 + qy == p.H - 1) << 1)) << 2) | ((ox0 + qx == 0) | ((ox0 + qx == p.W - 1) << 1))) & 15 : 0;
         STAMP(7);
 
         // output element offsets (-1: outside) and residual prefetch
@@ -362,6 +362,33 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
             f32x16 acc;
+            if constexpr (I8) {
+                // 9 k-steps (one tap = 32 input channels); fragment reads run three steps ahead of their MFMA
+                const char *qa = sQ + buf * L::Q_BYTES;
+                i32x16 iacc;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) iacc[k] = 0;
+                i32x4 wq[9], xq[9];
+                auto ldq = [&](int tap) {
+                    wq[tap] = *reinterpret_cast<const i32x4 *>(sW + woff + (tap * L::COUTP + pass * 32) * 32);
+                    xq[tap] = *reinterpret_cast<const i32x4 *>(qa + ((qoff[tap % 3] + (tap / 3) * HW * 32) ^ (((tap / 3) & 1) << 4)));
+                };
+                ldq(0); ldq(1); ldq(2);
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    if (tap + 3 < 9) ldq(tap + 3);
+                    iacc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wq[tap], xq[tap], iacc, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+                for (int st = 0; st < 6; ++st) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[k] = (float)iacc[k];
+            } else {
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[k] = 0.f;
             // 18 k-steps (9 taps x 2); fragment reads run three steps ahead of the MFMA that consumes them
@@ -386,13 +413,14 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            }
             STAMP(1);  // conv MFMAs
             // ---- this pass's 32 channels x (TH*16) pixels into the LDS staging tile
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
                 const int cl = 8 * qd + 4 * lh;
                 const float4 sc = *reinterpret_cast<const float4 *>(sSS + pass * 32 + cl);
-                const float4 sh = *reinterpret_cast<const float4 *>(sSS + L::COUTP + pass * 32 + cl);
+                const float4 sh = *reinterpret_cast<const float4 *>(sSS + L::COUTP + (I8 ? bcls * L::COUTP : 0) + pass * 32 + cl);
                 f16x4 o;
                 o[0] = (f16)act_fast(acc[4 * qd + 0] * sc.x + sh.x, aslope);
                 o[1] = (f16)act_fast(acc[4 * qd + 1] * sc.y + sh.y, aslope);
@@ -448,12 +476,12 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
 #endif
 }
 
-template <int NPASS, bool SFT, int NW>
+template <int NPASS, bool SFT, int NW, bool I8 = false>
 hipError_t launch_t(const Conv32Params &p, int n_cu, hipStream_t s)
 {
-    using L = Lay<NPASS, SFT, NW>;
+    using L = Lay<NPASS, SFT, NW, I8>;
     static DevOnce attr_once;   // hipFuncSetAttribute is per (function, device)
-    auto kern = conv32p_kernel<NPASS, SFT, NW>;
+    auto kern = conv32p_kernel<NPASS, SFT, NW, I8>;
     if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L::SMEM);
         if (e != hipSuccess) return e;
@@ -479,6 +507,12 @@ hipError_t conv32p_launch(Conv32Params p, int n_cu, hipStream_t s)
     if ((size_t)p.H * p.W * 64 >= 0xf0000000ull) return hipErrorInvalidValue;     // 32-bit byte offsets
     const bool sft = p.cond != nullptr;
     p.tiles_x = (p.W + TW - 1) / TW;
+    if (p.wpk8) {                                        // W8A8 layer: int8 MFMA on the quantised tile, 16x16 tiles only
+        p.tiles_y = (p.H + 15) / 16;
+        if (p.CoutPad == 32) return sft ? launch_t<1, true, 8, true>(p, n_cu, s) : launch_t<1, false, 8, true>(p, n_cu, s);
+        if (p.CoutPad == 128 && !sft) return launch_t<4, false, 8, true>(p, n_cu, s);
+        return hipErrorInvalidValue;
+    }
     // conv_last (32 -> 3, no SFT, planar store) is all per-tile latency: two 4-wave workgroups per CU hide it better
     // (0.286 -> 0.251 ms at 4K); every other layer is faster with the 16x16 tile
     const bool small_tile = nw == 4 || (p.CoutPad == 32 && !sft && p.mode == ST_PLANAR3 && !getenv("HDRTV_CONV32_NW"));

@@ -42,7 +42,6 @@ template <int N> __device__ __forceinline__ void wait_vm()
 
 struct Tile { int n0, oy0, ox0; };
 
-typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // C64: a 64-channel input (conv2, Up_conv5).  One LDS row is then a PAIR of horizontally adjacent pixels (pixel hx in
 // bytes 0..63, pixel hx+1 in bytes 64..127; each halo pixel is DMA'd twice), and the 3x3 filter becomes 3 rows x 2

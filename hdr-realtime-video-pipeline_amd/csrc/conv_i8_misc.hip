@@ -8,7 +8,6 @@
 
 namespace {
 
-typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // 128 pixels x 128 output channels per block, two stages of {A 16 KiB, B 16 KiB}: 64 KiB, so TWO blocks share a CU and
 // one block's loads and stores overlap the other's MFMAs (with one 144-KiB block per CU the phases ran back to back)

@@ -85,6 +85,26 @@ struct Pack {
         return true;
     }
     bool has(const std::string &name) const { return e.find(name) != e.end(); }
+    // A layer's weight tensor as the reference's layer computes it: `<layer>.weight`, or for the INT8 runtime layers
+    // (W8Conv2d / W8A8Conv2d / W8Linear / W8A8Linear, hdrtvnet_torch.py:233-410) weight_int8 * scale, the product
+    // rounded once to f16 as `weight_int8.to(cd) * scale` is on a GPU (cd = fp16)
+    bool getw(const std::string &layer, size_t numel, std::vector<float> &out, std::string &err) const
+    {
+        if (has(layer + ".weight")) return get(layer + ".weight", numel, out, err);
+        std::vector<int8_t> q;
+        if (!get_i8(layer + ".weight_int8", numel, q, err)) return false;
+        const std::string sn = has(layer + ".w_scale") ? layer + ".w_scale" : layer + ".scale";
+        auto it = e.find(sn);
+        if (it == e.end()) { err = "INT8 layer without scale: " + layer; return false; }
+        const size_t co = it->second.numel();
+        std::vector<float> sc;
+        if (co == 0 || numel % co || !get(sn, co, sc, err)) { if (err.empty()) err = "bad scale for " + layer; return false; }
+        out.resize(numel);
+        const size_t per = numel / co;
+        for (size_t i = 0; i < numel; ++i) out[i] = (float)(f16)((float)q[i] * (float)(f16)sc[i / per]);
+        return true;
+    }
+    bool is_w8a8(const std::string &layer) const { return has(layer + ".weight_int8") && has(layer + ".x_scale"); }
     bool get_i8(const std::string &name, size_t numel, std::vector<int8_t> &out, std::string &err) const
     {
         auto it = e.find(name);
@@ -125,6 +145,21 @@ struct ConvI8Layer {                        // W8A8 HG layer on int8 MFMA
     int cin = 0, cout = 0, cout_real = 0, ks = 0, out_f16 = 0;   // cout: padded to a multiple of 128
 };
 struct C3Layer { size_t wfrag = 0, scale = 0, shift = 0; int cout = 0; };
+// W8A8Conv2d's activation quantiser (hdrtvnet_torch.py:351-364) with a FLOAT zero point: value = scale * (code + off),
+// int8 code = q - 128.  Symmetric layers (no x_zero buffer): q = round(x / scale) + 128, off = 0.
+struct ActQf {
+    float scale = 1.f, zero = 0.f;
+    bool asym = true;
+    float inv() const { return 1.f / scale; }
+    float zoff() const { return asym ? -zero / scale : 128.f; }                           // u8 code = clamp(rint(x * inv + zoff), 0, 255)
+    double soff() const { return asym ? 128.0 * (double)scale + (double)zero : 0.0; }     // scale * off
+};
+struct QLayer {                             // W8A8 layer of the HR network on int8 MFMA (conv32p<..,i8> / conv_q8)
+    size_t wpk8 = 0, scale = 0, shift = 0;  // shift: [16 border classes][coutPad]
+    ActQf q;
+    int cin = 0, cout = 0, coutPad = 0, ks = 0, stride = 1;
+};
+struct QLastLayer { size_t wq = 0, ss = 0; ActQf q; bool on = false; };
 struct SftLayer { size_t wfrag = 0, bias = 0; };
 
 struct Tensor {
@@ -159,6 +194,9 @@ struct hdrtv_ctx {
     bool hg_i8 = false;                   // the HG pack is a W8A8 checkpoint: 15 layers run on int8 MFMA
     float hg_q0_inv = 0.f, hg_q0_zero = 0.f;   // quantiser of the fp16 -> int8 boundary (conv2's output)
     std::map<std::string, SftLayer> sft;
+    bool hr_i8 = false;                   // the HR pack holds W8A8 layers: they run on int8 MFMA (predequantize off)
+    std::map<std::string, QLayer> q32, q8;
+    QLastLayer q_trunk6, q_tail2;         // CondNet1.4 / CondNet2.4 as the W8A8 last layer of their fused chains
     std::map<std::string, size_t> f32v;   // raw fp32 vectors/matrices in the weight arena
     size_t zeros_off = 0;                 // 256 B of zeros in the weight arena
     size_t dump_off = 0;                  // 8 KiB write-only scratch (conv32p masked lanes)
@@ -229,7 +267,7 @@ bool pack_conv(hdrtv_ctx *c, const Pack &pk, const std::string &key, const std::
             if (nx == std::string::npos) nx = wname.size();
             const std::string one = wname.substr(pos, nx - pos);
             std::vector<float> w1, b1;
-            if (!pk.get(one + ".weight", (size_t)co1 * ci * ks * ks, w1, c->err)) return false;
+            if (!pk.getw(one, (size_t)co1 * ci * ks * ks, w1, c->err)) return false;
             if (!pk.get(one + ".bias", (size_t)co1, b1, c->err)) return false;
             w.insert(w.end(), w1.begin(), w1.end());
             b.insert(b.end(), b1.begin(), b1.end());
@@ -248,7 +286,7 @@ bool pack_conv(hdrtv_ctx *c, const Pack &pk, const std::string &key, const std::
     std::vector<float> g, be, mu, var;
     const bool has_bn = !bn_name.empty();
     if (has_bn) {
-        if (!pk.get(bn_name + ".weight", co, g, c->err) || !pk.get(bn_name + ".bias", co, be, c->err) ||
+        if (!pk.getw(bn_name, co, g, c->err) || !pk.get(bn_name + ".bias", co, be, c->err) ||
             !pk.get(bn_name + ".running_mean", co, mu, c->err) || !pk.get(bn_name + ".running_var", co, var, c->err))
             return false;
     }
@@ -308,7 +346,7 @@ bool pack_conv_i8(hdrtv_ctx *c, const Pack &pk, const std::string &key, const st
     std::vector<float> g, be, mu, var;
     const bool has_bn = !bn_name.empty();
     if (has_bn) {
-        if (!pk.get(bn_name + ".weight", co, g, c->err) || !pk.get(bn_name + ".bias", co, be, c->err) ||
+        if (!pk.getw(bn_name, co, g, c->err) || !pk.get(bn_name + ".bias", co, be, c->err) ||
             !pk.get(bn_name + ".running_mean", co, mu, c->err) || !pk.get(bn_name + ".running_var", co, var, c->err))
             return false;
     }
@@ -354,14 +392,138 @@ bool pack_conv_i8(hdrtv_ctx *c, const Pack &pk, const std::string &key, const st
     return true;
 }
 
+
+// ---------------------------------------------------------------- W8A8 layers of the HR network (AGCM + LE)
+bool read_actqf(hdrtv_ctx *c, const Pack &pk, const std::string &layer, ActQf &q)
+{
+    std::vector<float> xs, xz;
+    if (!pk.get(layer + ".x_scale", 1, xs, c->err)) return false;
+    q.scale = xs[0];
+    q.asym = pk.has(layer + ".x_zero");
+    q.zero = 0.f;
+    if (q.asym) {
+        if (!pk.get(layer + ".x_zero", 1, xz, c->err)) return false;
+        q.zero = xz[0];
+    }
+    if (!(q.scale > 0.f) || !std::isfinite(q.scale) || !std::isfinite(q.zero)) { c->err = "bad activation quantiser for " + layer; return false; }
+    return true;
+}
+struct QRaw { std::vector<int8_t> w; std::vector<float> ws, b; ActQf q; };
+bool read_qraw(hdrtv_ctx *c, const Pack &pk, const std::string &layer, int co, size_t per_co, QRaw &r)
+{
+    return pk.get_i8(layer + ".weight_int8", (size_t)co * per_co, r.w, c->err) && pk.get(layer + ".w_scale", co, r.ws, c->err) &&
+           pk.get(layer + ".bias", co, r.b, c->err) && read_actqf(c, pk, layer, r.q);
+}
+// y[n] = x_scale * w_scale[n] * acc + w_scale[n] * (128 x_scale + x_zero) * sum(w_int8[n] over the in-image taps) + bias[n]:
+// scale[coP] and shift[16][coP], class = (rows: bit0 first kernel row outside, bit1 last) << 2 | (columns likewise).
+// Packed row np holds original output channel rowmap[np].
+void q_tables(const QRaw &r, int co, int ci, int ks, int coP, const std::vector<int> &rowmap, std::vector<float> &scale,
+              std::vector<float> &shift)
+{
+    scale.assign(coP, 0.f);
+    shift.assign((size_t)16 * coP, 0.f);
+    const int taps = ks * ks;
+    for (int np = 0; np < co; ++np) {
+        const int n = rowmap[np];
+        std::vector<long> tsum(taps, 0);
+        for (int k = 0; k < ci; ++k)
+            for (int t = 0; t < taps; ++t) tsum[t] += r.w[((size_t)n * ci + k) * taps + t];
+        scale[np] = (float)((double)r.q.scale * (double)r.ws[n]);
+        for (int cls = 0; cls < 16; ++cls) {
+            const int cy = cls >> 2, cx = cls & 3;
+            long sum = 0;
+            for (int t = 0; t < taps; ++t) {
+                const int ky = t / ks, kx = t % ks;
+                const bool miss = ks == 3 && ((ky == 0 && (cy & 1)) || (ky == 2 && (cy & 2)) || (kx == 0 && (cx & 1)) || (kx == 2 && (cx & 2)));
+                if (!miss) sum += tsum[t];
+            }
+            shift[(size_t)cls * coP + np] = (float)((double)r.ws[n] * r.q.soff() * (double)sum + (double)r.b[n]);
+        }
+    }
+}
+// 3x3 / stride 1 / 32 input channels -> conv32p<.., i8>: wpk8 [9][coP][32], byte 16h + 4qd + k of a row = input channel
+// 8qd + 4h + k (the order in which conv32p's per-tile pass produces a pixel's codes); ps: PixelShuffle row permutation
+bool pack_conv32_i8(hdrtv_ctx *c, const Pack &pk, const std::string &key, int co, int ps_cps)
+{
+    QRaw r;
+    if (!read_qraw(c, pk, key, co, 32 * 9, r)) return false;
+    const int coP = (co + 31) / 32 * 32;
+    std::vector<int> rowmap(co);
+    for (int np = 0; np < co; ++np) rowmap[np] = ps_cps > 0 ? 4 * (np % ps_cps) + np / ps_cps : np;
+    std::vector<int8_t> wp((size_t)9 * coP * 32, (int8_t)0);
+    for (int np = 0; np < co; ++np)
+        for (int tap = 0; tap < 9; ++tap)
+            for (int h = 0; h < 2; ++h)
+                for (int qd = 0; qd < 4; ++qd)
+                    for (int k = 0; k < 4; ++k)
+                        wp[((size_t)tap * coP + np) * 32 + 16 * h + 4 * qd + k] = r.w[((size_t)rowmap[np] * 32 + 8 * qd + 4 * h + k) * 9 + tap];
+    std::vector<float> scale, shift;
+    q_tables(r, co, 32, 3, coP, rowmap, scale, shift);
+    QLayer L;
+    L.q = r.q; L.cin = 32; L.cout = co; L.coutPad = coP; L.ks = 3; L.stride = 1;
+    L.wpk8 = c->wts.put(wp.data(), wp.size());
+    L.scale = c->wts.put(scale.data(), scale.size() * 4);
+    L.shift = c->wts.put(shift.data(), shift.size() * 4);
+    c->q32[key] = L;
+    return true;
+}
+// any other W8A8 LE conv -> conv_q8: wpk8 [ks*ks][coP][ci], natural channel order
+bool pack_conv_q8(hdrtv_ctx *c, const Pack &pk, const std::string &key, int co, int ci, int ks, int stride)
+{
+    QRaw r;
+    if (!read_qraw(c, pk, key, co, (size_t)ci * ks * ks, r)) return false;
+    const int coP = (co + 31) / 32 * 32, taps = ks * ks;
+    std::vector<int> rowmap(co);
+    for (int np = 0; np < co; ++np) rowmap[np] = np;
+    std::vector<int8_t> wp((size_t)taps * coP * ci, (int8_t)0);
+    for (int n = 0; n < co; ++n)
+        for (int k = 0; k < ci; ++k)
+            for (int t = 0; t < taps; ++t) wp[((size_t)t * coP + n) * ci + k] = r.w[((size_t)n * ci + k) * taps + t];
+    std::vector<float> scale, shift;
+    q_tables(r, co, ci, ks, coP, rowmap, scale, shift);
+    QLayer L;
+    L.q = r.q; L.cin = ci; L.cout = co; L.coutPad = coP; L.ks = ks; L.stride = stride;
+    L.wpk8 = c->wts.put(wp.data(), wp.size());
+    L.scale = c->wts.put(scale.data(), scale.size() * 4);
+    L.shift = c->wts.put(shift.data(), shift.size() * 4);
+    c->q8[key] = L;
+    return true;
+}
+// 1x1 64 -> 16 as the W8A8 last layer of a fused chain (le_fused.hip qlast_apply): two int8 A fragments whose byte j of
+// lane (row, lh), MFMA m, is input channel 16s + (e < 4 ? 4lh + e : 8 + 4lh + e - 4) with s = 2m + j / 8, e = j % 8
+bool pack_q_last(hdrtv_ctx *c, const Pack &pk, const std::string &layer, QLastLayer &out)
+{
+    QRaw r;
+    if (!read_qraw(c, pk, layer, 16, 64, r)) return false;
+    std::vector<int8_t> fr((size_t)2 * 64 * 16, (int8_t)0);
+    for (int m = 0; m < 2; ++m)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 16; ++j) {
+                const int row = lane & 31, lh = lane >> 5, s = 2 * m + j / 8, e = j % 8;
+                const int ch = 16 * s + (e < 4 ? 4 * lh + e : 8 + 4 * lh + e - 4);
+                if (row < 16) fr[((size_t)m * 64 + lane) * 16 + j] = r.w[(size_t)row * 64 + ch];
+            }
+    std::vector<int> rowmap(16);
+    for (int i = 0; i < 16; ++i) rowmap[i] = i;
+    std::vector<float> scale, shift;
+    q_tables(r, 16, 64, 1, 32, rowmap, scale, shift);
+    std::vector<float> ss(64, 0.f);
+    for (int i = 0; i < 32; ++i) { ss[i] = scale[i]; ss[32 + i] = shift[i]; }
+    out.q = r.q;
+    out.wq = c->wts.put(fr.data(), fr.size());
+    out.ss = c->wts.put(ss.data(), ss.size() * 4);
+    out.on = true;
+    return true;
+}
+
 // 3x3 conv from 3 planar channels: A fragments [MT][2][64 lanes][8], k = (ky*3+kx)*3 + c (27 of 32 used)
 bool pack_c3(hdrtv_ctx *c, const Pack &pk, const std::string &key, const std::string &wname, int co, const std::string &bn_name)
 {
     std::vector<float> w, b;
-    if (!pk.get(wname + ".weight", (size_t)co * 27, w, c->err) || !pk.get(wname + ".bias", co, b, c->err)) return false;
+    if (!pk.getw(wname, (size_t)co * 27, w, c->err) || !pk.get(wname + ".bias", co, b, c->err)) return false;
     std::vector<float> scale(co, 1.f), shift(co, 0.f), g, be, mu, var;
     if (!bn_name.empty()) {
-        if (!pk.get(bn_name + ".weight", co, g, c->err) || !pk.get(bn_name + ".bias", co, be, c->err) ||
+        if (!pk.getw(bn_name, co, g, c->err) || !pk.get(bn_name + ".bias", co, be, c->err) ||
             !pk.get(bn_name + ".running_mean", co, mu, c->err) || !pk.get(bn_name + ".running_var", co, var, c->err))
             return false;
     }
@@ -397,10 +559,10 @@ bool pack_c3(hdrtv_ctx *c, const Pack &pk, const std::string &key, const std::st
 bool pack_sft(hdrtv_ctx *c, const Pack &pk, const std::string &key, const std::string &name)
 {
     std::vector<float> w0s, b0s, w1s, b1s, w0t, b0t, w1t, b1t;
-    if (!pk.get(name + ".SFT_scale_conv0.weight", 256, w0s, c->err) || !pk.get(name + ".SFT_scale_conv0.bias", 16, b0s, c->err) ||
-        !pk.get(name + ".SFT_scale_conv1.weight", 512, w1s, c->err) || !pk.get(name + ".SFT_scale_conv1.bias", 32, b1s, c->err) ||
-        !pk.get(name + ".SFT_shift_conv0.weight", 256, w0t, c->err) || !pk.get(name + ".SFT_shift_conv0.bias", 16, b0t, c->err) ||
-        !pk.get(name + ".SFT_shift_conv1.weight", 512, w1t, c->err) || !pk.get(name + ".SFT_shift_conv1.bias", 32, b1t, c->err))
+    if (!pk.getw(name + ".SFT_scale_conv0", 256, w0s, c->err) || !pk.get(name + ".SFT_scale_conv0.bias", 16, b0s, c->err) ||
+        !pk.getw(name + ".SFT_scale_conv1", 512, w1s, c->err) || !pk.get(name + ".SFT_scale_conv1.bias", 32, b1s, c->err) ||
+        !pk.getw(name + ".SFT_shift_conv0", 256, w0t, c->err) || !pk.get(name + ".SFT_shift_conv0.bias", 16, b0t, c->err) ||
+        !pk.getw(name + ".SFT_shift_conv1", 512, w1t, c->err) || !pk.get(name + ".SFT_shift_conv1.bias", 32, b1t, c->err))
         return false;
     std::vector<f16> fr(3 * 64 * 8);
     std::vector<float> bias(96);
@@ -428,7 +590,7 @@ bool pack_cond_trunk(hdrtv_ctx *c, const Pack &pk)
     std::vector<float> bias(64 * 5 + 32, 0.f);
     std::vector<float> w, b;
     // layer 1: 3x3 from 3 channels, natural k = (ky*3+kx)*3 + c
-    if (!pk.get(std::string(names[0]) + ".weight", 64 * 27, w, c->err) || !pk.get(std::string(names[0]) + ".bias", 64, b, c->err))
+    if (!pk.getw(std::string(names[0]), 64 * 27, w, c->err) || !pk.get(std::string(names[0]) + ".bias", 64, b, c->err))
         return false;
     for (int i = 0; i < 64; ++i) bias[i] = b[i];
     for (int mt = 0; mt < 2; ++mt)
@@ -440,7 +602,7 @@ bool pack_cond_trunk(hdrtv_ctx *c, const Pack &pk)
                 }
     // layers 2..5: 64x64 1x1, k permuted (operand is the previous accumulator)
     for (int l = 2; l <= 5; ++l) {
-        if (!pk.get(std::string(names[l - 1]) + ".weight", 64 * 64, w, c->err) || !pk.get(std::string(names[l - 1]) + ".bias", 64, b, c->err))
+        if (!pk.getw(std::string(names[l - 1]), 64 * 64, w, c->err) || !pk.get(std::string(names[l - 1]) + ".bias", 64, b, c->err))
             return false;
         for (int i = 0; i < 64; ++i) bias[64 * (l - 1) + i] = b[i];
         for (int mt = 0; mt < 2; ++mt)
@@ -452,7 +614,7 @@ bool pack_cond_trunk(hdrtv_ctx *c, const Pack &pk)
                     }
     }
     // layer 6: 16x64, rows 16..31 zero
-    if (!pk.get(std::string(names[5]) + ".weight", 16 * 64, w, c->err) || !pk.get(std::string(names[5]) + ".bias", 16, b, c->err)) return false;
+    if (!pk.getw(std::string(names[5]), 16 * 64, w, c->err) || !pk.get(std::string(names[5]) + ".bias", 16, b, c->err)) return false;
     for (int i = 0; i < 16; ++i) bias[320 + i] = b[i];
     for (int sidx = 0; sidx < 4; ++sidx)
         for (int lane = 0; lane < 64; ++lane)
@@ -469,8 +631,8 @@ bool pack_cond_trunk(hdrtv_ctx *c, const Pack &pk)
 bool pack_cond_tail(hdrtv_ctx *c, const Pack &pk, const std::string &l1, const std::string &l2)
 {
     std::vector<float> w1, b1, w2, b2;
-    if (!pk.get(l1 + ".weight", 64 * 64, w1, c->err) || !pk.get(l1 + ".bias", 64, b1, c->err) ||
-        !pk.get(l2 + ".weight", 16 * 64, w2, c->err) || !pk.get(l2 + ".bias", 16, b2, c->err))
+    if (!pk.getw(l1, 64 * 64, w1, c->err) || !pk.get(l1 + ".bias", 64, b1, c->err) ||
+        !pk.getw(l2, 16 * 64, w2, c->err) || !pk.get(l2 + ".bias", 16, b2, c->err))
         return false;
     std::vector<f16> fr((size_t)12 * 64 * 8, (f16)0.f);
     std::vector<float> bias(96, 0.f);
@@ -494,7 +656,9 @@ bool pack_cond_tail(hdrtv_ctx *c, const Pack &pk, const std::string &l1, const s
 bool put_f32(hdrtv_ctx *c, const Pack &pk, const std::string &key, const std::string &name, size_t numel)
 {
     std::vector<float> v;
-    if (!pk.get(name, numel, v, c->err)) return false;
+    const std::string suffix = ".weight";
+    const bool is_w = name.size() > suffix.size() && name.compare(name.size() - suffix.size(), suffix.size(), suffix) == 0;
+    if (is_w ? !pk.getw(name.substr(0, name.size() - suffix.size()), numel, v, c->err) : !pk.get(name, numel, v, c->err)) return false;
     c->f32v[key] = c->wts.put(v.data(), v.size() * 4);
     return true;
 }
@@ -544,9 +708,29 @@ bool build_weights(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
         return false;
 
     // ---- LE
+    // A W8A8 layer (weight_int8 + x_scale in the pack: the reference's `predequantize` off) runs on int8 MFMA when a
+    // kernel exists for it; the pack is rejected otherwise -- there is no silent fake-quant or fp16 substitute.
+    auto isq = [&](const std::string &L) { return hr.is_w8a8(L); };
+    {
+        const char *q_ok[] = {"LE.HR_conv1", "LE.HR_conv2", "LE.conv_last", "LE.up_conv1.0", "LE.up_conv2.0", "LE.up_conv3.0",
+                              "LE.down_conv1", "LE.down_conv2", "LE.down_conv3", "LE.CondNet1.4", "LE.CondNet2.0", "LE.CondNet2.4",
+                              "LE.CondNet3.0", "LE.CondNet3.2", "LE.CondNet3.4", "LE.CondNet4.0", "LE.CondNet4.2", "LE.CondNet4.4"};
+        const std::string suf = ".x_scale";
+        for (const auto &kv : hr.e) {
+            const std::string &k = kv.first;
+            if (k.size() <= suf.size() || k.compare(k.size() - suf.size(), suf.size(), suf) != 0) continue;
+            const std::string L = k.substr(0, k.size() - suf.size());
+            c->hr_i8 = true;
+            bool ok = L.rfind("LE.recon_trunk", 0) == 0 && (L.size() > 6 && (L.compare(L.size() - 6, 6, ".conv1") == 0 || L.compare(L.size() - 6, 6, ".conv2") == 0));
+            for (const char *q : q_ok) ok = ok || L == q;
+            if (!ok) { c->err = "W8A8 layer " + L + " has no int8 kernel in this build (predequantize='auto' runs it as the reference does on ROCm)"; return false; }
+        }
+    }
     if (!pack_cond_trunk(c, hr) || !pack_cond_tail(c, hr, "LE.CondNet2.2", "LE.CondNet2.4") ||
         !pack_c3(c, hr, "le.conv_first", "LE.conv_first", 32, ""))
         return false;
+    if (isq("LE.CondNet1.4") && !pack_q_last(c, hr, "LE.CondNet1.4", c->q_trunk6)) return false;
+    if (isq("LE.CondNet2.4") && !pack_q_last(c, hr, "LE.CondNet2.4", c->q_tail2)) return false;
     struct Spec { const char *name; int co, ci, ks, stride, ps; };
     const Spec le_convs[] = {
         {"LE.CondNet3.4", 16, 64, 1, 1, 0}, {"LE.CondNet4.4", 16, 64, 3, 2, 0},
@@ -554,23 +738,34 @@ bool build_weights(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
         {"LE.down_conv1", 32, 32, 3, 2, 0}, {"LE.down_conv2", 32, 32, 3, 2, 0}, {"LE.down_conv3", 32, 32, 3, 2, 0},
         {"LE.up_conv1.0", 128, 32, 3, 1, 32}, {"LE.up_conv2.0", 128, 32, 3, 1, 32}, {"LE.up_conv3.0", 128, 32, 3, 1, 32},
     };
-    for (const Spec &s : le_convs)
-        if (!pack_conv(c, hr, s.name, s.name, s.co, s.ci, s.ks, s.stride, "", s.ps)) return false;
-    // stride-2 layers from the 64-channel condition map: CondNet{2,3,4}.0 merged (192 outputs), .2 layers alone
-    if (!pack_conv(c, hr, "LE.CondNet234.0", "LE.CondNet2.0+LE.CondNet3.0+LE.CondNet4.0", 192, 64, 3, 2, "", 0, 64) ||
-        !pack_conv(c, hr, "LE.CondNet3.2", "LE.CondNet3.2", 64, 64, 3, 2, "", 0, 64) ||
-        !pack_conv(c, hr, "LE.CondNet4.2", "LE.CondNet4.2", 64, 64, 3, 2, "", 0, 64))
-        return false;
+    for (const Spec &s : le_convs) {
+        if (isq(s.name)) {
+            if (s.ks == 3 && s.stride == 1 ? !pack_conv32_i8(c, hr, s.name, s.co, s.ps) : !pack_conv_q8(c, hr, s.name, s.co, s.ci, s.ks, s.stride))
+                return false;
+        } else if (!pack_conv(c, hr, s.name, s.name, s.co, s.ci, s.ks, s.stride, "", s.ps)) {
+            return false;
+        }
+    }
+    // stride-2 layers from the 64-channel condition map: CondNet{2,3,4}.0 merged (192 outputs) unless one of them is W8A8
+    // (each W8A8 layer quantises the condition map with its own x_scale / x_zero); .2 layers alone
+    if (!isq("LE.CondNet2.0") && !isq("LE.CondNet3.0") && !isq("LE.CondNet4.0")) {
+        if (!pack_conv(c, hr, "LE.CondNet234.0", "LE.CondNet2.0+LE.CondNet3.0+LE.CondNet4.0", 192, 64, 3, 2, "", 0, 64)) return false;
+    } else {
+        for (const char *n : {"LE.CondNet2.0", "LE.CondNet3.0", "LE.CondNet4.0"})
+            if (isq(n) ? !pack_conv_q8(c, hr, n, 64, 64, 3, 2) : !pack_conv(c, hr, n, n, 64, 64, 3, 2, "", 0, 64)) return false;
+    }
+    for (const char *n : {"LE.CondNet3.2", "LE.CondNet4.2"})
+        if (isq(n) ? !pack_conv_q8(c, hr, n, 64, 64, 3, 2) : !pack_conv(c, hr, n, n, 64, 64, 3, 2, "", 0, 64)) return false;
     const char *trunks[5] = {"recon_trunk1", "recon_trunk2", "recon_trunk3", "recon_trunk4", "recon_trunk5"};
     const int trunk_n[5] = {1, 1, 4, 1, 1};
     for (int t = 0; t < 5; ++t)
         for (int b = 0; b < trunk_n[t]; ++b) {
             snprintf(nm, sizeof nm, "LE.%s.%d", trunks[t], b);
             const std::string base = nm;
-            if (!pack_conv(c, hr, base + ".conv1", base + ".conv1", 32, 32, 3, 1, "", 0) ||
-                !pack_conv(c, hr, base + ".conv2", base + ".conv2", 32, 32, 3, 1, "", 0) ||
-                !pack_sft(c, hr, base + ".sft1", base + ".sft1") || !pack_sft(c, hr, base + ".sft2", base + ".sft2"))
-                return false;
+            for (const char *cv : {".conv1", ".conv2"})
+                if (isq(base + cv) ? !pack_conv32_i8(c, hr, base + cv, 32, 0) : !pack_conv(c, hr, base + cv, base + cv, 32, 32, 3, 1, "", 0))
+                    return false;
+            if (!pack_sft(c, hr, base + ".sft1", base + ".sft1") || !pack_sft(c, hr, base + ".sft2", base + ".sft2")) return false;
         }
     if (!pack_sft(c, hr, "LE.SFT_layer1", "LE.SFT_layer1") || !pack_sft(c, hr, "LE.SFT_layer2", "LE.SFT_layer2")) return false;
 
@@ -638,7 +833,7 @@ bool build_weights(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
             return false;
         {   // fused tail: conv10 = [first 64 inputs: Up_conv5 | last 64 inputs: conv1_out]
             std::vector<float> w10, w1;
-            if (!hg->get("conv10.weight", 3 * 128, w10, c->err) || !hg->get("conv1.0.weight", 64 * 27, w1, c->err)) return false;
+            if (!hg->getw("conv10", 3 * 128, w10, c->err) || !hg->getw("conv1.0", 64 * 27, w1, c->err)) return false;
             std::vector<float> w10a(3 * 64);
             for (int o = 0; o < 3; ++o)
                 for (int k = 0; k < 64; ++k) w10a[o * 64 + k] = w10[o * 128 + k];
@@ -782,6 +977,11 @@ int do_reserve(hdrtv_ctx *c, int H, int W)
     ws_add(c, "le.cond1", 16, H, W, 0);
     ws_add(c, "le.x192", 192, s.H1, s.W1, 0);
     ws_add(c, "le.h2a", 64, s.H2, s.W2, 0); ws_add(c, "le.h2b", 64, s.H2, s.W2, 0);
+    if (c->hr_i8) {           // W8A8 condition nets: un-merged first layers, int8 codes between W8A8 layers
+        ws_add(c, "le.c2a", 64, s.H1, s.W1, 0); ws_add(c, "le.c3a", 64, s.H1, s.W1, 0); ws_add(c, "le.c4a", 64, s.H1, s.W1, 0);
+        ws_add(c, "le8.c3a", 64, s.H1, s.W1, 5); ws_add(c, "le8.c4a", 64, s.H1, s.W1, 5);
+        ws_add(c, "le8.h2a", 64, s.H2, s.W2, 5); ws_add(c, "le8.h2b", 64, s.H2, s.W2, 5);
+    }
     ws_add(c, "le.cond2", 16, s.H1, s.W1, 0); ws_add(c, "le.cond3", 16, s.H2, s.W2, 0); ws_add(c, "le.cond4", 16, s.H3, s.W3, 0);
     ws_add(c, "le.f0a", 32, H, W, 0); ws_add(c, "le.f0b", 32, H, W, 0); ws_add(c, "le.fea0", 32, H, W, 0);
     ws_add(c, "le.up3", 32, H, W, 0);
@@ -943,6 +1143,32 @@ struct Seq {
                              (mode == ST_PS_DOT3 ? 16.0 * Hd * Wd : outel * (L.out_f16 ? 2.0 : 1.0));
         chk(L.ks == 3 ? conv_pglds_i8_launch(p, c->n_cu, s) : conv1x1_i8_launch(p, s), key.c_str(), tag, macs, bytes);
     }
+    // W8A8 LE layer on int8 MFMA (conv_q8.hip).  src: f16 NHWC (quantised on load) or this layer's int8 codes; dst: f16, or
+    // (oq != nullptr) the int8 codes of the reading layer's quantiser *oq
+    void convq8(const std::string &key, const void *src, bool src_i8, int src_stride, int Hi, int Wi, int act, void *dst, int dstC,
+                const ActQf *oq)
+    {
+        if (!ok()) return;
+        auto it = c->q8.find(key);
+        if (it == c->q8.end()) { rc = fail(c, HDRTV_ESTATE, "no packed W8A8 conv %s", key.c_str()); return; }
+        const QLayer &L = it->second;
+        ConvQ8Params p;
+        memset(&p, 0, sizeof p);
+        p.src = src; p.src_i8 = src_i8 ? 1 : 0; p.Cin = L.cin; p.src_stride = src_stride; p.Hi = Hi; p.Wi = Wi;
+        p.ks = L.ks; p.stride = L.stride;
+        const int pad = L.ks / 2;
+        p.Ho = (Hi + 2 * pad - L.ks) / L.stride + 1; p.Wo = (Wi + 2 * pad - L.ks) / L.stride + 1;
+        p.wpk8 = wtp<int8_t>(c, L.wpk8); p.scale = wtp<float>(c, L.scale); p.shift = wtp<float>(c, L.shift);
+        p.CoutPad = L.coutPad; p.Cout = L.cout; p.act = act; p.q_inv = L.q.inv(); p.q_zoff = L.q.zoff();
+        p.dst = dst; p.dst_i8 = oq ? 1 : 0; p.dstC = dstC;
+        if (oq) { p.oq_inv = oq->inv(); p.oq_zoff = oq->zoff(); }
+        char tag[64];
+        snprintf(tag, sizeof tag, "conv_q8<%d,%d,%d>", L.cin, L.ks, L.stride);
+        const double macs = (double)p.Ho * p.Wo * L.cin * L.ks * L.ks * L.cout;
+        const double bytes = (double)Hi * Wi * L.cin * (src_i8 ? 1.0 : 2.0) + (double)L.ks * L.ks * L.cin * L.coutPad +
+                             (double)p.Ho * p.Wo * L.cout * (oq ? 1.0 : 2.0);
+        chk(conv_q8_launch(p, s), key.c_str(), tag, macs, bytes);
+    }
     void c3(const std::string &key, const f16 *in, int H, int W, int act, f16 *out, f16 *out_pool, float pool_q_inv = 0.f,
             float pool_q_zero = 0.f)
     {
@@ -959,16 +1185,26 @@ struct Seq {
     {
         if (!ok()) return;
         auto it = c->conv.find(key);
-        if (it == c->conv.end()) { rc = fail(c, HDRTV_ESTATE, "no packed conv %s", key.c_str()); return; }
-        const ConvLayer &L = it->second;
+        auto iq = c->q32.find(key);
+        if (it == c->conv.end() && iq == c->q32.end()) { rc = fail(c, HDRTV_ESTATE, "no packed conv %s", key.c_str()); return; }
+        const bool i8 = iq != c->q32.end();
+        ConvLayer L;
         Conv32Params p;
         memset(&p, 0, sizeof p);
+        if (i8) {             // W8A8 layer: int8 MFMA on the quantised tile
+            const QLayer &Q = iq->second;
+            L.cout = Q.cout; L.coutPad = Q.coutPad;
+            p.wpk8 = wtp<int8_t>(c, Q.wpk8); p.scale = wtp<float>(c, Q.scale); p.shift = wtp<float>(c, Q.shift);
+            p.q_inv = Q.q.inv(); p.q_zoff = Q.q.zoff();
+        } else {
+            L = it->second;
+            p.wpk = wtp<f16>(c, L.wpk); p.scale = wtp<float>(c, L.scale); p.shift = wtp<float>(c, L.shift);
+        }
         p.src = src; p.cond = cond; p.H = H; p.W = W;
         if (cond) {
             const SftLayer &S = c->sft.at(sft_key);
             p.sft_wfrag = wtp<f16>(c, S.wfrag); p.sft_bias = wtp<float>(c, S.bias);
         }
-        p.wpk = wtp<f16>(c, L.wpk); p.scale = wtp<float>(c, L.scale); p.shift = wtp<float>(c, L.shift);
         p.CoutPad = L.coutPad; p.Cout = L.cout; p.act = act; p.mode = mode;
         p.dst = dst; p.dstC = dstC; p.Hd = Hd; p.Wd = Wd; p.res1 = res1; p.res2 = res2;
         p.dst_planar = dst_planar; p.res_planar = res_planar; p.zeros = wtp<f16>(c, c->zeros_off);
@@ -979,9 +1215,9 @@ struct Seq {
         const double macs = npx * 32 * 9 * L.cout + (cond ? npx * 2 * (16 * 16 + 16 * 32) : 0.0);
         const double outb = mode == ST_PLANAR3 ? 6.0 * npx : 2.0 * npx * L.cout;
         const double bytes = npx * (64 + (cond ? 32 : 0)) + outb * (1 + (res1 ? 1 : 0) + (res2 ? 1 : 0) + (res_planar ? 1 : 0)) +
-                             2.0 * 9 * 32 * L.coutPad;
+                             (i8 ? 1.0 : 2.0) * 9 * 32 * L.coutPad;
         char tag[48];
-        snprintf(tag, sizeof tag, "conv32p<%d,%s>", L.coutPad / 32, cond ? "sft" : "plain");
+        snprintf(tag, sizeof tag, "conv32p<%d,%s%s>", L.coutPad / 32, cond ? "sft" : "plain", i8 ? ",i8" : "");
         chk(conv32p_launch(p, c->n_cu, s), key.c_str(), tag, macs, bytes);
     }
     // ResBlock_with_SFT (arch_util.py:89-95): y = x + conv2(sft2(relu(conv1(sft1(x,c))),c))  [+ extra]; 2 launches
@@ -1054,34 +1290,90 @@ int run_le(hdrtv_ctx *c, Seq &q, const f16 *img, f16 *out_planar)
     f16 *h2a = wsp<f16>(c, "le.h2a");
     // condition trunk
     // cond_first (3 layers) + CondNet1 (3 layers) in one launch: img -> cond (64 ch) and cond1 (16 ch)
+    auto qlast = [&](const QLastLayer &Q, QLastArgs &a) -> const QLastArgs * {
+        if (!Q.on) return nullptr;
+        a.wq = wtp<int8_t>(c, Q.wq); a.ss = wtp<float>(c, Q.ss); a.q_inv = Q.q.inv(); a.q_zoff = Q.q.zoff();
+        return &a;
+    };
+    QLastArgs qa6, qa2;
     if (q.ok())
-        q.chk(le_cond_trunk_launch(img, H, W, wtp<f16>(c, c->trunk_wfrag), wtp<float>(c, c->trunk_bias), cond, cond1, c->n_cu, q.s),
-              "LE.cond_trunk", "le_cond_trunk", (double)H * W * (27 * 64 + 4 * 64 * 64 + 64 * 16), (double)H * W * (6 + 128 + 32));
-    // CondNet2/3/4: the three 3x3/s2 first layers read `cond` once (one launch, 192 channels)
-    f16 *x192 = wsp<f16>(c, "le.x192"), *h2b = wsp<f16>(c, "le.h2b");
-    q.conv("LE.CondNet234.0", cond, 64, nullptr, 0, H, W, ACT_LRELU01, ST_NHWC, x192, 192, s.H1, s.W1);
-    // CondNet2.2 + .4 (1x1 64->64, LeakyReLU, 1x1 64->16) in one pass over x192's first 64 channels
+        q.chk(le_cond_trunk_launch(img, H, W, wtp<f16>(c, c->trunk_wfrag), wtp<float>(c, c->trunk_bias), cond, cond1, c->n_cu, q.s,
+                                   qlast(c->q_trunk6, qa6)),
+              "LE.cond_trunk", c->q_trunk6.on ? "le_cond_trunk<q6>" : "le_cond_trunk", (double)H * W * (27 * 64 + 4 * 64 * 64 + 64 * 16), (double)H * W * (6 + 128 + 32));
+    auto isq8 = [&](const char *L) { return c->q8.find(L) != c->q8.end(); };
+    auto qof = [&](const char *L) -> const ActQf * { auto it = c->q8.find(L); return it == c->q8.end() ? nullptr : &it->second.q; };
+    f16 *h2b = wsp<f16>(c, "le.h2b");
+    // CondNet{2,3,4}.0 (3x3 / stride 2 from the 64-channel condition map).  All-fp16 recipes read `cond` once (one launch,
+    // 192 channels); a W8A8 layer among them quantises `cond` with its own x_scale / x_zero and runs alone, writing the int8
+    // codes of the layer that reads it when that one is W8A8 too.
+    const f16 *a2 = nullptr, *a3 = nullptr, *a4 = nullptr;
+    const int8_t *a3q = nullptr, *a4q = nullptr;
+    int astride = 64;
+    if (c->conv.find("LE.CondNet234.0") != c->conv.end()) {
+        f16 *x192 = wsp<f16>(c, "le.x192");
+        q.conv("LE.CondNet234.0", cond, 64, nullptr, 0, H, W, ACT_LRELU01, ST_NHWC, x192, 192, s.H1, s.W1);
+        a2 = x192; a3 = x192 + 64; a4 = x192 + 128; astride = 192;
+    } else {
+        f16 *ca[3] = {wsp<f16>(c, "le.c2a"), wsp<f16>(c, "le.c3a"), wsp<f16>(c, "le.c4a")};
+        int8_t *ca8[3] = {nullptr, wsp<int8_t>(c, "le8.c3a"), wsp<int8_t>(c, "le8.c4a")};
+        const char *l0[3] = {"LE.CondNet2.0", "LE.CondNet3.0", "LE.CondNet4.0"}, *l2[3] = {nullptr, "LE.CondNet3.2", "LE.CondNet4.2"};
+        const f16 **af[3] = {&a2, &a3, &a4};
+        const int8_t **aq[3] = {nullptr, &a3q, &a4q};
+        for (int i = 0; i < 3; ++i) {
+            if (isq8(l0[i])) {
+                const ActQf *oq = l2[i] ? qof(l2[i]) : nullptr;
+                q.convq8(l0[i], cond, false, 64, H, W, ACT_LRELU01, oq ? (void *)ca8[i] : (void *)ca[i], 64, oq);
+                if (oq) *aq[i] = ca8[i]; else *af[i] = ca[i];
+            } else {
+                q.conv(l0[i], cond, 64, nullptr, 0, H, W, ACT_LRELU01, ST_NHWC, ca[i], 64, s.H1, s.W1);
+                *af[i] = ca[i];
+            }
+        }
+    }
+    // CondNet2.2 + .4 (1x1 64->64, LeakyReLU, 1x1 64->16) in one pass over CondNet2.0's 64 channels
     if (q.ok())
-        q.chk(cond_tail_launch(x192, 192, (size_t)s.H1 * s.W1, wtp<f16>(c, c->tail_wfrag), wtp<float>(c, c->tail_bias), cond2, c->n_cu, q.s),
-              "LE.CondNet2.2+4", "cond_tail", (double)s.H1 * s.W1 * (64 * 64 + 64 * 16), (double)s.H1 * s.W1 * (128 + 32));
-    q.conv("LE.CondNet3.2", x192 + 64, 64, nullptr, 0, s.H1, s.W1, ACT_LRELU01, ST_NHWC, h2a, 64, s.H2, s.W2, nullptr, nullptr,
-           nullptr, nullptr, nullptr, nullptr, nullptr, 192);
-    q.conv("LE.CondNet3.4", h2a, 64, nullptr, 0, s.H2, s.W2, ACT_NONE, ST_NHWC, cond3, 16, s.H2, s.W2);
-    q.conv("LE.CondNet4.2", x192 + 128, 64, nullptr, 0, s.H1, s.W1, ACT_LRELU01, ST_NHWC, h2b, 64, s.H2, s.W2, nullptr, nullptr,
-           nullptr, nullptr, nullptr, nullptr, nullptr, 192);
-    q.conv("LE.CondNet4.4", h2b, 64, nullptr, 0, s.H2, s.W2, ACT_NONE, ST_NHWC, cond4, 16, s.H3, s.W3);
+        q.chk(cond_tail_launch(a2, astride, (size_t)s.H1 * s.W1, wtp<f16>(c, c->tail_wfrag), wtp<float>(c, c->tail_bias), cond2, c->n_cu, q.s,
+                               qlast(c->q_tail2, qa2)),
+              "LE.CondNet2.2+4", c->q_tail2.on ? "cond_tail<q2>" : "cond_tail", (double)s.H1 * s.W1 * (64 * 64 + 64 * 16), (double)s.H1 * s.W1 * (128 + 32));
+    // CondNet3 / CondNet4: .2 (3x3 / stride 2, 64 -> 64, LeakyReLU) then .4 (1x1 resp. 3x3 / stride 2, 64 -> 16)
+    {
+        const f16 *af[2] = {a3, a4};
+        const int8_t *aq[2] = {a3q, a4q};
+        f16 *h2[2] = {h2a, h2b}, *cout[2] = {cond3, cond4};
+        const char *l2[2] = {"LE.CondNet3.2", "LE.CondNet4.2"}, *l4[2] = {"LE.CondNet3.4", "LE.CondNet4.4"};
+        for (int i = 0; i < 2; ++i) {
+            const void *h = h2[i];
+            bool h_i8 = false;
+            if (isq8(l2[i])) {
+                const ActQf *oq = qof(l4[i]);
+                int8_t *h8 = oq ? wsp<int8_t>(c, i ? "le8.h2b" : "le8.h2a") : nullptr;
+                q.convq8(l2[i], aq[i] ? (const void *)aq[i] : (const void *)af[i], aq[i] != nullptr, aq[i] ? 64 : astride, s.H1, s.W1,
+                         ACT_LRELU01, oq ? (void *)h8 : (void *)h2[i], 64, oq);
+                if (oq) { h = h8; h_i8 = true; }
+            } else {
+                q.conv(l2[i], af[i], 64, nullptr, 0, s.H1, s.W1, ACT_LRELU01, ST_NHWC, h2[i], 64, s.H2, s.W2, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, nullptr, astride);
+            }
+            if (isq8(l4[i])) q.convq8(l4[i], h, h_i8, 64, s.H2, s.W2, ACT_NONE, cout[i], 16, nullptr);
+            else q.conv(l4[i], h2[i], 64, nullptr, 0, s.H2, s.W2, ACT_NONE, ST_NHWC, cout[i], 16, i ? s.H3 : s.H2, i ? s.W3 : s.W2);
+        }
+    }
     // main branch: every SFT is fused into the 3x3 conv that follows it
     f16 *f0a = wsp<f16>(c, "le.f0a"), *f0b = wsp<f16>(c, "le.f0b"), *fea0 = wsp<f16>(c, "le.fea0"), *up3 = wsp<f16>(c, "le.up3");
     q.c3("le.conv_first", img, H, W, ACT_RELU, f0a, nullptr);
     q.conv32("LE.HR_conv1", f0a, cond1, "LE.SFT_layer1", H, W, ACT_RELU, ST_NHWC, fea0, 32, H, W);
     f16 *fea1a = wsp<f16>(c, "le.fea1a"), *fea1 = wsp<f16>(c, "le.fea1"), *l1b = wsp<f16>(c, "le.l1b");
-    q.conv("LE.down_conv1", fea0, 32, nullptr, 0, H, W, ACT_RELU, ST_NHWC, fea1a, 32, s.H1, s.W1);
+    auto down = [&](const char *key, const f16 *src, int Hi, int Wi, f16 *dst, int Ho, int Wo) {
+        if (isq8(key)) q.convq8(key, src, false, 32, Hi, Wi, ACT_RELU, dst, 32, nullptr);
+        else q.conv(key, src, 32, nullptr, 0, Hi, Wi, ACT_RELU, ST_NHWC, dst, 32, Ho, Wo);
+    };
+    down("LE.down_conv1", fea0, H, W, fea1a, s.H1, s.W1);
     q.resblock("LE.recon_trunk1.0", fea1a, cond2, s.H1, s.W1, l1b, fea1);
     f16 *fea2a = wsp<f16>(c, "le.fea2a"), *fea2 = wsp<f16>(c, "le.fea2"), *l2b = wsp<f16>(c, "le.l2b");
-    q.conv("LE.down_conv2", fea1, 32, nullptr, 0, s.H1, s.W1, ACT_RELU, ST_NHWC, fea2a, 32, s.H2, s.W2);
+    down("LE.down_conv2", fea1, s.H1, s.W1, fea2a, s.H2, s.W2);
     q.resblock("LE.recon_trunk2.0", fea2a, cond3, s.H2, s.W2, l2b, fea2);
     f16 *fea3 = wsp<f16>(c, "le.fea3"), *l3b = wsp<f16>(c, "le.l3b"), *t3x = wsp<f16>(c, "le.t3x"), *t3y = wsp<f16>(c, "le.t3y");
-    q.conv("LE.down_conv3", fea2, 32, nullptr, 0, s.H2, s.W2, ACT_RELU, ST_NHWC, fea3, 32, s.H3, s.W3);
+    down("LE.down_conv3", fea2, s.H2, s.W2, fea3, s.H3, s.W3);
     q.resblock("LE.recon_trunk3.0", fea3, cond4, s.H3, s.W3, l3b, t3x);
     q.resblock("LE.recon_trunk3.1", t3x, cond4, s.H3, s.W3, l3b, t3y);
     q.resblock("LE.recon_trunk3.2", t3y, cond4, s.H3, s.W3, l3b, t3x);

@@ -17,6 +17,7 @@ hipError_t conv_pglds_launch(ConvParams p, int n_cu, hipStream_t stream);
 hipError_t conv_pglds_i8_launch(ConvI8Params p, int n_cu, hipStream_t stream);
 hipError_t conv1x1_i8_launch(ConvI8Params p, hipStream_t stream);
 hipError_t conv32p_launch(Conv32Params p, int n_cu, hipStream_t stream);
+hipError_t conv_q8_launch(ConvQ8Params p, hipStream_t stream);
 hipError_t conv3x3s2_preg_launch(ConvParams p, int n_cu, hipStream_t stream);
 
 hipError_t pre_unpack_launch(const uint8_t *bgr, f16 *out, int H, int W, hipStream_t s);
@@ -41,10 +42,16 @@ hipError_t agcm_mlp_launch(const f16 *in, f16 *out, size_t npix, const f16 *frag
 hipError_t conv_c3_launch(const f16 *in, int H, int W, const f16 *wfrag, const float *scale, const float *shift, int cout,
                           int act, f16 *out, f16 *out_pool, int n_cu, hipStream_t s, float pool_q_inv = 0.f, float pool_q_zero = 0.f);
 // pool_q_inv > 0: out_pool holds int8 codes clamp(rint(v * pool_q_inv + pool_q_zero), -128, 127), COUT bytes per pixel
+// last layer of a fused chain as a W8A8 layer: int8 weight fragments [2][64 lanes][16 B], ss = scale[32] | shift[32]
+struct QLastArgs {
+    const int8_t *wq;
+    const float *ss;
+    float q_inv, q_zoff;
+};
 hipError_t le_cond_trunk_launch(const f16 *img, int H, int W, const f16 *wfrag, const float *bias, f16 *cond, f16 *cond1,
-                                int n_cu, hipStream_t s);
+                                int n_cu, hipStream_t s, const QLastArgs *q6 = nullptr);
 hipError_t cond_tail_launch(const f16 *x, int x_stride, size_t npx, const f16 *wfrag, const float *bias, f16 *out, int n_cu,
-                            hipStream_t s);
+                            hipStream_t s, const QLastArgs *q2 = nullptr);
 hipError_t hg_prep_launch(const f16 *base, int H, int W, int Hp, int Wp, f16 *img_pad, uint8_t *mask, float r, float thresh,
                           hipStream_t s);
 struct HgFinalFusedArgs {

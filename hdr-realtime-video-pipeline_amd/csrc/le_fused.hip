@@ -40,9 +40,45 @@ __device__ __forceinline__ f16x8 lrelu_pack(const f32x16 &a, int s)
     return __builtin_elementwise_max(o, o * (f16)0.1f);
 }
 
+// Last layer of a chain as a W8A8 layer (CondNet1.4 / CondNet2.4 in the reference's mixed and full INT8 recipes): the 64
+// LeakyReLU'd inputs of a pixel sit in four packed f16 fragments (fragment s, element e = channel 16s + 4lh + e for e < 4,
+// 16s + 8 + 4lh + e - 4 otherwise); they are quantised in registers and consumed by two v_mfma_i32_32x32x32_i8 whose
+// weight fragments the host packed in the same byte order (hdrtv_api.hip pack_q_last).  ss = scale[32] | shift[32].
+struct QLast {
+    const i32x4 *wq;       // [2][64 lanes]
+    const float *ss;
+    float q_inv, q_zoff;
+};
+__device__ __forceinline__ f32x16 qlast_apply(const QLast &q, const f16x8 *bf, int lane, int lh)
+{
+    i32x16 o;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) o[k] = 0;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const f16x8 a = bf[2 * m], b = bf[2 * m + 1];
+        i32x4 x;
+        x[0] = (int)quant4((float)a[0], (float)a[1], (float)a[2], (float)a[3], q.q_inv, q.q_zoff);
+        x[1] = (int)quant4((float)a[4], (float)a[5], (float)a[6], (float)a[7], q.q_inv, q.q_zoff);
+        x[2] = (int)quant4((float)b[0], (float)b[1], (float)b[2], (float)b[3], q.q_inv, q.q_zoff);
+        x[3] = (int)quant4((float)b[4], (float)b[5], (float)b[6], (float)b[7], q.q_inv, q.q_zoff);
+        o = __builtin_amdgcn_mfma_i32_32x32x32_i8(q.wq[m * 64 + lane], x, o, 0, 0, 0);
+    }
+    f32x16 r;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {                  // rows 0..15 only: registers 0..3 (rows 4lh + k) and 4..7 (rows 8 + 4lh + k)
+        const float4 sc = *reinterpret_cast<const float4 *>(q.ss + 8 * g + 4 * lh);
+        const float4 sh = *reinterpret_cast<const float4 *>(q.ss + 32 + 8 * g + 4 * lh);
+        r[4 * g + 0] = (float)o[4 * g + 0] * sc.x + sh.x; r[4 * g + 1] = (float)o[4 * g + 1] * sc.y + sh.y;
+        r[4 * g + 2] = (float)o[4 * g + 2] * sc.z + sh.z; r[4 * g + 3] = (float)o[4 * g + 3] * sc.w + sh.w;
+    }
+    return r;
+}
+
+template <bool Q6>
 __global__ __launch_bounds__(256, 2) void le_cond_trunk_kernel(const f16 *__restrict__ img, int H, int W,
                                                                const f16 *__restrict__ wfrag, const float *__restrict__ bias,
-                                                               f16 *__restrict__ cond, f16 *__restrict__ cond1)
+                                                               f16 *__restrict__ cond, f16 *__restrict__ cond1, QLast ql)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f16x8 *s_w = reinterpret_cast<f16x8 *>(smem);                               // [NFRAG][64]
@@ -173,10 +209,15 @@ __global__ __launch_bounds__(256, 2) void le_cond_trunk_kernel(const f16 *__rest
     // ---- layer 6: 64 -> 16 (rows 0..15 of one tile), no activation -> cond1 (NHWC 16)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        f32x16 o = bias_tile_l(s_b + 320, lh);
+        f32x16 o;
+        if constexpr (Q6) {
+            o = qlast_apply(ql, bf[j], lane, lh);
+        } else {
+            o = bias_tile_l(s_b + 320, lh);
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(36 + s) * 64 + lane], bf[j][s], o, 0, 0, 0);
+            for (int s = 0; s < 4; ++s)
+                o = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(36 + s) * 64 + lane], bf[j][s], o, 0, 0, 0);
+        }
         // rows 0..15 live in registers 0..3 (rows 0-3 / 4-7 by lane half) and 4..7 (rows 8-11 / 12-15)
         f16x4 lo, hi;
 #pragma unroll
@@ -201,9 +242,10 @@ __global__ __launch_bounds__(256, 2) void le_cond_trunk_kernel(const f16 *__rest
 // 32-pixel groups; both weight sets live in its registers; layer 1 reads its B fragments straight from the NHWC input
 // (16 bytes per lane and k-step), layer 2 takes layer 1's accumulator tiles as operands (weights K-permuted at pack
 // time, common.h acc_kperm16), exactly as the trunk above chains its layers.
+template <bool Q2>
 __global__ __launch_bounds__(256) void cond_tail_kernel(const f16 *__restrict__ x, int x_stride, size_t npx,
                                                         const f16 *__restrict__ wfrag, const float *__restrict__ bias,
-                                                        f16 *__restrict__ out)
+                                                        f16 *__restrict__ out, QLast ql)
 {
     const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
     const f16x8 *fr = reinterpret_cast<const f16x8 *>(wfrag);
@@ -237,9 +279,14 @@ __global__ __launch_bounds__(256) void cond_tail_kernel(const f16 *__restrict__ 
             h1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[1][s], cur[s], h1, 0, 0, 0);
         }
         const f16x8 bf[4] = {lrelu_pack(h0, 0), lrelu_pack(h0, 1), lrelu_pack(h1, 0), lrelu_pack(h1, 1)};
-        f32x16 o = b2;
+        f32x16 o;
+        if constexpr (Q2) {
+            o = qlast_apply(ql, bf, lane, lh);
+        } else {
+            o = b2;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) o = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[s], bf[s], o, 0, 0, 0);
+            for (int s = 0; s < 4; ++s) o = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[s], bf[s], o, 0, 0, 0);
+        }
         // rows 0..15 live in registers 0..3 (rows 4*lh + k) and 4..7 (rows 8 + 4*lh + k)
         const size_t px = g * 32 + l31;
         if (px < npx) {
@@ -260,30 +307,45 @@ constexpr int TRUNK_SMEM = NFRAG * 64 * 16 + ((NBIAS * 4 + 15) / 16) * 16 + ((3 
 }  // namespace
 
 hipError_t le_cond_trunk_launch(const f16 *img, int H, int W, const f16 *wfrag, const float *bias, f16 *cond, f16 *cond1,
-                                int n_cu, hipStream_t s)
+                                int n_cu, hipStream_t s, const QLastArgs *q6)
 {
     static DevOnce attr_once;   // hipFuncSetAttribute is per (function, device)
     if (attr_once.need()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(le_cond_trunk_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(le_cond_trunk_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, TRUNK_SMEM);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(le_cond_trunk_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, TRUNK_SMEM);
         if (e != hipSuccess) return e;
         attr_once.done();
     }
     const int ntiles = ((W + T_TW - 1) / T_TW) * ((H + T_TH - 1) / T_TH);
     const int grid = ntiles < 2 * n_cu ? ntiles : 2 * n_cu;          // two workgroups per CU (LDS: ~60 KiB each)
-    hipLaunchKernelGGL(le_cond_trunk_kernel, dim3(grid), dim3(256), TRUNK_SMEM, s, img, H, W, wfrag, bias, cond, cond1);
+    QLast ql{nullptr, nullptr, 0.f, 0.f};
+    if (q6) {
+        ql = QLast{reinterpret_cast<const i32x4 *>(q6->wq), q6->ss, q6->q_inv, q6->q_zoff};
+        hipLaunchKernelGGL(le_cond_trunk_kernel<true>, dim3(grid), dim3(256), TRUNK_SMEM, s, img, H, W, wfrag, bias, cond, cond1, ql);
+    } else {
+        hipLaunchKernelGGL(le_cond_trunk_kernel<false>, dim3(grid), dim3(256), TRUNK_SMEM, s, img, H, W, wfrag, bias, cond, cond1, ql);
+    }
     return hipGetLastError();
 }
 
 // x: NHWC with x_stride elements per pixel (the first 64 channels are read), out: NHWC 16.  wfrag: 12 fragments
 // (layer 1: 2 x 4 natural-k, layer 2: 4 K-permuted, rows 16..31 zero), bias: [64] + [32, upper half zero].
 hipError_t cond_tail_launch(const f16 *x, int x_stride, size_t npx, const f16 *wfrag, const float *bias, f16 *out, int n_cu,
-                            hipStream_t s)
+                            hipStream_t s, const QLastArgs *q2)
 {
     if (!npx || x_stride < 64 || (x_stride % 8)) return hipErrorInvalidValue;
     const size_t ngroups = (npx + 31) / 32;
     size_t grid = (ngroups + 3) / 4;
     if (grid > (size_t)8 * n_cu) grid = (size_t)8 * n_cu;
-    hipLaunchKernelGGL(cond_tail_kernel, dim3((unsigned)grid), dim3(256), 0, s, x, x_stride, npx, wfrag, bias, out);
+    QLast ql{nullptr, nullptr, 0.f, 0.f};
+    if (q2) {
+        ql = QLast{reinterpret_cast<const i32x4 *>(q2->wq), q2->ss, q2->q_inv, q2->q_zoff};
+        hipLaunchKernelGGL(cond_tail_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, x, x_stride, npx, wfrag, bias, out, ql);
+    } else {
+        hipLaunchKernelGGL(cond_tail_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, x, x_stride, npx, wfrag, bias, out, ql);
+    }
     return hipGetLastError();
 }

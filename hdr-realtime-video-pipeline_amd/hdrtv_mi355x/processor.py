@@ -89,10 +89,15 @@ class HDRTVNetMI355X:
             if not _W.is_int8_state(hr_state):
                 raise ValueError(f"precision '{self.precision}' needs an INT8 checkpoint (weight_int8 tensors)")
             if str(predequantize).lower() in ("off", "false", "0", "no"):
-                raise ValueError("predequantize='off' (fake-quant activations / native int8 MFMA) is not implemented "
-                                 "by the MI355X backend yet; use 'auto'")
-            hr_state = _W.dequantize_int8_state(hr_state, "fp16")
-            self._is_w8_model = False          # as the reference after pre-dequantization (1919)
+                # the quantised layers stay in place (hdrtvnet_torch.py:1893-1917 with predequantize off): W8A8 layers run
+                # on int8 MFMA with the reference's activation quantisers, W8 (weight-only) layers as fp16 convs of the
+                # dequantised weights, exactly what W8Conv2d.forward computes.  hdrtv_create rejects a checkpoint with a
+                # W8A8 layer it has no int8 kernel for.
+                hr_state = _W.normalize_int8_state(hr_state)
+                self._is_w8_model = True
+            else:
+                hr_state = _W.dequantize_int8_state(hr_state, "fp16")
+                self._is_w8_model = False          # as the reference after pre-dequantization (1919)
         elif _W.is_int8_state(hr_state):
             raise ValueError("INT8 checkpoint given with a floating-point precision; use precision='int8-full'/'int8-mixed'")
         try:
@@ -114,7 +119,7 @@ class HDRTVNetMI355X:
         self._hg_weights = hg_weights if self._use_hg else None
         self._hg_int8 = hg_state is not None and _W.is_int8_state(hg_state)
         self._hg_state_fp = hg_state if (hg_state is not None and not self._hg_int8) else None
-        hr_blob = _W.pack_state({k: hr_state[k] for k, _ in _arch_hr()})
+        hr_blob = _W.pack_state(hr_state if self._is_w8_model else {k: hr_state[k] for k, _ in _arch_hr()})
         hg_blob = _W.pack_state({k: v for k, v in hg_state.items()
                                  if not k.endswith("num_batches_tracked")}) if hg_state is not None else b""
         rc = self._lib.hdrtv_create(hr_blob, len(hr_blob), hg_blob if hg_blob else None, len(hg_blob),
@@ -132,7 +137,8 @@ class HDRTVNetMI355X:
         self._pin_input = self._pin_output = None
         self._gpu_out = self._gpu_agcm = self._gpu_u8 = None
         print(f"MI355X device : {self.device}")
-        print(f"MI355X precision: {self.precision}  (HG {('W8A8 on int8 MFMA' if self._hg_int8 else 'on') if self._use_hg else 'off'})")
+        print(f"MI355X precision: {self.precision}{' (W8A8 layers on int8 MFMA)' if self._is_w8_model else ''}  "
+              f"(HG {('W8A8 on int8 MFMA' if self._hg_int8 else 'on') if self._use_hg else 'off'})")
         if self._warmup_passes > 0:
             self._warmup()
 

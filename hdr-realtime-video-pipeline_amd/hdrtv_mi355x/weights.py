@@ -96,8 +96,12 @@ def save_pack(path, state) -> None:
 
 
 def check_hr_state(state) -> None:
-    """Raise ValueError unless ``state`` has exactly the HR (AGCM+LE) tensors."""
+    """Raise ValueError unless ``state`` has exactly the HR (AGCM+LE) tensors; an INT8 runtime layer may hold
+    ``weight_int8`` (+ ``scale`` / ``w_scale``, ``x_scale``, ``x_zero``) in place of ``weight``."""
     want = dict(arch.hr_params())
+    for k in list(want):
+        if k.endswith(".weight") and k not in state and k[:-len(".weight")] + ".weight_int8" in state:
+            want[k[:-len(".weight")] + ".weight_int8"] = want.pop(k)
     missing = [k for k in want if k not in state]
     if missing:
         raise ValueError(f"checkpoint is missing {len(missing)} tensors, e.g. {missing[0]}")
@@ -108,6 +112,26 @@ def check_hr_state(state) -> None:
 
 def is_int8_state(state) -> bool:
     return any(k.endswith(".weight_int8") for k in state)
+
+
+def normalize_int8_state(state) -> "OrderedDict[str, np.ndarray]":
+    """INT8 runtime checkpoint (hdrtvnet_torch.py:1755-1883) as plain arrays for the weight pack, quantised layers kept:
+    ``weight_int8`` int8, per-channel ``scale`` / ``w_scale`` and ``bias`` as stored, ``x_scale`` / ``x_zero`` as the fp32
+    scalars the reference promotes them to (``W8A8Conv2d._apply``, 339-349)."""
+    out = OrderedDict()
+    for k, v in state.items():
+        a = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+        if k.endswith(".weight_int8"):
+            out[k] = np.ascontiguousarray(a.astype(np.int8))
+        elif k.endswith((".x_scale", ".x_zero")):
+            out[k] = a.astype(np.float32).reshape(1)
+        elif a.dtype.kind == "f":
+            out[k] = a.astype(np.float32) if a.dtype == np.float64 else a
+        elif a.dtype.kind in "iu" and a.ndim == 0:
+            continue            # e.g. num_batches_tracked
+        else:
+            out[k] = a
+    return out
 
 
 def dequantize_int8_state(state, compute: str = "fp16") -> "OrderedDict[str, np.ndarray]":

@@ -1,0 +1,188 @@
+"""BASELINE configs[4], HR part: the reference's shipped INT8-QAT checkpoints executed with their quantised layers in
+place (``predequantize="off"``): W8A8 layers on int8 MFMA with the reference's own activation quantisers (float
+``x_zero``; zero padding applied after dequantisation -> border-aware correction), W8 layers as fp16 convs.
+
+Oracle: ``O.w8a8_state`` + the ordinary graphs = the reference's fake-quant execution in fp32, pinned by
+``tests/golden/int8_*_w8a8_*.npz`` (runs of the reference itself, tests/golden/gen_golden_w8a8.py).
+
+Bars.  The reference's own bound for a re-quantised graph is u8 MAE <= 5 and float MAE <= 0.02
+(scripts/validate_tensorrt_sources.py:598-609).  Measured values are printed; asserted bounds are ~3x those.
+Layer by layer, GIVEN THE DEVICE'S OWN INPUT, an int8 layer is exact integer arithmetic: its output may differ from the
+oracle's only where fp16 storage of the input or of the result moves a value across a rounding boundary.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU; torch.cuda.is_available() is False")
+    return torch
+
+
+def _proc(golden_dir, tag, **kw):
+    from hdrtv_mi355x.processor import HDRTVNetMI355X
+    return HDRTVNetMI355X(os.path.join(golden_dir, f"hr_int8_{tag}_qat.hdrw"), precision=f"int8-{tag}", predequantize="off",
+                          use_hg=False, warmup_passes=0, **kw)
+
+
+@pytest.fixture(scope="module")
+def proc_mixed(torch_cuda, golden_dir):
+    p = _proc(golden_dir, "mixed")
+    yield p
+    p.close()
+
+
+@pytest.fixture(scope="module")
+def sd_mixed(golden_dir):
+    from hdrtv_mi355x import weights as W
+    from oracle import hdrtvnet_oracle as O
+    return O.w8a8_state(W.load_pack(os.path.join(golden_dir, "hr_int8_mixed_qat.hdrw")))
+
+
+def _stats(name, got, want):
+    d = np.abs(np.asarray(got, np.float64) - np.asarray(want, np.float64))
+    print(f"  {name}: max_abs={d.max():.3e} mean_abs={d.mean():.3e} ref_absmean={np.abs(want).mean():.3e}")
+    return d.max(), d.mean()
+
+
+def _codes(x, w):
+    """int8 codes (q - 128) of W8A8 weight ``w``'s activation quantiser for the f16-stored tensor x."""
+    x = np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
+    s, z = np.float32(w.x_scale), np.float32(w.x_zero)
+    return (np.clip(np.rint((x - z) / s), 0, 255) - 128).astype(np.int32)
+
+
+def _deq(codes, w):
+    return ((np.asarray(codes, np.float32) + np.float32(128)) * np.float32(w.x_scale) + np.float32(w.x_zero)).astype(np.float32)
+
+
+def test_mixed_is_native_int8(proc_mixed):
+    assert proc_mixed._is_w8_model is True and proc_mixed.precision == "int8-mixed"
+
+
+def test_mixed_w8a8_vs_reference_run(proc_mixed, golden_dir):
+    """Against the reference's own fake-quant execution of HR_original_int8_mixed_qat.pt (CPU fp32, predequantize off)."""
+    d = np.load(os.path.join(golden_dir, "int8_mixed_qat_w8a8_64x96_gradient_s6.npz"))
+    kinds = [str(k) for k in d["layer_kinds"]]
+    assert sum(k.endswith("W8A8Conv2d:asym") for k in kinds) == 29
+    out, agcm = proc_mixed.infer(proc_mixed.preprocess(d["frame"]))
+    out_np = out.float().cpu().numpy()[0]
+    mx, mean = _stats("agcm (fp16 layers in the mixed recipe)", agcm.float().cpu().numpy()[0], d["agcm_out"])
+    assert mx <= 2e-3
+    mx, mean = _stats("out vs reference W8A8 run", out_np, d["out"])
+    assert mx <= 4e-2 and mean <= 2e-3
+    u8 = proc_mixed.postprocess(out).astype(int)
+    du8 = np.abs(u8 - d["u8_bgr"].astype(int))
+    print(f"  u8: max={du8.max()} MAE={du8.mean():.4f} (reference bar: MAE <= 5)")
+    assert du8.mean() <= 0.5 and du8.max() <= 8
+    launches, _ = proc_mixed.infer_stats()
+    prof_kernels = None
+    proc_mixed.profile_enable(True)
+    proc_mixed.infer(proc_mixed.preprocess(d["frame"]))
+    prof_kernels = [k for _, k, _, _, _ in proc_mixed.profile_read()]
+    proc_mixed.profile_enable(False)
+    n_i8 = sum(("i8" in k) or ("q8" in k) or ("<q" in k) for k in prof_kernels)
+    print(f"  {n_i8} of {launches} launches run W8A8 layers on int8 MFMA: {sorted(set(k for k in prof_kernels if 'i8' in k or 'q8' in k or '<q' in k))}")
+    # 29 W8A8 layers: 15 resblock convs + 3 up convs (conv32p<..,i8>), 3 down convs + CondNet3.{0,2,4} + CondNet4.{0,2,4} (conv_q8),
+    # CondNet1.4 and CondNet2.4 inside the two fused chains
+    assert n_i8 == 29
+
+
+def test_mixed_w8a8_layers_given_device_inputs(proc_mixed, sd_mixed, golden_dir):
+    """Every W8A8 kernel family against the oracle's fake-quant layer fed the DEVICE's input tensor."""
+    from oracle import hdrtvnet_oracle as O
+    d = np.load(os.path.join(golden_dir, "int8_mixed_qat_w8a8_64x96_gradient_s6.npz"))
+    sd = sd_mixed
+    out, agcm = proc_mixed.infer(proc_mixed.preprocess(d["frame"]))
+    T = lambda n: proc_mixed.tap(n).numpy()          # noqa: E731
+    cond = T("le.cond")
+
+    def flips(name, got, want):
+        diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
+        rate = float((diff != 0).mean())
+        print(f"  {name}: code flips {rate:.2e} (max step {int(diff.max())}) of {diff.size}")
+        return rate, int(diff.max())
+
+    # ---- conv_q8, f16 input -> int8 codes of the next layer: CondNet3.0 / 4.0 (3x3 stride 2, 64 -> 64, LeakyReLU)
+    for i, nxt in ((3, "LE.CondNet3.2"), (4, "LE.CondNet4.2")):
+        y = O.leaky(O.conv2d(cond, sd[f"LE.CondNet{i}.0.weight"], sd[f"LE.CondNet{i}.0.bias"], 2, 1), 0.1)
+        rate, step = flips(f"CondNet{i}.0 -> codes", T(f"le8.c{i}a"), _codes(y, sd[nxt + ".weight"]))
+        assert rate <= 2e-3 and step <= 1
+    # ---- conv_q8, int8 input -> int8 codes: CondNet3.2 / 4.2; then -> f16: CondNet3.4 (1x1) / CondNet4.4 (3x3 stride 2)
+    for i, tap_in, tap_mid, tap_out, s4 in ((3, "le8.c3a", "le8.h2a", "le.cond3", 1), (4, "le8.c4a", "le8.h2b", "le.cond4", 2)):
+        w2, w4 = sd[f"LE.CondNet{i}.2.weight"], sd[f"LE.CondNet{i}.4.weight"]
+        y = O.leaky(O.conv2d(_deq(T(tap_in), w2), w2, sd[f"LE.CondNet{i}.2.bias"], 2, 1), 0.1)
+        rate, step = flips(f"CondNet{i}.2 -> codes", T(tap_mid), _codes(y, w4))
+        assert rate <= 2e-3 and step <= 1
+        pad = w4.shape[2] // 2
+        y4 = O.conv2d(_deq(T(tap_mid), w4), w4, sd[f"LE.CondNet{i}.4.bias"], s4, pad)
+        mx, _ = _stats(f"CondNet{i}.4 (f16 out)", T(tap_out), y4)
+        assert mx <= 2e-3
+    # ---- fused chains with a W8A8 last layer: CondNet1 (le_cond_trunk<q6>), CondNet2 (cond_tail<q2>)
+    taps = {}
+    O.le(sd, agcm.float().cpu().numpy()[0], taps)
+    mx, _ = _stats("cond1 (CondNet1.4 W8A8 in the trunk)", T("le.cond1"), taps["LE.CondNet1"])
+    assert mx <= 1.5e-2
+    mx, _ = _stats("cond2 (CondNet2.4 W8A8 in the tail)", T("le.cond2"), taps["LE.CondNet2"])
+    assert mx <= 1.5e-2
+    # ---- conv_q8, f16 -> f16: down_conv1 (3x3 stride 2, 32 -> 32, ReLU)
+    y = O.relu(O.conv2d(T("le.fea0"), sd["LE.down_conv1.weight"], sd["LE.down_conv1.bias"], 2, 1))
+    mx, _ = _stats("down_conv1", T("le.fea1a"), y)
+    assert mx <= 2e-3
+    # ---- conv32p<1,sft,i8>: a whole ResBlock_with_SFT (fp16 SFT of W8 weights, two W8A8 convs, residual)
+    y = O.resblock_sft(sd, "LE.recon_trunk1.0", T("le.fea1a"), T("le.cond2"))
+    mx, mean = _stats("recon_trunk1.0 (2 x conv32p<1,sft,i8>)", T("le.fea1"), y)
+    assert mx <= 3e-2 and mean <= 1.5e-3
+    # ---- conv32p<4,plain,i8>: up_conv1 (32 -> 128, PixelShuffle, ReLU) + skip
+    y = O.relu(O.pixelshuffle2(O.conv2d(T("le.t3y"), sd["LE.up_conv1.0.weight"], sd["LE.up_conv1.0.bias"], 1, 1))) + T("le.fea2")
+    mx, _ = _stats("up_conv1 (conv32p<4,plain,i8>)", T("le.up1"), y)
+    assert mx <= 3e-3
+
+
+def test_mixed_w8a8_border_classes_unaligned(proc_mixed, sd_mixed):
+    """61 x 103 frame: odd sizes at every level (last row / column of stride-2 layers, _align_to crops), tiles that end
+    inside the image, all 16 border classes of the x_zero correction."""
+    from hdrtv_mi355x import weights as W
+    from oracle import hdrtvnet_oracle as O
+    f = W.synthetic_frame(61, 103, seed=9, kind="gradient")
+    out, agcm = proc_mixed.infer(proc_mixed.preprocess(f))
+    a = agcm.float().cpu().numpy()[0]
+    ref = O.le(sd_mixed, a)
+    mx, mean = _stats("LE out 61x103 vs oracle fake-quant (our AGCM)", out.float().cpu().numpy()[0], ref)
+    assert mx <= 4e-2 and mean <= 2e-3
+    d = np.abs(out.float().cpu().numpy()[0] - ref)
+    edge = max(d[:, 0].max(), d[:, -1].max(), d[:, :, 0].max(), d[:, :, -1].max())
+    print(f"  border rows / columns: max_abs={edge:.3e}; interior max_abs={d[:, 1:-1, 1:-1].max():.3e}")
+    assert edge <= 4e-2
+
+
+def test_mixed_w8a8_multi_tile(proc_mixed, sd_mixed):
+    """272 x 480: several tiles per workgroup in every persistent kernel, oracle finishes in seconds."""
+    from hdrtv_mi355x import weights as W
+    from oracle import hdrtvnet_oracle as O
+    f = W.synthetic_frame(272, 480, seed=12, kind="gradient")
+    out, agcm = proc_mixed.infer(proc_mixed.preprocess(f))
+    ref = O.le(sd_mixed, agcm.float().cpu().numpy()[0])
+    got = out.float().cpu().numpy()[0]
+    mx, mean = _stats("LE out 272x480 vs oracle fake-quant", got, ref)
+    assert mx <= 4e-2 and mean <= 2e-3
+    u8 = np.abs(O.postprocess_u8(got).astype(int) - O.postprocess_u8(ref).astype(int))
+    print(f"  u8 MAE {u8.mean():.4f} max {u8.max()}")
+    assert u8.mean() <= 0.5
+
+
+def test_full_checkpoint_and_predequantize_switch(golden_dir, torch_cuda):
+    """`predequantize` follows the reference's switch: auto/on -> fp16 convs (its ROCm default), off -> quantised layers."""
+    from hdrtv_mi355x.processor import HDRTVNetMI355X
+    p = HDRTVNetMI355X(os.path.join(golden_dir, "hr_int8_mixed_qat.hdrw"), precision="int8-mixed", use_hg=False, warmup_passes=0)
+    try:
+        assert p._is_w8_model is False
+    finally:
+        p.close()
