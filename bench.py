@@ -47,9 +47,13 @@ def parse():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--no-hg", action="store_true", help="debug: AGCM+LE only (not the headline config)")
     ap.add_argument("--int8", action="store_true",
-                    help="BASELINE configs[4] instead of the headline fp16 configuration: HR from the INT8-QAT checkpoint "
-                         "(int8 storage, fp16 compute, as the reference runs it on ROCm) and the HG head as a W8A8 checkpoint on "
+                    help="BASELINE configs[4] instead of the headline fp16 configuration: HR from the reference's INT8-QAT checkpoint "
+                         "with its W8A8 layers on int8 MFMA (predequantize off) and the HG head as a W8A8 checkpoint on "
                          "int8 MFMA (seeded + calibrated: the reference's int8 HG weights are not shipped)")
+    ap.add_argument("--int8-recipe", default="full", choices=("full", "mixed"),
+                    help="which shipped HR recipe --int8 runs: full (128 W8A8 layers) or mixed (29 W8A8 + 78 W8A16 + 21 fp16)")
+    ap.add_argument("--int8-predequantize", action="store_true",
+                    help="with --int8: run the HR checkpoint as the reference does on ROCm (int8 storage, fp16 compute)")
     ap.add_argument("--no-int8-extra", action="store_true",
                     help="skip the extra BASELINE configs[4] measurement (INT8-QAT, HG on int8 MFMA) reported beside the headline at N=1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -105,7 +109,7 @@ def int8_extra(args, dev, dev_frames, steps=20, warmup=3):
         H, Wd = args.height, args.width
         with contextlib.redirect_stdout(sys.stderr):
             proc = HDRTVNetMI355X(os.path.join(REPO, "tests", "golden", "hr_int8_full_qat.hdrw"), device=str(dev),
-                                  precision="int8-full", use_hg=True, hg_weights="seeded-w8a8:1234", warmup_passes=0)
+                                  precision="int8-full", predequantize="off", use_hg=True, hg_weights="seeded-w8a8:1234", warmup_passes=0)
         proc._ensure_buffers(H, Wd)
         lib, ctx = proc._lib, proc._ctx
         rgb48 = torch.empty((H, Wd, 3), dtype=torch.uint16, device=dev)
@@ -127,7 +131,7 @@ def int8_extra(args, dev, dev_frames, steps=20, warmup=3):
         torch.cuda.synchronize(dev)
         el = time.perf_counter() - t0
         proc.close()
-        return {"metric": "frames/sec, INT8-QAT HDRTVNet++ (HR int8 weights / fp16 compute, HG W8A8 on int8 MFMA), same frames",
+        return {"metric": "frames/sec, INT8-QAT HDRTVNet++ (HR: the shipped full-QAT checkpoint, W8A8 layers on int8 MFMA; HG W8A8 on int8 MFMA), same frames",
                 "value": round(steps / el, 3), "unit": "frames/s", "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
                 "dtype": "i8+f16"}
     except Exception as exc:  # noqa: BLE001  (an extra: never take the headline line down with it)
@@ -157,8 +161,9 @@ def main():
     H, Wd = args.height, args.width
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):       # stdout carries exactly one JSON line
-        proc = HDRTVNetMI355X(os.path.join(REPO, "tests", "golden", "hr_int8_full_qat.hdrw" if args.int8 else "hr_weights.hdrw"),
-                              device=f"cuda:{local_rank}", precision="int8-full" if args.int8 else "auto",
+        proc = HDRTVNetMI355X(os.path.join(REPO, "tests", "golden", f"hr_int8_{args.int8_recipe}_qat.hdrw" if args.int8 else "hr_weights.hdrw"),
+                              device=f"cuda:{local_rank}", precision=f"int8-{args.int8_recipe}" if args.int8 else "auto",
+                              predequantize="auto" if (args.int8_predequantize or not args.int8) else "off",
                               use_hg=use_hg, hg_weights=("seeded-w8a8:1234" if args.int8 else "seeded:1234") if use_hg else None,
                               warmup_passes=0)
     proc._ensure_buffers(H, Wd)
@@ -328,13 +333,17 @@ def main():
     launches, macs_frame = proc.infer_stats()
     if rank == 0:
         line = {
-            "metric": f"frames/sec (HDRTVNet++ AGCM+LE{'+HG' if use_hg else ''} {'INT8-QAT (HR int8 weights, fp16 compute; HG W8A8 on int8 MFMA)' if args.int8 else 'fp16'} "
+            "metric": f"frames/sec (HDRTVNet++ AGCM+LE{'+HG' if use_hg else ''} {'INT8-QAT (HR + HG W8A8 layers on int8 MFMA)' if args.int8 else 'fp16'} "
                       f"{args.width}x{args.height} + fused RGB48 post); p50 per-frame ms in p50_ms",
             "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "p50_ms": round(p50, 3), "p99_ms": round(p99, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i8+f16" if args.int8 else "f16",
             "data": "synthetic (seeded u8 noise + gradient/highlight frames; HR.pt weights, seeded HG weights)",
-            "config": {"workload": (f"configs[4]: INT8-QAT HDRTVNet++ {Wd}x{H}: HG head W8A8 on int8 MFMA (18 layers, 81 % of the MACs), AGCM+LE int8 weights dequantised to fp16 (the reference's ROCm behaviour)"
+            "config": {"workload": ((f"configs[4]: INT8-QAT HDRTVNet++ {Wd}x{H}: HR = the reference's HR_original_int8_{args.int8_recipe}_qat checkpoint, "
+                                     + ("int8 weights dequantised to fp16 (the reference's ROCm behaviour)" if args.int8_predequantize else
+                                        ("all 128 layers W8A8: 116 on int8 MFMA, the AGCM classifier / Linear heads (12 layers, 0.001 % of the MACs) as fp32 fake-quant"
+                                         if args.int8_recipe == "full" else "its 29 W8A8 layers on int8 MFMA, 78 W8A16 + 21 fp16 layers on fp16 MFMA"))
+                                     + "; HG head W8A8 on int8 MFMA (18 layers, 81 % of the MACs)")
                                     if args.int8 else
                                     f"configs[2]: full HDRTVNet++ fp16 {Wd}x{H} + fused RGB48 post, 1 frame per GPU per step")
                        if use_hg else f"DEBUG no-HG {Wd}x{H}",

@@ -23,12 +23,22 @@ namespace {
 
 // ------------------------------------------------------------------------------- classifier
 // in : Ci planes of Hi x Wi (f16 when IN_F16 else f32);  out: Co planes of Ho x Wo f32
+// W8A8 classifier convs (full INT8 recipe): the conv input is fake-quantised element by element in fp32, exactly the
+// reference's CPU arithmetic (W8A8Conv2d.forward, hdrtvnet_torch.py:353-356); the classifier is 0.001 % of the frame's
+// MACs and runs on the vector ALU in every precision.
+__device__ __forceinline__ float fake_q(float x, const FakeQ &q)
+{
+    const float c = fminf(fmaxf(__builtin_rintf(__builtin_fmaf(x, q.inv, q.zoff)), 0.f), 255.f);
+    return c * q.scale + q.zero;      // q.zero = x_zero (asymmetric) or -128 * x_scale (symmetric: the u8 code is x / x_scale + 128)
+}
+
 template <bool IN_F16>
 __global__ __launch_bounds__(256) void cls_block_kernel(const void *__restrict__ in_, int Ci, int Hi, int Wi,
                                                         const float *__restrict__ nmean, const float *__restrict__ nrstd,
                                                         const float *__restrict__ ngamma, const float *__restrict__ nbeta,
                                                         const float *__restrict__ Wt, const float *__restrict__ bias, int Co,
-                                                        float *__restrict__ out, int Ho, int Wo, float2 *__restrict__ part)
+                                                        float *__restrict__ out, int Ho, int Wo, float2 *__restrict__ part,
+                                                        FakeQ qin, FakeQ qstat)
 {
     __shared__ float s_sum[128][17];
     __shared__ float s_cnt[16];
@@ -49,11 +59,16 @@ __global__ __launch_bounds__(256) void cls_block_kernel(const void *__restrict__
                     const int ix = 2 * ox + kx;
                     if (ix < 0 || ix >= Wi) continue;
                     const size_t off = ((size_t)ci * Hi + iy) * Wi + ix;
-                    s += IN_F16 ? (float)reinterpret_cast<const f16 *>(in_)[off] : reinterpret_cast<const float *>(in_)[off];
+                    float xv = IN_F16 ? (float)reinterpret_cast<const f16 *>(in_)[off] : reinterpret_cast<const float *>(in_)[off];
+                    if (qin.on) {             // InstanceNorm of the previous block, then this conv's activation quantiser, per element
+                        if (nmean) xv = (xv - nmean[ci]) * nrstd[ci] * ngamma[ci] + nbeta[ci];
+                        xv = fake_q(xv, qin);
+                    }
+                    s += xv;
                     ++cnt;
                 }
             }
-            if (nmean) {
+            if (nmean && !qin.on) {
                 const float a = nrstd[ci] * ngamma[ci];
                 s = a * s + (nbeta[ci] - nmean[ci] * a) * (float)cnt;
             }
@@ -72,8 +87,10 @@ __global__ __launch_bounds__(256) void cls_block_kernel(const void *__restrict__
         float v = (acc + bias[co] * s_cnt[px]) / 9.f;
         v = v >= 0.f ? v : v * 0.2f;
         if (ok) out[(size_t)co * npix + p] = v;
-        // per-block partial sums for the InstanceNorm statistics (fixed order: deterministic)
-        float s1 = ok ? v : 0.f, s2 = ok ? v * v : 0.f;
+        // per-block partial sums for the InstanceNorm statistics (fixed order: deterministic); qstat: the reader of the
+        // mean is a W8A8 conv (model.20 behind the global average): average its fake-quantised input instead
+        const float vs = qstat.on ? fake_q(v, qstat) : v;
+        float s1 = ok ? vs : 0.f, s2 = ok ? vs * vs : 0.f;
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) {
             s1 += __shfl_xor(s1, o);
@@ -195,6 +212,55 @@ __global__ __launch_bounds__(256) void agcm_fold_kernel(const float *__restrict_
     }
 }
 
+// W8A8 AGCM (full INT8 recipe): the six Linear heads see the 6-vector through their own quantisers (W8A8Linear.forward,
+// hdrtvnet_torch.py:398-409, fp32), and the GFM modulation  conv(x) * s + t + conv(x)  of an int8 conv
+//     conv(x)[m] = P[m] * acc + Q[m]          (P = x_scale * w_scale, Q = w_scale * (128 x_scale + x_zero) * sum(w) + bias)
+// becomes the per-frame dequantisation constants of agcm_mlp_q8:  A = P (1 + s) / x_scale',  B = (Q (1 + s) + t) / x_scale'
+// (x_scale' = the next layer's; the last layer keeps real units), in the [mt][lane half][A16 | B16] register order.
+__global__ __launch_bounds__(256) void agcm_fold_q8_kernel(const float *__restrict__ mean5, FoldWeights fw, AgcmFoldQ8Args q,
+                                                           float *__restrict__ biasbuf)
+{
+    __shared__ float fea[6];
+    __shared__ float sc[3][64], sh[3][64];
+    const int tid = threadIdx.x;
+    if (tid < 6) {
+        float a = fw.b20[tid];
+        for (int k = 0; k < 128; ++k) a += fw.w20[tid * 128 + k] * mean5[k];     // mean5: mean of model.20's fake-quantised input
+        fea[tid] = a;
+        biasbuf[160 + tid] = a;
+    }
+    __syncthreads();
+    for (int e = tid; e < 3 * 64; e += 256) {
+        const int st = e / 64, m = e % 64;
+        const int n = st == 2 ? 3 : 64;
+        float s = 0.f, t = 0.f;
+        if (m < n) {
+            s = fw.bs[st][m];
+            t = fw.bt[st][m];
+            for (int k = 0; k < 6; ++k) {
+                s += fw.ws[st][m * 6 + k] * (q.qlin[st].on ? fake_q(fea[k], q.qlin[st]) : fea[k]);
+                t += fw.wt[st][m * 6 + k] * (q.qlin[3 + st].on ? fake_q(fea[k], q.qlin[3 + st]) : fea[k]);
+            }
+        }
+        sc[st][m] = s;
+        sh[st][m] = t;
+    }
+    __syncthreads();
+    // layer l = 0, 1: [mt][lh][A16|B16] at l * 128; layer 2: [lh][A16|B16] at 256 (rows 0..2 real)
+    for (int e = tid; e < 320; e += 256) {
+        const int l = e < 256 ? e / 128 : 2, r = e < 256 ? e % 128 : e - 256;
+        const int mt = l < 2 ? r / 64 : 0, lh = (r % 64) / 32, isB = (r % 32) / 16, j = r % 16;
+        const int m = 32 * mt + 8 * (j >> 2) + 4 * lh + (j & 3);
+        const float inv = l == 0 ? q.inv2 : (l == 1 ? q.inv3 : 1.f);
+        float v = 0.f;
+        if (l < 2 || m < 3) {
+            const float g = 1.f + sc[l][m];
+            v = isB ? (q.Q[l * 64 + m] * g + sh[l][m]) * inv : q.P[l * 64 + m] * g * inv;
+        }
+        q.consts[e] = v;
+    }
+}
+
 // -------------------------------------------------------------------------------------- MLP
 __device__ __forceinline__ f32x16 bias_tile(const float *b, int lh)
 {
@@ -274,15 +340,17 @@ __global__ __launch_bounds__(256) void agcm_mlp_kernel(const f16 *__restrict__ i
 
 hipError_t cls_block_launch(const void *in, int in_f16, int Ci, int Hi, int Wi, const float *nmean, const float *nrstd,
                             const float *ngamma, const float *nbeta, const float *Wt, const float *bias, int Co, float *out,
-                            int Ho, int Wo, float *part, hipStream_t s)
+                            int Ho, int Wo, float *part, hipStream_t s, const FakeQ *qin, const FakeQ *qstat)
 {
     const int grid = (Ho * Wo + 15) / 16;
+    const FakeQ off{0, 0.f, 0.f, 0.f, 0.f};
+    const FakeQ qi = qin ? *qin : off, qs = qstat ? *qstat : off;
     if (in_f16)
         hipLaunchKernelGGL(cls_block_kernel<true>, dim3(grid), dim3(256), 0, s, in, Ci, Hi, Wi, nmean, nrstd, ngamma, nbeta, Wt,
-                           bias, Co, out, Ho, Wo, reinterpret_cast<float2 *>(part));
+                           bias, Co, out, Ho, Wo, reinterpret_cast<float2 *>(part), qi, qs);
     else
         hipLaunchKernelGGL(cls_block_kernel<false>, dim3(grid), dim3(256), 0, s, in, Ci, Hi, Wi, nmean, nrstd, ngamma, nbeta,
-                           Wt, bias, Co, out, Ho, Wo, reinterpret_cast<float2 *>(part));
+                           Wt, bias, Co, out, Ho, Wo, reinterpret_cast<float2 *>(part), qi, qs);
     return hipGetLastError();
 }
 
@@ -300,6 +368,16 @@ hipError_t agcm_fold_launch(const AgcmFoldArgs &a, f16 *frags, float *biasbuf, h
     for (int i = 0; i < 3; ++i) { fw.ws[i] = a.ws[i]; fw.bs[i] = a.bs[i]; fw.wt[i] = a.wt[i]; fw.bt[i] = a.bt[i]; }
     fw.w1 = a.w1; fw.b1 = a.b1; fw.w2 = a.w2; fw.b2 = a.b2; fw.w3 = a.w3; fw.b3 = a.b3;
     hipLaunchKernelGGL(agcm_fold_kernel, dim3(1), dim3(256), 0, s, a.mean5, fw, frags, biasbuf);
+    return hipGetLastError();
+}
+
+hipError_t agcm_fold_q8_launch(const AgcmFoldArgs &a, const AgcmFoldQ8Args &q, float *biasbuf, hipStream_t s)
+{
+    FoldWeights fw;
+    fw.w20 = a.w20; fw.b20 = a.b20;
+    for (int i = 0; i < 3; ++i) { fw.ws[i] = a.ws[i]; fw.bs[i] = a.bs[i]; fw.wt[i] = a.wt[i]; fw.bt[i] = a.bt[i]; }
+    fw.w1 = a.w1; fw.b1 = a.b1; fw.w2 = a.w2; fw.b2 = a.b2; fw.w3 = a.w3; fw.b3 = a.b3;
+    hipLaunchKernelGGL(agcm_fold_q8_kernel, dim3(1), dim3(256), 0, s, a.mean5, fw, q, biasbuf);
     return hipGetLastError();
 }
 

@@ -127,6 +127,13 @@ struct Conv32Params {
     // input quantiser as u8 code = clamp(rint(x * q_inv + q_zoff), 0, 255), int8 code = u8 ^ q_flip per byte
     const int8_t *wpk8;
     float q_inv, q_zoff;
+    // W8A8 SFT convs in front (sq_wfrag != nullptr, needs wpk8 and cond): three int8 A fragments [3][64 lanes][16 B]
+    // (both first layers block-diagonal over K = 32; scale-out; shift-out), 6 x 32 dequantisation constants
+    // [set][lane half][16] and the quantisers: sq_inv / sq_zoff of the condition map per branch (0 scale, 1 shift),
+    // sq_hzoff of the hidden activations per branch (their 1 / x_scale is folded into the constants)
+    const int8_t *sq_wfrag;
+    const float *sq_const;
+    float sq_inv[2], sq_zoff[2], sq_hzoff[2];
 };
 
 // Parameter block of the W8A8 LE convolutions outside conv32p (conv_q8.hip).

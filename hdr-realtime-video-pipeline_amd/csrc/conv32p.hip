@@ -98,7 +98,7 @@ __device__ __forceinline__ f16x8 lrelu_pack16(const f32x16 &a, int s)
     return __builtin_elementwise_max(o, o * (f16)0.1f);
 }
 
-template <int NPASS, bool SFT, int NW, bool I8>
+template <int NPASS, bool SFT, int NW, bool I8, bool SQ = false>
 struct Lay {
     static constexpr int A_BYTES = Til<NW>::A_BYTES, C_BYTES = Til<NW>::C_BYTES, OUT_BYTES = Til<NW>::OUT_BYTES;
     static constexpr int COUTP = 32 * NPASS;
@@ -110,14 +110,16 @@ struct Lay {
     static constexpr int OFF_C = OFF_A + 2 * A_BYTES;
     static constexpr int OFF_Q = OFF_C + (SFT ? 2 * C_BYTES : 0);
     static constexpr int OFF_OUT = OFF_Q + 2 * Q_BYTES;
-    static constexpr int SMEM = OFF_OUT + OUT_BYTES;
+    static constexpr int OFF_K = OFF_OUT + OUT_BYTES;                   // SQ: 6 x 32 dequantisation constants of the SFT convs
+    static constexpr int SMEM = OFF_K + (SQ ? 768 : 0);
     static_assert(SMEM <= 160 * 1024, "LDS budget");
 };
 
-template <int NPASS, bool SFT, int NW, bool I8>
+template <int NPASS, bool SFT, int NW, bool I8, bool SQ>
 __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
 {
-    using L = Lay<NPASS, SFT, NW, I8>;
+    static_assert(!SQ || (SFT && I8), "W8A8 SFT convs come with a W8A8 conv behind them");
+    using L = Lay<NPASS, SFT, NW, I8, SQ>;
     constexpr bool PREP = SFT || I8;          // a per-tile pass over the landed halo tile exists
     using T = Til<NW>;
     constexpr int TH = T::TH, NT = T::NT, NPIX = T::NPIX, A_BYTES = T::A_BYTES, C_BYTES = T::C_BYTES;
@@ -128,6 +130,7 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
     char *sC = smem + L::OFF_C;
     char *sQ = smem + L::OFF_Q;
     char *sO = smem + L::OFF_OUT;
+    const float *sK = reinterpret_cast<const float *>(smem + L::OFF_K);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -201,7 +204,14 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
     f16x8 sa0, sa1s, sa1t;
     f32x16 sbh, sbs, sbt;
     int g_pos[T::G_PW], g_c[T::G_PW], g_x[T::G_PW], g_q[T::G_PW];
-    if (SFT) {
+    i32x4 qa0, qa1s, qa1t;                                     // SQ: int8 A fragments of the three SFT MFMAs
+    float cq_inv = 0.f, cq_zoff = 0.f;                         // SQ: this lane half's condition quantiser (lh 0: scale branch, 1: shift branch)
+    if constexpr (SQ) {
+        const i32x4 *fr = reinterpret_cast<const i32x4 *>(p.sq_wfrag);
+        qa0 = fr[lane]; qa1s = fr[64 + lane]; qa1t = fr[128 + lane];
+        cq_inv = p.sq_inv[lh]; cq_zoff = p.sq_zoff[lh];
+        for (int e = tid; e < 192; e += NT) reinterpret_cast<float *>(smem + L::OFF_K)[e] = p.sq_const[e];
+    } else if (SFT) {
         const f16x8 *fr = reinterpret_cast<const f16x8 *>(p.sft_wfrag);
         sa0 = fr[lane]; sa1s = fr[64 + lane]; sa1t = fr[128 + lane];
         sbh = tile16(p.sft_bias, lh); sbs = tile16(p.sft_bias + 32, lh); sbt = tile16(p.sft_bias + 64, lh);
@@ -233,7 +243,48 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
                 const bool inimg = g_pos[gi] >= 0 && (unsigned)(iy0 + (g_pos[gi] & 255)) < uH &&
                                    (unsigned)(ix0 + (g_pos[gi] >> 8)) < uW;
                 f32x16 sc, sh;
-                if constexpr (SFT) {
+                if constexpr (SQ) {
+                    // W8A8 SFT convs (arch_util.py:60-72 with W8A8Conv2d layers): both first layers read the condition pixel
+                    // through their own quantiser -> one K = 32 MFMA whose lanes 0..31 carry the scale branch's codes of
+                    // all 16 channels and lanes 32..63 the shift branch's (weights block-diagonal); hidden rows 0..15 /
+                    // 16..31 are dequantised, LeakyReLU'd and re-quantised for the second layers in registers.
+                    const char *crow = cbuf + g_c[gi] - lh * 16;
+                    const f16x8 c0 = *reinterpret_cast<const f16x8 *>(crow), c1 = *reinterpret_cast<const f16x8 *>(crow + 16);
+                    i32x4 cb;
+                    cb[0] = (int)quant4((float)c0[0], (float)c0[1], (float)c0[2], (float)c0[3], cq_inv, cq_zoff);
+                    cb[1] = (int)quant4((float)c0[4], (float)c0[5], (float)c0[6], (float)c0[7], cq_inv, cq_zoff);
+                    cb[2] = (int)quant4((float)c1[0], (float)c1[1], (float)c1[2], (float)c1[3], cq_inv, cq_zoff);
+                    cb[3] = (int)quant4((float)c1[4], (float)c1[5], (float)c1[6], (float)c1[7], cq_inv, cq_zoff);
+                    i32x16 z16;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) z16[k] = 0;
+                    const i32x16 hacc = __builtin_amdgcn_mfma_i32_32x32x32_i8(qa0, cb, z16, 0, 0, 0);
+                    const float *K = sK + lh * 16;             // [set][lh][16]: hidden scale', shift'; scale-out scale, shift; shift-out scale, shift
+                    float t[16];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 ka = *reinterpret_cast<const float4 *>(K + 4 * g), kb = *reinterpret_cast<const float4 *>(K + 32 + 4 * g);
+                        const float zo = p.sq_hzoff[g >> 1];
+                        const float u0 = (float)hacc[4 * g + 0] * ka.x + kb.x, u1 = (float)hacc[4 * g + 1] * ka.y + kb.y,
+                                    u2 = (float)hacc[4 * g + 2] * ka.z + kb.z, u3 = (float)hacc[4 * g + 3] * ka.w + kb.w;
+                        t[4 * g + 0] = fmaxf(u0, 0.1f * u0) + zo; t[4 * g + 1] = fmaxf(u1, 0.1f * u1) + zo;
+                        t[4 * g + 2] = fmaxf(u2, 0.1f * u2) + zo; t[4 * g + 3] = fmaxf(u3, 0.1f * u3) + zo;
+                    }
+                    i32x4 hs = {0, 0, 0, 0}, ht = {0, 0, 0, 0};
+                    hs[0] = (int)quant4(t[0], t[1], t[2], t[3], 1.f, 0.f);   hs[1] = (int)quant4(t[4], t[5], t[6], t[7], 1.f, 0.f);
+                    ht[0] = (int)quant4(t[8], t[9], t[10], t[11], 1.f, 0.f); ht[1] = (int)quant4(t[12], t[13], t[14], t[15], 1.f, 0.f);
+                    const i32x16 a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(qa1s, hs, z16, 0, 0, 0);
+                    const i32x16 a2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(qa1t, ht, z16, 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 k2 = *reinterpret_cast<const float4 *>(K + 64 + 4 * g), k3 = *reinterpret_cast<const float4 *>(K + 96 + 4 * g);
+                        const float4 k4 = *reinterpret_cast<const float4 *>(K + 128 + 4 * g), k5 = *reinterpret_cast<const float4 *>(K + 160 + 4 * g);
+                        sc[4 * g + 0] = (float)a1[4 * g + 0] * k2.x + k3.x; sc[4 * g + 1] = (float)a1[4 * g + 1] * k2.y + k3.y;
+                        sc[4 * g + 2] = (float)a1[4 * g + 2] * k2.z + k3.z; sc[4 * g + 3] = (float)a1[4 * g + 3] * k2.w + k3.w;
+                        sh[4 * g + 0] = (float)a2[4 * g + 0] * k4.x + k5.x; sh[4 * g + 1] = (float)a2[4 * g + 1] * k4.y + k5.y;
+                        sh[4 * g + 2] = (float)a2[4 * g + 2] * k4.z + k5.z; sh[4 * g + 3] = (float)a2[4 * g + 3] * k4.w + k5.w;
+                    }
+                } else if constexpr (SFT) {
                     const f16x8 cf = *reinterpret_cast<const f16x8 *>(cbuf + g_c[gi]);
                     const f32x16 h = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa0, cf, sbh, 0, 0, 0);
                     const f16x8 hs = lrelu_pack16(h, 0), ht = lrelu_pack16(h, 1);
@@ -476,12 +527,12 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
 #endif
 }
 
-template <int NPASS, bool SFT, int NW, bool I8 = false>
+template <int NPASS, bool SFT, int NW, bool I8 = false, bool SQ = false>
 hipError_t launch_t(const Conv32Params &p, int n_cu, hipStream_t s)
 {
-    using L = Lay<NPASS, SFT, NW, I8>;
+    using L = Lay<NPASS, SFT, NW, I8, SQ>;
     static DevOnce attr_once;   // hipFuncSetAttribute is per (function, device)
-    auto kern = conv32p_kernel<NPASS, SFT, NW, I8>;
+    auto kern = conv32p_kernel<NPASS, SFT, NW, I8, SQ>;
     if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L::SMEM);
         if (e != hipSuccess) return e;
@@ -509,10 +560,12 @@ hipError_t conv32p_launch(Conv32Params p, int n_cu, hipStream_t s)
     p.tiles_x = (p.W + TW - 1) / TW;
     if (p.wpk8) {                                        // W8A8 layer: int8 MFMA on the quantised tile, 16x16 tiles only
         p.tiles_y = (p.H + 15) / 16;
+        if (p.CoutPad == 32 && sft && p.sq_wfrag) return launch_t<1, true, 8, true, true>(p, n_cu, s);
         if (p.CoutPad == 32) return sft ? launch_t<1, true, 8, true>(p, n_cu, s) : launch_t<1, false, 8, true>(p, n_cu, s);
         if (p.CoutPad == 128 && !sft) return launch_t<4, false, 8, true>(p, n_cu, s);
         return hipErrorInvalidValue;
     }
+    if (p.sq_wfrag) return hipErrorInvalidValue;         // W8A8 SFT convs in front of an fp16 conv: no kernel (no shipped recipe has it)
     // conv_last (32 -> 3, no SFT, planar store) is all per-tile latency: two 4-wave workgroups per CU hide it better
     // (0.286 -> 0.251 ms at 4K); every other layer is faster with the 16x16 tile
     const bool small_tile = nw == 4 || (p.CoutPad == 32 && !sft && p.mode == ST_PLANAR3 && !getenv("HDRTV_CONV32_NW"));

@@ -88,7 +88,7 @@ struct Pack {
     // A layer's weight tensor as the reference's layer computes it: `<layer>.weight`, or for the INT8 runtime layers
     // (W8Conv2d / W8A8Conv2d / W8Linear / W8A8Linear, hdrtvnet_torch.py:233-410) weight_int8 * scale, the product
     // rounded once to f16 as `weight_int8.to(cd) * scale` is on a GPU (cd = fp16)
-    bool getw(const std::string &layer, size_t numel, std::vector<float> &out, std::string &err) const
+    bool getw(const std::string &layer, size_t numel, std::vector<float> &out, std::string &err, bool round_f16 = true) const
     {
         if (has(layer + ".weight")) return get(layer + ".weight", numel, out, err);
         std::vector<int8_t> q;
@@ -101,7 +101,8 @@ struct Pack {
         if (co == 0 || numel % co || !get(sn, co, sc, err)) { if (err.empty()) err = "bad scale for " + layer; return false; }
         out.resize(numel);
         const size_t per = numel / co;
-        for (size_t i = 0; i < numel; ++i) out[i] = (float)(f16)((float)q[i] * (float)(f16)sc[i / per]);
+        // round_f16 = false: a W8A8 layer evaluated as fp32 fake-quant (AGCM classifier / Linear heads): weight_int8.float() * w_scale
+        for (size_t i = 0; i < numel; ++i) out[i] = round_f16 ? (float)(f16)((float)q[i] * (float)(f16)sc[i / per]) : (float)q[i] * sc[i / per];
         return true;
     }
     bool is_w8a8(const std::string &layer) const { return has(layer + ".weight_int8") && has(layer + ".x_scale"); }
@@ -160,7 +161,12 @@ struct QLayer {                             // W8A8 layer of the HR network on i
     int cin = 0, cout = 0, coutPad = 0, ks = 0, stride = 1;
 };
 struct QLastLayer { size_t wq = 0, ss = 0; ActQf q; bool on = false; };
-struct SftLayer { size_t wfrag = 0, bias = 0; };
+struct SftLayer {
+    size_t wfrag = 0, bias = 0;
+    bool q = false;                         // all four 1x1 convs are W8A8: int8 fragments + dequantisation constants
+    size_t qfrag = 0, qconst = 0;
+    float inv[2] = {0, 0}, zoff[2] = {0, 0}, hzoff[2] = {0, 0};
+};
 
 struct Tensor {
     size_t off = 0;
@@ -197,6 +203,11 @@ struct hdrtv_ctx {
     bool hr_i8 = false;                   // the HR pack holds W8A8 layers: they run on int8 MFMA (predequantize off)
     std::map<std::string, QLayer> q32, q8;
     QLastLayer q_trunk6, q_tail2;         // CondNet1.4 / CondNet2.4 as the W8A8 last layer of their fused chains
+    // fully quantised chains (le_chain_q8.hip) and the fp32 fake-quant of the AGCM classifier / Linear heads
+    bool trunk_q8 = false, tail_q8 = false, agcm_q8 = false;
+    size_t tq_frag = 0, tq_const = 0, tl_frag = 0, tl_const = 0, ag_frag = 0, ag_P = 0, ag_Q = 0;
+    ActQf tq_q[6], tl_q[2], ag_q[3];
+    FakeQ cls_q[6] = {}, lin_q[6] = {};
     std::map<std::string, size_t> f32v;   // raw fp32 vectors/matrices in the weight arena
     size_t zeros_off = 0;                 // 256 B of zeros in the weight arena
     size_t dump_off = 0;                  // 8 KiB write-only scratch (conv32p masked lanes)
@@ -468,10 +479,20 @@ bool pack_conv32_i8(hdrtv_ctx *c, const Pack &pk, const std::string &key, int co
     return true;
 }
 // any other W8A8 LE conv -> conv_q8: wpk8 [ks*ks][coP][ci], natural channel order
-bool pack_conv_q8(hdrtv_ctx *c, const Pack &pk, const std::string &key, int co, int ci, int ks, int stride)
+bool pack_conv_q8(hdrtv_ctx *c, const Pack &pk, const std::string &key, int co, int ci, int ks, int stride, int ci_real = 0)
 {
     QRaw r;
-    if (!read_qraw(c, pk, key, co, (size_t)ci * ks * ks, r)) return false;
+    if (ci_real && ci_real != ci) {           // fewer real input channels than the kernel's 32-byte pixel: zero weights for the rest
+        QRaw s;
+        if (!read_qraw(c, pk, key, co, (size_t)ci_real * ks * ks, s)) return false;
+        r = s;
+        r.w.assign((size_t)co * ci * ks * ks, (int8_t)0);
+        for (int n = 0; n < co; ++n)
+            for (int k = 0; k < ci_real; ++k)
+                for (int t = 0; t < ks * ks; ++t) r.w[((size_t)n * ci + k) * ks * ks + t] = s.w[((size_t)n * ci_real + k) * ks * ks + t];
+    } else if (!read_qraw(c, pk, key, co, (size_t)ci * ks * ks, r)) {
+        return false;
+    }
     const int coP = (co + 31) / 32 * 32, taps = ks * ks;
     std::vector<int> rowmap(co);
     for (int np = 0; np < co; ++np) rowmap[np] = np;
@@ -513,6 +534,141 @@ bool pack_q_last(hdrtv_ctx *c, const Pack &pk, const std::string &layer, QLastLa
     out.wq = c->wts.put(fr.data(), fr.size());
     out.ss = c->wts.put(ss.data(), ss.size() * 4);
     out.on = true;
+    return true;
+}
+
+
+// ---- fully quantised chains (le_chain_q8.hip)
+// 1x1 layer [co][ci] -> int8 A fragments [co/32 (>= 1)][ci/32][64 lanes][16]: byte j of lane (row, lh), K-step kb, is input channel
+// 32kb + 8(j/4) + 4lh + j%4 when the operand is the previous layer's accumulator tile (chained), 32kb + 16lh + j when it is read
+// from an NHWC int8 tensor (natural)
+void chain_frags(const QRaw &r, int co, int ci, bool chained, std::vector<int8_t> &out)
+{
+    const int nmt = (co + 31) / 32, nkb = ci / 32;
+    const size_t base = out.size();
+    out.resize(base + (size_t)nmt * nkb * 64 * 16, (int8_t)0);
+    for (int mt = 0; mt < nmt; ++mt)
+        for (int kb = 0; kb < nkb; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 16; ++j) {
+                    const int row = 32 * mt + (lane & 31), lh = lane >> 5;
+                    const int ch = 32 * kb + (chained ? 8 * (j >> 2) + 4 * lh + (j & 3) : 16 * lh + j);
+                    if (row < co) out[base + (((size_t)mt * nkb + kb) * 64 + lane) * 16 + j] = r.w[(size_t)row * ci + ch];
+                }
+}
+// dequantisation constants of a chained layer in register order [mt][lh][A16 | B16]; inv_next = 1 / x_scale of the layer that
+// reads the result as codes (1 = keep real units); per_co = weights per output channel (taps included)
+void chain_consts(const QRaw &r, int co, size_t per_co, double inv_next, std::vector<float> &out)
+{
+    const int nmt = (co + 31) / 32;
+    for (int mt = 0; mt < nmt; ++mt)
+        for (int lh = 0; lh < 2; ++lh)
+            for (int ab = 0; ab < 2; ++ab)
+                for (int j = 0; j < 16; ++j) {
+                    const int row = 32 * mt + 8 * (j >> 2) + 4 * lh + (j & 3);
+                    double v = 0.0;
+                    if (row < co) {
+                        long sum = 0;
+                        for (size_t k = 0; k < per_co; ++k) sum += r.w[(size_t)row * per_co + k];
+                        v = ab ? ((double)r.ws[row] * r.q.soff() * (double)sum + (double)r.b[row]) * inv_next
+                               : (double)r.q.scale * (double)r.ws[row] * inv_next;
+                    }
+                    out.push_back((float)v);
+                }
+}
+bool pack_trunk_q8(hdrtv_ctx *c, const Pack &pk)
+{
+    const char *names[6] = {"LE.cond_first.0", "LE.cond_first.2", "LE.cond_first.4", "LE.CondNet1.0", "LE.CondNet1.2", "LE.CondNet1.4"};
+    QRaw r[6];
+    for (int l = 0; l < 6; ++l)
+        if (!read_qraw(c, pk, names[l], l == 5 ? 16 : 64, l == 0 ? 27 : 64, r[l])) return false;
+    std::vector<int8_t> fr;
+    // layer 1: k = (ky*3+kx)*3 + c = 16 lh + j
+    fr.resize((size_t)2 * 64 * 16, (int8_t)0);
+    for (int mt = 0; mt < 2; ++mt)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 16; ++j) {
+                const int row = 32 * mt + (lane & 31), k = 16 * (lane >> 5) + j;
+                if (k < 27) fr[((size_t)mt * 64 + lane) * 16 + j] = r[0].w[((size_t)row * 3 + k % 3) * 9 + k / 3];
+            }
+    for (int l = 1; l < 6; ++l) chain_frags(r[l], l == 5 ? 16 : 64, 64, true, fr);
+    std::vector<float> K;
+    const double inv2 = 1.0 / r[1].q.scale;
+    // L1 A [mt][lh][16], then B [cls][mt][lh][16] from the border-class table
+    std::vector<int> rowmap(64);
+    for (int i = 0; i < 64; ++i) rowmap[i] = i;
+    std::vector<float> sc, sh;
+    q_tables(r[0], 64, 3, 3, 64, rowmap, sc, sh);
+    for (int mt = 0; mt < 2; ++mt)
+        for (int lh = 0; lh < 2; ++lh)
+            for (int j = 0; j < 16; ++j) K.push_back((float)((double)sc[32 * mt + 8 * (j >> 2) + 4 * lh + (j & 3)] * inv2));
+    for (int cls = 0; cls < 16; ++cls)
+        for (int mt = 0; mt < 2; ++mt)
+            for (int lh = 0; lh < 2; ++lh)
+                for (int j = 0; j < 16; ++j) K.push_back((float)((double)sh[(size_t)cls * 64 + 32 * mt + 8 * (j >> 2) + 4 * lh + (j & 3)] * inv2));
+    chain_consts(r[1], 64, 64, 1.0 / r[2].q.scale, K);
+    chain_consts(r[2], 64, 64, 1.0, K);                     // `cond` is stored in real units (f16)
+    chain_consts(r[3], 64, 64, 1.0 / r[4].q.scale, K);
+    chain_consts(r[4], 64, 64, 1.0 / r[5].q.scale, K);
+    chain_consts(r[5], 16, 64, 1.0, K);
+    if (K.size() != 1664 || fr.size() != (size_t)20 * 1024) { c->err = "internal: trunk_q8 pack size"; return false; }
+    for (int l = 0; l < 6; ++l) c->tq_q[l] = r[l].q;
+    c->tq_frag = c->wts.put(fr.data(), fr.size());
+    c->tq_const = c->wts.put(K.data(), K.size() * 4);
+    c->trunk_q8 = true;
+    return true;
+}
+bool pack_tail_q8(hdrtv_ctx *c, const Pack &pk)
+{
+    QRaw r[2];
+    if (!read_qraw(c, pk, "LE.CondNet2.2", 64, 64, r[0]) || !read_qraw(c, pk, "LE.CondNet2.4", 16, 64, r[1])) return false;
+    std::vector<int8_t> fr;
+    chain_frags(r[0], 64, 64, false, fr);
+    chain_frags(r[1], 16, 64, true, fr);
+    std::vector<float> K;
+    chain_consts(r[0], 64, 64, 1.0 / r[1].q.scale, K);
+    chain_consts(r[1], 16, 64, 1.0, K);
+    c->tl_q[0] = r[0].q; c->tl_q[1] = r[1].q;
+    c->tl_frag = c->wts.put(fr.data(), fr.size());
+    c->tl_const = c->wts.put(K.data(), K.size() * 4);
+    c->tail_q8 = true;
+    return true;
+}
+bool pack_agcm_q8(hdrtv_ctx *c, const Pack &pk)
+{
+    QRaw r[3];
+    if (!read_qraw(c, pk, "AGCM.conv_first", 64, 3, r[0]) || !read_qraw(c, pk, "AGCM.HRconv", 64, 64, r[1]) ||
+        !read_qraw(c, pk, "AGCM.conv_last", 3, 64, r[2]))
+        return false;
+    std::vector<int8_t> fr((size_t)2 * 64 * 16, (int8_t)0);
+    for (int mt = 0; mt < 2; ++mt)
+        for (int lane = 0; lane < 32; ++lane)            // lane half 0 only: bytes 0..2 = colour channels
+            for (int j = 0; j < 3; ++j) fr[((size_t)mt * 64 + lane) * 16 + j] = r[0].w[(size_t)(32 * mt + lane) * 3 + j];
+    chain_frags(r[1], 64, 64, true, fr);
+    chain_frags(r[2], 3, 64, true, fr);
+    std::vector<float> P(192, 0.f), Q(192, 0.f);
+    const int co[3] = {64, 64, 3}, ci[3] = {3, 64, 64};
+    for (int l = 0; l < 3; ++l)
+        for (int m = 0; m < co[l]; ++m) {
+            long sum = 0;
+            for (int k = 0; k < ci[l]; ++k) sum += r[l].w[(size_t)m * ci[l] + k];
+            P[l * 64 + m] = (float)((double)r[l].q.scale * r[l].ws[m]);
+            Q[l * 64 + m] = (float)((double)r[l].ws[m] * r[l].q.soff() * (double)sum + (double)r[l].b[m]);
+        }
+    for (int l = 0; l < 3; ++l) c->ag_q[l] = r[l].q;
+    c->ag_frag = c->wts.put(fr.data(), fr.size());
+    c->ag_P = c->wts.put(P.data(), P.size() * 4);
+    c->ag_Q = c->wts.put(Q.data(), Q.size() * 4);
+    c->agcm_q8 = true;
+    return true;
+}
+bool read_fakeq(hdrtv_ctx *c, const Pack &pk, const std::string &layer, FakeQ &f)
+{
+    f = FakeQ{0, 0.f, 0.f, 0.f, 0.f};
+    if (!pk.is_w8a8(layer)) return true;
+    ActQf q;
+    if (!read_actqf(c, pk, layer, q)) return false;
+    f.on = 1; f.inv = q.inv(); f.zoff = q.zoff(); f.scale = q.scale; f.zero = q.asym ? q.zero : -128.f * q.scale;
     return true;
 }
 
@@ -578,6 +734,49 @@ bool pack_sft(hdrtv_ctx *c, const Pack &pk, const std::string &key, const std::s
     SftLayer L;
     L.wfrag = c->wts.put(fr.data(), fr.size() * sizeof(f16));
     L.bias = c->wts.put(bias.data(), bias.size() * 4);
+    const char *cv[4] = {".SFT_scale_conv0", ".SFT_shift_conv0", ".SFT_scale_conv1", ".SFT_shift_conv1"};
+    int nq = 0;
+    for (const char *n : cv) nq += pk.is_w8a8(name + n) ? 1 : 0;
+    if (nq != 0 && nq != 4) { c->err = "SFT layer " + name + ": W8A8 on some of its four convs only is not supported"; return false; }
+    if (nq == 4) {
+        // conv32p's SQ path (conv32p.hip): fragment / constant layouts documented there and in common.h Conv32Params
+        QRaw r[4];
+        for (int i = 0; i < 4; ++i)
+            if (!read_qraw(c, pk, name + cv[i], i < 2 ? 16 : 32, 16, r[i])) return false;
+        std::vector<int8_t> qf((size_t)3 * 64 * 16, (int8_t)0);
+        std::vector<float> K(192, 0.f);
+        auto wsum = [](const QRaw &q, int row) { long t = 0; for (int k = 0; k < 16; ++k) t += q.w[row * 16 + k]; return (double)t; };
+        for (int lane = 0; lane < 64; ++lane) {
+            const int row = lane & 31, lh = lane >> 5;
+            for (int j = 0; j < 16; ++j) {
+                if (row < 16 && lh == 0) qf[((size_t)0 * 64 + lane) * 16 + j] = r[0].w[row * 16 + j];
+                if (row >= 16 && lh == 1) qf[((size_t)0 * 64 + lane) * 16 + j] = r[1].w[(row - 16) * 16 + j];
+                if (j < 8) {
+                    const int hid = (j < 4 ? 4 * lh + j : 8 + 4 * lh + j - 4);
+                    qf[((size_t)1 * 64 + lane) * 16 + j] = r[2].w[row * 16 + hid];
+                    qf[((size_t)2 * 64 + lane) * 16 + j] = r[3].w[row * 16 + hid];
+                }
+            }
+        }
+        for (int lh = 0; lh < 2; ++lh)
+            for (int j = 0; j < 16; ++j) {
+                const int row = 8 * (j >> 2) + 4 * lh + (j & 3);
+                const int br = row >> 4, idx = row & 15;          // hidden row: branch 0 scale / 1 shift
+                const QRaw &h = r[br], &o = r[2 + br];
+                const double inv1 = 1.0 / (double)o.q.scale;
+                K[0 * 32 + lh * 16 + j] = (float)((double)h.q.scale * h.ws[idx] * inv1);
+                K[1 * 32 + lh * 16 + j] = (float)(((double)h.ws[idx] * h.q.soff() * wsum(h, idx) + (double)h.b[idx]) * inv1);
+                for (int b = 0; b < 2; ++b) {                     // second layers: output channel = row
+                    const QRaw &q = r[2 + b];
+                    K[(2 + 2 * b) * 32 + lh * 16 + j] = (float)((double)q.q.scale * q.ws[row]);
+                    K[(3 + 2 * b) * 32 + lh * 16 + j] = (float)((double)q.ws[row] * q.q.soff() * wsum(q, row) + (double)q.b[row] + (b == 0 ? 1.0 : 0.0));
+                }
+            }
+        L.q = true;
+        L.qfrag = c->wts.put(qf.data(), qf.size());
+        L.qconst = c->wts.put(K.data(), K.size() * 4);
+        for (int b = 0; b < 2; ++b) { L.inv[b] = r[b].q.inv(); L.zoff[b] = r[b].q.zoff(); L.hzoff[b] = r[2 + b].q.zoff(); }
+    }
     c->sft[key] = L;
     return true;
 }
@@ -658,7 +857,8 @@ bool put_f32(hdrtv_ctx *c, const Pack &pk, const std::string &key, const std::st
     std::vector<float> v;
     const std::string suffix = ".weight";
     const bool is_w = name.size() > suffix.size() && name.compare(name.size() - suffix.size(), suffix.size(), suffix) == 0;
-    if (is_w ? !pk.getw(name.substr(0, name.size() - suffix.size()), numel, v, c->err) : !pk.get(name, numel, v, c->err)) return false;
+    const std::string layer = is_w ? name.substr(0, name.size() - suffix.size()) : std::string();
+    if (is_w ? !pk.getw(layer, numel, v, c->err, !pk.is_w8a8(layer)) : !pk.get(name, numel, v, c->err)) return false;
     c->f32v[key] = c->wts.put(v.data(), v.size() * 4);
     return true;
 }
@@ -707,30 +907,54 @@ bool build_weights(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
         !put_f32(c, hr, "agcm.w3", "AGCM.conv_last.weight", 192) || !put_f32(c, hr, "agcm.b3", "AGCM.conv_last.bias", 3))
         return false;
 
+    {   // W8A8 AGCM layers: classifier convs and Linear heads as fp32 fake-quant, the three GFM convs as an int8 chain
+        const int idx6[6] = {0, 4, 8, 12, 16, 20};
+        for (int i = 0; i < 6; ++i) {
+            snprintf(nm, sizeof nm, "AGCM.classifier.model.%d", idx6[i]);
+            if (!read_fakeq(c, hr, nm, c->cls_q[i])) return false;
+        }
+        const char *lin[6] = {"AGCM.cond_scale_first", "AGCM.cond_scale_HR", "AGCM.cond_scale_last",
+                              "AGCM.cond_shift_first", "AGCM.cond_shift_HR", "AGCM.cond_shift_last"};
+        bool any_lin = false;
+        for (int i = 0; i < 6; ++i) {
+            if (!read_fakeq(c, hr, lin[i], c->lin_q[i])) return false;
+            any_lin = any_lin || c->lin_q[i].on;
+        }
+        const int nq = (int)hr.is_w8a8("AGCM.conv_first") + (int)hr.is_w8a8("AGCM.HRconv") + (int)hr.is_w8a8("AGCM.conv_last");
+        if (nq == 3) { if (!pack_agcm_q8(c, hr)) return false; }
+        else if (nq != 0 || any_lin) { c->err = "W8A8 AGCM: conv_first, HRconv and conv_last must be W8A8 together (Linear heads only with them)"; return false; }
+    }
+
     // ---- LE
     // A W8A8 layer (weight_int8 + x_scale in the pack: the reference's `predequantize` off) runs on int8 MFMA when a
     // kernel exists for it; the pack is rejected otherwise -- there is no silent fake-quant or fp16 substitute.
     auto isq = [&](const std::string &L) { return hr.is_w8a8(L); };
     {
-        const char *q_ok[] = {"LE.HR_conv1", "LE.HR_conv2", "LE.conv_last", "LE.up_conv1.0", "LE.up_conv2.0", "LE.up_conv3.0",
-                              "LE.down_conv1", "LE.down_conv2", "LE.down_conv3", "LE.CondNet1.4", "LE.CondNet2.0", "LE.CondNet2.4",
-                              "LE.CondNet3.0", "LE.CondNet3.2", "LE.CondNet3.4", "LE.CondNet4.0", "LE.CondNet4.2", "LE.CondNet4.4"};
         const std::string suf = ".x_scale";
         for (const auto &kv : hr.e) {
             const std::string &k = kv.first;
-            if (k.size() <= suf.size() || k.compare(k.size() - suf.size(), suf.size(), suf) != 0) continue;
-            const std::string L = k.substr(0, k.size() - suf.size());
-            c->hr_i8 = true;
-            bool ok = L.rfind("LE.recon_trunk", 0) == 0 && (L.size() > 6 && (L.compare(L.size() - 6, 6, ".conv1") == 0 || L.compare(L.size() - 6, 6, ".conv2") == 0));
-            for (const char *q : q_ok) ok = ok || L == q;
-            if (!ok) { c->err = "W8A8 layer " + L + " has no int8 kernel in this build (predequantize='auto' runs it as the reference does on ROCm)"; return false; }
+            if (k.size() > suf.size() && k.compare(k.size() - suf.size(), suf.size(), suf) == 0) c->hr_i8 = true;
         }
+        // the fused chains exist for the combinations the reference's recipes use (Appendix B of SURVEY.md)
+        const char *tr[6] = {"LE.cond_first.0", "LE.cond_first.2", "LE.cond_first.4", "LE.CondNet1.0", "LE.CondNet1.2", "LE.CondNet1.4"};
+        int ntr = 0;
+        for (const char *n : tr) ntr += isq(n) ? 1 : 0;
+        if (!(ntr == 0 || ntr == 6 || (ntr == 1 && isq("LE.CondNet1.4")))) {
+            c->err = "W8A8 condition trunk: cond_first.{0,2,4} + CondNet1.{0,2,4} must be W8A8 together (or CondNet1.4 alone)";
+            return false;
+        }
+        if (isq("LE.CondNet2.2") && !(isq("LE.CondNet2.4") && isq("LE.CondNet2.0"))) {
+            c->err = "W8A8 CondNet2.2 needs W8A8 CondNet2.0 and CondNet2.4 (its input and output are int8 codes in the fused tail)";
+            return false;
+        }
+        if (ntr == 6 && !pack_trunk_q8(c, hr)) return false;
+        if (isq("LE.CondNet2.2") && !pack_tail_q8(c, hr)) return false;
     }
-    if (!pack_cond_trunk(c, hr) || !pack_cond_tail(c, hr, "LE.CondNet2.2", "LE.CondNet2.4") ||
-        !pack_c3(c, hr, "le.conv_first", "LE.conv_first", 32, ""))
+    if (!pack_cond_trunk(c, hr) || !pack_cond_tail(c, hr, "LE.CondNet2.2", "LE.CondNet2.4")) return false;
+    if (isq("LE.conv_first") ? !pack_conv_q8(c, hr, "LE.conv_first", 32, 32, 3, 1, 3) : !pack_c3(c, hr, "le.conv_first", "LE.conv_first", 32, ""))
         return false;
-    if (isq("LE.CondNet1.4") && !pack_q_last(c, hr, "LE.CondNet1.4", c->q_trunk6)) return false;
-    if (isq("LE.CondNet2.4") && !pack_q_last(c, hr, "LE.CondNet2.4", c->q_tail2)) return false;
+    if (!c->trunk_q8 && isq("LE.CondNet1.4") && !pack_q_last(c, hr, "LE.CondNet1.4", c->q_trunk6)) return false;
+    if (!c->tail_q8 && isq("LE.CondNet2.4") && !pack_q_last(c, hr, "LE.CondNet2.4", c->q_tail2)) return false;
     struct Spec { const char *name; int co, ci, ks, stride, ps; };
     const Spec le_convs[] = {
         {"LE.CondNet3.4", 16, 64, 1, 1, 0}, {"LE.CondNet4.4", 16, 64, 3, 2, 0},
@@ -981,6 +1205,9 @@ int do_reserve(hdrtv_ctx *c, int H, int W)
         ws_add(c, "le.c2a", 64, s.H1, s.W1, 0); ws_add(c, "le.c3a", 64, s.H1, s.W1, 0); ws_add(c, "le.c4a", 64, s.H1, s.W1, 0);
         ws_add(c, "le8.c3a", 64, s.H1, s.W1, 5); ws_add(c, "le8.c4a", 64, s.H1, s.W1, 5);
         ws_add(c, "le8.h2a", 64, s.H2, s.W2, 5); ws_add(c, "le8.h2b", 64, s.H2, s.W2, 5);
+        ws_add(c, "le8.c2a", 64, s.H1, s.W1, 5);
+        ws_add(c, "le8.img32", 32, H, W, 5);            // conv_first's input as NHWC codes (3 real channels)
+        ws_add(c, "agcm.qconst", 320, 1, 1, 3);
     }
     ws_add(c, "le.cond2", 16, s.H1, s.W1, 0); ws_add(c, "le.cond3", 16, s.H2, s.W2, 0); ws_add(c, "le.cond4", 16, s.H3, s.W3, 0);
     ws_add(c, "le.f0a", 32, H, W, 0); ws_add(c, "le.f0b", 32, H, W, 0); ws_add(c, "le.fea0", 32, H, W, 0);
@@ -1201,9 +1428,15 @@ struct Seq {
             p.wpk = wtp<f16>(c, L.wpk); p.scale = wtp<float>(c, L.scale); p.shift = wtp<float>(c, L.shift);
         }
         p.src = src; p.cond = cond; p.H = H; p.W = W;
+        bool sq = false;
         if (cond) {
             const SftLayer &S = c->sft.at(sft_key);
             p.sft_wfrag = wtp<f16>(c, S.wfrag); p.sft_bias = wtp<float>(c, S.bias);
+            if (S.q) {        // W8A8 SFT convs: int8 MFMA on the quantised condition pixel
+                sq = true;
+                p.sq_wfrag = wtp<int8_t>(c, S.qfrag); p.sq_const = wtp<float>(c, S.qconst);
+                for (int b = 0; b < 2; ++b) { p.sq_inv[b] = S.inv[b]; p.sq_zoff[b] = S.zoff[b]; p.sq_hzoff[b] = S.hzoff[b]; }
+            }
         }
         p.CoutPad = L.coutPad; p.Cout = L.cout; p.act = act; p.mode = mode;
         p.dst = dst; p.dstC = dstC; p.Hd = Hd; p.Wd = Wd; p.res1 = res1; p.res2 = res2;
@@ -1217,7 +1450,7 @@ struct Seq {
         const double bytes = npx * (64 + (cond ? 32 : 0)) + outb * (1 + (res1 ? 1 : 0) + (res2 ? 1 : 0) + (res_planar ? 1 : 0)) +
                              (i8 ? 1.0 : 2.0) * 9 * 32 * L.coutPad;
         char tag[48];
-        snprintf(tag, sizeof tag, "conv32p<%d,%s%s>", L.coutPad / 32, cond ? "sft" : "plain", i8 ? ",i8" : "");
+        snprintf(tag, sizeof tag, "conv32p<%d,%s%s>", L.coutPad / 32, cond ? (sq ? "sft-i8" : "sft") : "plain", i8 ? ",i8" : "");
         chk(conv32p_launch(p, c->n_cu, s), key.c_str(), tag, macs, bytes);
     }
     // ResBlock_with_SFT (arch_util.py:89-95): y = x + conv2(sft2(relu(conv1(sft1(x,c))),c))  [+ extra]; 2 launches
@@ -1253,7 +1486,9 @@ int run_agcm(hdrtv_ctx *c, Seq &q, const f16 *rgb, const f16 *cond, f16 *agcm_ou
         const float *bias = wtp<float>(c, c->f32v.at(b));
         const int nblk = (s.ch[i + 1] * s.cw[i + 1] + 15) / 16;
         q.chk(cls_block_launch(in, i == 0, cls_ci[i], s.ch[i], s.cw[i], nm, nr, ng, nb, w, bias, cls_co[i], out, s.ch[i + 1],
-                               s.cw[i + 1], wsp<float>(c, "agcm.part"), q.s), "cls_block", "cls_block", (double)s.ch[i] * s.cw[i] * cls_ci[i] * cls_co[i]);
+                               s.cw[i + 1], wsp<float>(c, "agcm.part"), q.s, c->cls_q[i].on ? &c->cls_q[i] : nullptr,
+                               (i == 4 && c->cls_q[5].on) ? &c->cls_q[5] : nullptr),
+              "cls_block", c->cls_q[i].on ? "cls_block<fq>" : "cls_block", (double)s.ch[i] * s.cw[i] * cls_ci[i] * cls_co[i]);
         snprintf(a, sizeof a, "agcm.mean%d", i + 1);
         snprintf(b, sizeof b, "agcm.rstd%d", i + 1);
         q.chk(cls_stats_launch(wsp<float>(c, "agcm.part"), cls_co[i], nblk, s.ch[i + 1] * s.cw[i + 1], 1e-5f, wsp<float>(c, a),
@@ -1272,6 +1507,19 @@ int run_agcm(hdrtv_ctx *c, Seq &q, const f16 *rgb, const f16 *cond, f16 *agcm_ou
     fa.w1 = wtp<float>(c, c->f32v.at("agcm.w1")); fa.b1 = wtp<float>(c, c->f32v.at("agcm.b1"));
     fa.w2 = wtp<float>(c, c->f32v.at("agcm.w2")); fa.b2 = wtp<float>(c, c->f32v.at("agcm.b2"));
     fa.w3 = wtp<float>(c, c->f32v.at("agcm.w3")); fa.b3 = wtp<float>(c, c->f32v.at("agcm.b3"));
+    if (c->agcm_q8) {         // W8A8 GFM convs: per-frame dequantisation constants, then the int8 chain
+        AgcmFoldQ8Args qa;
+        qa.q20 = c->cls_q[5];
+        for (int i = 0; i < 6; ++i) qa.qlin[i] = c->lin_q[i];
+        qa.P = wtp<float>(c, c->ag_P); qa.Q = wtp<float>(c, c->ag_Q);
+        qa.inv2 = c->ag_q[1].inv(); qa.inv3 = c->ag_q[2].inv();
+        qa.consts = wsp<float>(c, "agcm.qconst");
+        q.chk(agcm_fold_q8_launch(fa, qa, wsp<float>(c, "agcm.bias"), q.s), "agcm_fold", "agcm_fold<q8>", 128.0 * 6 + 6.0 * (64 + 64 + 3) * 2);
+        q.chk(agcm_mlp_q8_launch(rgb, agcm_out, (size_t)c->H * c->W, wtp<int8_t>(c, c->ag_frag), qa.consts, c->ag_q[0].inv(), c->ag_q[0].zoff(),
+                                 c->ag_q[1].zoff(), c->ag_q[2].zoff(), q.s),
+              "agcm_mlp", "agcm_mlp<q8>", (double)c->H * c->W * (3 * 64 + 64 * 64 + 64 * 3), 12.0 * c->H * c->W);
+        return q.rc;
+    }
     q.chk(agcm_fold_launch(fa, wsp<f16>(c, "agcm.frags"), wsp<float>(c, "agcm.bias"), q.s), "agcm_fold", "agcm_fold",
           128.0 * 6 + 6.0 * (64 + 64 + 3) * 2);
     q.chk(agcm_mlp_launch(rgb, agcm_out, (size_t)c->H * c->W, wsp<f16>(c, "agcm.frags"), wsp<float>(c, "agcm.bias"), q.s),
@@ -1296,7 +1544,14 @@ int run_le(hdrtv_ctx *c, Seq &q, const f16 *img, f16 *out_planar)
         return &a;
     };
     QLastArgs qa6, qa2;
-    if (q.ok())
+    if (q.ok() && c->trunk_q8) {
+        TrunkQ8Args ta;
+        ta.wfrag = wtp<int8_t>(c, c->tq_frag); ta.consts = wtp<float>(c, c->tq_const);
+        ta.q1_inv = c->tq_q[0].inv(); ta.q1_zoff = c->tq_q[0].zoff(); ta.q4_inv = c->tq_q[3].inv();
+        for (int i = 0; i < 5; ++i) ta.zoff[i] = c->tq_q[i + 1].zoff();
+        q.chk(le_cond_trunk_q8_launch(img, H, W, ta, cond, cond1, c->n_cu, q.s), "LE.cond_trunk", "le_cond_trunk_q8",
+              (double)H * W * (27 * 64 + 4 * 64 * 64 + 64 * 16), (double)H * W * (6 + 128 + 32));
+    } else if (q.ok())
         q.chk(le_cond_trunk_launch(img, H, W, wtp<f16>(c, c->trunk_wfrag), wtp<float>(c, c->trunk_bias), cond, cond1, c->n_cu, q.s,
                                    qlast(c->q_trunk6, qa6)),
               "LE.cond_trunk", c->q_trunk6.on ? "le_cond_trunk<q6>" : "le_cond_trunk", (double)H * W * (27 * 64 + 4 * 64 * 64 + 64 * 16), (double)H * W * (6 + 128 + 32));
@@ -1307,7 +1562,7 @@ int run_le(hdrtv_ctx *c, Seq &q, const f16 *img, f16 *out_planar)
     // 192 channels); a W8A8 layer among them quantises `cond` with its own x_scale / x_zero and runs alone, writing the int8
     // codes of the layer that reads it when that one is W8A8 too.
     const f16 *a2 = nullptr, *a3 = nullptr, *a4 = nullptr;
-    const int8_t *a3q = nullptr, *a4q = nullptr;
+    const int8_t *a2q = nullptr, *a3q = nullptr, *a4q = nullptr;
     int astride = 64;
     if (c->conv.find("LE.CondNet234.0") != c->conv.end()) {
         f16 *x192 = wsp<f16>(c, "le.x192");
@@ -1315,13 +1570,13 @@ int run_le(hdrtv_ctx *c, Seq &q, const f16 *img, f16 *out_planar)
         a2 = x192; a3 = x192 + 64; a4 = x192 + 128; astride = 192;
     } else {
         f16 *ca[3] = {wsp<f16>(c, "le.c2a"), wsp<f16>(c, "le.c3a"), wsp<f16>(c, "le.c4a")};
-        int8_t *ca8[3] = {nullptr, wsp<int8_t>(c, "le8.c3a"), wsp<int8_t>(c, "le8.c4a")};
+        int8_t *ca8[3] = {wsp<int8_t>(c, "le8.c2a"), wsp<int8_t>(c, "le8.c3a"), wsp<int8_t>(c, "le8.c4a")};
         const char *l0[3] = {"LE.CondNet2.0", "LE.CondNet3.0", "LE.CondNet4.0"}, *l2[3] = {nullptr, "LE.CondNet3.2", "LE.CondNet4.2"};
         const f16 **af[3] = {&a2, &a3, &a4};
-        const int8_t **aq[3] = {nullptr, &a3q, &a4q};
+        const int8_t **aq[3] = {&a2q, &a3q, &a4q};
         for (int i = 0; i < 3; ++i) {
             if (isq8(l0[i])) {
-                const ActQf *oq = l2[i] ? qof(l2[i]) : nullptr;
+                const ActQf *oq = l2[i] ? qof(l2[i]) : (c->tail_q8 ? &c->tl_q[0] : nullptr);    // CondNet2.0 feeds the fused tail
                 q.convq8(l0[i], cond, false, 64, H, W, ACT_LRELU01, oq ? (void *)ca8[i] : (void *)ca[i], 64, oq);
                 if (oq) *aq[i] = ca8[i]; else *af[i] = ca[i];
             } else {
@@ -1331,7 +1586,12 @@ int run_le(hdrtv_ctx *c, Seq &q, const f16 *img, f16 *out_planar)
         }
     }
     // CondNet2.2 + .4 (1x1 64->64, LeakyReLU, 1x1 64->16) in one pass over CondNet2.0's 64 channels
-    if (q.ok())
+    if (q.ok() && c->tail_q8) {
+        if (!a2q) return q.rc = fail(c, HDRTV_ESTATE, "internal: W8A8 CondNet2 tail without int8 input");
+        q.chk(cond_tail_q8_launch(a2q, (size_t)s.H1 * s.W1, wtp<int8_t>(c, c->tl_frag), wtp<float>(c, c->tl_const), c->tl_q[1].zoff(), cond2,
+                                  c->n_cu, q.s),
+              "LE.CondNet2.2+4", "cond_tail_q8", (double)s.H1 * s.W1 * (64 * 64 + 64 * 16), (double)s.H1 * s.W1 * (64 + 32));
+    } else if (q.ok())
         q.chk(cond_tail_launch(a2, astride, (size_t)s.H1 * s.W1, wtp<f16>(c, c->tail_wfrag), wtp<float>(c, c->tail_bias), cond2, c->n_cu, q.s,
                                qlast(c->q_tail2, qa2)),
               "LE.CondNet2.2+4", c->q_tail2.on ? "cond_tail<q2>" : "cond_tail", (double)s.H1 * s.W1 * (64 * 64 + 64 * 16), (double)s.H1 * s.W1 * (128 + 32));
@@ -1360,7 +1620,14 @@ int run_le(hdrtv_ctx *c, Seq &q, const f16 *img, f16 *out_planar)
     }
     // main branch: every SFT is fused into the 3x3 conv that follows it
     f16 *f0a = wsp<f16>(c, "le.f0a"), *f0b = wsp<f16>(c, "le.f0b"), *fea0 = wsp<f16>(c, "le.fea0"), *up3 = wsp<f16>(c, "le.up3");
-    q.c3("le.conv_first", img, H, W, ACT_RELU, f0a, nullptr);
+    if (isq8("LE.conv_first")) {      // W8A8: the 3 planes as NHWC int8 codes (3 of 32 bytes real), then the generic int8 conv
+        int8_t *img32 = wsp<int8_t>(c, "le8.img32");
+        const QLayer &Lq = c->q8.at("LE.conv_first");
+        if (q.ok()) q.chk(planar3_to_q8_launch(img, (size_t)H * W, Lq.q.inv(), Lq.q.zoff(), img32, q.s), "le.conv_first.pack", "planar3_to_q8", 0.0, 38.0 * H * W);
+        q.convq8("LE.conv_first", img32, true, 32, H, W, ACT_RELU, f0a, 32, nullptr);
+    } else {
+        q.c3("le.conv_first", img, H, W, ACT_RELU, f0a, nullptr);
+    }
     q.conv32("LE.HR_conv1", f0a, cond1, "LE.SFT_layer1", H, W, ACT_RELU, ST_NHWC, fea0, 32, H, W);
     f16 *fea1a = wsp<f16>(c, "le.fea1a"), *fea1 = wsp<f16>(c, "le.fea1"), *l1b = wsp<f16>(c, "le.l1b");
     auto down = [&](const char *key, const f16 *src, int Hi, int Wi, f16 *dst, int Ho, int Wo) {

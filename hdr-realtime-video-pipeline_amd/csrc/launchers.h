@@ -26,9 +26,11 @@ hipError_t cond_resize_launch(const f16 *in, f16 *out, int H, int W, int Ho, int
 hipError_t post_u8_launch(const void *in, int is_f32, int H, int W, uint8_t *bgr, hipStream_t s);
 hipError_t post_rgb48_launch(const void *in, int is_f32, int H, int W, uint16_t *rgb, int pq, float peak, hipStream_t s);
 
+// activation fake-quantiser of a W8A8 layer evaluated in fp32 (classifier convs, Linear heads): on = 0 passes x through
+struct FakeQ { int on; float inv, zoff, scale, zero; };
 hipError_t cls_block_launch(const void *in, int in_f16, int Ci, int Hi, int Wi, const float *nmean, const float *nrstd,
                             const float *ngamma, const float *nbeta, const float *Wt, const float *bias, int Co, float *out,
-                            int Ho, int Wo, float *part, hipStream_t s);
+                            int Ho, int Wo, float *part, hipStream_t s, const FakeQ *qin = nullptr, const FakeQ *qstat = nullptr);
 hipError_t cls_stats_launch(const float *part, int C, int nblk, int n, float eps, float *mean, float *rstd, hipStream_t s);
 struct AgcmFoldArgs {
     const float *mean5;
@@ -52,6 +54,26 @@ hipError_t le_cond_trunk_launch(const f16 *img, int H, int W, const f16 *wfrag, 
                                 int n_cu, hipStream_t s, const QLastArgs *q6 = nullptr);
 hipError_t cond_tail_launch(const f16 *x, int x_stride, size_t npx, const f16 *wfrag, const float *bias, f16 *out, int n_cu,
                             hipStream_t s, const QLastArgs *q2 = nullptr);
+// ---- fully quantised (W8A8) per-pixel chains (le_chain_q8.hip); layouts documented there
+struct TrunkQ8Args {
+    const int8_t *wfrag;           // [20][64 lanes][16 B]
+    const float *consts;           // [1664]
+    float q1_inv, q1_zoff, q4_inv;
+    float zoff[5];
+};
+hipError_t le_cond_trunk_q8_launch(const f16 *img, int H, int W, const TrunkQ8Args &a, f16 *cond, f16 *cond1, int n_cu, hipStream_t s);
+hipError_t cond_tail_q8_launch(const int8_t *x, size_t npx, const int8_t *wfrag, const float *consts, float zoff2, f16 *out, int n_cu,
+                               hipStream_t s);
+hipError_t agcm_mlp_q8_launch(const f16 *in, f16 *out, size_t npix, const int8_t *wfrag, const float *consts, float q1_inv, float q1_zoff,
+                              float zoff2, float zoff3, hipStream_t s);
+hipError_t planar3_to_q8_launch(const f16 *in, size_t npix, float inv, float zoff, int8_t *out, hipStream_t s);
+struct AgcmFoldQ8Args {
+    FakeQ q20, qlin[6];            // model.20; cond_scale_{first,HR,last}, cond_shift_{first,HR,last}
+    const float *P, *Q;            // [3][64] each: x_scale * w_scale[m]; w_scale[m] * (128 x_scale + x_zero) * sum(w) + bias[m]
+    float inv2, inv3;              // 1 / x_scale of HRconv and conv_last
+    float *consts;                 // out: 320 per-frame constants of agcm_mlp_q8
+};
+hipError_t agcm_fold_q8_launch(const AgcmFoldArgs &a, const AgcmFoldQ8Args &q, float *biasbuf, hipStream_t s);
 hipError_t hg_prep_launch(const f16 *base, int H, int W, int Hp, int Wp, f16 *img_pad, uint8_t *mask, float r, float thresh,
                           hipStream_t s);
 struct HgFinalFusedArgs {

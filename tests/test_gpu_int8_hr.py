@@ -6,7 +6,12 @@ Oracle: ``O.w8a8_state`` + the ordinary graphs = the reference's fake-quant exec
 ``tests/golden/int8_*_w8a8_*.npz`` (runs of the reference itself, tests/golden/gen_golden_w8a8.py).
 
 Bars.  The reference's own bound for a re-quantised graph is u8 MAE <= 5 and float MAE <= 0.02
-(scripts/validate_tensorrt_sources.py:598-609).  Measured values are printed; asserted bounds are ~3x those.
+(scripts/validate_tensorrt_sources.py:598-609).  Measured values are printed; asserted bounds are ~2-3x those.
+End to end these QAT graphs are chaotic in the small: one activation that lands on the other side of a rounding boundary
+moves a code by one step, and the fully quantised graph (128 quantisers, steps up to 0.1) amplifies it.  The oracle
+ITSELF, re-run with its conv inputs / outputs rounded to fp16 (what any fp16 execution of the graph stores), deviates
+from its fp32 run by mean 5.8e-3 / u8 MAE 1.47 (full) and 4.5e-4 / 0.12 (mixed) on the golden frame
+(tests/test_oracle_golden.py::test_w8a8_fp16_storage_sensitivity); the device sits at that level, not above it.
 Layer by layer, GIVEN THE DEVICE'S OWN INPUT, an int8 layer is exact integer arithmetic: its output may differ from the
 oracle's only where fp16 storage of the input or of the result moves a value across a rounding boundary.
 """
@@ -176,6 +181,111 @@ def test_mixed_w8a8_multi_tile(proc_mixed, sd_mixed):
     u8 = np.abs(O.postprocess_u8(got).astype(int) - O.postprocess_u8(ref).astype(int))
     print(f"  u8 MAE {u8.mean():.4f} max {u8.max()}")
     assert u8.mean() <= 0.5
+
+
+@pytest.fixture(scope="module")
+def proc_full(torch_cuda, golden_dir):
+    p = _proc(golden_dir, "full")
+    yield p
+    p.close()
+
+
+@pytest.fixture(scope="module")
+def sd_full(golden_dir):
+    from hdrtv_mi355x import weights as W
+    from oracle import hdrtvnet_oracle as O
+    return O.w8a8_state(W.load_pack(os.path.join(golden_dir, "hr_int8_full_qat.hdrw")))
+
+
+def test_full_w8a8_vs_reference_run(proc_full, golden_dir):
+    """HR_original_int8_full_qat.pt: all 128 Conv2d / Linear layers are W8A8 (asymmetric, float x_zero).  122 of them run on
+    int8 MFMA; the AGCM classifier's six 1x1 convs and the six Linear heads (0.001 % of the MACs, scalar code in every
+    precision) are evaluated as the reference's fp32 fake-quant."""
+    d = np.load(os.path.join(golden_dir, "int8_full_qat_w8a8_64x96_gradient_s6.npz"))
+    kinds = [str(k) for k in d["layer_kinds"]]
+    assert sum("W8A8" in k for k in kinds) == 128
+    out, agcm = proc_full.infer(proc_full.preprocess(d["frame"]))
+    out_np = out.float().cpu().numpy()[0]
+    bias = proc_full.tap("agcm.bias").numpy().ravel()
+    print("  fea6 (device):", np.array2string(bias[160:166], precision=5))
+    mx, mean = _stats("agcm_out vs reference W8A8 run", agcm.float().cpu().numpy()[0], d["agcm_out"])
+    assert mx <= 2.5e-2 and mean <= 2e-3
+    mx, mean = _stats("out vs reference W8A8 run", out_np, d["out"])
+    assert mx <= 0.15 and mean <= 1.2e-2            # the reference's float MAE bar: 0.02
+    u8 = proc_full.postprocess(out).astype(int)
+    du8 = np.abs(u8 - d["u8_bgr"].astype(int))
+    print(f"  u8: max={du8.max()} MAE={du8.mean():.4f} (reference bar: MAE <= 5)")
+    assert du8.mean() <= 2.5 and du8.max() <= 30
+    proc_full.profile_enable(True)
+    proc_full.infer(proc_full.preprocess(d["frame"]))
+    prof = proc_full.profile_read()
+    proc_full.profile_enable(False)
+    kern = sorted(set(k for _, k, _, _, _ in prof))
+    print("  kernels:", kern)
+    assert not any(k in ("agcm_mlp", "le_cond_trunk", "cond_tail", "conv_c3<32>", "conv32p<1,sft>", "conv32p<1,sft,i8>", "conv32p<1,plain>",
+                         "conv32p<4,plain>", "conv3x3s2_preg<64>", "conv3x3s2_preg<192>") or k.startswith("conv_igemm") for k in kern)
+
+
+def test_full_w8a8_layers_given_device_inputs(proc_full, sd_full, golden_dir):
+    """The kernels only the full recipe uses, each against the oracle's fake-quant layers fed the DEVICE's input."""
+    from oracle import hdrtvnet_oracle as O
+    d = np.load(os.path.join(golden_dir, "int8_full_qat_w8a8_64x96_gradient_s6.npz"))
+    sd = sd_full
+    t, c = proc_full.preprocess(d["frame"])
+    out, agcm = proc_full.infer((t, c))
+    T = lambda n: proc_full.tap(n).numpy()          # noqa: E731
+    tn, cn = t.float().cpu().numpy()[0], c.float().cpu().numpy()[0]
+    # ---- AGCM: classifier (fp32 fake-quant) -> 6-vector; Linear heads + int8 GFM chain -> agcm_out
+    fea = O.agcm_classifier(sd, cn)
+    mx, _ = _stats("fea6 (W8A8 classifier, fp32 fake-quant)", T("agcm.bias").ravel()[160:166], fea)
+    assert mx <= 5e-3
+    taps = {}
+    ref_agcm = O.agcm(sd, tn, cn, taps)
+    a = agcm.float().cpu().numpy()[0]
+    mx, mean = _stats("agcm_out (agcm_mlp<q8>)", a, ref_agcm)
+    assert mx <= 2.5e-2 and mean <= 2e-3
+    # ---- trunk / tail / conv_first given the device's AGCM output
+    lt = {}
+    O.le(sd, a, lt)
+    mx, mean = _stats("cond (le_cond_trunk_q8, 64 ch)", T("le.cond"), lt["LE.cond_first"])
+    assert mx <= 3e-2 and mean <= 1e-3
+    c1 = O.conv2d(O.leaky(O.conv2d(O.leaky(O.conv2d(T("le.cond"), sd["LE.CondNet1.0.weight"], sd["LE.CondNet1.0.bias"]), 0.1),
+                                   sd["LE.CondNet1.2.weight"], sd["LE.CondNet1.2.bias"]), 0.1), sd["LE.CondNet1.4.weight"], sd["LE.CondNet1.4.bias"])
+    mx, mean = _stats("cond1 given device cond", T("le.cond1"), c1)
+    assert mx <= 2e-2 and mean <= 1e-3
+    w20, w22, w24 = sd["LE.CondNet2.0.weight"], sd["LE.CondNet2.2.weight"], sd["LE.CondNet2.4.weight"]
+    y = O.leaky(O.conv2d(T("le.cond"), w20, sd["LE.CondNet2.0.bias"], 2, 1), 0.1)
+    diff = np.abs(T("le8.c2a").astype(np.int32) - _codes(y, w22))
+    print(f"  CondNet2.0 -> codes: flips {(diff != 0).mean():.2e} max step {int(diff.max())}")
+    assert (diff != 0).mean() <= 2e-3 and diff.max() <= 1
+    y = O.conv2d(O.leaky(O.conv2d(_deq(T("le8.c2a"), w22), w22, sd["LE.CondNet2.2.bias"]), 0.1), w24, sd["LE.CondNet2.4.bias"])
+    mx, mean = _stats("cond2 (cond_tail_q8) given device codes", T("le.cond2"), y)
+    assert mx <= 1e-2 and mean <= 5e-4
+    y = O.relu(O.conv2d(a, sd["LE.conv_first.weight"], sd["LE.conv_first.bias"], 1, 1))
+    mx, _ = _stats("conv_first (planar3_to_q8 + conv_q8<32,3,1>)", T("le.f0a"), y)
+    assert mx <= 2e-3
+    # ---- conv32p<1,sft-i8,i8>: SFT_layer1 + HR_conv1, and a whole ResBlock_with_SFT, all six convs W8A8
+    y = O.relu(O.conv2d(O.sft(sd, "LE.SFT_layer1", T("le.f0a"), T("le.cond1")), sd["LE.HR_conv1.weight"], sd["LE.HR_conv1.bias"], 1, 1))
+    mx, mean = _stats("SFT_layer1 + HR_conv1", T("le.fea0"), y)
+    assert mx <= 4e-2 and mean <= 2e-3
+    y = O.resblock_sft(sd, "LE.recon_trunk1.0", T("le.fea1a"), T("le.cond2"))
+    mx, mean = _stats("recon_trunk1.0 (2 x conv32p<1,sft-i8,i8>)", T("le.fea1"), y)
+    assert mx <= 4e-2 and mean <= 2e-3
+
+
+def test_full_w8a8_unaligned_and_multi_tile(proc_full, sd_full):
+    from hdrtv_mi355x import weights as W
+    from oracle import hdrtvnet_oracle as O
+    for hw, seed in (((61, 103), 9), ((272, 480), 12)):
+        f = W.synthetic_frame(hw[0], hw[1], seed=seed, kind="gradient")
+        out, agcm = proc_full.infer(proc_full.preprocess(f))
+        rt, rc = O.preprocess(f)
+        ref, ref_agcm = O.hr_forward(sd_full, rt, rc)
+        got = out.float().cpu().numpy()[0]
+        mx, mean = _stats(f"HR out {hw[0]}x{hw[1]} vs oracle fake-quant (end to end)", got, ref)
+        u8 = np.abs(O.postprocess_u8(got).astype(int) - O.postprocess_u8(ref).astype(int))
+        print(f"  u8 MAE {u8.mean():.4f} max {u8.max()}")
+        assert mx <= 0.15 and mean <= 1.2e-2 and u8.mean() <= 2.5
 
 
 def test_full_checkpoint_and_predequantize_switch(golden_dir, torch_cuda):

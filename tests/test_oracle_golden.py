@@ -234,3 +234,34 @@ def test_hg_w8a8_fake_quant_execution(golden_dir):
         O.use_backend("c")
     print(f"  ATen operators: out max {emax:.2e} mean {emean:.2e} taps max {tmax:.2e}")
     assert emax <= 1e-6 and tmax <= 1e-6
+
+
+def test_w8a8_fp16_storage_sensitivity(golden_dir):
+    """How far an fp16 execution of the reference's fake-quant graphs sits from its fp32 execution, by construction: the
+    oracle re-run with every conv input / output rounded to fp16.  This is the yardstick the int8-MFMA path's end-to-end
+    bars (tests/test_gpu_int8_hr.py) are set against: a fully quantised QAT graph amplifies single-step code flips."""
+    from hdrtv_mi355x import weights as W
+    from oracle import hdrtvnet_oracle as O
+    f = W.synthetic_frame(64, 96, seed=6, kind="gradient")
+    rt, rc = O.preprocess(f)
+    orig = O.conv2d
+
+    def conv16(x, w, b=None, stride=1, pad=0):
+        y = orig(np.asarray(x, np.float32).astype(np.float16).astype(np.float32), w, b, stride, pad)
+        return y.astype(np.float16).astype(np.float32)
+
+    got = {}
+    for tag in ("mixed", "full"):
+        sd = O.w8a8_state(W.load_pack(os.path.join(golden_dir, f"hr_int8_{tag}_qat.hdrw")))
+        ref, _ = O.hr_forward(sd, rt, rc)
+        O.conv2d = conv16
+        try:
+            out16, _ = O.hr_forward(sd, rt.astype(np.float16).astype(np.float32), rc.astype(np.float16).astype(np.float32))
+        finally:
+            O.conv2d = orig
+        d = np.abs(out16 - ref)
+        u8 = np.abs(O.postprocess_u8(out16).astype(int) - O.postprocess_u8(ref).astype(int))
+        got[tag] = (float(d.mean()), float(u8.mean()))
+        print(f"  {tag}: fp16-storage oracle vs fp32 oracle: mean_abs={d.mean():.3e} max_abs={d.max():.3e} u8 MAE={u8.mean():.3f}")
+    assert 1e-4 <= got["mixed"][0] <= 2e-3 and 1e-3 <= got["full"][0] <= 2e-2
+    assert got["full"][1] <= 5.0          # still inside the reference's own bar
