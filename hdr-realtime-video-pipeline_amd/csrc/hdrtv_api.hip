@@ -197,6 +197,7 @@ struct hdrtv_ctx {
     std::map<std::string, C3Layer> c3;
     std::map<std::string, ConvI8Layer> conv8;
     float mask_r = 0.75f;                 // HG_Composite(mask_r=0.75), HG_Composite_arch.py:21
+    int cond_mode = 0;                    // 0 AA-bicubic, 1 bilinear (fast_condition_resize), 2 zero (HDRTVNET_ZERO_COND)
     bool hg_i8 = false;                   // the HG pack is a W8A8 checkpoint: 15 layers run on int8 MFMA
     float hg_q0_inv = 0.f, hg_q0_zero = 0.f;   // quantiser of the fp16 -> int8 boundary (conv2's output)
     std::map<std::string, SftLayer> sft;
@@ -1798,6 +1799,14 @@ int hdrtv_destroy(hdrtv_ctx *c)
 
 int hdrtv_has_hg(const hdrtv_ctx *c) { return c && c->has_hg ? 1 : 0; }
 
+int hdrtv_set_cond_mode(hdrtv_ctx *c, int mode)
+{
+    if (!c) return HDRTV_EINVAL;
+    if (mode < 0 || mode > 2) return fail(c, HDRTV_EINVAL, "cond mode must be 0 (bicubic-aa), 1 (bilinear) or 2 (zero)");
+    c->cond_mode = mode;
+    return HDRTV_OK;
+}
+
 int hdrtv_set_hg_mask_r(hdrtv_ctx *c, float r)
 {
     if (!c) return HDRTV_EINVAL;
@@ -1820,8 +1829,15 @@ int hdrtv_preprocess(hdrtv_ctx *c, void *stream, const uint8_t *bgr, int H, int 
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     Seq q{c, s};
-    q.chk(pre_unpack_launch(bgr, (f16 *)rgb, H, W, s), "pre_unpack");
     const Shapes sh = shapes_for(H, W);
+    static const bool split = getenv("HDRTV_PRE_SPLIT") != nullptr;      // developer A/B: the two-kernel form
+    if (H / 4 >= 1 && W / 4 >= 1 && !(split && c->cond_mode == 0)) {
+        q.chk(pre_fused_launch(bgr, (f16 *)rgb, (f16 *)cond, H, W, sh.h4, sh.w4, wsp<float>(c, "aa.wx"), wsp<int>(c, "aa.xmn"),
+                               wsp<int>(c, "aa.xns"), wsp<float>(c, "aa.wy"), wsp<int>(c, "aa.ymn"), wsp<int>(c, "aa.yns"), c->cond_mode, s),
+              "pre_fused");
+        return q.rc;
+    }
+    q.chk(pre_unpack_launch(bgr, (f16 *)rgb, H, W, s), "pre_unpack");
     q.chk(cond_resize_launch((const f16 *)rgb, (f16 *)cond, H, W, sh.h4, sh.w4, wsp<float>(c, "aa.wx"), wsp<int>(c, "aa.xmn"),
                              wsp<int>(c, "aa.xns"), wsp<float>(c, "aa.wy"), wsp<int>(c, "aa.ymn"), wsp<int>(c, "aa.yns"), s),
           "cond_resize");

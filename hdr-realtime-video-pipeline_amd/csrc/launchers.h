@@ -23,6 +23,8 @@ hipError_t conv3x3s2_preg_launch(ConvParams p, int n_cu, hipStream_t stream);
 hipError_t pre_unpack_launch(const uint8_t *bgr, f16 *out, int H, int W, hipStream_t s);
 hipError_t cond_resize_launch(const f16 *in, f16 *out, int H, int W, int Ho, int Wo, const float *wx, const int *xmn,
                               const int *xns, const float *wy, const int *ymn, const int *yns, hipStream_t s);
+hipError_t pre_fused_launch(const uint8_t *bgr, f16 *out, f16 *cond, int H, int W, int Ho, int Wo, const float *wx, const int *xmn,
+                            const int *xns, const float *wy, const int *ymn, const int *yns, int mode, hipStream_t s);
 hipError_t post_u8_launch(const void *in, int is_f32, int H, int W, uint8_t *bgr, hipStream_t s);
 hipError_t post_rgb48_launch(const void *in, int is_f32, int H, int W, uint16_t *rgb, int pq, float peak, hipStream_t s);
 

@@ -102,6 +102,123 @@ __global__ __launch_bounds__(256) void cond_resize_kernel(const f16 *__restrict_
     }
 }
 
+// ---- pre_fused: both halves of preprocess in one pass over the u8 frame ----------------------
+// A workgroup owns a 32 x 8 tile of the 0.25x condition map = 128 x 32 input pixels.  It stages the 140 x 44 u8 BGR
+// patch those outputs' 16-tap windows cover (aligned dword loads, each byte converted once to the f16 value
+// fp16(float(u8) * fp32(1/255)) the reference's tensor holds), writes the 128 x 32 pixels it owns to the three f16 planes
+// with 16-byte stores, and resamples the SAME values into the condition tile: horizontal pass then vertical pass,
+// fp32, the tap order and rounding of cond_resize_kernel (= ATen's separable _upsample_bicubic2d_aa).  The frame is read
+// from HBM once (3 B per pixel; halo re-reads hit L2) instead of 3 B + 6 B.
+// mode 1: HDRTVNetTorch(fast_condition_resize=True) -- F.interpolate(0.25, bilinear, align_corners=False): source
+// coordinate 4d + 1.5, i.e. the mean of pixels (4d+1, 4d+2) in each direction (hdrtvnet_torch.py:2269-2276).
+// mode 2: HDRTVNET_ZERO_COND -- the condition map is zero (hdrtvnet_torch.py:2265-2267).
+constexpr int PF_OW = 32, PF_OH = 8, PF_IW = 140, PF_IH = 44, PF_ROWDW = 107;   // 107 dwords cover 420 B at any alignment
+
+__global__ __launch_bounds__(256) void pre_fused_kernel(const uint8_t *__restrict__ bgr, f16 *__restrict__ out, f16 *__restrict__ cond,
+                                                        int H, int W, int Ho, int Wo, const float *__restrict__ wx,
+                                                        const int *__restrict__ xmn, const int *__restrict__ xns,
+                                                        const float *__restrict__ wy, const int *__restrict__ ymn,
+                                                        const int *__restrict__ yns, int mode)
+{
+    __shared__ f16 s_in[3][PF_IH][PF_IW + 2];
+    __shared__ float s_h[3][PF_IH][PF_OW + 1];
+    const int tid = threadIdx.x;
+    const int ox0 = blockIdx.x * PF_OW, oy0 = blockIdx.y * PF_OH;
+    const int ix0 = xmn[ox0], iy0 = ymn[oy0];
+    const size_t total = (size_t)H * W * 3;
+    const float k255 = (float)(1.0 / 255.0);
+    for (int e = tid; e < PF_IH * PF_ROWDW; e += 256) {
+        const int r = e / PF_ROWDW, d = e - r * PF_ROWDW;
+        const int iy = iy0 + r;
+        if (iy >= H) continue;
+        const size_t row0 = ((size_t)iy * W + ix0) * 3;
+        const size_t addr = (row0 & ~(size_t)3) + 4 * (size_t)d;
+        if (addr >= total) continue;
+        uint32_t word;
+        if (addr + 4 <= total) {
+            word = *reinterpret_cast<const uint32_t *>(bgr + addr);
+        } else {
+            word = 0;
+            for (size_t k = 0; addr + k < total; ++k) word |= (uint32_t)bgr[addr + k] << (8 * k);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int b = (int)((long)addr + k - (long)row0);
+            if (b >= 0 && b < PF_IW * 3) {
+                const int q = (b * 683) >> 11, ch = b - 3 * q;             // b / 3 for b < 600
+                if (ix0 + q < W) s_in[2 - ch][r][q] = (f16)__fmul_rn((float)((word >> (8 * k)) & 0xff), k255);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the pixels this tile owns -> f16 planes.  The last tile of a row / column also owns the W % 4 (H % 4) remainder.
+    const int wx0 = 4 * ox0, wy0 = 4 * oy0;
+    const int wx1 = (ox0 + PF_OW >= Wo) ? W : wx0 + 4 * PF_OW, wy1 = (oy0 + PF_OH >= Ho) ? H : wy0 + 4 * PF_OH;
+    constexpr int NCX = 4 * PF_OW / 8 + 1, NRY = 4 * PF_OH + 3;
+    const size_t npix = (size_t)H * W;
+    for (int e = tid; e < 3 * NRY * NCX; e += 256) {
+        const int c = e / (NRY * NCX), rr = (e / NCX) % NRY, j = e % NCX;
+        const int y = wy0 + rr, x = wx0 + 8 * j;
+        if (y >= wy1 || x >= wx1) continue;
+        const f16 *src = &s_in[c][y - iy0][x - ix0];
+        f16 *dst = out + c * npix + (size_t)y * W + x;
+        if (x + 8 <= wx1) {
+            f16x8 v;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = src[i];
+            *reinterpret_cast<f16x8 *>(dst) = v;
+        } else {
+            for (int i = 0; x + i < wx1; ++i) dst[i] = src[i];
+        }
+    }
+    if (mode == 2) {
+        for (int e = tid; e < 3 * PF_OH * PF_OW; e += 256) {
+            const int c = e / (PF_OH * PF_OW), r = (e / PF_OW) % PF_OH, o = e % PF_OW;
+            if (ox0 + o < Wo && oy0 + r < Ho) cond[((size_t)c * Ho + oy0 + r) * Wo + ox0 + o] = (f16)0.f;
+        }
+        return;
+    }
+    if (mode == 1) {
+        for (int e = tid; e < 3 * PF_OH * PF_OW; e += 256) {
+            const int c = e / (PF_OH * PF_OW), r = (e / PF_OW) % PF_OH, o = e % PF_OW;
+            const int ox = ox0 + o, oy = oy0 + r;
+            if (ox < Wo && oy < Ho) {
+                const int y1 = 4 * oy + 1, x1 = 4 * ox + 1;
+                const int yp = y1 < H - 1 ? 1 : 0, xp = x1 < W - 1 ? 1 : 0;
+                const float a = (float)s_in[c][y1 - iy0][x1 - ix0], b = (float)s_in[c][y1 - iy0][x1 + xp - ix0];
+                const float cc = (float)s_in[c][y1 + yp - iy0][x1 - ix0], dd = (float)s_in[c][y1 + yp - iy0][x1 + xp - ix0];
+                // upsample_bilinear2d: h0lambda * (w0lambda * a + w1lambda * b) + h1lambda * (w0lambda * c + w1lambda * d), lambdas 0.5
+                const float top = __fadd_rn(__fmul_rn(0.5f, a), __fmul_rn(0.5f, b)), bot = __fadd_rn(__fmul_rn(0.5f, cc), __fmul_rn(0.5f, dd));
+                cond[((size_t)c * Ho + oy) * Wo + ox] = (f16)__fadd_rn(__fmul_rn(0.5f, top), __fmul_rn(0.5f, bot));
+            }
+        }
+        return;
+    }
+    for (int e = tid; e < 3 * PF_IH * PF_OW; e += 256) {
+        const int c = e / (PF_IH * PF_OW), r = (e / PF_OW) % PF_IH, o = e % PF_OW;
+        const int ox = ox0 + o;
+        float sacc = 0.f;
+        if (ox < Wo && iy0 + r < H) {
+            const int base = xmn[ox] - ix0, n = xns[ox];
+            const float *w = wx + (size_t)ox * AA_TAPS;
+            for (int j = 0; j < n; ++j) sacc = __fadd_rn(sacc, __fmul_rn(w[j], (float)s_in[c][r][base + j]));
+        }
+        s_h[c][r][o] = sacc;
+    }
+    __syncthreads();
+    for (int e = tid; e < 3 * PF_OH * PF_OW; e += 256) {
+        const int c = e / (PF_OH * PF_OW), r = (e / PF_OW) % PF_OH, o = e % PF_OW;
+        const int ox = ox0 + o, oy = oy0 + r;
+        if (ox < Wo && oy < Ho) {
+            const int base = ymn[oy] - iy0, n = yns[oy];
+            const float *w = wy + (size_t)oy * AA_TAPS;
+            float sacc = 0.f;
+            for (int j = 0; j < n; ++j) sacc = __fadd_rn(sacc, __fmul_rn(w[j], s_h[c][base + j][o]));
+            cond[((size_t)c * Ho + oy) * Wo + ox] = (f16)sacc;
+        }
+    }
+}
+
 // ---- post-process quantisers ----------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ void load8(const T *p, float (&v)[8]);
@@ -270,6 +387,16 @@ hipError_t cond_resize_launch(const f16 *in, f16 *out, int H, int W, int Ho, int
 {
     dim3 grid((Wo + RT_W - 1) / RT_W, (Ho + RT_H - 1) / RT_H, 3);
     hipLaunchKernelGGL(cond_resize_kernel, grid, dim3(256), 0, s, in, out, H, W, Ho, Wo, wx, xmn, xns, wy, ymn, yns);
+    return hipGetLastError();
+}
+
+// mode 0: 0.25x antialiased bicubic; 1: bilinear (fast_condition_resize); 2: zero condition.  Needs Ho = H / 4 >= 1, Wo = W / 4 >= 1.
+hipError_t pre_fused_launch(const uint8_t *bgr, f16 *out, f16 *cond, int H, int W, int Ho, int Wo, const float *wx, const int *xmn,
+                            const int *xns, const float *wy, const int *ymn, const int *yns, int mode, hipStream_t s)
+{
+    if (Ho != H / 4 || Wo != W / 4 || Ho < 1 || Wo < 1) return hipErrorInvalidValue;
+    dim3 grid((Wo + PF_OW - 1) / PF_OW, (Ho + PF_OH - 1) / PF_OH, 1);
+    hipLaunchKernelGGL(pre_fused_kernel, grid, dim3(256), 0, s, bgr, out, cond, H, W, Ho, Wo, wx, xmn, xns, wy, ymn, yns, mode);
     return hipGetLastError();
 }
 

@@ -23,6 +23,7 @@ SYMBOLS = [
     ("hdrtv_destroy", _I, [_VP]),
     ("hdrtv_has_hg", _I, [_VP]),
     ("hdrtv_set_hg_mask_r", _I, [_VP, C.c_float]),
+    ("hdrtv_set_cond_mode", _I, [_VP, _I]),
     ("hdrtv_reserve", _I, [_VP, _I, _I]),
     ("hdrtv_preprocess", _I, [_VP, _VP, _VP, _I, _I, _VP, _VP]),
     ("hdrtv_infer", _I, [_VP, _VP, _VP, _VP, _I, _I, _VP, _I, _VP]),

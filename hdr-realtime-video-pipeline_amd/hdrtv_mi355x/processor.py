@@ -25,6 +25,16 @@ from . import lib as _L
 from . import weights as _W
 
 
+def _split_composite(state):
+    """An ``HG_Composite`` checkpoint (keys ``base.AGCM.* / base.LE.* / hg.*``, hdrtvnet_torch.py:1797-1830 and
+    HG_Composite_arch.py:30-76) -> (HR state, HG state or None); any other state passes through as (state, None)."""
+    if not any(k.startswith("base.") for k in state):
+        return state, None
+    hr = {k[5:]: v for k, v in state.items() if k.startswith("base.")}
+    hg = {k[3:]: v for k, v in state.items() if k.startswith("hg.")}
+    return hr, (hg or None)
+
+
 def _load_state(path_or_state, what):
     """Accepts a mapping, an ``.hdrw`` pack, or a torch checkpoint (raw state_dict or the
     reference's ``{"state_dict":..., "architecture":...}`` wrapper, hdrtvnet_torch.py:1491)."""
@@ -54,8 +64,16 @@ class HDRTVNetMI355X:
     18 quantised layers on int8 MFMA (BASELINE configs[4]); any other layout is rejected.  As in the reference
     (hdrtvnet_torch.py:2065-2086): an explicit but missing path raises ``FileNotFoundError``;
     with no path given and ``use_hg=True`` the model silently continues without HG.
-    ``compile_*``, ``use_cuda_graphs``, ``force_channels_last``, ``predequantize`` are accepted
-    and ignored: there is nothing to JIT (kernels are precompiled for gfx950).
+    An ``HG_Composite`` checkpoint (``base.*`` + ``hg.*`` keys, the layout of the reference's
+    ``pytorch_int8/hg/HR_HG_*.pt``) is split into its two halves; with ``use_hg=True`` and no HG tensors anywhere the
+    reference's search order applies (``_resolve_hg_weights``, 2016-2042: explicit path, ``HG.pt`` next to the model,
+    ``<cwd>/src/models/weights/original/HG.pt``).
+    ``compile_*`` and ``force_channels_last`` are accepted and ignored: there is nothing to JIT (kernels are precompiled
+    for gfx950).  ``predequantize``: "auto" / True run an INT8 checkpoint as fp16 convs of the dequantised weights (the
+    reference's ROCm behaviour), "off" / False keep its W8A8 layers and run them on int8 MFMA.
+    ``use_cuda_graphs=True`` replays ``infer`` from a captured hipGraph (2306-2331).  ``fast_condition_resize=True`` (or
+    ``HDRTVNET_FAST_COND_RESIZE=1``) derives the condition map with the bilinear 0.25x resize, ``HDRTVNET_ZERO_COND=1``
+    zeroes it (1539-1543, 2262-2276).
     """
 
     def __init__(self, model_path, device="auto", precision="auto",
@@ -65,8 +83,11 @@ class HDRTVNetMI355X:
                  warmup_passes=3, fast_condition_resize=False):
         self.model_path = model_path
         self._warmup_passes = int(warmup_passes)
-        if fast_condition_resize:
-            raise ValueError("fast_condition_resize (bilinear cond) is not implemented by the MI355X backend")
+        env_true = lambda n: str(os.environ.get(n, "")).strip().lower() in ("1", "true", "yes", "on")   # noqa: E731
+        self._fast_condition_resize = bool(fast_condition_resize) or env_true("HDRTVNET_FAST_COND_RESIZE")
+        self._fast_zero_condition = env_true("HDRTVNET_ZERO_COND")
+        self._use_cuda_graphs = bool(use_cuda_graphs)
+        self._graphs = {}
         self.device = self._resolve_device(device)
         self.precision = self._resolve_precision(precision)
         self._use_cuda = True
@@ -81,7 +102,7 @@ class HDRTVNetMI355X:
         self._lib = _L.load()
         self._ctx = C.c_void_p()
 
-        hr_state = _load_state(model_path, "model weights")
+        hr_state, hg_from_ckpt = _split_composite(_load_state(model_path, "model weights"))
         if self.precision.startswith("int8"):
             # hdrtvnet_torch.py:1748-1963: an INT8 runtime checkpoint.  On ROCm the reference
             # pre-dequantizes it to native fp16 convs at load time ("auto", 1893-1899): INT8 is
@@ -112,10 +133,27 @@ class HDRTVNetMI355X:
             elif isinstance(hg_weights, str) and hg_weights.startswith("seeded-w8a8:"):
                 hg_state = _W.seeded_hg_w8a8_state(int(hg_weights.split(":", 1)[1]))
             elif hg_weights is not None:
-                hg_state = _load_state(hg_weights, "HG weights")     # FileNotFoundError if missing
+                hg_state = _split_composite(_load_state(hg_weights, "HG weights"))     # FileNotFoundError if missing
+                hg_state = hg_state[1] if hg_state[1] is not None else hg_state[0]
+            elif hg_from_ckpt is not None:
+                hg_state = hg_from_ckpt                                # HG_Composite checkpoint: its own hg.* half
             else:
-                print("WARNING: HG weights not given; continuing with no-HG model.")
-                self._use_hg = False
+                found, searched = self._resolve_hg_weights(model_path)
+                if found:
+                    hg_state = _load_state(found, "HG weights")
+                    hg_weights = found
+                elif self.precision.startswith("int8"):
+                    # hdrtvnet_torch.py:1928-1937: an INT8 no-HG checkpoint with HG requested needs split HG weights
+                    raise FileNotFoundError("INT8 HG weights were requested but not found.\n  Searched paths:\n" +
+                                            "\n".join(f"  - {p}" for p in searched) + "\n  Pass hg_weights or disable HG.")
+                else:
+                    print("WARNING: HG weights not found; continuing with no-HG model.\n  Searched paths:\n" +
+                          "\n".join(f"  - {p}" for p in searched))
+                    self._use_hg = False
+            if hg_state is not None and _W.is_int8_state(hg_state) and not self._is_w8_model and self.precision.startswith("int8") \
+                    and not _W.is_hg_w8a8_layout(hg_state):
+                # a quantised HG half in a layout the int8 HG kernels do not serve, with predequantize on: fp16 convs
+                hg_state = _W.dequantize_int8_state(hg_state, "fp16")
         self._hg_weights = hg_weights if self._use_hg else None
         self._hg_int8 = hg_state is not None and _W.is_int8_state(hg_state)
         self._hg_state_fp = hg_state if (hg_state is not None and not self._hg_int8) else None
@@ -132,6 +170,8 @@ class HDRTVNetMI355X:
                 raise ValueError(f"model backend failed - {msg}")
             raise RuntimeError(f"model backend failed - {msg}")
 
+        if self._fast_zero_condition or self._fast_condition_resize:
+            self._chk(self._lib.hdrtv_set_cond_mode(self._ctx, 2 if self._fast_zero_condition else 1), "hdrtv_set_cond_mode")
         self._buf_hw = None
         self._gpu_input = self._gpu_cond = self._gpu_raw = None
         self._pin_input = self._pin_output = None
@@ -165,6 +205,19 @@ class HDRTVNetMI355X:
             return p          # INT8 storage, fp16 compute (the reference's own ROCm behaviour)
         raise ValueError("precision 'fp32' is not implemented by the MI355X backend (fp16 compute only)")
 
+    def _resolve_hg_weights(self, model_path):
+        """hdrtvnet_torch.py:2016-2042 (the user override is handled by the caller): HG.pt next to the checkpoint, then
+        the repo-default location relative to the working directory; ``.hdrw`` packs are accepted beside ``.pt``."""
+        cands = []
+        if not isinstance(model_path, dict):
+            d = os.path.dirname(os.path.abspath(str(model_path)))
+            cands += [os.path.join(d, "HG.pt"), os.path.join(d, "HG.hdrw")]
+        cands.append(os.path.join(os.getcwd(), "src", "models", "weights", "original", "HG.pt"))
+        for p in cands:
+            if os.path.isfile(p):
+                return p, cands
+        return None, cands
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
@@ -183,6 +236,7 @@ class HDRTVNetMI355X:
         """hdrtvnet_torch.py:2198-2233."""
         if self._buf_hw == (h, w):
             return
+        self._graphs.clear()                      # captured graphs point into the buffers replaced below
         with torch.cuda.device(self.device):
             self._chk(self._lib.hdrtv_reserve(self._ctx, h, w), "hdrtv_reserve")
             ch, cw = max(1, h // 4), max(1, w // 4)
@@ -268,9 +322,42 @@ class HDRTVNetMI355X:
         cond = cond.contiguous()
         if tuple(cond.shape[2:]) != (max(1, h // 4), max(1, w // 4)):
             raise ValueError("cond must be [1,3,H//4,W//4]")
+        if self._use_cuda_graphs:
+            return self._infer_graph(tensor, cond, h, w)
         self._chk(self._lib.hdrtv_infer(self._ctx, self._stream(), tensor.data_ptr(), cond.data_ptr(), h, w,
                                         self._gpu_out.data_ptr(), _L.F32 if self._use_hg else _L.F16,
                                         self._gpu_agcm.data_ptr()), "hdrtv_infer")
+        return self._gpu_out, self._gpu_agcm
+
+    def _infer_graph(self, tensor, cond, h, w):
+        """hdrtvnet_torch.py:2306-2331: static input buffers, one capture per shape, replay afterwards.  The ~66 launches of
+        hdrtv_infer are captured into a hipGraph on torch's capture stream (the C ABI is stream-ordered and allocation-free
+        after hdrtv_reserve); a capture failure falls back to eager launches as the reference does."""
+        if tensor.data_ptr() != self._gpu_input.data_ptr():
+            self._gpu_input.copy_(tensor)
+        if cond.data_ptr() != self._gpu_cond.data_ptr():
+            self._gpu_cond.copy_(cond)
+
+        def launch():
+            self._chk(self._lib.hdrtv_infer(self._ctx, self._stream(), self._gpu_input.data_ptr(), self._gpu_cond.data_ptr(), h, w,
+                                            self._gpu_out.data_ptr(), _L.F32 if self._use_hg else _L.F16,
+                                            self._gpu_agcm.data_ptr()), "hdrtv_infer")
+
+        g = self._graphs.get((h, w))
+        if g is None:
+            launch()                                   # eager once: one-time kernel attributes are set outside the capture
+            torch.cuda.synchronize(self.device)
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    launch()
+            except Exception as exc:  # noqa: BLE001
+                print(f"WARNING: hipGraph capture failed ({exc}); continuing with eager launches.")
+                self._use_cuda_graphs = False
+                launch()
+                return self._gpu_out, self._gpu_agcm
+            self._graphs[(h, w)] = g
+        g.replay()
         return self._gpu_out, self._gpu_agcm
 
     @torch.inference_mode()

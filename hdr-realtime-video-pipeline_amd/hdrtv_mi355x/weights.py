@@ -114,6 +114,13 @@ def is_int8_state(state) -> bool:
     return any(k.endswith(".weight_int8") for k in state)
 
 
+def is_hg_w8a8_layout(state) -> bool:
+    """True when a quantised HG state has exactly the W8A8 layers the int8 HG kernels serve (HG_W8A8_GROUPS below)."""
+    want = {name for layers in HG_W8A8_GROUPS.values() for name in layers}
+    have = {k[: -len(".x_scale")] for k in state if k.endswith(".x_scale")}
+    return have == want
+
+
 def normalize_int8_state(state) -> "OrderedDict[str, np.ndarray]":
     """INT8 runtime checkpoint (hdrtvnet_torch.py:1755-1883) as plain arrays for the weight pack, quantised layers kept:
     ``weight_int8`` int8, per-channel ``scale`` / ``w_scale`` and ``bias`` as stored, ``x_scale`` / ``x_zero`` as the fp32

@@ -75,6 +75,27 @@ class PinnedFrame:
                 p._lib.hdrtv_ring_release(p._ctx, self._slot)
 
 
+class HostFrame:
+    """What ``_tensor_to_rgb48_bytes`` returns when no ring slot frees up within 250 ms (feeders.py:209-235): the frame
+    in the single blocking pinned buffer, already complete; same surface as ``PinnedFrame`` (the reference returns
+    ``bytes`` there, which its sink treats like a released frame)."""
+
+    def __init__(self, array):
+        self._a = array
+
+    def wait_ready(self):
+        return None
+
+    def buffer_view(self):
+        return memoryview(self._a).cast("B")
+
+    def numpy(self):
+        return self._a
+
+    def release(self):
+        return None
+
+
 class HeadlessPipelineWorker:
     def __init__(self, weights_dir, use_hg=True, proc_w=1920, proc_h=1080, hg_weights=None,
                  status_cb=None, buffer_frames=1):
@@ -93,6 +114,10 @@ class HeadlessPipelineWorker:
         self._hdr_thread = None
         self._hdr_stop = threading.Event()
         self._ring_shape = None
+        self._hdr_sink = None              # remembered so that a hot-swap (_load_model) can restart the feeder
+        self._hdr_error = None             # exception that ended the feeder thread, re-raised by _process_frame
+        self._fallback = None              # (pinned host u16 tensor, device u16 tensor) of the ring-exhaustion fallback
+        self.ring_fallbacks = 0
 
     # ---------------------------------------------------------------- status
     def _emit(self, msg):
@@ -130,11 +155,15 @@ class HeadlessPipelineWorker:
         cw, ch = self._proc_w, self._proc_h
         if announce_ready:
             self._emit(f"Loading model: {key} ...")
+        sink = self._hdr_sink                  # a running feeder is restarted on the new processor (hot-swap)
         if self._processor is not None:
-            self._stop_hdr_feeder()
+            if not self._stop_hdr_feeder(keep_sink=True):
+                self._emit("ERROR: HDR feeder did not stop; keeping the current model")
+                return False
             self._processor.close()
             self._processor = None
             self._ring_shape = None            # the pinned ring lived in the closed context
+            self._fallback = None
             torch.cuda.empty_cache()
         try:
             hg = self._hg_override
@@ -156,6 +185,8 @@ class HeadlessPipelineWorker:
         if warmup:
             self._silent_warmup(self._processor, cw, ch)
         self._precision_key = key
+        if sink is not None:
+            self._start_hdr_feeder(sink)
         if announce_ready:
             self._emit(f"Ready - {key} [MI355X]")
         return True
@@ -190,6 +221,9 @@ class HeadlessPipelineWorker:
         event are queued as ``(present_t, tensor, event)``."""
         if self._processor is None:
             raise RuntimeError("no model loaded")
+        if self._hdr_error is not None:        # the feeder thread died: surface it instead of silently dropping frames
+            err, self._hdr_error = self._hdr_error, None
+            raise RuntimeError(f"HDR feeder failed: {err!r}") from err
         start, end = self._cuda_timing_events()
         start.record(torch.cuda.current_stream())
         pw, ph = int(proc_w or self._proc_w), int(proc_h or self._proc_h)
@@ -229,7 +263,8 @@ class HeadlessPipelineWorker:
     def _tensor_to_rgb48_bytes(self, tensor, stream=None):
         """feeders.py:193-249, GPU branch: quantise to RGB48 directly into a pinned ring slot and
         return a ``PinnedFrame`` guarded by the slot's ready event.  Ring exhaustion (no slot free
-        within 250 ms) raises, where the reference falls back to a blocking single buffer."""
+        within 250 ms, feeders.py:166-167) falls back to one blocking pinned buffer as the reference
+        does (209-235): convert, copy, synchronise the stream, hand the finished frame over."""
         p = self._processor
         t = tensor[0] if isinstance(tensor, (tuple, list)) else tensor
         h, w = int(t.shape[-2]), int(t.shape[-1])
@@ -237,10 +272,22 @@ class HeadlessPipelineWorker:
             p._chk(p._lib.hdrtv_ring_create(p._ctx, _RING_FRAMES, h, w), "hdrtv_ring_create")
             self._ring_shape = (h, w)
         host, dev = C.c_void_p(), C.c_void_p()
-        slot = p._chk(p._lib.hdrtv_ring_acquire(p._ctx, 250, C.byref(host), C.byref(dev)), "hdrtv_ring_acquire")
         st = stream or torch.cuda.current_stream(p.device)
         sp = C.c_void_p(st.cuda_stream)
         dt = _L.F32 if t.dtype == torch.float32 else _L.F16
+        slot = p._lib.hdrtv_ring_acquire(p._ctx, 250, C.byref(host), C.byref(dev))
+        if slot == _L.ESTATE:
+            self.ring_fallbacks += 1
+            if self._fallback is None or tuple(self._fallback[0].shape) != (h, w, 3):
+                self._fallback = (torch.empty((h, w, 3), dtype=torch.uint16, pin_memory=True),
+                                  torch.empty((h, w, 3), dtype=torch.uint16, device=p.device))
+            fb_host, fb_dev = self._fallback
+            p._chk(p._lib.hdrtv_post_rgb48(p._ctx, sp, t.contiguous().data_ptr(), dt, h, w, fb_dev.data_ptr()), "hdrtv_post_rgb48")
+            with torch.cuda.stream(st):
+                fb_host.copy_(fb_dev, non_blocking=True)
+            st.synchronize()
+            return HostFrame(fb_host.numpy().copy())       # the reference's host_np.tobytes(): a private copy
+        p._chk(slot, "hdrtv_ring_acquire")
         p._chk(p._lib.hdrtv_post_rgb48(p._ctx, sp, t.contiguous().data_ptr(), dt, h, w, dev), "hdrtv_post_rgb48")
         p._chk(p._lib.hdrtv_ring_commit(p._ctx, slot, sp), "hdrtv_ring_commit")
         return PinnedFrame(self, slot, host.value, (h, w, 3))
@@ -249,6 +296,8 @@ class HeadlessPipelineWorker:
         """feeders.py:632-657 + 440-496: a thread that waits for each frame's ready event,
         converts on a side stream into the pinned ring and hands the frame to ``sink``."""
         self._stop_hdr_feeder()
+        self._hdr_sink = sink
+        self._hdr_error = None
         if self._processor is not None and self._ring_shape != (self._proc_h, self._proc_w):
             # pin the ring now (3 x 50 MB at 4K takes tens of ms) rather than inside the first frame's deadline
             p = self._processor
@@ -261,40 +310,53 @@ class HeadlessPipelineWorker:
         self._hdr_stop.clear()
         dev = self._processor.device
 
+        hq = self._hdr_queue
+
         def run():
-            side = torch.cuda.Stream(device=dev)
-            while not self._hdr_stop.is_set():
-                try:
-                    item = self._hdr_queue.get(timeout=0.05)
-                except _queue.Empty:
-                    continue
-                if item is None:
-                    break
-                present_t, tensor, ready = item
-                ready.synchronize()                      # cross-thread device sync (feeders.py:469-473)
-                with torch.cuda.stream(side):
-                    payload = self._tensor_to_rgb48_bytes(tensor, side)
-                if present_t is not None:
-                    delay = present_t - time.perf_counter()
-                    if delay > 0:
-                        time.sleep(delay)
-                sink(payload)
+            try:
+                side = torch.cuda.Stream(device=dev)
+                while not self._hdr_stop.is_set():
+                    try:
+                        item = hq.get(timeout=0.05)
+                    except _queue.Empty:
+                        continue
+                    if item is None:
+                        break
+                    present_t, tensor, ready = item
+                    ready.synchronize()                      # cross-thread device sync (feeders.py:469-473)
+                    with torch.cuda.stream(side):
+                        payload = self._tensor_to_rgb48_bytes(tensor, side)
+                    if present_t is not None:
+                        delay = present_t - time.perf_counter()
+                        if delay > 0:
+                            time.sleep(delay)
+                    sink(payload)
+            except BaseException as exc:  # noqa: BLE001  (a dead daemon thread must not be silent: _process_frame re-raises)
+                self._hdr_error = exc
 
         self._hdr_thread = threading.Thread(target=run, name="hdr-feeder", daemon=True)
         self._hdr_thread.start()
 
-    def _stop_hdr_feeder(self):
+    def _stop_hdr_feeder(self, keep_sink=False):
+        """Stops the feeder thread.  Returns False (and leaves everything in place) if the thread is still running after
+        10 s: the processor must not be closed under a thread that may be inside the C library."""
         if self._hdr_thread is not None:
             self._hdr_stop.set()
             try:
                 self._hdr_queue.put_nowait(None)
             except Exception:  # noqa: BLE001
                 pass
-            self._hdr_thread.join(timeout=2.0)
+            self._hdr_thread.join(timeout=10.0)
+            if self._hdr_thread.is_alive():
+                return False
         self._hdr_thread, self._hdr_queue = None, None
+        if not keep_sink:
+            self._hdr_sink = None
+        return True
 
     def close(self):
-        self._stop_hdr_feeder()
+        if not self._stop_hdr_feeder():
+            raise RuntimeError("HDR feeder thread did not stop; not destroying the processor under it")
         if self._processor is not None:
             self._processor.close()
             self._processor = None

@@ -53,6 +53,10 @@ int hdrtv_destroy(hdrtv_ctx *ctx);
 /* 1 if the context was created with HG weights. */
 int hdrtv_has_hg(const hdrtv_ctx *ctx);
 
+/* How hdrtv_preprocess derives the 0.25x condition map (hdrtvnet_torch.py:2262-2294): 0 = antialiased bicubic (default),
+ * 1 = bilinear, the reference's fast_condition_resize=True / HDRTVNET_FAST_COND_RESIZE, 2 = zeros, HDRTVNET_ZERO_COND. */
+int hdrtv_set_cond_mode(hdrtv_ctx *ctx, int mode);
+
 /* HG_Composite(mask_r=0.75) (HG_Composite_arch.py:21, 78-84): the highlight mask is max_c(base) > r + 0.1 * (1 - r).
  * The reference fixes r at construction; 0 <= r < 1.  Takes effect at the next hdrtv_infer. */
 int hdrtv_set_hg_mask_r(hdrtv_ctx *ctx, float r);

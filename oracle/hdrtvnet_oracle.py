@@ -186,6 +186,23 @@ def bicubic_aa_quarter(x):
     return y
 
 
+def bilinear_quarter(x):
+    """hdrtvnet_torch.py:2269-2276 (``fast_condition_resize``): F.interpolate(0.25, bilinear, align_corners=False,
+    recompute_scale_factor=False).  Source coordinate 4 d + 1.5: both lambdas are 0.5, the taps are (4d+1, 4d+2) clamped to
+    the last row / column; arithmetic order of ATen's upsample_bilinear2d."""
+    x = np.asarray(x, np.float32)
+    c, h, w = x.shape
+    ho, wo = max(1, h // 4), max(1, w // 4)
+    y1 = 4 * np.arange(ho) + 1
+    x1 = 4 * np.arange(wo) + 1
+    y2 = np.minimum(y1 + 1, h - 1)
+    x2 = np.minimum(x1 + 1, w - 1)
+    half = np.float32(0.5)
+    top = half * x[:, y1][:, :, x1] + half * x[:, y1][:, :, x2]
+    bot = half * x[:, y2][:, :, x1] + half * x[:, y2][:, :, x2]
+    return (half * top + half * bot).astype(np.float32)
+
+
 _C_OPS = {k: globals()[k] for k in ("conv2d", "avgpool3s2p1", "instnorm", "batchnorm", "maxpool2", "pixelshuffle2",
                                     "bicubic_aa_quarter", "relu", "leaky")}
 

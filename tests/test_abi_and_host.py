@@ -84,3 +84,55 @@ def test_goldens_match_generators(golden_dir):
     assert np.array_equal(d["frame"], weights.synthetic_frame(96, 128, seed=3, kind="gradient"))
     d = np.load(os.path.join(golden_dir, "hr_64x96_noise_s0.npz"))
     assert np.array_equal(d["frame"], weights.synthetic_frame(64, 96, seed=0, kind="noise"))
+
+
+def test_composite_state_is_split():
+    """HG_Composite checkpoints (base.* + hg.*): the HR half passes check_hr_state, the HG half keeps its keys."""
+    import numpy as np
+    from hdrtv_mi355x import arch, weights as W
+    from hdrtv_mi355x.processor import _split_composite
+    hr = {k: np.zeros(shp, np.float32) for k, shp in arch.hr_params()}
+    hg = W.seeded_hg_state(1)
+    comp = {"base." + k: v for k, v in hr.items()}
+    comp.update({"hg." + k: v for k, v in hg.items()})
+    a, b = _split_composite(comp)
+    W.check_hr_state(a)
+    assert set(b) == set(hg)
+    a2, b2 = _split_composite(hr)
+    assert a2 is hr and b2 is None
+    # an INT8 runtime layer holds weight_int8 in place of weight
+    q = dict(hr)
+    w = q.pop("LE.down_conv1.weight")
+    q["LE.down_conv1.weight_int8"] = np.zeros(w.shape, np.int8)
+    W.check_hr_state(q)
+
+
+def test_corrupted_weight_pack_is_rejected():
+    """A truncated / inconsistent .hdrw blob through the C ABI: error code, never an out-of-bounds read."""
+    import ctypes as C
+    import struct
+    import numpy as np
+    from hdrtv_mi355x import lib as L, weights as W
+    lib = L.load()
+    blob = bytearray(W.pack_state({"a": np.arange(8, dtype=np.float32), "b": np.zeros((2, 3), np.float16)}))
+
+    def create(b):
+        ctx = C.c_void_p()
+        rc = lib.hdrtv_create(bytes(b), len(b), None, 0, 0, C.byref(ctx))
+        msg = lib.hdrtv_last_error(ctx).decode()
+        lib.hdrtv_destroy(ctx)
+        return rc, msg
+
+    rc, msg = create(blob)                          # well-formed table, but not an HR model: a tensor is missing
+    assert rc == L.EWEIGHTS and "missing" in msg
+    bad = bytearray(blob)
+    struct.pack_into("<Q", bad, 16 + 120, 2 ** 63)  # offset far outside (and off + nbytes would wrap)
+    assert create(bad)[0] == L.EWEIGHTS
+    bad = bytearray(blob)
+    struct.pack_into("<Q", bad, 16 + 128, 4)        # nbytes does not match the shape
+    rc, msg = create(bad)
+    assert rc == L.EWEIGHTS and "size does not match" in msg
+    bad = bytearray(blob)
+    struct.pack_into("<I", bad, 16 + 96, 9)         # unknown dtype
+    assert create(bad)[0] == L.EWEIGHTS
+    assert create(blob[:100])[0] == L.EWEIGHTS       # truncated table

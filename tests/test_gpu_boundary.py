@@ -1,0 +1,230 @@
+"""The constructor surface of HDRTVNetTorch beyond the defaults: condition-map shortcuts, hipGraph
+replay behind use_cuda_graphs, HG_Composite checkpoints, and the worker's failure paths (ring exhaustion fallback,
+feeder errors, hot-swap with a sink attached)."""
+import os
+import threading
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+OUT_MAX, OUT_MEAN = 6e-3, 5e-4
+
+
+def _hr(golden_dir, **kw):
+    from hdrtv_mi355x.processor import HDRTVNetMI355X
+    return HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), use_hg=kw.pop("use_hg", False), warmup_passes=0, **kw)
+
+
+def test_cond_modes_vs_reference_runs(golden_dir, monkeypatch):
+    d = np.load(os.path.join(golden_dir, "cond_modes_61x103_gradient_s7.npz"))
+    p = _hr(golden_dir, fast_condition_resize=True)
+    try:
+        t, c = p.preprocess(d["frame"])
+        dc = np.abs(c.float().cpu().numpy()[0] - d["cond_bilinear"]).max()
+        out, agcm = p.infer((t, c))
+        do = np.abs(out.float().cpu().numpy()[0] - d["out_bilinear"])
+        print(f"  bilinear cond: max_abs={dc:.3e}; out max_abs={do.max():.3e} mean_abs={do.mean():.3e}")
+        assert dc <= 1.2e-3 and do.max() <= OUT_MAX and do.mean() <= OUT_MEAN
+    finally:
+        p.close()
+    monkeypatch.setenv("HDRTVNET_ZERO_COND", "1")
+    p = _hr(golden_dir)
+    try:
+        t, c = p.preprocess(d["frame"])
+        assert not c.any()
+        out, agcm = p.infer((t, c))
+        do = np.abs(out.float().cpu().numpy()[0] - d["out_zero"])
+        print(f"  zero cond: out max_abs={do.max():.3e} mean_abs={do.mean():.3e}")
+        assert do.max() <= OUT_MAX and do.mean() <= OUT_MEAN
+    finally:
+        p.close()
+
+
+def test_pre_fused_cond_exact_at_4k(golden_dir):
+    """The fused preprocess kernel at BASELINE size: planes exact, condition map against the oracle's separable
+    antialiased bicubic fed the same fp16-rounded tensor."""
+    from hdrtv_mi355x import weights as W
+    from oracle import hdrtvnet_oracle as O
+    p = _hr(golden_dir)
+    try:
+        for hw in ((2160, 3840), (1081, 1923)):
+            f = W.synthetic_frame(hw[0], hw[1], seed=5, kind="noise")
+            t, c = p.preprocess(f)
+            tn = t.float().cpu().numpy()[0]
+            assert np.array_equal(tn, ((f[:, :, ::-1].astype(np.float32) * np.float32(1 / 255.0)).astype(np.float16)
+                                       .astype(np.float32)).transpose(2, 0, 1))
+            ref = O.bicubic_aa_quarter(tn).astype(np.float16).astype(np.float32)
+            dd = np.abs(c.float().cpu().numpy()[0] - ref)
+            print(f"  cond {hw}: max_abs={dd.max():.3e} differing={int((dd != 0).sum())} of {dd.size}")
+            assert dd.max() <= 1e-3
+    finally:
+        p.close()
+
+
+def test_hip_graph_replay_is_bit_identical(golden_dir):
+    import torch
+    from hdrtv_mi355x import weights as W
+    f = W.synthetic_frame(272, 480, seed=3, kind="gradient")
+    outs, p50 = [], []
+    for graphs in (False, True):
+        p = _hr(golden_dir, use_hg=True, hg_weights="seeded:1234", use_cuda_graphs=graphs)
+        try:
+            t, c = p.preprocess(f)
+            for _ in range(3):
+                out, agcm = p.infer((t, c))
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(20):
+                t0 = time.perf_counter()
+                out, agcm = p.infer((t, c))
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            p50.append(sorted(ts)[10])
+            assert p._use_cuda_graphs is graphs
+            outs.append((out.clone(), agcm.clone()))
+        finally:
+            p.close()
+    print(f"  infer p50 at 272x480: eager {p50[0]:.3f} ms, hipGraph replay {p50[1]:.3f} ms")
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_hg_composite_checkpoint_layout(golden_dir):
+    """An HG_Composite state (base.* + hg.*), the layout of pytorch_int8/hg/HR_HG_*.pt, fp16 and INT8."""
+    from hdrtv_mi355x import weights as W
+    from hdrtv_mi355x.processor import HDRTVNetMI355X
+    d = np.load(os.path.join(golden_dir, "hg_96x128_gradient_s3.npz"))
+    hr = W.load_pack(os.path.join(golden_dir, "hr_weights.hdrw"))
+    comp = {"base." + k: v for k, v in hr.items()}
+    comp.update({"hg." + k: v for k, v in W.seeded_hg_state(1234).items()})
+    p = HDRTVNetMI355X(comp, use_hg=True, warmup_passes=0)
+    try:
+        assert p._use_hg
+        out, _ = p.infer(p.preprocess(d["frame"]))
+        dd = np.abs(out.cpu().numpy()[0] - d["out"])
+        assert np.percentile(dd, 99.9) <= 8e-3
+    finally:
+        p.close()
+    hr8 = W.load_pack(os.path.join(golden_dir, "hr_int8_mixed_qat.hdrw"))
+    comp = {"base." + k: v for k, v in hr8.items()}
+    comp.update({"hg." + k: v for k, v in W.seeded_hg_w8a8_state(1234).items()})
+    for pd in ("auto", "off"):
+        p = HDRTVNetMI355X(comp, precision="int8-mixed", predequantize=pd, use_hg=True, warmup_passes=0)
+        try:
+            assert p._use_hg and p._hg_int8 and p._is_w8_model is (pd == "off")
+            out, _ = p.infer(p.preprocess(d["frame"]))
+            assert np.isfinite(out.cpu().numpy()).all()
+        finally:
+            p.close()
+    with pytest.raises(FileNotFoundError):        # INT8 no-HG checkpoint + HG requested + nothing to find (1928-1937)
+        HDRTVNetMI355X(os.path.join(golden_dir, "hr_int8_mixed_qat.hdrw"), precision="int8-mixed", use_hg=True, warmup_passes=0)
+
+
+def _worker(golden_dir, tmp_path, **kw):
+    from hdrtv_mi355x.worker import HeadlessPipelineWorker
+    wdir = tmp_path / "weights" / "original"
+    (wdir / "pytorch_int8" / "hr").mkdir(parents=True)
+    os.symlink(os.path.join(golden_dir, "hr_weights.hdrw"), wdir / "HR.hdrw")
+    os.symlink(os.path.join(golden_dir, "hr_int8_mixed_qat.hdrw"), wdir / "pytorch_int8" / "hr" / "HR_original_int8_mixed_qat.hdrw")
+    return HeadlessPipelineWorker(str(tmp_path / "weights"), use_hg=False, proc_w=96, proc_h=64, **kw)
+
+
+def test_hot_swap_keeps_the_sink_fed(golden_dir, tmp_path):
+    """request_precision with a sink attached: the feeder is restarted on the new processor and frames keep arriving."""
+    from hdrtv_mi355x import playback as P
+    w = _worker(golden_dir, tmp_path, buffer_frames=2)
+    assert w._load_model("FP16")
+    got = []
+    lock = threading.Lock()
+
+    def sink(payload):
+        with lock:
+            got.append(payload.numpy().copy())
+        payload.release()
+
+    w._start_hdr_feeder(sink)
+    src = P.SyntheticSource(96, 64, fps=240.0, n_frames=24, pool=2, kind="gradient")
+    pb = P.RealtimePlayback(w, src, sink=True, realtime=False)
+
+    orig = w._process_frame          # flips the preset after 8 frames, as the GUI's precision combo does mid-playback
+
+    def counting(**kw):
+        r = orig(**kw)
+        if kw["frame_idx"] == 8:
+            pb.request_precision("INT8 Mixed (QAT)")
+        return r
+    w._process_frame = counting
+    res = pb.run()
+    deadline = time.perf_counter() + 10.0
+    while len(got) < res["frames_processed"] and time.perf_counter() < deadline:
+        time.sleep(0.01)
+    assert w._precision_key == "INT8 Mixed (QAT)" and w._hdr_queue is not None
+    assert res["frames_processed"] == 24 and len(got) >= 22, (len(got), w.status_messages[-3:])
+    w.close()
+
+
+def test_ring_exhaustion_falls_back_and_feeder_errors_surface(golden_dir, tmp_path):
+    from hdrtv_mi355x import weights as W
+    from hdrtv_mi355x.worker import HostFrame, PinnedFrame
+    from oracle import hdrtvnet_oracle as O
+    w = _worker(golden_dir, tmp_path)
+    assert w._load_model("FP16")
+    f = W.synthetic_frame(64, 96, seed=77, kind="noise")
+    _, _, prepared, _, _ = w._process_frame(frame=f, frame_idx=0, mpv_w=None)
+    want = O.post_rgb48(prepared.float().cpu().numpy()[0])
+    held = [w._tensor_to_rgb48_bytes(prepared) for _ in range(3)]          # the whole ring, never released
+    assert all(isinstance(h, PinnedFrame) for h in held)
+    t0 = time.perf_counter()
+    fb = w._tensor_to_rgb48_bytes(prepared)                                 # 250 ms acquire timeout, then the blocking buffer
+    assert isinstance(fb, HostFrame) and time.perf_counter() - t0 >= 0.2 and w.ring_fallbacks == 1
+    assert np.array_equal(fb.numpy(), want)
+    for h in held:
+        assert np.array_equal(h.numpy(), want)
+        h.release()
+    assert isinstance(w._tensor_to_rgb48_bytes(prepared), PinnedFrame)
+    # a sink that raises ends the feeder thread; the next _process_frame reports it instead of dropping frames silently
+    w._ring_shape = None
+
+    def bad_sink(payload):
+        payload.release()
+        raise BrokenPipeError("sink went away")
+
+    w._start_hdr_feeder(bad_sink)
+    w._process_frame(frame=f, frame_idx=1, mpv_w=True)
+    deadline = time.perf_counter() + 5.0
+    while w._hdr_error is None and time.perf_counter() < deadline:
+        time.sleep(0.01)
+    with pytest.raises(RuntimeError, match="HDR feeder failed"):
+        w._process_frame(frame=f, frame_idx=2, mpv_w=True)
+    w.close()
+
+
+def test_dispatcher_on_the_device(golden_dir):
+    """hdrtv_mi355x/dispatch.py with the product's worker body: two worker processes (both on this box's one GPU), frames
+    round-robin, RGB48 frames back in order and bit-identical to an in-process processor's."""
+    import ctypes as C
+    import torch
+    from hdrtv_mi355x import lib as L, weights as W
+    from hdrtv_mi355x.dispatch import FrameDispatcher
+    h, w, n = 64, 96, 9
+    frames = [W.synthetic_frame(h, w, seed=200 + i, kind="gradient" if i % 2 else "noise") for i in range(n)]
+    p = _hr(golden_dir, use_hg=True, hg_weights="seeded:1234")
+    want = []
+    u16 = torch.empty((h, w, 3), dtype=torch.uint16, device="cuda")
+    for f in frames:
+        out, _ = p.infer(p.preprocess(f))
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        assert p._lib.hdrtv_post_rgb48(p._ctx, st, out.data_ptr(), L.F32, h, w, u16.data_ptr()) == 0
+        want.append(u16.cpu().numpy().copy())
+    p.close()
+    got = {}
+    args = {"model_path": os.path.join(golden_dir, "hr_weights.hdrw"), "use_hg": True, "hg_weights": "seeded:1234"}
+    with FrameDispatcher(2, h, w, lambda i, v: got.__setitem__(i, v.copy()), init_args=args, devices=[0, 0], slots=2) as d:
+        for f in frames:
+            d.submit(f)
+        d.flush(timeout=120)
+    assert sorted(got) == list(range(n))
+    for i in range(n):
+        assert np.array_equal(got[i], want[i]), i

@@ -265,3 +265,15 @@ def test_w8a8_fp16_storage_sensitivity(golden_dir):
         print(f"  {tag}: fp16-storage oracle vs fp32 oracle: mean_abs={d.mean():.3e} max_abs={d.max():.3e} u8 MAE={u8.mean():.3f}")
     assert 1e-4 <= got["mixed"][0] <= 2e-3 and 1e-3 <= got["full"][0] <= 2e-2
     assert got["full"][1] <= 5.0          # still inside the reference's own bar
+
+
+def test_cond_modes_oracle_vs_reference(golden_dir, hr_state):
+    """fast_condition_resize (bilinear 0.25x) and HDRTVNET_ZERO_COND against runs of the reference with those switches."""
+    d = np.load(os.path.join(golden_dir, "cond_modes_61x103_gradient_s7.npz"))
+    t, _ = O.preprocess(d["frame"])
+    cb = O.bilinear_quarter(t)
+    assert cb.shape == d["cond_bilinear"].shape and np.abs(cb - d["cond_bilinear"]).max() <= 1e-6
+    out, agcm = O.hr_forward(hr_state, t, cb)
+    assert np.abs(out - d["out_bilinear"]).max() <= 2e-5 and np.abs(agcm - d["agcm_bilinear"]).max() <= 2e-5
+    out, agcm = O.hr_forward(hr_state, t, np.zeros_like(cb))
+    assert np.abs(out - d["out_zero"]).max() <= 2e-5 and np.abs(agcm - d["agcm_zero"]).max() <= 2e-5

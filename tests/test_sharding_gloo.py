@@ -58,3 +58,62 @@ def test_round_robin_two_ranks(tmp_path):
     for i in range(n):       # order restored by index; results identical to a single-rank run
         want = O.process(hr, W.synthetic_frame(64, 96, seed=100 + i, kind="noise"))
         assert np.array_equal(np.load(os.path.join(str(tmp_path), f"f{i}.npy")), want)
+
+
+def _standin_worker(rank, device_index, init_args):
+    """CPU stand-in for one GPU worker of the dispatcher: a deterministic u8 -> u16 map, slower on even ranks so that
+    frames finish out of order."""
+    import time
+
+    def process(frame, out):
+        time.sleep(init_args["delay"][rank % len(init_args["delay"])] * (1 + (int(frame[0, 0, 0]) % 3)))
+        np.multiply(frame, 257, out=out, dtype=np.uint16, casting="unsafe")
+        out[0, 0, 1] = rank
+
+    return process
+
+
+def _failing_worker(rank, device_index, init_args):
+    def process(frame, out):
+        if rank == 1:
+            raise RuntimeError("device fell off the bus")
+        out[...] = 0
+    return process
+
+
+def test_dispatcher_round_robin_restores_order():
+    """The product's multi-GPU dispatcher (hdrtv_mi355x/dispatch.py) with two stand-in workers: frame i is processed by
+    worker i mod 2, completions arrive out of order, the sink sees indices 0, 1, 2, ... with the right contents."""
+    from hdrtv_mi355x.dispatch import FrameDispatcher
+    h, w, n = 24, 32, 23
+    seen = []
+
+    def sink(idx, view):
+        seen.append((idx, int(view[0, 0, 1]), view.copy()))
+
+    frames = [np.full((h, w, 3), (7 * i) % 251, np.uint8) for i in range(n)]
+    with FrameDispatcher(2, h, w, sink, make_worker=_standin_worker, init_args={"delay": [0.03, 0.002]}, slots=3) as d:
+        for f in frames:
+            d.submit(f)
+        d.flush(timeout=60)
+        depth = d.max_reorder_depth
+    assert [s[0] for s in seen] == list(range(n))                       # presentation order = source order
+    assert [s[1] for s in seen] == [i % 2 for i in range(n)]            # frame i ran on worker i mod N
+    for i, (_, _, got) in enumerate(seen):
+        want = frames[i].astype(np.uint16) * 257
+        want[0, 0, 1] = i % 2
+        assert np.array_equal(got, want)
+    assert depth >= 2                                                   # the reorder stage really held frames back
+
+
+def test_dispatcher_reports_worker_failure():
+    from hdrtv_mi355x.dispatch import FrameDispatcher
+    import pytest
+    d = FrameDispatcher(2, 8, 8, lambda i, v: None, make_worker=_failing_worker, init_args={}, slots=2)
+    try:
+        with pytest.raises(RuntimeError, match="fell off the bus"):
+            for _ in range(8):
+                d.submit(np.zeros((8, 8, 3), np.uint8))
+            d.flush(timeout=30)
+    finally:
+        d.close()
