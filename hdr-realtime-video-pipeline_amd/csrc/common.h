@@ -154,6 +154,22 @@ struct ConvQ8Params {
     int dstC;
 };
 
+// 1..3 W8A8 layers (3x3, stride 2, 64 -> 64) reading one f16 NHWC tensor through their own quantisers (conv_q8.hip)
+struct ConvQ8Group {
+    const int8_t *wpk8;    // [9][64][64]
+    const float *scale, *shift;
+    float q_inv, q_zoff;
+    void *dst;             // NHWC 64: f16, or int8 codes of the reading layer's quantiser
+    int dst_i8;
+    float oq_inv, oq_zoff;
+    int act;
+};
+struct ConvQ8MultiParams {
+    const f16 *src;
+    int src_stride, Hi, Wi, Ho, Wo, ngroups;
+    ConvQ8Group g[3];
+};
+
 // Letterbox (letterbox.hip): u8 BGR [sh][sw][3] -> u8 BGR [dh][dw][3], resized region [y0, y0+new_h) x [x0, x0+new_w)
 enum { LB_COPY = 0, LB_AREA_INT = 1, LB_AREA_FRAC = 2, LB_CUBIC = 3 };
 struct LetterboxParams {

@@ -1,0 +1,93 @@
+// conv_tile_f16.hip -- LE's three stride-2 down-convolutions in fp16 (gfx950).
+//
+// Reference: HDRUNet3T1.down_conv{1,2,3} (3x3, stride 2, pad 1, 32 -> 32, ReLU; HDRUNet3T1_arch.py:170-178).
+// 80 B of HBM per input pixel against 288 MAC per output channel: bytes decide.  One workgroup = 4 waves = an 8 x 16
+// output tile; its 17 x 33 halo patch (64 B per pixel) is staged once with 16-byte accesses, a wave owns two output rows
+// (32 pixels = N of v_mfma_f32_32x32x16_f16), M = the 32 output channels, K = 16 input channels of one tap per MFMA, and
+// every wave keeps the layer's whole 18 KiB of weights in 72 VGPRs (its A fragments are the same for all its pixels).
+// 36 KiB of LDS: four workgroups per CU overlap each other's loads and MFMAs.  The int8 twin of this kernel (conv_q8.hip) ran these layers at 0.23 ms per frame at 3840x2160 when
+// the generic implicit-GEMM kernel needed 0.39 ms, hence this one.
+#include "launchers.h"
+
+namespace {
+
+constexpr int TT_TH = 8, TT_TW = 16, TT_CIN = 32, TT_NCH = 4;     // 4 x 16-byte chunks per pixel / weight row
+__device__ __forceinline__ int tsw(int r) { return (r >> 2) & 3; }   // rows 256 B apart use different chunk positions
+
+template <int S>
+__global__ __launch_bounds__(256, 4) void conv_t16_kernel(ConvParams p)
+{
+    constexpr int HH = (TT_TH - 1) * S + 3, HWD = (TT_TW - 1) * S + 3, NPX = HH * HWD, ROWB = TT_CIN * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *sX = smem;                                           // [NPX][32] f16, chunk-swizzled
+    float *sS = reinterpret_cast<float *>(smem + ((NPX * ROWB + 255) & ~255)); // scale[32], shift[32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int tiles_x = (p.Wo + TT_TW - 1) / TT_TW;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int oy0 = ty * TT_TH, ox0 = tx * TT_TW;
+    const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+    f16x8 wv[18];
+#pragma unroll
+    for (int st = 0; st < 18; ++st) wv[st] = *reinterpret_cast<const f16x8 *>(p.wpk + (size_t)((st >> 1) * 32 + l31) * TT_CIN + ((st & 1) * 2 + lh) * 8);
+    if (tid < 64) sS[tid] = tid < 32 ? p.scale[tid] : p.shift[tid - 32];
+    for (int e = tid; e < NPX * TT_NCH; e += 256) {
+        const int hp = e >> 2, ch = e & 3;
+        const int hy = hp / HWD, hx = hp - hy * HWD;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        f16x8 v;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (f16)0.f;           // zero padding
+        if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi)
+            v = *reinterpret_cast<const f16x8 *>(p.src0 + ((size_t)iy * p.Wi + ix) * p.s0_stride + ch * 8);
+        *reinterpret_cast<f16x8 *>(sX + hp * ROWB + ((ch ^ tsw(hp)) << 4)) = v;
+    }
+    __syncthreads();
+    const int qy = 2 * wave + (l31 >> 4), qx = l31 & 15;
+    f32x16 acc;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int hp = (qy * S + tap / 3) * HWD + qx * S + tap % 3;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ch = ks * 2 + lh;
+            const f16x8 xv = *reinterpret_cast<const f16x8 *>(sX + hp * ROWB + ((ch ^ tsw(hp)) << 4));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[tap * 2 + ks], xv, acc, 0, 0, 0);
+        }
+    }
+    const int oy = oy0 + qy, ox = ox0 + qx;
+    if (oy < p.Ho && ox < p.Wo) {
+        const float aslope = act_slope(p.act);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = 8 * g + 4 * lh;
+            const float4 sc = *reinterpret_cast<const float4 *>(sS + n), sh = *reinterpret_cast<const float4 *>(sS + 32 + n);
+            f16x4 o;
+            o[0] = (f16)act_fast(acc[4 * g + 0] * sc.x + sh.x, aslope); o[1] = (f16)act_fast(acc[4 * g + 1] * sc.y + sh.y, aslope);
+            o[2] = (f16)act_fast(acc[4 * g + 2] * sc.z + sh.z, aslope); o[3] = (f16)act_fast(acc[4 * g + 3] * sc.w + sh.w, aslope);
+            *reinterpret_cast<f16x4 *>(p.dst + ((size_t)oy * p.Wo + ox) * p.dstC + n) = o;
+        }
+    }
+}
+
+}  // namespace
+
+// 3x3 / stride 2 / pad 1, 32 -> 32 (CoutPad == 32), weights [9][32][32] f16 (pack_conv with cin_t = 32), NHWC in and out
+hipError_t conv_t16_launch(ConvParams p, hipStream_t s)
+{
+    if (p.c0 != 32 || p.c1 != 0 || p.CoutPad != 32 || (p.s0_stride % 8) || (p.dstC % 4) || p.mode != ST_NHWC || p.res1 || p.res2 ||
+        p.Ho != (p.Hi - 1) / 2 + 1 || p.Wo != (p.Wi - 1) / 2 + 1)
+        return hipErrorInvalidValue;
+    constexpr int NPX = 17 * 33;
+    const int smem = ((NPX * 64 + 255) & ~255) + 256;
+    static DevOnce attr_once;   // hipFuncSetAttribute is per (function, device)
+    if (attr_once.need()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_t16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        attr_once.done();
+    }
+    const int grid = ((p.Wo + TT_TW - 1) / TT_TW) * ((p.Ho + TT_TH - 1) / TT_TH);
+    hipLaunchKernelGGL(conv_t16_kernel<2>, dim3(grid), dim3(256), smem, s, p);
+    return hipGetLastError();
+}

@@ -1329,8 +1329,11 @@ struct Seq {
         static const int nt_slow = [] { const char *e = getenv("HDRTV_PGLDS_NT_SLOW"); return e ? atoi(e) : 0; }();
         p.nt_slow = nt_slow == 2 ? (L.coutPad >= 512) : nt_slow;
         const bool s2g = L.ks == 3 && L.stride == 2 && L.cin_t == 64 && L.bn == L.coutPad && (L.coutPad == 64 || L.coutPad == 192);
+        static const bool no_t16 = getenv("HDRTV_NO_T16") != nullptr;       // developer A/B: the generic implicit-GEMM kernel
+        const bool t16 = !no_t16 && L.ks == 3 && L.stride == 2 && L.cin == 32 && L.coutPad == 32 && !src1 && mode == ST_NHWC && !res1 && !res2;
         char tag[64];
-        if (s2g) snprintf(tag, sizeof tag, "conv3x3s2_preg<%d>", L.coutPad);
+        if (t16) snprintf(tag, sizeof tag, "conv_t16<32,3,2>");
+        else if (s2g) snprintf(tag, sizeof tag, "conv3x3s2_preg<%d>", L.coutPad);
         else if (pglds) snprintf(tag, sizeof tag, "conv_pglds<%s>", mode == ST_POOL ? "pool" : (mode == ST_PS ? "ps" : (mode == ST_PS_DOT3 ? "ps_dot3" : "nhwc")));
         else if (glds1) snprintf(tag, sizeof tag, "conv_glds1");
         else snprintf(tag, sizeof tag, "conv_igemm<%d,%d,%d,%d>", L.cin_t, L.bn, L.ks, L.stride);
@@ -1340,7 +1343,7 @@ struct Seq {
                                               : (mode == ST_PLANAR3 ? 3.0 * Hd * Wd
                                                                     : (mode == ST_PS_DOT3 ? 8.0 * Hd * Wd : (double)p.Ho * p.Wo * L.cout));
         bytes += 2.0 * outel * (1 + (res1 ? 1 : 0) + (res2 ? 1 : 0) + (res_planar ? 1 : 0));
-        chk(s2g ? conv3x3s2_preg_launch(p, c->n_cu, s)
+        chk(t16 ? conv_t16_launch(p, s) : s2g ? conv3x3s2_preg_launch(p, c->n_cu, s)
                 : (pglds ? conv_pglds_launch(p, c->n_cu, s)
                          : (glds1 ? conv_glds1_launch(p, s) : conv_igemm_launch(p, L.cin_t, L.bn, L.ks, L.stride, s))),
             key.c_str(), tag, macs, bytes);
@@ -1575,11 +1578,31 @@ int run_le(hdrtv_ctx *c, Seq &q, const f16 *img, f16 *out_planar)
         const char *l0[3] = {"LE.CondNet2.0", "LE.CondNet3.0", "LE.CondNet4.0"}, *l2[3] = {nullptr, "LE.CondNet3.2", "LE.CondNet4.2"};
         const f16 **af[3] = {&a2, &a3, &a4};
         const int8_t **aq[3] = {&a2q, &a3q, &a4q};
+        // the W8A8 ones together: `cond` is read once and quantised per layer in registers (conv_q8_multi)
+        ConvQ8MultiParams mp;
+        memset(&mp, 0, sizeof mp);
+        mp.src = cond; mp.src_stride = 64; mp.Hi = H; mp.Wi = W; mp.Ho = s.H1; mp.Wo = s.W1;
+        double m_macs = 0.0, m_bytes = 2.0 * 64 * H * W;
+        for (int i = 0; i < 3; ++i) {
+            if (!isq8(l0[i])) continue;
+            const QLayer &L = c->q8.at(l0[i]);
+            const ActQf *oq = l2[i] ? qof(l2[i]) : (c->tail_q8 ? &c->tl_q[0] : nullptr);    // CondNet2.0 feeds the fused tail
+            ConvQ8Group &G = mp.g[mp.ngroups++];
+            G.wpk8 = wtp<int8_t>(c, L.wpk8); G.scale = wtp<float>(c, L.scale); G.shift = wtp<float>(c, L.shift);
+            G.q_inv = L.q.inv(); G.q_zoff = L.q.zoff(); G.act = ACT_LRELU01;
+            G.dst = oq ? (void *)ca8[i] : (void *)ca[i]; G.dst_i8 = oq ? 1 : 0;
+            if (oq) { G.oq_inv = oq->inv(); G.oq_zoff = oq->zoff(); *aq[i] = ca8[i]; } else { *af[i] = ca[i]; }
+            m_macs += (double)s.H1 * s.W1 * 64 * 9 * 64;
+            m_bytes += (double)s.H1 * s.W1 * 64 * (oq ? 1.0 : 2.0) + 9.0 * 64 * 64;
+        }
+        if (mp.ngroups && q.ok()) {
+            char tag[48];
+            snprintf(tag, sizeof tag, "conv_q8_multi<%d>", mp.ngroups);
+            q.chk(conv_q8_multi_launch(mp, c->n_cu, q.s), "LE.CondNet234.0", tag, m_macs, m_bytes);
+        }
         for (int i = 0; i < 3; ++i) {
             if (isq8(l0[i])) {
-                const ActQf *oq = l2[i] ? qof(l2[i]) : (c->tail_q8 ? &c->tl_q[0] : nullptr);    // CondNet2.0 feeds the fused tail
-                q.convq8(l0[i], cond, false, 64, H, W, ACT_LRELU01, oq ? (void *)ca8[i] : (void *)ca[i], 64, oq);
-                if (oq) *aq[i] = ca8[i]; else *af[i] = ca[i];
+                continue;
             } else {
                 q.conv(l0[i], cond, 64, nullptr, 0, H, W, ACT_LRELU01, ST_NHWC, ca[i], 64, s.H1, s.W1);
                 *af[i] = ca[i];
