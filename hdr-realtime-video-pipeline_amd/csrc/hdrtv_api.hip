@@ -231,6 +231,7 @@ struct hdrtv_ctx {
     LetterboxParams lb{};
     void *lb_dev = nullptr;
     size_t lb_cap = 0;
+    float *pq_bnd = nullptr;              // hdrtv_post_pq_rgb48: the 65536 code boundaries of the PQ quantiser (built on first use)
     // objective metrics partial sums
     double *mt_dev = nullptr;
     size_t mt_cap = 0;
@@ -1812,6 +1813,7 @@ int hdrtv_destroy(hdrtv_ctx *c)
     (void)hipDeviceSynchronize();
     hdrtv_ring_destroy(c);
     for (hipEvent_t ev : c->prof_ev) (void)hipEventDestroy(ev);
+    if (c->pq_bnd) (void)hipFree(c->pq_bnd);
     if (c->lb_dev) (void)hipFree(c->lb_dev);
     if (c->mt_dev) (void)hipFree(c->mt_dev);
     if (c->ws.dev) (void)hipFree(c->ws.dev);
@@ -1904,11 +1906,49 @@ int hdrtv_post_rgb48(hdrtv_ctx *c, void *stream, const void *in, int dtype, int 
     return e == hipSuccess ? HDRTV_OK : fail(c, HDRTV_EHIP, "post_rgb48: %s", hipGetErrorString(e));
 }
 
+// ST.2084 OETF in double precision (constants gui_objective_metrics.py:63-67) -> u16 code, floor(pq * 65535 + 0.5): the
+// definition the oracle's orc_pq_code states.  bnd[v] = the smallest fp32 y in [0, 1] with code(y) >= v.
+static int pq_code64(float y)
+{
+    const double yp = std::pow((double)y, 0.1593017578125);
+    const double v = std::pow((0.8359375 + 18.8515625 * yp) / (1.0 + 18.6875 * yp), 78.84375);
+    const double q = std::floor(v * 65535.0 + 0.5);
+    return (int)(q < 0.0 ? 0.0 : (q > 65535.0 ? 65535.0 : q));
+}
+static void pq_boundaries(std::vector<float> &bnd)
+{
+    bnd.assign(65536, 0.f);
+    for (int v = 1; v <= 65535; ++v) {
+        // analytic inverse (EOTF) as the first guess, then walk the fp32 grid to the exact boundary
+        const double p = ((double)v - 0.5) / 65535.0, t = std::pow(p, 1.0 / 78.84375);
+        const double num = std::max(t - 0.8359375, 0.0), den = 18.8515625 - 18.6875 * t;
+        float f = (float)std::min(1.0, std::max(0.0, std::pow(num / den, 1.0 / 0.1593017578125)));
+        while (f > 0.f && pq_code64(std::nextafterf(f, -1.f)) >= v) f = std::nextafterf(f, -1.f);
+        while (f < 1.f && pq_code64(f) < v) f = std::nextafterf(f, 2.f);
+        bnd[v] = f;
+    }
+    // first-guess table of the kernel (prepost.hip pq_code): exact codes at the fp32 values ((127 - 27) * 64 + i) << 17
+    const int base = (127 - 27) << 6, n = 27 * 64 + 2;
+    bnd.resize(65536 + n);
+    for (int i = 0; i < n; ++i) {
+        const uint32_t bits = (uint32_t)(base + i) << 17;
+        float y;
+        memcpy(&y, &bits, 4);
+        bnd[65536 + i] = (float)pq_code64(y > 1.f ? 1.f : y);
+    }
+}
+
 int hdrtv_post_pq_rgb48(hdrtv_ctx *c, void *stream, const void *in, int dtype, int H, int W, float peak_nits, uint16_t *dst)
 {
     if (!c || !in || !dst || H <= 0 || W <= 0 || !(peak_nits > 0.f)) return fail(c, HDRTV_EINVAL, "bad argument");
     HIPCHK(c, hipSetDevice(c->device));
-    hipError_t e = post_rgb48_launch(in, dtype == HDRTV_F32, H, W, dst, 1, peak_nits, (hipStream_t)stream);
+    if (!c->pq_bnd) {
+        std::vector<float> bnd;
+        pq_boundaries(bnd);
+        if (hipMalloc((void **)&c->pq_bnd, bnd.size() * 4) != hipSuccess) { c->pq_bnd = nullptr; return fail(c, HDRTV_ENOMEM, "post_pq_rgb48: table allocation failed"); }
+        HIPCHK(c, hipMemcpy(c->pq_bnd, bnd.data(), bnd.size() * 4, hipMemcpyHostToDevice));
+    }
+    hipError_t e = post_rgb48_launch(in, dtype == HDRTV_F32, H, W, dst, 1, peak_nits, (hipStream_t)stream, c->pq_bnd);
     return e == hipSuccess ? HDRTV_OK : fail(c, HDRTV_EHIP, "post_pq_rgb48: %s", hipGetErrorString(e));
 }
 
@@ -1986,7 +2026,8 @@ static bool letterbox_setup(hdrtv_ctx *c, int sh, int sw, int dh, int dw)
     }
     const size_t bytes = ints.size() * 4 + flts.size() * 4 + 16;
     if (bytes > c->lb_cap) {
-        if (c->lb_dev) (void)hipFree(c->lb_dev);
+        if (c->pq_bnd) (void)hipFree(c->pq_bnd);
+    if (c->lb_dev) (void)hipFree(c->lb_dev);
         c->lb_dev = nullptr; c->lb_cap = 0;
         if (hipMalloc(&c->lb_dev, bytes) != hipSuccess) { c->lb_dev = nullptr; return false; }
         c->lb_cap = bytes;

@@ -28,7 +28,8 @@ hipError_t cond_resize_launch(const f16 *in, f16 *out, int H, int W, int Ho, int
 hipError_t pre_fused_launch(const uint8_t *bgr, f16 *out, f16 *cond, int H, int W, int Ho, int Wo, const float *wx, const int *xmn,
                             const int *xns, const float *wy, const int *ymn, const int *yns, int mode, hipStream_t s);
 hipError_t post_u8_launch(const void *in, int is_f32, int H, int W, uint8_t *bgr, hipStream_t s);
-hipError_t post_rgb48_launch(const void *in, int is_f32, int H, int W, uint16_t *rgb, int pq, float peak, hipStream_t s);
+hipError_t post_rgb48_launch(const void *in, int is_f32, int H, int W, uint16_t *rgb, int pq, float peak, hipStream_t s,
+                             const float *pq_bnd = nullptr);
 
 // activation fake-quantiser of a W8A8 layer evaluated in fp32 (classifier convs, Linear heads): on = 0 passes x through
 struct FakeQ { int on; float inv, zoff, scale, zero; };

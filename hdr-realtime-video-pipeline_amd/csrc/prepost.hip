@@ -122,31 +122,56 @@ __global__ __launch_bounds__(256) void pre_fused_kernel(const uint8_t *__restric
 {
     __shared__ f16 s_in[3][PF_IH][PF_IW + 2];
     __shared__ float s_h[3][PF_IH][PF_OW + 1];
+    __shared__ float s_wx[PF_OW][AA_TAPS], s_wy[PF_OH][AA_TAPS];      // this tile's tap tables (pitch 17: conflict-free across outputs)
+    __shared__ int s_xb[PF_OW], s_xn[PF_OW], s_yb[PF_OH], s_yn[PF_OH];
     const int tid = threadIdx.x;
     const int ox0 = blockIdx.x * PF_OW, oy0 = blockIdx.y * PF_OH;
     const int ix0 = xmn[ox0], iy0 = ymn[oy0];
+    for (int e = tid; e < PF_OW * AA_TAPS; e += 256) {
+        const int o = e / AA_TAPS;
+        s_wx[o][e - o * AA_TAPS] = ox0 + o < Wo ? wx[(size_t)(ox0 + o) * AA_TAPS + (e - o * AA_TAPS)] : 0.f;
+    }
+    if (tid < PF_OH * AA_TAPS) {
+        const int o = tid / AA_TAPS;
+        s_wy[o][tid - o * AA_TAPS] = oy0 + o < Ho ? wy[(size_t)(oy0 + o) * AA_TAPS + (tid - o * AA_TAPS)] : 0.f;
+    }
+    if (tid < PF_OW) { const bool in = ox0 + tid < Wo; s_xb[tid] = in ? xmn[ox0 + tid] - ix0 : 0; s_xn[tid] = in ? xns[ox0 + tid] : 0; }
+    if (tid >= 64 && tid < 64 + PF_OH) { const int o = tid - 64; const bool in = oy0 + o < Ho; s_yb[o] = in ? ymn[oy0 + o] - iy0 : 0; s_yn[o] = in ? yns[oy0 + o] : 0; }
     const size_t total = (size_t)H * W * 3;
     const float k255 = (float)(1.0 / 255.0);
-    for (int e = tid; e < PF_IH * PF_ROWDW; e += 256) {
+    // all of this thread's dword loads first (19 independent loads in flight), then the byte unpacking: a loop that loads and
+    // unpacks one dword at a time pays one HBM round trip per dword
+    constexpr int NLD = (PF_IH * PF_ROWDW + 255) / 256;
+    uint32_t word[NLD];
+    long rel[NLD];                                     // byte offset of the dword's first byte from its row segment's start; < -3: skip
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int e = tid + 256 * i;
         const int r = e / PF_ROWDW, d = e - r * PF_ROWDW;
         const int iy = iy0 + r;
-        if (iy >= H) continue;
-        const size_t row0 = ((size_t)iy * W + ix0) * 3;
+        const size_t row0 = ((size_t)(iy < H ? iy : 0) * W + ix0) * 3;
         const size_t addr = (row0 & ~(size_t)3) + 4 * (size_t)d;
-        if (addr >= total) continue;
-        uint32_t word;
-        if (addr + 4 <= total) {
-            word = *reinterpret_cast<const uint32_t *>(bgr + addr);
-        } else {
-            word = 0;
-            for (size_t k = 0; addr + k < total; ++k) word |= (uint32_t)bgr[addr + k] << (8 * k);
+        const bool ok = e < PF_IH * PF_ROWDW && iy < H && addr < total;
+        rel[i] = ok ? (long)addr - (long)row0 : -1000;
+        word[i] = 0;
+        if (ok) {
+            if (addr + 4 <= total) {
+                word[i] = *reinterpret_cast<const uint32_t *>(bgr + addr);
+            } else {
+                for (size_t k = 0; addr + k < total; ++k) word[i] |= (uint32_t)bgr[addr + k] << (8 * k);
+            }
         }
+    }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int e = tid + 256 * i;
+        const int r = e / PF_ROWDW;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int b = (int)((long)addr + k - (long)row0);
+            const int b = (int)rel[i] + k;
             if (b >= 0 && b < PF_IW * 3) {
                 const int q = (b * 683) >> 11, ch = b - 3 * q;             // b / 3 for b < 600
-                if (ix0 + q < W) s_in[2 - ch][r][q] = (f16)__fmul_rn((float)((word >> (8 * k)) & 0xff), k255);
+                if (ix0 + q < W) s_in[2 - ch][r][q] = (f16)__fmul_rn((float)((word[i] >> (8 * k)) & 0xff), k255);
             }
         }
     }
@@ -196,12 +221,18 @@ __global__ __launch_bounds__(256) void pre_fused_kernel(const uint8_t *__restric
     }
     for (int e = tid; e < 3 * PF_IH * PF_OW; e += 256) {
         const int c = e / (PF_IH * PF_OW), r = (e / PF_OW) % PF_IH, o = e % PF_OW;
-        const int ox = ox0 + o;
         float sacc = 0.f;
-        if (ox < Wo && iy0 + r < H) {
-            const int base = xmn[ox] - ix0, n = xns[ox];
-            const float *w = wx + (size_t)ox * AA_TAPS;
-            for (int j = 0; j < n; ++j) sacc = __fadd_rn(sacc, __fmul_rn(w[j], (float)s_in[c][r][base + j]));
+        if (iy0 + r < H) {
+            // all 16 taps unrolled (a counted loop serialises on LDS latency): taps beyond this output's count have weight 0 in
+            // the table and re-read the last valid sample, so they add exactly +0
+            const int base = s_xb[o], n1 = s_xn[o] - 1;     // n1 < 0 for outputs beyond the image
+            if (n1 >= 0) {
+                float xv[16], wv[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { xv[j] = (float)s_in[c][r][base + (j < n1 ? j : n1)]; wv[j] = s_wx[o][j]; }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) sacc = __fadd_rn(sacc, __fmul_rn(wv[j], xv[j]));
+            }
         }
         s_h[c][r][o] = sacc;
     }
@@ -210,10 +241,12 @@ __global__ __launch_bounds__(256) void pre_fused_kernel(const uint8_t *__restric
         const int c = e / (PF_OH * PF_OW), r = (e / PF_OW) % PF_OH, o = e % PF_OW;
         const int ox = ox0 + o, oy = oy0 + r;
         if (ox < Wo && oy < Ho) {
-            const int base = ymn[oy] - iy0, n = yns[oy];
-            const float *w = wy + (size_t)oy * AA_TAPS;
-            float sacc = 0.f;
-            for (int j = 0; j < n; ++j) sacc = __fadd_rn(sacc, __fmul_rn(w[j], s_h[c][base + j][o]));
+            const int base = s_yb[r], n1 = s_yn[r] - 1;
+            float sacc = 0.f, xv[16], wv[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { xv[j] = s_h[c][base + (j < n1 ? j : n1)][o]; wv[j] = s_wy[r][j]; }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) sacc = __fadd_rn(sacc, __fmul_rn(wv[j], xv[j]));
             cond[((size_t)c * Ho + oy) * Wo + ox] = (f16)sacc;
         }
     }
@@ -299,9 +332,37 @@ __device__ __forceinline__ float pq_oetf(float nits)
     return powf((PQ_C1 + PQ_C2 * yp) / (1.f + PQ_C3 * yp), PQ_M2);
 }
 
+// Exact u16 code of a PQ level: code(y) = floor(pq(y) * 65535 + 0.5) with the OETF in double precision, as an integer
+// function of the fp32 argument y.  bnd[v] (v = 1..65535) is the smallest fp32 y whose code is >= v (built on the host in
+// double, hdrtv_api.hip pq_boundaries; 256 KiB, L2-resident); the fp32 evaluation lands within a few codes of the answer
+// and two compares against the table settle it.  The result does not depend on any device math-library rounding.
+// First guess without transcendental functions: lut[i] (appended to bnd at PQ_LUT_OFF) is the exact code at the fp32 value whose
+// bit pattern is (PQ_LUT_BASE + i) << 17 -- 64 steps per binary octave from 2^-27 to 1, the curve's own near-logarithmic
+// spacing -- and the code in between is interpolated on the low 17 mantissa bits (within 2 codes of the truth everywhere).
+constexpr int PQ_LUT_BASE = (127 - 27) << 6, PQ_LUT_N = 27 * 64 + 2, PQ_LUT_OFF = 65536;
+__device__ __forceinline__ uint32_t pq_code(float lin, float peak, const float *__restrict__ bnd)
+{
+    float y = __fdiv_rn(__fmul_rn(lin, peak), 10000.f);
+    y = fminf(fmaxf(y, 0.f), 1.f);
+    const uint32_t bits = __float_as_uint(y);
+    int c = 0;
+    if ((int)(bits >> 17) >= PQ_LUT_BASE) {
+        const int i = (int)(bits >> 17) - PQ_LUT_BASE;
+        const int c0 = (int)bnd[PQ_LUT_OFF + i], c1 = (int)bnd[PQ_LUT_OFF + i + 1];
+        c = c0 + (int)(((uint32_t)(c1 - c0) * (bits & 0x1ffffu)) >> 17);
+    }
+    while (c < 65535 && y >= bnd[c + 1]) ++c;
+    while (c > 0 && y < bnd[c]) --c;
+    return (uint32_t)c;
+}
+__device__ __forceinline__ float gamut_row(float m0, float m1, float m2, float r, float g, float b)
+{
+    return __fmaf_rn(m2, b, __fmaf_rn(m1, g, __fmul_rn(m0, r)));      // the oracle's rounding sequence
+}
+
 template <typename T, bool PQ>
 __global__ __launch_bounds__(256) void post_rgb48_kernel(const T *__restrict__ in, uint16_t *__restrict__ rgb,
-                                                         size_t npix, float peak)
+                                                         size_t npix, float peak, const float *__restrict__ bnd)
 {
     const size_t ngrp = npix / 8;
     for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngrp; g += (size_t)gridDim.x * blockDim.x) {
@@ -318,17 +379,12 @@ __global__ __launch_bounds__(256) void post_rgb48_kernel(const T *__restrict__ i
                 float cr = r[i + k], cg = gg[i + k], cb = b[i + k];
                 if (PQ) {
                     // ITU-R BT.2087 BT.709 -> BT.2020 (linear light)
-                    const float xr = 0.6274f * cr + 0.3293f * cg + 0.0433f * cb;
-                    const float xg = 0.0691f * cr + 0.9195f * cg + 0.0114f * cb;
-                    const float xb = 0.0164f * cr + 0.0880f * cg + 0.8956f * cb;
+                    const float xr = gamut_row(0.6274f, 0.3293f, 0.0433f, cr, cg, cb);
+                    const float xg = gamut_row(0.0691f, 0.9195f, 0.0114f, cr, cg, cb);
+                    const float xb = gamut_row(0.0164f, 0.0880f, 0.8956f, cr, cg, cb);
                     const float c3[3] = {xr, xg, xb};
 #pragma unroll
-                    for (int ch = 0; ch < 3; ++ch) {
-                        const float lin = fminf(fmaxf(c3[ch], 0.f), 1.f);
-                        float qv = __fadd_rn(__fmul_rn(pq_oetf(lin * peak), 65535.f), 0.5f);
-                        qv = fminf(fmaxf(qv, 0.f), 65535.f);
-                        q[k * 3 + ch] = (uint32_t)(int)qv;
-                    }
+                    for (int ch = 0; ch < 3; ++ch) q[k * 3 + ch] = pq_code(fminf(fmaxf(c3[ch], 0.f), 1.f), peak, bnd);
                 } else {
                     q[k * 3 + 0] = quant_u16(cr);
                     q[k * 3 + 1] = quant_u16(cg);
@@ -349,15 +405,13 @@ __global__ __launch_bounds__(256) void post_rgb48_kernel(const T *__restrict__ i
         float c3[3] = {(float)in[i], (float)in[npix + i], (float)in[2 * npix + i]};
         if (PQ) {
             const float cr = c3[0], cg = c3[1], cb = c3[2];
-            c3[0] = 0.6274f * cr + 0.3293f * cg + 0.0433f * cb;
-            c3[1] = 0.0691f * cr + 0.9195f * cg + 0.0114f * cb;
-            c3[2] = 0.0164f * cr + 0.0880f * cg + 0.8956f * cb;
+            c3[0] = gamut_row(0.6274f, 0.3293f, 0.0433f, cr, cg, cb);
+            c3[1] = gamut_row(0.0691f, 0.9195f, 0.0114f, cr, cg, cb);
+            c3[2] = gamut_row(0.0164f, 0.0880f, 0.8956f, cr, cg, cb);
         }
         for (int ch = 0; ch < 3; ++ch) {
             if (PQ) {
-                const float lin = fminf(fmaxf(c3[ch], 0.f), 1.f);
-                float qv = __fadd_rn(__fmul_rn(pq_oetf(lin * peak), 65535.f), 0.5f);
-                rgb[i * 3 + ch] = (uint16_t)(int)fminf(fmaxf(qv, 0.f), 65535.f);
+                rgb[i * 3 + ch] = (uint16_t)pq_code(fminf(fmaxf(c3[ch], 0.f), 1.f), peak, bnd);
             } else {
                 rgb[i * 3 + ch] = (uint16_t)quant_u16(c3[ch]);
             }
@@ -410,16 +464,19 @@ hipError_t post_u8_launch(const void *in, int is_f32, int H, int W, uint8_t *bgr
     return hipGetLastError();
 }
 
-hipError_t post_rgb48_launch(const void *in, int is_f32, int H, int W, uint16_t *rgb, int pq, float peak, hipStream_t s)
+// pq != 0 needs pq_bnd: device table of the 65536 code boundaries (entry 0 unused)
+hipError_t post_rgb48_launch(const void *in, int is_f32, int H, int W, uint16_t *rgb, int pq, float peak, hipStream_t s,
+                             const float *pq_bnd)
 {
+    if (pq && !pq_bnd) return hipErrorInvalidValue;
     const size_t npix = (size_t)H * W;
     const dim3 g(ew_grid(npix / 8)), b(256);
     if (is_f32) {
-        if (pq) hipLaunchKernelGGL((post_rgb48_kernel<float, true>), g, b, 0, s, (const float *)in, rgb, npix, peak);
-        else hipLaunchKernelGGL((post_rgb48_kernel<float, false>), g, b, 0, s, (const float *)in, rgb, npix, peak);
+        if (pq) hipLaunchKernelGGL((post_rgb48_kernel<float, true>), g, b, 0, s, (const float *)in, rgb, npix, peak, pq_bnd);
+        else hipLaunchKernelGGL((post_rgb48_kernel<float, false>), g, b, 0, s, (const float *)in, rgb, npix, peak, pq_bnd);
     } else {
-        if (pq) hipLaunchKernelGGL((post_rgb48_kernel<f16, true>), g, b, 0, s, (const f16 *)in, rgb, npix, peak);
-        else hipLaunchKernelGGL((post_rgb48_kernel<f16, false>), g, b, 0, s, (const f16 *)in, rgb, npix, peak);
+        if (pq) hipLaunchKernelGGL((post_rgb48_kernel<f16, true>), g, b, 0, s, (const f16 *)in, rgb, npix, peak, pq_bnd);
+        else hipLaunchKernelGGL((post_rgb48_kernel<f16, false>), g, b, 0, s, (const f16 *)in, rgb, npix, peak, pq_bnd);
     }
     return hipGetLastError();
 }

@@ -304,19 +304,35 @@ void orc_gamut709_2020(const float *rgb_chw, int H, int W, float *out_chw)
     }
 }
 
+/* The u16 code of a PQ signal level, as an INTEGER function of the fp32 argument y = clip(L / 10000, 0, 1): the OETF
+ * evaluated in double precision, code = floor(pq(y) * 65535 + 0.5).  fp32 powf differs between libraries by an ulp or two,
+ * which moves one code in a few thousand; in double the result is the correctly rounded code for every fp32 y (the OETF
+ * is monotone and the fp32 grid is ~1e8 times coarser than double rounding).  The device reproduces this function
+ * exactly from a table of the 65535 code boundaries (csrc/hdrtv_api.hip pq_boundaries). */
+uint16_t orc_pq_code(float y)
+{
+    const double yp = pow((double)y, 0.1593017578125);
+    const double v = pow((0.8359375 + 18.8515625 * yp) / (1.0 + 18.6875 * yp), 78.84375);
+    const double q = floor(v * 65535.0 + 0.5);
+    return (uint16_t)(q < 0.0 ? 0.0 : (q > 65535.0 ? 65535.0 : q));
+}
+
 /* Display post-process: linear-light BT.709 in [0,1] (1.0 = peak_nits) -> BT.2020 ->
- * PQ -> u16 RGB HWC.  Composition of the two operators above. */
+ * PQ -> u16 RGB HWC.  fp32 with every rounding spelled out: lin = fma(m2, b, fma(m1, g, m0 * r)), clipped to [0, 1];
+ * y = clip((lin * peak) / 10000, 0, 1); code = orc_pq_code(y). */
 void orc_post_pq_rgb48(const float *rgb_chw, int H, int W, float peak_nits, uint16_t *rgb)
 {
     const size_t HW = (size_t)H * W;
     for (size_t i = 0; i < HW; ++i) {
         const float r = rgb_chw[i], g = rgb_chw[HW + i], b = rgb_chw[2 * HW + i];
         for (int c = 0; c < 3; ++c) {
-            float lin = M709_2020[3 * c] * r + M709_2020[3 * c + 1] * g + M709_2020[3 * c + 2] * b;
+            volatile float m0 = M709_2020[3 * c] * r;
+            float lin = fmaf(M709_2020[3 * c + 2], b, fmaf(M709_2020[3 * c + 1], g, m0));
             lin = lin < 0.0f ? 0.0f : (lin > 1.0f ? 1.0f : lin);
-            float q = orc_pq_oetf(lin * peak_nits) * 65535.0f + 0.5f;
-            q = q < 0.0f ? 0.0f : (q > 65535.0f ? 65535.0f : q);
-            rgb[i * 3 + c] = (uint16_t)q;
+            volatile float nits = lin * peak_nits;
+            float y = nits / 10000.0f;
+            y = y < 0.0f ? 0.0f : (y > 1.0f ? 1.0f : y);
+            rgb[i * 3 + c] = orc_pq_code(y);
         }
     }
 }
