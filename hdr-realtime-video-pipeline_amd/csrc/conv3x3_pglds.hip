@@ -8,10 +8,12 @@
 //   * the next tile's first halo chunk, its first weight taps and its 128 scale/shift pairs are
 //     DMA'd during the current tile's last taps, so a tile costs no prologue latency and no block
 //     launch (the K = 9 layers conv2 / Up_conv5 spent ~40 % of their time there);
-//   * the epilogue runs out of the accumulator registers: scale/shift from LDS, stores straight to
-//     global memory (8-byte channel quads; pooling / pixel shuffle / the fused 64->3 dot products
-//     are done in registers), no LDS round trip and no barrier, so the tile buffers stay free for
-//     the DMAs already in flight.  Every wave issues the SAME number of stores per tile
+//   * the epilogue runs out of the accumulator registers: scale/shift from LDS, pooling / pixel
+//     shuffle / the fused 64->3 dot products in registers, then a transposition through a
+//     wave-private strip of the halo buffer the tile has just released (LDS operations of one wave
+//     execute in order: no barrier) so that global stores are 16 bytes per lane and 8 lanes cover a
+//     pixel's 128-byte channel run; the other tile buffers stay free for the DMAs already in
+//     flight.  Every wave issues the SAME number of stores per tile
 //     (out-of-image lanes write a trash line instead of being masked): vmcnt counts loads, stores
 //     and LDS-DMA together in issue order, so the counted wait after a tile boundary depends on it.
 // MFMA shape 16x16x32 (lane = row & 15, k-group = lane >> 4): under load the chip holds a higher

@@ -1327,8 +1327,11 @@ struct Seq {
         const bool pglds = g64 && L.ks == 3 && L.cout == L.coutPad;      // HG 3x3 convs: persistent LDS-DMA kernel
         const bool glds1 = g64 && L.ks == 1 && mode == ST_NHWC;          // HG 1x1 fuse convs
         p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
-        static const int nt_slow = [] { const char *e = getenv("HDRTV_PGLDS_NT_SLOW"); return e ? atoi(e) : 0; }();
-        p.nt_slow = nt_slow == 2 ? (L.coutPad >= 512) : nt_slow;
+        static const int nt_slow = [] { const char *e = getenv("HDRTV_PGLDS_NT_SLOW"); return e ? atoi(e) : 3; }();
+        // default: the Up convs (Cout = 4 Cin: 4 .. 16 Cout-tiles per pixel tile) walk Cout-tile slowest -- an XCD then shares one
+        // weight slab instead of re-fetching up to 16 (-17 % L2 misses, profiles/r02_pmc_traffic_tile_order.json); the other
+        // layers walk it fastest so that the blocks of an XCD share halo tiles (+45 .. +75 % misses the other way round)
+        p.nt_slow = nt_slow == 3 ? (mode == ST_PS) : (nt_slow == 2 ? (L.coutPad >= 512) : nt_slow);
         const bool s2g = L.ks == 3 && L.stride == 2 && L.cin_t == 64 && L.bn == L.coutPad && (L.coutPad == 64 || L.coutPad == 192);
         static const bool no_t16 = getenv("HDRTV_NO_T16") != nullptr;       // developer A/B: the generic implicit-GEMM kernel
         const bool t16 = !no_t16 && L.ks == 3 && L.stride == 2 && L.cin == 32 && L.coutPad == 32 && !src1 && mode == ST_NHWC && !res1 && !res2;
