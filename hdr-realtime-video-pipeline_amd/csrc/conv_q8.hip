@@ -128,95 +128,138 @@ __global__ __launch_bounds__(256) void conv_q8_kernel(ConvQ8Params p)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Up to three 3x3 / stride-2 / 64 -> 64 W8A8 layers that read ONE f16 tensor through their own quantisers (CondNet2.0,
-// CondNet3.0, CondNet4.0 all read the full-resolution condition map, HDRUNet3T1_arch.py:47-55): the 17 x 33 halo patch is
-// fetched from HBM once, quantised in registers with each layer's (x_scale, x_zero) into that layer's int8 tile, and the
-// layers' convolutions run back to back from LDS.  8 waves: wave = (output-channel half, 32-pixel group) of an 8 x 16 tile.
+// CondNet3.0, CondNet4.0 all read the full-resolution condition map, HDRUNet3T1_arch.py:47-55), organised like the fp16
+// kernel of the same layers (conv3x3s2_preg.hip): persistent workgroups walk 8 x 16 output tiles, four waves per layer,
+// wave w keeps the K = 576 filter rows of 16 output channels of its layer in 36 VGPRs (nine 16x16x64 int8 A fragments:
+// one tap = 64 channels = one K step), no weight traffic and no per-tap barrier.  The 17 x 33 x 64-channel f16 halo of
+// the NEXT tile is fetched into registers (six 16-byte loads per thread in flight) while the current tile is convolved
+// from LDS; between tiles every thread quantises its share once per layer -- each layer's (x_scale, x_zero) -- into that
+// layer's 36 KiB code tile.  The condition map is read from HBM once.  Halo columns are staged de-interleaved (even
+// columns first), so the 16 pixels of a stride-2 tap are 16 consecutive 64-byte LDS rows, conflict-free under the
+// (row >> 2) & 3 chunk swizzle.  Epilogue straight from the accumulators: dequantise with the border-class shift,
+// LeakyReLU, then f16 or the reading layer's int8 codes, 8 / 4 bytes per lane.
 template <int NG>
-__global__ __launch_bounds__(512) void conv_q8_multi_kernel(ConvQ8MultiParams p)
+__global__ __launch_bounds__(256 * NG, 1) void conv_q8_multi_kernel(ConvQ8MultiParams p)
 {
-    constexpr int CIN = 64, NCH = 4, S = 2, KS = 3;
-    constexpr int HH = (Q8_TH - 1) * S + KS, HWD = (Q8_TW - 1) * S + KS, NPX = HH * HWD;     // 17 x 33
-    constexpr int XB = (NPX * CIN + 255) & ~255, WB = KS * KS * 64 * CIN;
+    constexpr int NT = 256 * NG, TH = Q8_TH, TW = Q8_TW;
+    constexpr int HH = 2 * TH + 1, HWD = 2 * TW + 1, NPX = HH * HWD, NEVEN = TW + 1;     // 17 x 33 halo, even columns first
+    constexpr int XB = (NPX * 64 + 255) & ~255;
+    constexpr int NIT = (NPX * 8 + NT - 1) / NT;               // 16-byte f16 items (8 channels) per thread and tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *sX = smem;                           // [NG][NPX][64] codes
-    char *sW = smem + NG * XB;                 // [9][64][64], one layer at a time
-    float *sS = reinterpret_cast<float *>(sW + WB);   // scale[64] + shift[16][64] of the current layer
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-    const int pg = wave & 3, ch_half = wave >> 2;
-    const int tiles_x = (p.Wo + Q8_TW - 1) / Q8_TW, ntiles = tiles_x * ((p.Ho + Q8_TH - 1) / Q8_TH);
-    const int qy = 2 * pg + (l31 >> 4), qx = l31 & 15;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, sub = wave & 3;
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int tiles_x = (p.Wo + TW - 1) / TW, ntiles = tiles_x * ((p.Ho + TH - 1) / TH);
+    const ConvQ8Group &G = p.g[grp];
+
+    // ---- this wave's filter rows: one A fragment per tap (16 output channels x 64 input channels)
+    i32x4 wfr[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+        wfr[tap] = *reinterpret_cast<const i32x4 *>(G.wpk8 + ((size_t)tap * 64 + sub * 16 + l15) * 64 + kg * 16);
+    const int n0 = sub * 16 + 4 * kg;
+    const float4 sc = *reinterpret_cast<const float4 *>(G.scale + n0);
+    const float aslope = act_slope(G.act);
+
+    // ---- halo items of this thread: LDS row q (de-interleaved column order), 8-channel chunk c8
+    f16x8 pre[NIT];
+    auto fetch = [&](int t) {
         const int ty = t / tiles_x, tx = t - ty * tiles_x;
-        const int oy0 = ty * Q8_TH, ox0 = tx * Q8_TW;
-        const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
-        __syncthreads();                       // the previous tile's last layer is done with sX
-        for (int e = tid; e < NPX * NCH; e += 512) {
-            const int hp = e / NCH, ch = e - hp * NCH;
-            const int hy = hp / HWD, hx = hp - hy * HWD;
+        const int iy0 = 2 * ty * TH - 1, ix0 = 2 * tx * TW - 1;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int e = tid + k * NT;
+            const int q = e >> 3, c8 = e & 7;
+            const int hy = q / HWD, col = q - hy * HWD;
+            const int hx = col < NEVEN ? 2 * col : 2 * (col - NEVEN) + 1;
             const int iy = iy0 + hy, ix = ix0 + hx;
-            const bool in = iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
-            f16x8 a, b;
-            if (in) {
-                const f16 *g = p.src + ((size_t)iy * p.Wi + ix) * p.src_stride + ch * 16;
-                a = *reinterpret_cast<const f16x8 *>(g);
-                b = *reinterpret_cast<const f16x8 *>(g + 8);
-            }
-            const int off = hp * CIN + ((ch ^ rsw<NCH>(hp)) << 4);
+            const bool ok = q < NPX && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+            // out-of-image items are marked with a NaN in channel 0 (never produced by the network: inputs are finite)
+            f16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (f16)0.f;
+            if (ok) v = *reinterpret_cast<const f16x8 *>(p.src + ((size_t)iy * p.Wi + ix) * p.src_stride + c8 * 8);
+            pre[k] = v;
+        }
+    };
+    auto okmask = [&](int t, int k) -> bool {
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        const int e = tid + k * NT, q = e >> 3;
+        const int hy = q / HWD, col = q - hy * HWD;
+        const int hx = col < NEVEN ? 2 * col : 2 * (col - NEVEN) + 1;
+        const int iy = 2 * ty * TH - 1 + hy, ix = 2 * tx * TW - 1 + hx;
+        return q < NPX && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+    };
+    auto quantise = [&](int t) {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int e = tid + k * NT;
+            const int q = e >> 3, c8 = e & 7;
+            if (q >= NPX) continue;
+            const bool ok = okmask(t, k);
+            const int off = q * 64 + (((c8 >> 1) ^ ((q >> 2) & 3)) << 4) + (c8 & 1) * 8;
+            const f16x8 v = pre[k];
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
-                i32x4 v = {0, 0, 0, 0};
-                if (in) {
+                uint2 w = make_uint2(0u, 0u);                  // out-of-image pixels: code 0
+                if (ok) {
                     const float inv = p.g[g].q_inv, zo = p.g[g].q_zoff;
-                    v[0] = (int)quant4((float)a[0], (float)a[1], (float)a[2], (float)a[3], inv, zo);
-                    v[1] = (int)quant4((float)a[4], (float)a[5], (float)a[6], (float)a[7], inv, zo);
-                    v[2] = (int)quant4((float)b[0], (float)b[1], (float)b[2], (float)b[3], inv, zo);
-                    v[3] = (int)quant4((float)b[4], (float)b[5], (float)b[6], (float)b[7], inv, zo);
+                    w.x = quant4((float)v[0], (float)v[1], (float)v[2], (float)v[3], inv, zo);
+                    w.y = quant4((float)v[4], (float)v[5], (float)v[6], (float)v[7], inv, zo);
                 }
-                *reinterpret_cast<i32x4 *>(sX + g * XB + off) = v;
+                *reinterpret_cast<uint2 *>(smem + g * XB + off) = w;
             }
         }
-        const int oy = oy0 + qy, ox = ox0 + qx;
-        const int ty0 = oy * S - 1, tx0 = ox * S - 1;
-        const int bcls = ((((ty0 < 0) | ((ty0 + 2 >= p.Hi) << 1)) << 2) | ((tx0 < 0) | ((tx0 + 2 >= p.Wi) << 1))) & 15;
-        const bool live = oy < p.Ho && ox < p.Wo;
-#pragma unroll 1
-        for (int g = 0; g < NG; ++g) {
-            const ConvQ8Group &G = p.g[g];
-            __syncthreads();                   // tile staged (g = 0) / previous layer done with sW and sS
-            for (int e = tid; e < KS * KS * 64 * NCH; e += 512) {
-                const int r = e / NCH, ch = e - r * NCH;
-                *reinterpret_cast<i32x4 *>(sW + r * CIN + ((ch ^ rsw<NCH>(r)) << 4)) =
-                    *reinterpret_cast<const i32x4 *>(G.wpk8 + (size_t)r * CIN + ch * 16);
-            }
-            for (int e = tid; e < 17 * 64; e += 512) sS[e] = e < 64 ? G.scale[e] : G.shift[e - 64];
-            __syncthreads();
-            const char *x = sX + g * XB;
-            i32x16 acc;
+    };
+
+    // read offsets: LDS row = c + l15 for a compile-time c; the swizzle needs bits 2..3 of (c + l15) = of ((c & 3) + l15) + (c & 12):
+    // four lane constants (carry of the low two bits) instead of one per c
+    int xl[4];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) acc[k] = 0;
+    for (int c3 = 0; c3 < 4; ++c3) xl[c3] = (c3 + l15) >> 2;
+    const char *X = smem + grp * XB + l15 * 64;
+
+    int t = blockIdx.x;
+    const int step = gridDim.x;
+    if (t < ntiles) { fetch(t); quantise(t); }
+    __syncthreads();
+    for (; t < ntiles; t += step) {
+        if (t + step < ntiles) fetch(t + step);            // in flight while this tile is convolved
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        const int ox = tx * TW + l15;
+        const int tx0 = 2 * ox - 1;
+        const int bx = (tx0 < 0) | ((tx0 + 2 >= p.Wi) << 1);
+#pragma unroll 1
+        for (int hf = 0; hf < 2; ++hf) {                   // two halves of four output rows: 16 accumulator registers, not 32
+            i32x4 acc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = i32x4{0, 0, 0, 0};
+            const char *Xh = X + hf * (8 * HWD * 64);      // output row 4 hf + i reads halo rows 2 (4 hf + i) + ky: 8 rows further down
+            const int swh = hf * ((8 * HWD) >> 2);         // ... and (8 * HWD) = 264 rows = 66 swizzle periods of 4: bits 2..3 shift by 66 & 3 = 2
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
-                const int hp = (qy * S + tap / 3) * HWD + qx * S + tap % 3;
-                const int wr = tap * 64 + ch_half * 32 + l31;
+                const int ky = tap / 3, kx = tap % 3;
 #pragma unroll
-                for (int kc = 0; kc < 2; ++kc) {
-                    const int ch = kc * 2 + lh;
-                    const i32x4 wv = *reinterpret_cast<const i32x4 *>(sW + wr * CIN + ((ch ^ rsw<NCH>(wr)) << 4));
-                    const i32x4 xv = *reinterpret_cast<const i32x4 *>(x + hp * CIN + ((ch ^ rsw<NCH>(hp)) << 4));
-                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wv, xv, acc, 0, 0, 0);
+                for (int i = 0; i < 4; ++i) {
+                    const int c = (2 * i + ky) * HWD + (kx & 1) * NEVEN + (kx >> 1);
+                    const int sw = (xl[c & 3] + ((c >> 2) & 3) + swh) & 3;
+                    const i32x4 x = *reinterpret_cast<const i32x4 *>(Xh + c * 64 + ((kg ^ sw) << 4));
+                    acc[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wfr[tap], x, acc[i], 0, 0, 0);
                 }
             }
-            if (live) {
-                const float aslope = act_slope(G.act);
+            // ---- epilogue from the accumulators: lane = (pixel column l15, output channels n0 .. n0 + 3), one row per i
 #pragma unroll
-                for (int gg = 0; gg < 4; ++gg) {
-                    const int n = ch_half * 32 + 8 * gg + 4 * lh;
-                    const float4 sc = *reinterpret_cast<const float4 *>(sS + n);
-                    const float4 sh = *reinterpret_cast<const float4 *>(sS + 64 + bcls * 64 + n);
-                    const float v0 = act_fast((float)acc[4 * gg + 0] * sc.x + sh.x, aslope), v1 = act_fast((float)acc[4 * gg + 1] * sc.y + sh.y, aslope),
-                                v2 = act_fast((float)acc[4 * gg + 2] * sc.z + sh.z, aslope), v3 = act_fast((float)acc[4 * gg + 3] * sc.w + sh.w, aslope);
-                    const size_t o = ((size_t)oy * p.Wo + ox) * 64 + n;
+            for (int i = 0; i < 4; ++i) {
+                const int oy = ty * TH + 4 * hf + i;
+                if (oy < p.Ho && ox < p.Wo) {
+                    const int ty0 = 2 * oy - 1;
+                    const int bcls = ((((ty0 < 0) | ((ty0 + 2 >= p.Hi) << 1)) << 2) | bx) & 15;
+                    const float4 sh = *reinterpret_cast<const float4 *>(G.shift + bcls * 64 + n0);
+                    const float v0 = act_fast((float)acc[i][0] * sc.x + sh.x, aslope), v1 = act_fast((float)acc[i][1] * sc.y + sh.y, aslope),
+                                v2 = act_fast((float)acc[i][2] * sc.z + sh.z, aslope), v3 = act_fast((float)acc[i][3] * sc.w + sh.w, aslope);
+                    const size_t o = ((size_t)oy * p.Wo + ox) * 64 + n0;
                     if (G.dst_i8) {
                         *reinterpret_cast<unsigned *>(reinterpret_cast<int8_t *>(G.dst) + o) =
                             quant4((float)(f16)v0, (float)(f16)v1, (float)(f16)v2, (float)(f16)v3, G.oq_inv, G.oq_zoff);
@@ -228,6 +271,9 @@ __global__ __launch_bounds__(512) void conv_q8_multi_kernel(ConvQ8MultiParams p)
                 }
             }
         }
+        __syncthreads();                                   // every wave is done reading the code tiles
+        if (t + step < ntiles) quantise(t + step);
+        __syncthreads();
     }
 }
 
@@ -255,7 +301,7 @@ template <int NG>
 hipError_t launch_multi(const ConvQ8MultiParams &p, int n_cu, hipStream_t s)
 {
     constexpr int NPX = 17 * 33, XB = (NPX * 64 + 255) & ~255;
-    constexpr int smem = NG * XB + 9 * 64 * 64 + 17 * 64 * 4;
+    constexpr int smem = NG * XB;
     static_assert(smem <= 160 * 1024, "LDS budget");
     static DevOnce attr_once;   // hipFuncSetAttribute is per (function, device)
     auto kern = conv_q8_multi_kernel<NG>;
@@ -265,9 +311,7 @@ hipError_t launch_multi(const ConvQ8MultiParams &p, int n_cu, hipStream_t s)
         attr_once.done();
     }
     const int ntiles = ((p.Wo + Q8_TW - 1) / Q8_TW) * ((p.Ho + Q8_TH - 1) / Q8_TH);
-    const int per_cu = (160 * 1024) / smem;
-    const int cap = n_cu * (per_cu < 1 ? 1 : per_cu);
-    hipLaunchKernelGGL(kern, dim3(ntiles < cap ? ntiles : cap), dim3(512), smem, s, p);
+    hipLaunchKernelGGL(kern, dim3(ntiles < n_cu ? ntiles : n_cu), dim3(256 * NG), smem, s, p);
     return hipGetLastError();
 }
 
