@@ -102,6 +102,12 @@ struct ConvI8Params {
     int tiles_x, tiles_y;
     const int8_t *padline;       // 128 B of the input tensor's zero-point code (k - 128): out-of-image halo pixels
     void *trash;                 // >= 2 KiB scratch that out-of-image lanes store to (never read)
+    // Float zero point (x_zero not an integer multiple of x_scale): padline holds code 0 -- padded taps add nothing to the
+    // sum -- and delta[16 border classes][Cout] is added to `shift` for pixels whose 3x3 window leaves the image (the constant
+    // the missing taps would otherwise contribute; class = (row bits) << 2 | (column bits), bit0 first tap outside, bit1 last)
+    const float *delta;
+    const int *delta_acc;        // the same constant in accumulator units (rounded), for the ST_PS_DOT3 epilogue
+    float lo_clamp;              // lowest output code: -128, or the code of 0.0 behind a ReLU whose reader has x_zero < 0
 };
 
 // Parameter block of the persistent 32-channel conv (conv32p.hip): 3x3, stride 1, Cin = 32.

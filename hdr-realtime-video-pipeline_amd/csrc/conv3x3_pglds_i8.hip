@@ -236,7 +236,34 @@ __global__ __launch_bounds__(512) void conv_pglds_i8_kernel(ConvI8Params p)
         // wave-private strip of the halo buffer this tile just finished with (free until the next tile's tap 6); LDS
         // operations of one wave execute in order: no barrier
         char *stg = sA + ((gch - 1) & 1) * A_BYTES + wave * 5120;
+        // float zero point (p.delta): pixels whose 3x3 window leaves the image get their border class's constant added to the
+        // shift.  Only tiles on the image border take the branch (wave-uniform test first); the class is recomputed per use
+        // rather than kept, this kernel has no registers to spare
+        const bool edge_tile = p.delta && (cur.oy0 == 0 || cur.ox0 == 0 || cur.oy0 + TH >= p.Hi || cur.ox0 + TW >= p.Wi);
+        auto shift_of = [&](const float4 &sh, int i, int j) -> float4 {
+            if (!edge_tile) return sh;
+            const int oy_ = cur.oy0 + wp * 4 + j, ox_ = cur.ox0 + l15;
+            const int cls = ((((oy_ == 0) | ((oy_ == p.Hi - 1) << 1)) << 2) | ((ox_ == 0) | ((ox_ == p.Wi - 1) << 1))) & 15;
+            if (!cls) return sh;
+            const float4 d = *reinterpret_cast<const float4 *>(p.delta + (size_t)cls * p.Cout + cur.n0 + cw + i * 16);
+            return make_float4(sh.x + d.x, sh.y + d.y, sh.z + d.z, sh.w + d.w);
+        };
         if constexpr (MODE == ST_PS_DOT3) {
+            // float zero point: this epilogue has no register to spare for per-use shift corrections, and its output is rounded to
+            // f16 anyway, so the border constant is applied to the integer sums, rounded to accumulator units (error <= half a
+            // unit = x_scale * w_scale / 2, three orders of magnitude below the f16 rounding that follows)
+            if (edge_tile) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int oy_ = cur.oy0 + wp * 4 + j, ox_ = cur.ox0 + l15;
+                    const int cls = ((((oy_ == 0) | ((oy_ == p.Hi - 1) << 1)) << 2) | ((ox_ == 0) | ((ox_ == p.Wi - 1) << 1))) & 15;
+                    if (cls) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            acc[i][j] += *reinterpret_cast<const i32x4 *>(p.delta_acc + (size_t)cls * p.Cout + cur.n0 + cw + i * 16);
+                    }
+                }
+            }
             // Up_conv5: {scale, shift} give real values; ReLU, f16 rounding (the tensor the reference's fp16 conv10 reads),
             // pixel shuffle, then the first half of conv10 as 3 dot products per pixel (conv3x3_pglds.hip, same epilogue)
             const float *s_w = reinterpret_cast<const float *>(smem + DOTW_OFF);
@@ -287,10 +314,12 @@ __global__ __launch_bounds__(512) void conv_pglds_i8_kernel(ConvI8Params p)
                 const float4 sh = *reinterpret_cast<const float4 *>(ss + 128 + cw + i * 16);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    q[i][j][0] = fminf(fmaxf(__builtin_rintf((float)acc[i][j][0] * sc.x + sh.x), -128.f), 127.f);
-                    q[i][j][1] = fminf(fmaxf(__builtin_rintf((float)acc[i][j][1] * sc.y + sh.y), -128.f), 127.f);
-                    q[i][j][2] = fminf(fmaxf(__builtin_rintf((float)acc[i][j][2] * sc.z + sh.z), -128.f), 127.f);
-                    q[i][j][3] = fminf(fmaxf(__builtin_rintf((float)acc[i][j][3] * sc.w + sh.w), -128.f), 127.f);
+                    const float4 sj = shift_of(sh, i, j);
+                    const float lo = p.lo_clamp;
+                    q[i][j][0] = fminf(fmaxf(__builtin_rintf((float)acc[i][j][0] * sc.x + sj.x), lo), 127.f);
+                    q[i][j][1] = fminf(fmaxf(__builtin_rintf((float)acc[i][j][1] * sc.y + sj.y), lo), 127.f);
+                    q[i][j][2] = fminf(fmaxf(__builtin_rintf((float)acc[i][j][2] * sc.z + sj.z), lo), 127.f);
+                    q[i][j][3] = fminf(fmaxf(__builtin_rintf((float)acc[i][j][3] * sc.w + sj.w), lo), 127.f);
                     acc[i][j] = i32x4{0, 0, 0, 0};
                 }
             }

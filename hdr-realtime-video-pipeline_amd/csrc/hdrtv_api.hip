@@ -142,7 +142,9 @@ struct ConvLayer {
     int cin = 0, cout = 0, coutPad = 0, ks = 0, stride = 1, cin_t = 0, bn = 0;
 };
 struct ConvI8Layer {                        // W8A8 HG layer on int8 MFMA
-    size_t wpk = 0, scale = 0, shift = 0, padline = 0;
+    size_t wpk = 0, scale = 0, shift = 0, padline = 0, delta = 0, delta_acc = 0;
+    bool has_delta = false;
+    float lo_clamp = -128.f;
     int cin = 0, cout = 0, cout_real = 0, ks = 0, out_f16 = 0;   // cout: padded to a multiple of 128
 };
 struct C3Layer { size_t wfrag = 0, scale = 0, shift = 0; int cout = 0; };
@@ -330,22 +332,25 @@ bool pack_conv(hdrtv_ctx *c, const Pack &pk, const std::string &key, const std::
 //     y = x_scale * w_scale[n] * (acc + (128 - k) * sum(w_int8[n])) + bias[n]      (then BatchNorm, folded)
 // and the epilogue's {scale, shift} map acc straight to the OUTPUT tensor's codes (out_scale, out_k) or, out_scale == 0,
 // to real units for an fp16 consumer.
-struct ActQ { float scale = 0.f; int k = 0; };
+// activation quantiser of a W8A8 HG layer: value = scale * (q - kf), q the reference's u8 code, kf = -x_zero / x_scale.  An integer
+// kf in 0..255 (k) is an exact code for 0.0: padding is then a constant line of that code and the whole layer is integer-exact;
+// any other zero point (e.g. calibrate_w8a8's x_zero = running minimum) pads with code 128 (a zero in the centred sum) and
+// corrects the pixels on the image border with a per-class constant (ConvI8Params.delta).
+struct ActQ { float scale = 0.f; double kf = 0.0; int k = 0; bool integer = true; };
 bool read_actq(hdrtv_ctx *c, const Pack &pk, const std::string &layer, ActQ &q)
 {
     std::vector<float> xs, xz;
     if (!pk.get(layer + ".x_scale", 1, xs, c->err) || !pk.get(layer + ".x_zero", 1, xz, c->err)) return false;
-    const double k = -(double)xz[0] / (double)xs[0];
-    if (!(xs[0] > 0.f) || std::fabs(k - std::nearbyint(k)) > 1e-3 || k < -0.5 || k > 255.5) {
-        c->err = "W8A8 HG layer " + layer + ": the int8 path needs x_zero = -k * x_scale with an integer k in 0..255";
-        return false;
-    }
+    if (!(xs[0] > 0.f) || !std::isfinite(xs[0]) || !std::isfinite(xz[0])) { c->err = "W8A8 HG layer " + layer + ": bad x_scale / x_zero"; return false; }
     q.scale = xs[0];
-    q.k = (int)std::nearbyint(k);
+    q.kf = -(double)xz[0] / (double)xs[0];
+    q.k = (int)std::nearbyint(q.kf);
+    q.integer = std::fabs(q.kf - q.k) <= 1e-3 && q.k >= 0 && q.k <= 255;
+    if (q.integer) q.kf = q.k;
     return true;
 }
 bool pack_conv_i8(hdrtv_ctx *c, const Pack &pk, const std::string &key, const std::string &wname, int co, int ci, int ks,
-                  const std::string &bn_name, int ps_cps, const ActQ &out)
+                  const std::string &bn_name, int ps_cps, const ActQ &out, bool relu)
 {
     std::vector<int8_t> w;
     std::vector<float> ws, b;
@@ -365,14 +370,19 @@ bool pack_conv_i8(hdrtv_ctx *c, const Pack &pk, const std::string &key, const st
     }
     const int nch = c64 ? 1 : ci / 128, taps = ks * ks;
     std::vector<int8_t> wp((size_t)(c64 ? 6 : taps) * nch * coP * 128, (int8_t)0);
-    std::vector<float> scale(coP, 0.f), shift(coP, 0.f);
+    std::vector<float> scale(coP, 0.f), shift(coP, 0.f), delta;
+    std::vector<int> delta_acc;
+    const bool need_delta = !in.integer && ks == 3;
+    if (need_delta) { delta.assign((size_t)16 * coP, 0.f); delta_acc.assign((size_t)16 * coP, 0); }
     for (int np = 0; np < co; ++np) {
         const int n = ps_cps > 0 ? 4 * (np % ps_cps) + np / ps_cps : np;
         long wsum = 0;
+        long tsum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int k = 0; k < ci; ++k)
             for (int tap = 0; tap < taps; ++tap) {
                 const int8_t v = w[((size_t)n * ci + k) * taps + tap];
                 wsum += v;
+                tsum[tap] += v;
                 if (c64) {      // row-tap (ky, 0) = [w(ky,0) | w(ky,1)], row-tap (ky, 2) = [w(ky,2) | 0]
                     const int ky = tap / 3, kx = tap % 3;
                     wp[((size_t)(ky * 2 + (kx == 2)) * coP + np) * 128 + (kx == 1 ? 64 : 0) + k] = v;
@@ -381,21 +391,40 @@ bool pack_conv_i8(hdrtv_ctx *c, const Pack &pk, const std::string &key, const st
                 }
             }
         const double a = (double)in.scale * (double)ws[n];
-        double sc = a, sh = a * (double)(128 - in.k) * (double)wsum + (double)b[n];
+        double sc = a, sh = a * (128.0 - in.kf) * (double)wsum + (double)b[n], gs = 1.0;
         if (has_bn) {
-            const double gs = (double)g[n] / std::sqrt((double)var[n] + 1e-5);
+            gs = (double)g[n] / std::sqrt((double)var[n] + 1e-5);
             sc *= gs;
             sh = (sh - (double)mu[n]) * gs + (double)be[n];
         }
         if (out.scale > 0.f) {      // to the codes (q - 128) of the consumer's quantiser
             sc /= (double)out.scale;
-            sh = sh / (double)out.scale + (double)out.k - 128.0;
+            sh = sh / (double)out.scale + out.kf - 128.0;
+            gs /= (double)out.scale;
         }
         scale[np] = (float)sc;
         shift[np] = (float)sh;
+        if (need_delta)             // padded taps hold code 0 = value scale * (128 - kf), not 0.0: take their share back out
+            for (int cls = 1; cls < 16; ++cls) {
+                const int cy = cls >> 2, cx = cls & 3;
+                long miss = 0;
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int ky = tap / 3, kx = tap % 3;
+                    if ((ky == 0 && (cy & 1)) || (ky == 2 && (cy & 2)) || (kx == 0 && (cx & 1)) || (kx == 2 && (cx & 2))) miss += tsum[tap];
+                }
+                delta[(size_t)cls * coP + np] = (float)(-a * (128.0 - in.kf) * (double)miss * gs);
+                delta_acc[(size_t)cls * coP + np] = (int)std::nearbyint(-(128.0 - in.kf) * (double)miss);
+            }
     }
-    std::vector<int8_t> pad(128, (int8_t)(in.k - 128));
+    std::vector<int8_t> pad(128, (int8_t)(in.integer ? in.k - 128 : 0));
     ConvI8Layer L;
+    if (need_delta) {
+        L.delta = c->wts.put(delta.data(), delta.size() * 4);
+        L.delta_acc = c->wts.put(delta_acc.data(), delta_acc.size() * 4);
+        L.has_delta = true;
+    }
+    // behind a ReLU the smallest value is 0.0, whose code is above the bottom of the range when the reader's x_zero < 0
+    if (relu && out.scale > 0.f) L.lo_clamp = (float)(std::min(255.0, std::max(0.0, std::nearbyint(out.kf))) - 128.0);
     L.cin = ci; L.cout = coP; L.cout_real = co; L.ks = ks; L.out_f16 = out.scale > 0.f ? 0 : 1;
     L.wpk = c->wts.put(wp.data(), wp.size());
     L.scale = c->wts.put(scale.data(), scale.size() * 4);
@@ -1038,21 +1067,19 @@ bool build_weights(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
                 if (L.shares) {
                     ActQ o2;
                     if (!read_actq(c, *hg, L.shares, o2)) return false;
-                    if (o2.scale != out.scale || o2.k != out.k) {
+                    if (o2.scale != out.scale || o2.kf != out.kf) {
                         c->err = std::string("W8A8 HG: ") + L.consumer + " and " + L.shares + " read one tensor and must share x_scale / x_zero";
                         return false;
                     }
                 }
-                const bool relu = L.ks == 3;       // conv blocks and Up blocks end in ReLU: their output codes start at k = 0
-                if (relu && L.consumer && out.k != 0) { c->err = std::string("W8A8 HG: post-ReLU tensor in front of ") + L.consumer + " needs x_zero = 0"; return false; }
+                const bool relu = L.ks == 3;       // conv blocks and Up blocks end in ReLU
                 const std::string wname = L.ks == 3 ? std::string(L.name) + ".0" : std::string(L.name);
-                if (!pack_conv_i8(c, *hg, std::string("hg.") + L.name, wname, L.co, L.ci, L.ks, L.bn, L.ps, out)) return false;
+                if (!pack_conv_i8(c, *hg, std::string("hg.") + L.name, wname, L.co, L.ci, L.ks, L.bn, L.ps, out, relu)) return false;
             }
             ActQ q0;                       // the fp16 -> int8 boundary: conv1's pooled output, read by conv2
             if (!read_actq(c, *hg, "conv2.0", q0)) return false;
-            if (q0.k != 0) { c->err = "W8A8 HG: post-ReLU tensor in front of conv2.0 needs x_zero = 0"; return false; }
             c->hg_q0_inv = 1.f / q0.scale;
-            c->hg_q0_zero = (float)(q0.k - 128);
+            c->hg_q0_zero = (float)(q0.kf - 128.0);
         }
         if (!put_f32(c, *hg, "hg.w10", "conv10.weight", 3 * 128) || !put_f32(c, *hg, "hg.b10", "conv10.bias", 3) ||
             !put_f32(c, *hg, "hg.wl", "conv_last.weight", 18) || !put_f32(c, *hg, "hg.bl", "conv_last.bias", 3))
@@ -1367,6 +1394,9 @@ struct Seq {
         p.wpk = wtp<int8_t>(c, L.wpk); p.scale = wtp<float>(c, L.scale); p.shift = wtp<float>(c, L.shift);
         p.Cout = L.cout; p.mode = mode; p.out_f16 = L.out_f16; p.dst = dst; p.dstC = dstC; p.Hd = Hd; p.Wd = Wd;
         p.padline = wtp<int8_t>(c, L.padline);
+        p.delta = L.has_delta ? wtp<float>(c, L.delta) : nullptr;
+        p.delta_acc = L.has_delta ? wtp<int>(c, L.delta_acc) : nullptr;
+        p.lo_clamp = L.lo_clamp;
         p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
         p.dotw = dotw; p.dst_dot = dst_dot;
         char tag[64];

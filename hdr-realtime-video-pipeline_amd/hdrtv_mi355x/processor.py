@@ -132,6 +132,9 @@ class HDRTVNetMI355X:
                 hg_state = _W.seeded_hg_state(int(hg_weights.split(":", 1)[1]))
             elif isinstance(hg_weights, str) and hg_weights.startswith("seeded-w8a8:"):
                 hg_state = _W.seeded_hg_w8a8_state(int(hg_weights.split(":", 1)[1]))
+            elif isinstance(hg_weights, str) and hg_weights.startswith("seeded-w8a8-minmax:"):
+                # the same stand-in calibrated the reference's way (x_zero = running minimum: float zero points)
+                hg_state = _W.seeded_hg_w8a8_state(int(hg_weights.split(":", 1)[1]), integer_zero=False)
             elif hg_weights is not None:
                 hg_state = _split_composite(_load_state(hg_weights, "HG weights"))     # FileNotFoundError if missing
                 hg_state = hg_state[1] if hg_state[1] is not None else hg_state[0]

@@ -245,25 +245,31 @@ HG_W8A8_GROUPS = OrderedDict([
 ])
 
 
-def activation_qparams(lo: float, hi: float):
+def activation_qparams(lo: float, hi: float, integer_zero: bool = True):
     """Range -> (x_scale, x_zero) of the reference's asymmetric u8 activation quantiser
-    (``x_q = round((x - x_zero) / x_scale).clamp(0, 255)``) with an INTEGER zero point: x_zero = -k * x_scale,
+    (``x_q = round((x - x_zero) / x_scale).clamp(0, 255)``).  ``integer_zero`` (default): x_zero = -k * x_scale,
     k in 0..255, x_scale fp16-representable so that k * x_scale is exact in fp32.  Zero padding (applied after
-    dequantisation in the reference) is then the code k exactly, which lets an integer kernel pad with a constant."""
+    dequantisation in the reference) is then the code k exactly, which lets an integer kernel pad with a constant.
+    ``integer_zero=False``: the reference's own ``calibrate_w8a8(method="max")`` rule (hdrtvnet_torch.py:1001-1099):
+    x_zero = running minimum, x_scale = (max - min) / 255 -- a float zero point."""
+    if not integer_zero:
+        lo, hi = float(lo), float(hi)
+        s = np.float32(max(hi - lo, 1e-6) / 255.0)
+        return float(s), float(np.float32(lo))
     lo, hi = min(float(lo), 0.0), max(float(hi), 0.0)
     s = np.float32(np.float16(max(hi - lo, 1e-6) / 255.0 * 1.0005))       # never round the range down
     k = int(np.clip(np.rint(-lo / float(s)), 0, 255))
     return float(s), float(np.float32(-k) * s)
 
 
-def hg_w8a8_state(hg_state, act_ranges) -> "OrderedDict[str, np.ndarray]":
+def hg_w8a8_state(hg_state, act_ranges, integer_zero: bool = True) -> "OrderedDict[str, np.ndarray]":
     """fp HG state + ``{group: (lo, hi)}`` calibration ranges -> runtime W8A8 state in the reference's key layout
     (``<layer>.weight_int8`` int8, ``.w_scale`` per output channel, ``.bias``, ``.x_scale``, ``.x_zero``;
     W8A8Conv2d.__init__, hdrtvnet_torch.py:309-337: w_scale = max|w| / 127, round, clamp).  BatchNorm tensors and the
     fp16 layers pass through unchanged."""
     layer_q = {}
     for group, layers in HG_W8A8_GROUPS.items():
-        qp = activation_qparams(*act_ranges[group])
+        qp = activation_qparams(*act_ranges[group], integer_zero=integer_zero)
         for name in layers:
             layer_q[name] = qp
     out = OrderedDict()
@@ -283,7 +289,7 @@ def hg_w8a8_state(hg_state, act_ranges) -> "OrderedDict[str, np.ndarray]":
     return out
 
 
-def seeded_hg_w8a8_state(seed: int = 1234) -> "OrderedDict[str, np.ndarray]":
+def seeded_hg_w8a8_state(seed: int = 1234, integer_zero: bool = True) -> "OrderedDict[str, np.ndarray]":
     """The seeded HG stand-in quantised with the calibration table shipped in ``data/`` (ranges measured with the fp32
     network on the synthetic gradient frames; tests/golden/gen_golden_hg_w8a8.py writes it)."""
     import json
@@ -291,4 +297,4 @@ def seeded_hg_w8a8_state(seed: int = 1234) -> "OrderedDict[str, np.ndarray]":
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", f"hg_w8a8_calib_seed{seed}.json")
     with open(path) as f:
         ranges = {k: tuple(v) for k, v in json.load(f)["ranges"].items()}
-    return hg_w8a8_state(seeded_hg_state(seed), ranges)
+    return hg_w8a8_state(seeded_hg_state(seed), ranges, integer_zero=integer_zero)
