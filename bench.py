@@ -455,7 +455,7 @@ def main():
             "tflops_end_to_end": round(2 * macs_frame * value / world / 1e12, 1),
             "value_device_only": round(device_only, 3),
             "value_pcie_inclusive": round(pcie, 3) if pcie else None,
-            "value_is": "u8 frames resident in HBM -> pre_unpack + cond_resize + infer + post_rgb48 -> pinned host RGB48 ring (hipMemcpyAsync + hipEvent); "
+            "value_is": "u8 frames resident in HBM -> pre_fused + infer + post_rgb48 -> pinned host RGB48 ring (hipMemcpyAsync + hipEvent); "
                         "value_device_only leaves the RGB48 frame in HBM; value_pcie_inclusive also uploads each frame from pinned host memory",
             "roofline": roof,
         }

@@ -8,7 +8,8 @@ import pytest
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("name", ["r01_final_bench_default.json", "r01_int8_bench.json"])
+@pytest.mark.parametrize("name", ["r01_final_bench_default.json", "r01_int8_bench.json", "r02_bench_default.json",
+                                  "r02_bench_cpu_full_protocol.json"])
 def test_committed_bench_lines_follow_the_contract(name):
     d = json.load(open(os.path.join(REPO, "profiles", name)))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -27,6 +28,14 @@ def test_committed_bench_lines_follow_the_contract(name):
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and 0 < c["value"] < d["value"]
+    if name.startswith("r02"):          # round-2 protocol: ring-inclusive value, 1 % low, eager-CPU baseline per stage
+        assert d["one_percent_low_fps"] <= 1000.0 / d["p50_ms"] * 1.001 and d["value_device_only"] > 0 and "pinned host" in d["metric"]
+        assert c["cores"] <= c["physical_cores_available"] and c["cpu_model"] and c["backend"].startswith("PyTorch CPU eager")
+        for r in c["runs"]:
+            assert {"size", "warmup", "timed_frames", "pre_ms", "run_ms", "post_ms", "frames_per_s"} <= set(r)
+        if c["protocol"] == "full":
+            assert [(r["size"], r["warmup"], r["timed_frames"]) for r in c["runs"]] == [("960x540", 5, 20), ("1920x1080", 5, 20), ("3840x2160", 0, 2)]
+        assert d["roofline"]["traffic_source"].startswith("profiles/pmc_traffic")
 
 
 def test_bench_defaults_are_the_headline_configuration():
