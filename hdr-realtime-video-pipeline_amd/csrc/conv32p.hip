@@ -38,6 +38,7 @@
 // Out-of-image DMA lanes read the zeroed guard that the workspace keeps behind every tensor
 // (hdrtv_api.hip ws_add), so one scalar base + a 32-bit lane offset addresses every piece.
 #include <cstdlib>
+#include <type_traits>
 
 #include "launchers.h"
 
@@ -231,91 +232,122 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
             g_q[gi] = hp * 32 + ((lh ^ (hy & 1)) << 4);
         }
     }
-    // y = x*(scale+1)+shift in place on a landed halo tile (arch_util.py:68-72)
-    auto sft_tile = [&](int tt, int buf) {
+    // y = x*(scale+1)+shift in place on a landed halo tile (arch_util.py:68-72).  A wave owns one or two 32-pixel groups;
+    // with only two waves per SIMD the pass is bound by LDS and MFMA latency, not issue, so it runs in three sweeps over
+    // the wave's groups: every LDS read first (condition fragment and the four activation quads: all in flight together),
+    // then the MLPs (the second group's MFMAs fill the first's result latency), then modulate / quantise and write.
+    // Reads for pad slots stay inside the tile buffers (NG * 32 slots fit A_BYTES / C_BYTES); only the writes are masked.
+    static_assert(T::NG * 32 * 64 <= A_BYTES && T::NG * 32 * 32 <= C_BYTES, "pad-slot reads stay inside the halo buffers");
+    auto sft_groups = [&](auto ngc, int tt, int buf) __attribute__((always_inline)) {
+        constexpr int N = decltype(ngc)::value;
         const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
         const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
         char *a = sA + buf * A_BYTES;
         const char *cbuf = sC + buf * C_BYTES;
+        bool inimg[N];
+        f16x4 yv[N][4];
+        f16x8 c0[N], c1[N];
+        f32x16 sc[N], sh[N];
 #pragma unroll
-        for (int gi = 0; gi < T::G_PW; ++gi) {
-            if (wave + gi * NW < T::NG) {                      // wave-uniform
-                const bool inimg = g_pos[gi] >= 0 && (unsigned)(iy0 + (g_pos[gi] & 255)) < uH &&
-                                   (unsigned)(ix0 + (g_pos[gi] >> 8)) < uW;
-                f32x16 sc, sh;
-                if constexpr (SQ) {
-                    // W8A8 SFT convs (arch_util.py:60-72 with W8A8Conv2d layers): both first layers read the condition pixel
-                    // through their own quantiser -> one K = 32 MFMA whose lanes 0..31 carry the scale branch's codes of
-                    // all 16 channels and lanes 32..63 the shift branch's (weights block-diagonal); hidden rows 0..15 /
-                    // 16..31 are dequantised, LeakyReLU'd and re-quantised for the second layers in registers.
-                    const char *crow = cbuf + g_c[gi] - lh * 16;
-                    const f16x8 c0 = *reinterpret_cast<const f16x8 *>(crow), c1 = *reinterpret_cast<const f16x8 *>(crow + 16);
-                    i32x4 cb;
-                    cb[0] = (int)quant4((float)c0[0], (float)c0[1], (float)c0[2], (float)c0[3], cq_inv, cq_zoff);
-                    cb[1] = (int)quant4((float)c0[4], (float)c0[5], (float)c0[6], (float)c0[7], cq_inv, cq_zoff);
-                    cb[2] = (int)quant4((float)c1[0], (float)c1[1], (float)c1[2], (float)c1[3], cq_inv, cq_zoff);
-                    cb[3] = (int)quant4((float)c1[4], (float)c1[5], (float)c1[6], (float)c1[7], cq_inv, cq_zoff);
-                    i32x16 z16;
+        for (int gi = 0; gi < N; ++gi) {
+            inimg[gi] = g_pos[gi] >= 0 && (unsigned)(iy0 + (g_pos[gi] & 255)) < uH && (unsigned)(ix0 + (g_pos[gi] >> 8)) < uW;
+            if constexpr (SQ) {
+                const char *crow = cbuf + g_c[gi] - lh * 16;
+                c0[gi] = *reinterpret_cast<const f16x8 *>(crow);
+                c1[gi] = *reinterpret_cast<const f16x8 *>(crow + 16);
+            } else if constexpr (SFT) {
+                c0[gi] = *reinterpret_cast<const f16x8 *>(cbuf + g_c[gi]);
+            }
+        }
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) z16[k] = 0;
-                    const i32x16 hacc = __builtin_amdgcn_mfma_i32_32x32x32_i8(qa0, cb, z16, 0, 0, 0);
-                    const float *K = sK + lh * 16;             // [set][lh][16]: hidden scale', shift'; scale-out scale, shift; shift-out scale, shift
-                    float t[16];
+        for (int gi = 0; gi < N; ++gi) {           // behind the condition reads: the first MFMA waits for those only
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float4 ka = *reinterpret_cast<const float4 *>(K + 4 * g), kb = *reinterpret_cast<const float4 *>(K + 32 + 4 * g);
-                        const float zo = p.sq_hzoff[g >> 1];
-                        const float u0 = (float)hacc[4 * g + 0] * ka.x + kb.x, u1 = (float)hacc[4 * g + 1] * ka.y + kb.y,
-                                    u2 = (float)hacc[4 * g + 2] * ka.z + kb.z, u3 = (float)hacc[4 * g + 3] * ka.w + kb.w;
-                        t[4 * g + 0] = fmaxf(u0, 0.1f * u0) + zo; t[4 * g + 1] = fmaxf(u1, 0.1f * u1) + zo;
-                        t[4 * g + 2] = fmaxf(u2, 0.1f * u2) + zo; t[4 * g + 3] = fmaxf(u3, 0.1f * u3) + zo;
-                    }
-                    i32x4 hs = {0, 0, 0, 0}, ht = {0, 0, 0, 0};
-                    hs[0] = (int)quant4(t[0], t[1], t[2], t[3], 1.f, 0.f);   hs[1] = (int)quant4(t[4], t[5], t[6], t[7], 1.f, 0.f);
-                    ht[0] = (int)quant4(t[8], t[9], t[10], t[11], 1.f, 0.f); ht[1] = (int)quant4(t[12], t[13], t[14], t[15], 1.f, 0.f);
-                    const i32x16 a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(qa1s, hs, z16, 0, 0, 0);
-                    const i32x16 a2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(qa1t, ht, z16, 0, 0, 0);
+            for (int qd = 0; qd < 4; ++qd) yv[gi][qd] = *reinterpret_cast<const f16x4 *>(a + (g_x[gi] ^ (qd << 4)));
+        }
+        __builtin_amdgcn_sched_barrier(0);         // keep every read above the MLPs (hipcc otherwise sinks group 1's to its MFMA)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float4 k2 = *reinterpret_cast<const float4 *>(K + 64 + 4 * g), k3 = *reinterpret_cast<const float4 *>(K + 96 + 4 * g);
-                        const float4 k4 = *reinterpret_cast<const float4 *>(K + 128 + 4 * g), k5 = *reinterpret_cast<const float4 *>(K + 160 + 4 * g);
-                        sc[4 * g + 0] = (float)a1[4 * g + 0] * k2.x + k3.x; sc[4 * g + 1] = (float)a1[4 * g + 1] * k2.y + k3.y;
-                        sc[4 * g + 2] = (float)a1[4 * g + 2] * k2.z + k3.z; sc[4 * g + 3] = (float)a1[4 * g + 3] * k2.w + k3.w;
-                        sh[4 * g + 0] = (float)a2[4 * g + 0] * k4.x + k5.x; sh[4 * g + 1] = (float)a2[4 * g + 1] * k4.y + k5.y;
-                        sh[4 * g + 2] = (float)a2[4 * g + 2] * k4.z + k5.z; sh[4 * g + 3] = (float)a2[4 * g + 3] * k4.w + k5.w;
-                    }
-                } else if constexpr (SFT) {
-                    const f16x8 cf = *reinterpret_cast<const f16x8 *>(cbuf + g_c[gi]);
-                    const f32x16 h = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa0, cf, sbh, 0, 0, 0);
-                    const f16x8 hs = lrelu_pack16(h, 0), ht = lrelu_pack16(h, 1);
-                    sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa1s, hs, sbs, 0, 0, 0);
-                    sh = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa1t, ht, sbt, 0, 0, 0);
+        for (int gi = 0; gi < N; ++gi) {
+            if constexpr (SQ) {
+                // W8A8 SFT convs (arch_util.py:60-72 with W8A8Conv2d layers): both first layers read the condition pixel
+                // through their own quantiser -> one K = 32 MFMA whose lanes 0..31 carry the scale branch's codes of
+                // all 16 channels and lanes 32..63 the shift branch's (weights block-diagonal); hidden rows 0..15 /
+                // 16..31 are dequantised, LeakyReLU'd and re-quantised for the second layers in registers.
+                i32x4 cb;
+                cb[0] = (int)quant4((float)c0[gi][0], (float)c0[gi][1], (float)c0[gi][2], (float)c0[gi][3], cq_inv, cq_zoff);
+                cb[1] = (int)quant4((float)c0[gi][4], (float)c0[gi][5], (float)c0[gi][6], (float)c0[gi][7], cq_inv, cq_zoff);
+                cb[2] = (int)quant4((float)c1[gi][0], (float)c1[gi][1], (float)c1[gi][2], (float)c1[gi][3], cq_inv, cq_zoff);
+                cb[3] = (int)quant4((float)c1[gi][4], (float)c1[gi][5], (float)c1[gi][6], (float)c1[gi][7], cq_inv, cq_zoff);
+                i32x16 z16;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) z16[k] = 0;
+                const i32x16 hacc = __builtin_amdgcn_mfma_i32_32x32x32_i8(qa0, cb, z16, 0, 0, 0);
+                const float *K = sK + lh * 16;             // [set][lh][16]: hidden scale', shift'; scale-out scale, shift; shift-out scale, shift
+                float t[16];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 ka = *reinterpret_cast<const float4 *>(K + 4 * g), kb = *reinterpret_cast<const float4 *>(K + 32 + 4 * g);
+                    const float zo = p.sq_hzoff[g >> 1];
+                    const float u0 = (float)hacc[4 * g + 0] * ka.x + kb.x, u1 = (float)hacc[4 * g + 1] * ka.y + kb.y,
+                                u2 = (float)hacc[4 * g + 2] * ka.z + kb.z, u3 = (float)hacc[4 * g + 3] * ka.w + kb.w;
+                    t[4 * g + 0] = fmaxf(u0, 0.1f * u0) + zo; t[4 * g + 1] = fmaxf(u1, 0.1f * u1) + zo;
+                    t[4 * g + 2] = fmaxf(u2, 0.1f * u2) + zo; t[4 * g + 3] = fmaxf(u3, 0.1f * u3) + zo;
                 }
-                if (g_pos[gi] >= 0) {
-                    i32x4 codes;
+                i32x4 hs = {0, 0, 0, 0}, ht = {0, 0, 0, 0};
+                hs[0] = (int)quant4(t[0], t[1], t[2], t[3], 1.f, 0.f);   hs[1] = (int)quant4(t[4], t[5], t[6], t[7], 1.f, 0.f);
+                ht[0] = (int)quant4(t[8], t[9], t[10], t[11], 1.f, 0.f); ht[1] = (int)quant4(t[12], t[13], t[14], t[15], 1.f, 0.f);
+                const i32x16 a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(qa1s, hs, z16, 0, 0, 0);
+                const i32x16 a2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(qa1t, ht, z16, 0, 0, 0);
 #pragma unroll
-                    for (int qd = 0; qd < 4; ++qd) {
-                        char *addr = a + (g_x[gi] ^ (qd << 4));
-                        f16x4 y = *reinterpret_cast<const f16x4 *>(addr);
-                        if constexpr (SFT) {
-                            f16x4 s1, s0;
+                for (int g = 0; g < 4; ++g) {
+                    const float4 k2 = *reinterpret_cast<const float4 *>(K + 64 + 4 * g), k3 = *reinterpret_cast<const float4 *>(K + 96 + 4 * g);
+                    const float4 k4 = *reinterpret_cast<const float4 *>(K + 128 + 4 * g), k5 = *reinterpret_cast<const float4 *>(K + 160 + 4 * g);
+                    sc[gi][4 * g + 0] = (float)a1[4 * g + 0] * k2.x + k3.x; sc[gi][4 * g + 1] = (float)a1[4 * g + 1] * k2.y + k3.y;
+                    sc[gi][4 * g + 2] = (float)a1[4 * g + 2] * k2.z + k3.z; sc[gi][4 * g + 3] = (float)a1[4 * g + 3] * k2.w + k3.w;
+                    sh[gi][4 * g + 0] = (float)a2[4 * g + 0] * k4.x + k5.x; sh[gi][4 * g + 1] = (float)a2[4 * g + 1] * k4.y + k5.y;
+                    sh[gi][4 * g + 2] = (float)a2[4 * g + 2] * k4.z + k5.z; sh[gi][4 * g + 3] = (float)a2[4 * g + 3] * k4.w + k5.w;
+                }
+            } else if constexpr (SFT) {
+                const f32x16 h = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa0, c0[gi], sbh, 0, 0, 0);
+                const f16x8 hs = lrelu_pack16(h, 0), ht = lrelu_pack16(h, 1);
+                sc[gi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa1s, hs, sbs, 0, 0, 0);
+                sh[gi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa1t, ht, sbt, 0, 0, 0);
+            }
+        }
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) { s1[k] = (f16)sc[4 * qd + k]; s0[k] = (f16)sh[4 * qd + k]; }
-                            y = y * s1 + s0;
-                        }
-                        if constexpr (I8) {
-                            // u8 code q = clamp(rint((y - x_zero) / x_scale), 0, 255) as one FMA + rint + saturating pack
-                            const unsigned w = quant4((float)y[0], (float)y[1], (float)y[2], (float)y[3], p.q_inv, p.q_zoff);
-                            codes[qd] = inimg ? (int)w : 0;
-                        } else {
-                            if (!inimg) { y[0] = (f16)0.f; y[1] = (f16)0.f; y[2] = (f16)0.f; y[3] = (f16)0.f; }
-                            *reinterpret_cast<f16x4 *>(addr) = y;
-                        }
-                    }
-                    if constexpr (I8) *reinterpret_cast<i32x4 *>(sQ + buf * L::Q_BYTES + g_q[gi]) = codes;
+        for (int gi = 0; gi < N; ++gi) {
+            i32x4 codes;
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                f16x4 y = yv[gi][qd];
+                if constexpr (SFT) {
+                    f16x4 s1, s0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { s1[k] = (f16)sc[gi][4 * qd + k]; s0[k] = (f16)sh[gi][4 * qd + k]; }
+                    y = y * s1 + s0;
+                }
+                if constexpr (I8) {
+                    // u8 code q = clamp(rint((y - x_zero) / x_scale), 0, 255) as one FMA + rint + saturating pack
+                    const unsigned w = quant4((float)y[0], (float)y[1], (float)y[2], (float)y[3], p.q_inv, p.q_zoff);
+                    codes[qd] = inimg[gi] ? (int)w : 0;
+                } else {
+                    if (!inimg[gi]) { y[0] = (f16)0.f; y[1] = (f16)0.f; y[2] = (f16)0.f; y[3] = (f16)0.f; }
+                    yv[gi][qd] = y;
+                }
+            }
+            if (g_pos[gi] >= 0) {
+                if constexpr (I8) {
+                    *reinterpret_cast<i32x4 *>(sQ + buf * L::Q_BYTES + g_q[gi]) = codes;
+                } else {
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) *reinterpret_cast<f16x4 *>(a + (g_x[gi] ^ (qd << 4))) = yv[gi][qd];
                 }
             }
         }
+    };
+    auto sft_tile = [&](int tt, int buf) __attribute__((always_inline)) {
+        static_assert(T::G_PW == 2, "a wave owns one or two groups");
+        if (wave + NW < T::NG) sft_groups(std::integral_constant<int, 2>{}, tt, buf);      // wave-uniform
+        else if (wave < T::NG) sft_groups(std::integral_constant<int, 1>{}, tt, buf);
     };
 
     // ---- prologue: tile 0 landed (and SFT-transformed), tile 1 in flight
@@ -479,9 +511,12 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
                 o[3] = (f16)act_fast(acc[4 * qd + 3] * sc.w + sh.w, aslope);
                 *reinterpret_cast<f16x4 *>(sO + q * OUT_ROWB + cl * 2) = o;
             }
-            // the last pass also makes sure the next tile's LDS-DMA has landed before the barrier
             STAMP(2);  // staging write
-            if (pass == NPASS - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // The first pass makes sure the next tile's LDS-DMA and this tile's residual prefetches have landed (vmcnt counts
+            // in order and the DMA is the older one, so waiting for the residuals waits for it anyway).  The builtin, not
+            // inline asm: hipcc's waitcnt pass then KNOWS nothing is pending and puts no vmcnt wait into any store phase --
+            // where a vmcnt(0) in front of the second chunk would also wait for the first chunk's store to complete.
+            if (pass == 0) __builtin_amdgcn_s_waitcnt(0x0f70);               // vmcnt(0), expcnt / lgkmcnt untouched
             STAMP(3);  // wait for DMA(t+1) / outstanding memory ops
             __syncthreads();
             STAMP(4);  // barrier 1
@@ -496,17 +531,17 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
                     }
                 }
             } else {
+                // both staging chunks first (one LDS latency, not two), then the adds and the stores
+                f16x8 v[2];
+#pragma unroll
+                for (int it = 0; it < 2; ++it) v[it] = *reinterpret_cast<const f16x8 *>(sO + ((tid + it * NT) >> 2) * OUT_ROWB + c8 * 16);
 #pragma unroll
                 for (int it = 0; it < 2; ++it) {
-                    if (ooff[pass][it] >= 0) {
-                        const int qq = (tid + it * NT) >> 2;
-                        f16x8 v = *reinterpret_cast<const f16x8 *>(sO + qq * OUT_ROWB + c8 * 16);
-                        // residual adds in packed f16, one rounding per add as the reference's fp16 model does
-                        // (x + conv2(..) then + skip, arch_util.py:95, HDRUNet3T1_arch.py:186-198); 6 VALU per 8
-                        // values instead of ~40 through fp32 -- this kernel is instruction-issue-bound
-                        v = (v + rs1[pass][it]) + rs2[pass][it];
-                        *reinterpret_cast<f16x8 *>(p.dst + ooff[pass][it]) = v;
-                    }
+                    // residual adds in packed f16, one rounding per add as the reference's fp16 model does
+                    // (x + conv2(..) then + skip, arch_util.py:95, HDRUNet3T1_arch.py:186-198); 6 VALU per 8
+                    // values instead of ~40 through fp32 -- this kernel is instruction-issue-bound
+                    v[it] = (v[it] + rs1[pass][it]) + rs2[pass][it];
+                    if (ooff[pass][it] >= 0) *reinterpret_cast<f16x8 *>(p.dst + ooff[pass][it]) = v[it];
                 }
             }
             if (pass < NPASS - 1) __syncthreads();      // staging tile is reused by the next pass
