@@ -126,7 +126,8 @@ struct Conv32Params {
     f16 *dst_planar;
     const f16 *res_planar;
     const f16 *zeros;
-    f16 *dump;             // >= 8 KiB scratch that masked-off lanes store to (keeps store counts exact)
+    f16 *dump;             // diagnostic builds (make STAMP=1): per-phase cycle sums
+    char *trash;           // conv32s: >= 8 KiB write-only scratch that masked-off lanes store to (keeps store counts exact)
     int tiles_x, tiles_y;
     // W8A8 layer (wpk8 != nullptr): int8 weights [9][CoutPad][32] with the K axis in code-tile order
     // (byte 16h + 4qd + k = input channel 8qd + 4h + k), scale[CoutPad], shift[16 border classes][CoutPad], and the

@@ -408,3 +408,38 @@ def test_uhd_le_vs_oracle(proc_hr, hr_state):
     assert mx <= OUT_MAX and mean <= OUT_MEAN
     mx, _ = _stats("agcm 2160x3840", agcm.float().cpu().numpy()[0], ragcm)
     assert mx <= AGCM_MAX
+
+
+@pytest.mark.parametrize("variant", ["fp16", "int8-full", "int8-mixed"])
+def test_one_barrier_conv32_schedule_is_bit_identical(torch_cuda, golden_dir, monkeypatch, variant):
+    """conv32s.hip (one barrier per tile, wave-private epilogue, counted vmcnt waits) against conv32p.hip's single-pass
+    kernels it replaces (HDRTV_CONV32_OLD=1): same tiles, same per-element arithmetic, so the LE output and every
+    intermediate must agree bit for bit -- at 4K (126 tiles per workgroup: the steady state of the three-buffer
+    pipeline), at 1080p and at sizes with ragged right / bottom tiles (masked lanes store to the trash line)."""
+    from hdrtv_mi355x import weights as W
+    from hdrtv_mi355x.processor import HDRTVNetMI355X
+    torch = torch_cuda
+    if variant == "fp16":
+        p = HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), use_hg=False, warmup_passes=0)
+    else:
+        tag = variant.split("-")[1]
+        p = HDRTVNetMI355X(os.path.join(golden_dir, f"hr_int8_{tag}_qat.hdrw"), precision=variant, predequantize="off",
+                           use_hg=False, warmup_passes=0)
+    taps = ("le.fea0", "le.fea1", "le.fea3", "le.up1", "le.up3", "le.out")
+    try:
+        for (h, w), seed in (((2160, 3840), 41), ((1080, 1920), 42), ((270, 486), 43), ((61, 103), 44)):
+            f = W.synthetic_frame(h, w, seed=seed, kind="gradient" if seed % 2 else "noise")
+            res = []
+            for old in ("1", None):
+                if old:
+                    monkeypatch.setenv("HDRTV_CONV32_OLD", old)
+                else:
+                    monkeypatch.delenv("HDRTV_CONV32_OLD", raising=False)
+                out, _ = p.infer(p.preprocess(f))
+                res.append([out.clone()] + [p.tap(t).clone() for t in taps])
+            for name, a, b in zip(("out",) + taps, res[0], res[1]):
+                assert torch.isfinite(a).all(), (h, w, name)
+                assert torch.equal(a, b), (h, w, name)
+    finally:
+        monkeypatch.delenv("HDRTV_CONV32_OLD", raising=False)
+        p.close()

@@ -92,3 +92,43 @@ def test_conv32p_asm_loads_are_read_only_after_the_wait(tmp_path):
                     break
             checked += 1
     assert checked >= 2
+
+
+def test_conv32s_counted_waits(tmp_path):
+    """conv32s.hip (one barrier per tile) waits for the next tile's LDS-DMA by COUNT: per tile and wave it issues exactly
+    NPIECES global_load_lds and then, on each of the two phase orders, NSTORE global stores, and the loop's closing wait is
+    vmcnt(NSTORE).  hipcc's own vmcnt(0) (residuals, first nameable LDS read with a DMA in flight) must sit in the epilogue,
+    behind every MFMA of the tile -- in the MFMA or SFT phase it would stall the wave on the DMA it has just issued."""
+    kernels = _asm("conv32s.hip", tmp_path)
+    seen = 0
+    for name, body in kernels.items():
+        m = re.search(r"conv32s_kernelILb(\d)ELb(\d)ELb(\d)ELb(\d)E", name)
+        if not m:
+            continue
+        sft, i8, sq, planar = (int(v) for v in m.groups())
+        npieces, nstore = 6 + (3 if sft else 0), 3 if planar else 2      # DMA pieces of an issuing wave (0-3); stores of every wave
+        assert "scratch_" not in body, name
+        lines = [ln for ln in body.split("\n") if ln.strip() and not ln.strip().startswith(";")]
+        # the steady-state loop = the basic blocks hipcc labels as belonging to the loop that holds the barrier
+        groups, cur = {}, None
+        for ln in lines:
+            lm = re.match(r"\.L(BB\d+_\d+):", ln)
+            if lm:
+                hm = re.search(r"Header=(BB\d+_\d+)", ln)
+                cur = hm.group(1) if hm else (lm.group(1) if "Loop Header" in ln else None)
+            if cur:
+                groups.setdefault(cur, []).append(ln)
+        main = [g for g in groups.values() if any(re.match(r"\s*s_barrier", ln) for ln in g)]
+        assert len(main) == 1, (name, len(main))
+        loop = main[0]
+        assert len([ln for ln in loop if "global_load_lds_dwordx4" in ln]) == npieces, name
+        # NSTORE per phase order; the epilogue is shared by both orders
+        nst = len([ln for ln in loop if re.match(r"\s*global_store", ln)])
+        assert nst == nstore, (name, nst)
+        bar = max(i for i, ln in enumerate(loop) if re.match(r"\s*s_barrier", ln))
+        assert re.search(rf"s_waitcnt vmcnt\({nstore}\) lgkmcnt\(0\)", loop[bar - 1]), (name, loop[bar - 1])
+        w0 = [i for i, ln in enumerate(loop) if re.search(r"s_waitcnt vmcnt\(0\)", ln)]
+        assert len(w0) == 1 and w0[0] < bar, (name, w0)
+        assert not any("v_mfma" in ln for ln in loop[w0[0]:bar]), name
+        seen += 1
+    assert seen == 7

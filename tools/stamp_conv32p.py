@@ -34,10 +34,14 @@ buf = torch.empty(cc.value, dtype=torch.float32, device="cuda")
 from hdrtv_mi355x.processor import _hip_memcpy_d2d
 _hip_memcpy_d2d(buf.data_ptr(), ptr.value, cc.value * 4); torch.cuda.synchronize()
 st = buf.cpu().numpy().view(np.uint64).reshape(-1, 8).astype(np.float64)
-st = st[st.sum(1) > 0]
-names = ["0 offsets+resid", "1 conv MFMA", "2 staging write", "3 wait vmcnt", "4 barrier1", "5 DMA issue+stores", "6 SFT(t+1)", "7 barrier2+loop"]
-tot = st.sum(1).mean()
-print(f"waves sampled {len(st)}, mean cycles per wave {tot:.0f}")
-for i, n in enumerate(names):
-    print(f"  {n:22s} {st[:, i].mean():12.0f}  {100 * st[:, i].mean() / tot:5.1f} %   (min {st[:, i].min():.0f} max {st[:, i].max():.0f})")
+if os.environ.get("HDRTV_CONV32_OLD"):
+    names = ["0 offsets+resid", "1 conv MFMA", "2 staging write", "3 wait vmcnt", "4 barrier1", "5 DMA issue+stores", "6 SFT(t+1)", "7 barrier2+loop"]
+else:       # conv32s.hip
+    names = ["0 addr+resid+DMA issue", "1 conv MFMA", "2 SFT(t+1)", "3 epilogue+vmcnt(0)", "4 closing wait", "5 barrier", "6 -", "7 loop"]
+for sel, rows in (("all waves", st), ("waves 0-3 (MFMA first)", st.reshape(-1, 8, 8)[:, :4].reshape(-1, 8) if len(st) % 8 == 0 else st),
+                  ("waves 4-7 (SFT first)", st.reshape(-1, 8, 8)[:, 4:].reshape(-1, 8) if len(st) % 8 == 0 else st)):
+    tot = rows.sum(1).mean()
+    print(f"{sel}: sampled {len(rows)}, mean cycles per wave {tot:.0f}")
+    for i, n in enumerate(names):
+        print(f"  {n:24s} {rows[:, i].mean():12.0f}  {100 * rows[:, i].mean() / tot:5.1f} %   (min {rows[:, i].min():.0f} max {rows[:, i].max():.0f})")
 p.close()
