@@ -703,7 +703,15 @@ bool read_fakeq(hdrtv_ctx *c, const Pack &pk, const std::string &layer, FakeQ &f
     return true;
 }
 
-// 3x3 conv from 3 planar channels: A fragments [MT][2][64 lanes][8], k = (ky*3+kx)*3 + c (27 of 32 used)
+// A-fragment element of the 3-channel 3x3 convs (le_hg_misc.hip): k-step ky, lane half lh, slot j = pixel kx = 2 lh + j / 4,
+// channel j % 4; the 4th pixel and the 4th channel are padding
+static inline float c3_welem(const std::vector<float> &w, int m, int ky, int lh, int j)
+{
+    const int kx = 2 * lh + (j >> 2), ch = j & 3;
+    return (kx < 3 && ch < 3) ? w[((size_t)m * 3 + ch) * 9 + ky * 3 + kx] : 0.f;
+}
+
+// 3x3 conv from 3 planar channels: A fragments [MT][3 kernel rows][64 lanes][8]
 bool pack_c3(hdrtv_ctx *c, const Pack &pk, const std::string &key, const std::string &wname, int co, const std::string &bn_name)
 {
     std::vector<float> w, b;
@@ -722,17 +730,12 @@ bool pack_c3(hdrtv_ctx *c, const Pack &pk, const std::string &key, const std::st
         } else shift[n] = b[n];
     }
     const int mt = co / 32;
-    std::vector<f16> fr((size_t)mt * 2 * 64 * 8, (f16)0.f);
+    std::vector<f16> fr((size_t)mt * 3 * 64 * 8, (f16)0.f);
     for (int i = 0; i < mt; ++i)
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ky = 0; ky < 3; ++ky)
             for (int lane = 0; lane < 64; ++lane)
-                for (int j = 0; j < 8; ++j) {
-                    const int m = i * 32 + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
-                    if (k < 27) {
-                        const int tap = k / 3, ch = k % 3;
-                        fr[(((size_t)i * 2 + ks) * 64 + lane) * 8 + j] = (f16)w[((size_t)m * 3 + ch) * 9 + tap];
-                    }
-                }
+                for (int j = 0; j < 8; ++j)
+                    fr[(((size_t)i * 3 + ky) * 64 + lane) * 8 + j] = (f16)c3_welem(w, i * 32 + (lane & 31), ky, lane >> 5, j);
     C3Layer L;
     L.cout = co;
     L.wfrag = c->wts.put(fr.data(), fr.size() * sizeof(f16));
@@ -1091,17 +1094,15 @@ bool build_weights(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
             for (int o = 0; o < 3; ++o)
                 for (int k = 0; k < 64; ++k) w10a[o * 64 + k] = w10[o * 128 + k];
             c->hg_w10a = c->wts.put(w10a.data(), w10a.size() * 4);
-            std::vector<f16> fr((size_t)8 * 64 * 8, (f16)0.f);
+            std::vector<f16> fr((size_t)10 * 64 * 8, (f16)0.f);      // 6 conv1 fragments (as pack_c3), 4 of conv10's second half
             for (int lane = 0; lane < 64; ++lane)
                 for (int j = 0; j < 8; ++j) {
                     const int r = lane & 31, pslot = 8 * (lane >> 5) + j;
                     for (int i = 0; i < 2; ++i)
-                        for (int ks = 0; ks < 2; ++ks) {
-                            const int k = 16 * ks + pslot;
-                            if (k < 27) fr[(((size_t)i * 2 + ks) * 64 + lane) * 8 + j] = (f16)w1[((size_t)(i * 32 + r) * 3 + k % 3) * 9 + k / 3];
-                        }
+                        for (int ky = 0; ky < 3; ++ky)
+                            fr[(((size_t)i * 3 + ky) * 64 + lane) * 8 + j] = (f16)c3_welem(w1, i * 32 + r, ky, lane >> 5, j);
                     for (int sidx = 0; sidx < 4; ++sidx)
-                        if (r < 3) fr[((size_t)(4 + sidx) * 64 + lane) * 8 + j] = (f16)w10[r * 128 + 64 + 16 * sidx + acc_kperm16(pslot)];
+                        if (r < 3) fr[((size_t)(6 + sidx) * 64 + lane) * 8 + j] = (f16)w10[r * 128 + 64 + 16 * sidx + acc_kperm16(pslot)];
                 }
             c->hgf_wfrag = c->wts.put(fr.data(), fr.size() * sizeof(f16));
         }

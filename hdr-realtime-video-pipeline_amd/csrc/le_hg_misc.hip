@@ -1,8 +1,12 @@
 // le_hg_misc.hip -- the non-GEMM-shaped pieces of LE and HG on gfx950.
 //
-//  conv_c3     3x3 conv from a planar 3-channel image (K = 27, padded to 32) to NHWC f16:
-//              LE.conv_first, LE.cond_first.0 (HDRUNet3T1_arch.py:14,41), HG.conv1
-//              (Hallucination_arch.py:59).  im2col fragments are built from an LDS halo tile.
+//  conv_c3     3x3 conv from a planar 3-channel image to NHWC f16: LE.conv_first (HDRUNet3T1_arch.py:14), HG.conv1
+//              (Hallucination_arch.py:59).  The halo tile sits in LDS as 4-channel pixels (r, g, b, 0: 8 bytes) and the
+//              GEMM's K axis is (ky | kx4, c4): one k-step of 16 per kernel row = 4 pixels x 4 channels, of which the
+//              4th pixel and the 4th channel meet zero weights.  A lane's B fragment of a k-step is then 16 CONTIGUOUS
+//              bytes (pixels kx = 2*lh, 2*lh+1 of row ky) -- one ds_read2_b64 instead of eight 2-byte gathers; 3 MFMAs per
+//              32 output channels instead of 2 (K = 48 against 32: the matrix pipe is idle here anyway).  The gather was
+//              half of these kernels' time (4K: conv_first 0.171 -> 0.087 ms, conv1 0.222 -> 0.146 ms with it stubbed out).
 //  hg_prep     HG_Composite._make_mask + reflect pad to a multiple of 32 (HG_Composite_arch.py:78-101)
 //  hg_final_fused   the HG tail: conv1 recomputed, second half of conv10 (1x1 over cat(Up_conv5, conv1)),
 //              conv_last (1x1 over cat(conv10, img)) and out = mask*out + img, cropped
@@ -15,6 +19,43 @@ namespace {
 // ================================================================================== conv_c3
 constexpr int C3_TH = 8, C3_TW = 32;
 constexpr int C3_HH = C3_TH + 2, C3_HW = C3_TW + 2;
+constexpr int C3_PW = C3_HW + 2;          // pixel pitch of the LDS patch: columns 34, 35 are the kx = 3 dummy reads (zero weights)
+constexpr int C3_NP = (C3_HH * C3_HW + 255) / 256;       // halo pixels per thread
+
+// B fragment of kernel row ky for output pixel (row, l31): pixels l31 + 2*lh and l31 + 2*lh + 1 of patch row row + ky
+__device__ __forceinline__ f16x8 c3_frag(const f16x4 *s_px, int row, int ky, int l31, int lh)
+{
+    const f16x4 *q = s_px + (row + ky) * C3_PW + l31 + 2 * lh;
+    const f16x4 a = q[0], b = q[1];
+    return f16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
+// one tile's halo pixels, fetched a tile ahead into registers: thread e = tid + 256 i owns patch pixel (e / 34, e % 34)
+struct C3Pre { f16 v[C3_NP][3]; };
+__device__ __forceinline__ void c3_fetch(C3Pre &pre, const f16 *__restrict__ in, int H, int W, int oy0, int ox0, int tid)
+{
+#pragma unroll
+    for (int i = 0; i < C3_NP; ++i) {
+        const int e = tid + 256 * i;
+        const int r = e / C3_HW, q = e % C3_HW;
+        const int iy = oy0 - 1 + r, ix = ox0 - 1 + q;
+        const bool ok = e < C3_HH * C3_HW && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const size_t o = ok ? (size_t)iy * W + ix : 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            pre.v[i][c] = in[(size_t)c * H * W + o];
+            if (!ok) pre.v[i][c] = (f16)0.f;
+        }
+    }
+}
+__device__ __forceinline__ void c3_stage(const C3Pre &pre, f16x4 *s_px, int tid)
+{
+#pragma unroll
+    for (int i = 0; i < C3_NP; ++i) {
+        const int e = tid + 256 * i;
+        if (e < C3_HH * C3_HW) s_px[(e / C3_HW) * C3_PW + e % C3_HW] = f16x4{pre.v[i][0], pre.v[i][1], pre.v[i][2], (f16)0.f};
+    }
+}
 
 template <int COUT>
 __global__ __launch_bounds__(256) void conv_c3_kernel(const f16 *__restrict__ in, int H, int W, const f16 *__restrict__ wfrag,
@@ -24,73 +65,43 @@ __global__ __launch_bounds__(256) void conv_c3_kernel(const f16 *__restrict__ in
 {
     constexpr int MT = COUT / 32;
     constexpr int ROWB = COUT * 2 + 16;
-    __shared__ f16 s_in[3][C3_HH][C3_HW + 2];
+    __shared__ __attribute__((aligned(16))) f16x4 s_px[C3_HH * C3_PW];
     __shared__ __attribute__((aligned(16))) char s_out[C3_TH * C3_TW * ROWB];
     __shared__ __attribute__((aligned(16))) float s_ss[2 * COUT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int tiles_x = (W + C3_TW - 1) / C3_TW, ntiles = tiles_x * ((H + C3_TH - 1) / C3_TH);
     if (tid < COUT) { s_ss[tid] = scale[tid]; s_ss[COUT + tid] = shift[tid]; }
-    f16x8 wf[MT][2];
+    f16x8 wf[MT][3];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) wf[i][ks] = reinterpret_cast<const f16x8 *>(wfrag)[(i * 2 + ks) * 64 + lane];
-    // im2col offsets of this lane's 16 k slots: k = (ky*3+kx)*3 + c
-    int koff[2][8];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = 16 * ks + 8 * lh + j;
-            const int tap = k / 3, c = k % 3;
-            koff[ks][j] = k < 27 ? (c * C3_HH + tap / 3) * (C3_HW + 2) + tap % 3 : -1;
-        }
+        for (int ky = 0; ky < 3; ++ky) wf[i][ky] = reinterpret_cast<const f16x8 *>(wfrag)[(i * 3 + ky) * 64 + lane];
+    for (int e = tid; e < C3_HH * 2; e += 256) s_px[(e >> 1) * C3_PW + C3_HW + (e & 1)] = f16x4{(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
     // persistent over 8x32-pixel tiles, the next tile's image patch fetched while this one computes
-    constexpr int NE = (3 * C3_HH * C3_HW + 255) / 256;
-    f16 pre[NE];
-    auto fetch = [&](int t) {
-        const int ox0 = (t % tiles_x) * C3_TW, oy0 = (t / tiles_x) * C3_TH;
-#pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            const int e = tid + 256 * i;
-            const int c = e / (C3_HH * C3_HW), r = (e / C3_HW) % C3_HH, q = e % C3_HW;
-            const int iy = oy0 - 1 + r, ix = ox0 - 1 + q;
-            const bool ok = e < 3 * C3_HH * C3_HW && iy >= 0 && iy < H && ix >= 0 && ix < W;
-            pre[i] = in[ok ? ((size_t)c * H + iy) * W + ix : 0];
-            if (!ok) pre[i] = (f16)0.f;
-        }
-    };
+    C3Pre pre;
+    auto fetch = [&](int t) { c3_fetch(pre, in, H, W, (t / tiles_x) * C3_TH, (t % tiles_x) * C3_TW, tid); };
     const float aslope = act_slope(act);
     int t = blockIdx.x;
     if (t < ntiles) fetch(t);
     for (; t < ntiles; t += gridDim.x) {
     const int ox0 = (t % tiles_x) * C3_TW, oy0 = (t / tiles_x) * C3_TH;
-    __syncthreads();                                   // the previous tile is done with s_in and s_out
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        const int e = tid + 256 * i;
-        const int c = e / (C3_HH * C3_HW), r = (e / C3_HW) % C3_HH, q = e % C3_HW;
-        if (e < 3 * C3_HH * C3_HW) s_in[c][r][q] = pre[i];
-    }
+    __syncthreads();                                   // the previous tile is done with s_px and s_out
+    c3_stage(pre, s_px, tid);
     __syncthreads();
     if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
-    const f16 *sflat = &s_in[0][0][0];
     f32x16 acc[MT][2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int row = 2 * wave + j;
-        const int base = row * (C3_HW + 2) + l31;
-        f16x8 xf[2];
+        f16x8 xf[3];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) xf[ks][e] = koff[ks][e] >= 0 ? sflat[base + koff[ks][e]] : (f16)0.f;
+        for (int ky = 0; ky < 3; ++ky) xf[ky] = c3_frag(s_px, row, ky, l31, lh);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i][0], xf[0], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i][1], xf[1], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i][ky], xf[ky], acc[i][j], 0, 0, 0);
         }
     }
 #pragma unroll
@@ -188,7 +199,7 @@ struct HgFinalFusedParams {
     const f16 *img;        // planar f16 [3][Hp][Wp]
     const uint8_t *mask;   // [Hp][Wp]
     const float *part;     // f32 [Hp][Wp][4]: conv10 over Up_conv5's 64 channels
-    const f16 *wfrag;      // 4 conv1 fragments (natural k) + 4 conv10-second-half fragments (k permuted)
+    const f16 *wfrag;      // 6 conv1 fragments (2 x 3 kernel rows) + 4 conv10-second-half fragments (k permuted)
     const float *scale, *shift;   // conv1 folded BatchNorm [64]
     const float *b10, *wl, *bl;   // conv10 bias [3], conv_last [3][6] + [3]
     void *out;
@@ -197,38 +208,30 @@ struct HgFinalFusedParams {
 
 __global__ __launch_bounds__(256) void hg_final_fused_kernel(HgFinalFusedParams p)
 {
-    __shared__ f16 s_in[3][C3_HH][C3_HW + 2];
+    __shared__ __attribute__((aligned(16))) f16x4 s_px[C3_HH * C3_PW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int tiles_x = (p.W + C3_TW - 1) / C3_TW, ntiles = tiles_x * ((p.H + C3_TH - 1) / C3_TH);
     const f16x8 *fr = reinterpret_cast<const f16x8 *>(p.wfrag);
-    f16x8 w1[2][2], w2[4];
+    f16x8 w1[2][3], w2[4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) w1[i][ks] = fr[(i * 2 + ks) * 64 + lane];
+        for (int ky = 0; ky < 3; ++ky) w1[i][ky] = fr[(i * 3 + ky) * 64 + lane];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) w2[s] = fr[(4 + s) * 64 + lane];
+    for (int s = 0; s < 4; ++s) w2[s] = fr[(6 + s) * 64 + lane];
+    for (int e = tid; e < C3_HH * 2; e += 256) s_px[(e >> 1) * C3_PW + C3_HW + (e & 1)] = f16x4{(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
     // folded-BatchNorm scale/shift through LDS (kept out of registers: this kernel is latency-bound and
     // lives on occupancy), and the per-pixel inputs of the tail prefetched before any arithmetic
     __shared__ __attribute__((aligned(16))) float s_ss[128];
     if (tid < 64) { s_ss[tid] = p.scale[tid]; s_ss[64 + tid] = p.shift[tid]; }
     // persistent over 8x32-pixel tiles; the next tile's image patch, partial sums and mask are fetched while
     // this one computes (a tile is ~10 MFMAs per wave: unpipelined, the kernel was all load latency)
-    constexpr int NE = (3 * C3_HH * C3_HW + 255) / 256;
-    f16 pre[NE];
+    C3Pre pre;
     float4 pt_pre[2];
     uint8_t m_pre[2];
     auto fetch = [&](int t) {
         const int ox0 = (t % tiles_x) * C3_TW, oy0 = (t / tiles_x) * C3_TH;
-#pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            const int e = tid + 256 * i;
-            const int c = e / (C3_HH * C3_HW), r = (e / C3_HW) % C3_HH, q = e % C3_HW;
-            const int iy = oy0 - 1 + r, ix = ox0 - 1 + q;
-            const bool ok = e < 3 * C3_HH * C3_HW && iy >= 0 && iy < p.Hp && ix >= 0 && ix < p.Wp;
-            pre[i] = p.img[ok ? ((size_t)c * p.Hp + iy) * p.Wp + ix : 0];
-            if (!ok) pre[i] = (f16)0.f;
-        }
+        c3_fetch(pre, p.img, p.Hp, p.Wp, oy0, ox0, tid);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int y = oy0 + 2 * wave + j, x = ox0 + l31;
@@ -238,19 +241,13 @@ __global__ __launch_bounds__(256) void hg_final_fused_kernel(HgFinalFusedParams 
             m_pre[j] = p.mask[pix];
         }
     };
-    const f16 *sflat = &s_in[0][0][0];
     const size_t plane_o = (size_t)p.H * p.W;
     int t = blockIdx.x;
     if (t < ntiles) fetch(t);
     for (; t < ntiles; t += gridDim.x) {
     const int ox0 = (t % tiles_x) * C3_TW, oy0 = (t / tiles_x) * C3_TH;
-    __syncthreads();                                   // the previous tile is done with s_in
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        const int e = tid + 256 * i;
-        const int c = e / (C3_HH * C3_HW), r = (e / C3_HW) % C3_HH, q = e % C3_HW;
-        if (e < 3 * C3_HH * C3_HW) s_in[c][r][q] = pre[i];
-    }
+    __syncthreads();                                   // the previous tile is done with s_px
+    c3_stage(pre, s_px, tid);
     const float4 pt_cur[2] = {pt_pre[0], pt_pre[1]};
     const float m_cur[2] = {(float)m_pre[0], (float)m_pre[1]};
     __syncthreads();
@@ -258,24 +255,17 @@ __global__ __launch_bounds__(256) void hg_final_fused_kernel(HgFinalFusedParams 
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int row = 2 * wave + j;
-        const int base = row * (C3_HW + 2) + l31;
-        f16x8 xf[2];
+        f16x8 xf[3];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int k = 16 * ks + 8 * lh + e;
-                const int tap = k / 3, c = k % 3;
-                xf[ks][e] = k < 27 ? sflat[base + (c * C3_HH + tap / 3) * (C3_HW + 2) + tap % 3] : (f16)0.f;
-            }
+        for (int ky = 0; ky < 3; ++ky) xf[ky] = c3_frag(s_px, row, ky, l31, lh);
         f16x8 bf[4];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             f32x16 h;
 #pragma unroll
             for (int k = 0; k < 16; ++k) h[k] = 0.f;
-            h = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[i][0], xf[0], h, 0, 0, 0);
-            h = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[i][1], xf[1], h, 0, 0, 0);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) h = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[i][ky], xf[ky], h, 0, 0, 0);
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -298,8 +288,8 @@ __global__ __launch_bounds__(256) void hg_final_fused_kernel(HgFinalFusedParams 
             const float4 pt = pt_cur[j];
             const float c10[3] = {(float)(f16)(o[0] + pt.x + p.b10[0]), (float)(f16)(o[1] + pt.y + p.b10[1]),
                                   (float)(f16)(o[2] + pt.z + p.b10[2])};
-            const int ctr = (row + 1) * (C3_HW + 2) + l31 + 1;
-            const float im[3] = {(float)sflat[ctr], (float)sflat[C3_HH * (C3_HW + 2) + ctr], (float)sflat[2 * C3_HH * (C3_HW + 2) + ctr]};
+            const f16x4 ctr = s_px[(row + 1) * C3_PW + l31 + 1];
+            const float im[3] = {(float)ctr[0], (float)ctr[1], (float)ctr[2]};
             const float m = m_cur[j];
             const size_t oo = (size_t)y * p.W + x;
 #pragma unroll
