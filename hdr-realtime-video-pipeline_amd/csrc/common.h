@@ -128,6 +128,9 @@ struct Conv32Params {
     const f16 *zeros;
     f16 *dump;             // diagnostic builds (make STAMP=1): per-phase cycle sums
     char *trash;           // conv32s: >= 8 KiB write-only scratch that masked-off lanes store to (keeps store counts exact)
+    // conv32s, HR_conv1 only: conv_first fused in front (c3_img != nullptr; src is then unused): the planar 3-channel image,
+    // and conv_first's three A fragments [3 kernel rows][64 lanes][8] (pack_c3's K order, bias in the centre tap's 4th channel)
+    const f16 *c3_img, *c3_wfrag;
     int tiles_x, tiles_y;
     // W8A8 layer (wpk8 != nullptr): int8 weights [9][CoutPad][32] with the K axis in code-tile order
     // (byte 16h + 4qd + k = input channel 8qd + 4h + k), scale[CoutPad], shift[16 border classes][CoutPad], and the

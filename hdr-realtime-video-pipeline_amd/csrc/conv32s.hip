@@ -83,16 +83,21 @@ __device__ __forceinline__ f16x8 lrelu_pack16(const f32x16 &a, int s)
     return __builtin_elementwise_max(o, o * (f16)0.1f);
 }
 
-template <bool SFT, bool I8, bool SQ>
+// C3 (HR_conv1 with conv_first fused in front): the 3-plane image patch of a tile, 20 x 20 pixels of 4 channels (8 bytes;
+// pitch 24: columns 20..23 are the kx4 = 3 / pad-slot dummy reads and stay zero), double-buffered
+constexpr int P3_H = TH + 4, P3_W = TW + 4, P3_PW = 24, P3_BYTES = P3_H * P3_PW * 8;
+
+template <bool SFT, bool I8, bool SQ, bool C3 = false>
 struct Lay {
-    static constexpr int NA = I8 ? 2 : 3;                                // halo buffers (see header)
+    static constexpr int NA = (I8 || C3) ? 2 : 3;                        // halo buffers (see header; C3: nothing is DMA'd into them)
     static constexpr int W_BYTES = 9 * 32 * (I8 ? 32 : 64);
     static constexpr int SS_BYTES = I8 ? 32 * 4 * 17 : 32 * 8;          // I8: scale[32] + shift[16 border classes][32]
     static constexpr int Q_BYTES = I8 ? NG * 32 * 32 : 0;               // int8 code tile: 32 B per halo slot
     static constexpr int OFF_A = W_BYTES;
     static constexpr int OFF_C = OFF_A + NA * A_BYTES;
     static constexpr int OFF_Q = OFF_C + (SFT ? 2 * C_BYTES : 0);
-    static constexpr int OFF_OUT = OFF_Q + 2 * Q_BYTES;
+    static constexpr int OFF_P3 = OFF_Q + 2 * Q_BYTES;
+    static constexpr int OFF_OUT = OFF_P3 + (C3 ? 2 * P3_BYTES : 0);
     static constexpr int SMEM = OFF_OUT + NW * STRIP;                   // dynamic part; the constant tables are static arrays
     static_assert(SMEM + SS_BYTES + (SQ ? 768 : 0) <= 160 * 1024, "LDS budget");
 };
@@ -100,11 +105,12 @@ struct Lay {
 // s_waitcnt immediate of gfx9: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14
 constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 15) | (7 << 4) | ((lgkm & 15) << 8) | ((vm >> 4) << 14); }
 
-template <bool SFT, bool I8, bool SQ, bool PLANAR>
+template <bool SFT, bool I8, bool SQ, bool PLANAR, bool C3 = false>
 __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
 {
     static_assert(!SQ || (SFT && I8), "W8A8 SFT convs come with a W8A8 conv behind them");
-    using L = Lay<SFT, I8, SQ>;
+    static_assert(!C3 || (SFT && !I8 && !PLANAR), "conv_first is fused in front of SFT_layer1 + HR_conv1 (fp16) only");
+    using L = Lay<SFT, I8, SQ, C3>;
     constexpr bool PREP = SFT || I8;
     constexpr int NA = L::NA;
     constexpr int NSTORE = PLANAR ? 3 : 2;             // stores per wave and tile, issued unconditionally
@@ -118,6 +124,7 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
     char *sA = smem + L::OFF_A;
     char *sC = smem + L::OFF_C;
     char *sQ = smem + L::OFF_Q;
+    f16x4 *sP3 = reinterpret_cast<f16x4 *>(smem + L::OFF_P3);
     const float *sK = sKw;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -153,11 +160,13 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
         const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
         const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
         const int pix0 = iy0 * p.W + ix0;                      // may be negative; valid lanes land >= 0
+        if constexpr (!C3) {
 #pragma unroll
-        for (int it = 0; it < A_PW; ++it) {
-            const bool ok = a_pos[it] >= 0 && (unsigned)(iy0 + (a_pos[it] & 255)) < uH && (unsigned)(ix0 + (a_pos[it] >> 8)) < uW;
-            const unsigned off = ok ? (unsigned)(pix0 * 64 + a_off[it]) : src_guard + ((lane & 3) << 4);
-            glds16(reinterpret_cast<const char *>(p.src) + off, abuf + (wave + it * NWI) * 1024);
+            for (int it = 0; it < A_PW; ++it) {
+                const bool ok = a_pos[it] >= 0 && (unsigned)(iy0 + (a_pos[it] & 255)) < uH && (unsigned)(ix0 + (a_pos[it] >> 8)) < uW;
+                const unsigned off = ok ? (unsigned)(pix0 * 64 + a_off[it]) : src_guard + ((lane & 3) << 4);
+                glds16(reinterpret_cast<const char *>(p.src) + off, abuf + (wave + it * NWI) * 1024);
+            }
         }
         if (SFT) {
 #pragma unroll
@@ -191,12 +200,41 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
         }
     }
 
+    // ---- C3: this thread's pixel of a tile's 20 x 20 image patch (threads 0..399), fetched into registers in R and
+    // written to LDS in E, two tiles ahead of the pass that reads it
+    const int p3r = tid / P3_W, p3c = tid - p3r * P3_W;
+    f16 p3v[3];
+    auto p3_fetch = [&](int tq) __attribute__((always_inline)) {
+        const int t = tq < ntiles ? tq : ntiles - 1;
+        const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+        const int iy = ty * TH - 2 + p3r, ix = tx * TW - 2 + p3c;
+        const bool ok = tid < P3_H * P3_W && (unsigned)iy < uH && (unsigned)ix < uW;
+        const size_t o = ok ? (size_t)iy * p.W + ix : 0;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            p3v[ch] = p.c3_img[(size_t)ch * p.H * p.W + o];
+            if (!ok) p3v[ch] = (f16)0.f;
+        }
+    };
+    auto p3_stage = [&](int buf) __attribute__((always_inline)) {
+        if (tid < P3_H * P3_W) sP3[buf * (P3_BYTES / 8) + p3r * P3_PW + p3c] = f16x4{p3v[0], p3v[1], p3v[2], (f16)1.f};   // 1: the bias slot
+    };
+    f16x8 c3w[3];                                            // conv_first's A fragments (kernel rows), le_hg_misc.hip's K order
+    if constexpr (C3) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) c3w[ky] = reinterpret_cast<const f16x8 *>(p.c3_wfrag)[ky * 64 + lane];
+        for (int e = tid; e < 2 * P3_H * (P3_PW - P3_W); e += NT) {         // the dummy columns stay zero
+            const int b = e / (P3_H * (P3_PW - P3_W)), r = (e / (P3_PW - P3_W)) % P3_H, cc = e % (P3_PW - P3_W);
+            sP3[b * (P3_BYTES / 8) + r * P3_PW + P3_W + cc] = f16x4{(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+        }
+    }
+
     // ---- SFT / quantise pass: lane constants of this wave's 32-slot groups, fragments and biases
     constexpr int G_PW = 2;
     const int gid[G_PW] = {wave >= 4 ? wave - 4 : 8 + wave, wave};     // waves 4-7: groups w-4 and w; waves 0-3: group 8+w
     f16x8 sa0, sa1s, sa1t;
     f32x16 sbh, sbs, sbt;
-    int g_pos[G_PW], g_c[G_PW], g_x[G_PW], g_q[G_PW];
+    int g_pos[G_PW], g_c[G_PW], g_x[G_PW], g_q[G_PW], g_p3[G_PW];
     i32x4 qa0, qa1s, qa1t;
     float cq_inv = 0.f, cq_zoff = 0.f;
     if constexpr (SQ) {
@@ -220,11 +258,13 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
             g_c[gi] = hp * 32 + lh * 16;
             g_x[gi] = hp * 64 + (swz32(hx) << 4) + 8 * lh;      // channel quad qd lives at g_x ^ (qd << 4)
             g_q[gi] = hp * 32 + ((lh ^ (hy & 1)) << 4);         // code tile: halves swap on odd halo rows
+            // C3: halo pixel (hy, hx) is patch pixel (hy + 1, hx + 1); the fragment of kernel row ky starts one up / left
+            g_p3[gi] = g_pos[gi] >= 0 ? hy * P3_PW + hx + 2 * lh : 2 * lh;
         }
     }
     // y = x*(scale+1)+shift in place on a landed halo tile (arch_util.py:68-72), three sweeps over the wave's groups:
     // every LDS read, the MLPs, modulate / quantise and write (see conv32p.hip)
-    auto sft_groups = [&](auto ngc, int tt, char *a, const char *cbuf, char *qbuf) __attribute__((always_inline)) {
+    auto sft_groups = [&](auto ngc, int tt, char *a, const char *cbuf, char *qbuf, const f16x4 *p3) __attribute__((always_inline)) {
         constexpr int N = decltype(ngc)::value;
         const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
         const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
@@ -243,12 +283,38 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
                 c0[gi] = *reinterpret_cast<const f16x8 *>(cbuf + g_c[gi]);
             }
         }
+        f16x8 xc3[N][3];
 #pragma unroll
         for (int gi = 0; gi < N; ++gi) {
+            if constexpr (C3) {
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) yv[gi][qd] = *reinterpret_cast<const f16x4 *>(a + (g_x[gi] ^ (qd << 4)));
+                for (int ky = 0; ky < 3; ++ky) {
+                    const f16x4 *q = p3 + g_p3[gi] + ky * P3_PW;
+                    const f16x4 u = q[0], v = q[1];
+                    xc3[gi][ky] = f16x8{u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+                }
+            } else {
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) yv[gi][qd] = *reinterpret_cast<const f16x4 *>(a + (g_x[gi] ^ (qd << 4)));
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (C3) {
+            // conv_first (3x3, 3 -> 32, bias, ReLU; HDRUNet3T1_arch.py:168) on the halo pixels, exactly as conv_c3<32> computes
+            // it (same K order, the bias in the centre tap's 4th-channel slot, one rounding to f16): the tile SFT_layer1 modulates
+#pragma unroll
+            for (int gi = 0; gi < N; ++gi) {
+                f32x16 h;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) h[k] = 0.f;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) h = __builtin_amdgcn_mfma_f32_32x32x16_f16(c3w[ky], xc3[gi][ky], h, 0, 0, 0);
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) yv[gi][qd][k] = (f16)act_fast(h[4 * qd + k], 0.f);     // bias: inside the sum (K slot)
+            }
+        }
 #pragma unroll
         for (int gi = 0; gi < N; ++gi) {
             if constexpr (SQ) {
@@ -325,9 +391,9 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
             }
         }
     };
-    auto prep_tile = [&](int tt, char *a, const char *cbuf, char *qbuf) __attribute__((always_inline)) {
-        if (wave >= 4) sft_groups(std::integral_constant<int, 2>{}, tt, a, cbuf, qbuf);      // wave-uniform
-        else sft_groups(std::integral_constant<int, 1>{}, tt, a, cbuf, qbuf);
+    auto prep_tile = [&](int tt, char *a, const char *cbuf, char *qbuf, const f16x4 *p3) __attribute__((always_inline)) {
+        if (wave >= 4) sft_groups(std::integral_constant<int, 2>{}, tt, a, cbuf, qbuf, p3);  // wave-uniform
+        else sft_groups(std::integral_constant<int, 1>{}, tt, a, cbuf, qbuf, p3);
     };
 
     // ---- prologue: tiles 0 and 1 in flight, tile 0 landed and transformed
@@ -336,10 +402,14 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
         issue_tile(t0, sA, sC);
         issue_tile(t0 + step, sA + A_BYTES, sC + C_BYTES);
     }
+    if constexpr (C3) {
+        p3_fetch(t0); p3_stage(0);
+        p3_fetch(t0 + step); p3_stage(1);
+    }
     __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));
     __builtin_amdgcn_s_barrier();
     if (PREP) {
-        prep_tile(t0, sA, sC, sQ);
+        prep_tile(t0, sA, sC, sQ, sP3);
         __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));      // LDS writes of the pass done; vmcnt untouched
         __builtin_amdgcn_s_barrier();
     }
@@ -393,6 +463,7 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
                 rs2[it] = *reinterpret_cast<const i32x4 *>((in && p.res2) ? p.res2 + off : p.zeros);
             }
         }
+        if constexpr (C3) p3_fetch(t + 2 * step);              // R: this thread's pixel of the patch of tile t+2
         // X: tile t+2 in flight
         if (wave < NWI) issue_tile(t + 2 * step, sA + db * A_BYTES, sC + cb * C_BYTES);
         __builtin_amdgcn_sched_barrier(0);
@@ -499,15 +570,16 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
         if (wave < 4) {
             conv_mfma();
             STAMP(1);  // conv MFMAs
-            if (PREP && t + step < ntiles) prep_tile(t + step, sA + nb * A_BYTES, sC + cn * C_BYTES, sQ + cn * L::Q_BYTES);
+            if (PREP && t + step < ntiles) prep_tile(t + step, sA + nb * A_BYTES, sC + cn * C_BYTES, sQ + cn * L::Q_BYTES, sP3 + cn * (P3_BYTES / 8));
             STAMP(2);  // SFT / quantise pass of the next tile
         } else {
-            if (PREP && t + step < ntiles) prep_tile(t + step, sA + nb * A_BYTES, sC + cn * C_BYTES, sQ + cn * L::Q_BYTES);
+            if (PREP && t + step < ntiles) prep_tile(t + step, sA + nb * A_BYTES, sC + cn * C_BYTES, sQ + cn * L::Q_BYTES, sP3 + cn * (P3_BYTES / 8));
             STAMP(2);
             conv_mfma();
             STAMP(1);
         }
         epilogue();
+        if constexpr (C3) p3_stage(cb);                        // patch of tile t+2 (read by P in the next iteration but one... of parity cb)
         STAMP(3);      // epilogue incl. hipcc's vmcnt(0) (residuals + the DMA of tile t+2)
         // the DMA of tile t+2 is older than this tile's NSTORE stores: landed once at most NSTORE operations are pending
         __builtin_amdgcn_s_waitcnt(waitcnt_imm(NSTORE, 0));
@@ -523,12 +595,12 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
 #endif
 }
 
-template <bool SFT, bool I8, bool SQ, bool PLANAR>
+template <bool SFT, bool I8, bool SQ, bool PLANAR, bool C3 = false>
 hipError_t launch_t(const Conv32Params &p, int n_cu, hipStream_t s)
 {
-    using L = Lay<SFT, I8, SQ>;
+    using L = Lay<SFT, I8, SQ, C3>;
     static DevOnce attr_once;   // hipFuncSetAttribute is per (function, device)
-    auto kern = conv32s_kernel<SFT, I8, SQ, PLANAR>;
+    auto kern = conv32s_kernel<SFT, I8, SQ, PLANAR, C3>;
     if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L::SMEM);
         if (e != hipSuccess) return e;
@@ -552,11 +624,13 @@ hipError_t conv32s_launch(Conv32Params p, int n_cu, hipStream_t s)
     p.tiles_x = (p.W + TW - 1) / TW;
     p.tiles_y = (p.H + TH - 1) / TH;
     if (p.wpk8) {
+        if (p.c3_img) return hipErrorInvalidValue;
         if (planar) return sft ? hipErrorInvalidValue : launch_t<false, true, false, true>(p, n_cu, s);
         if (sft && p.sq_wfrag) return launch_t<true, true, true, false>(p, n_cu, s);
         return sft ? launch_t<true, true, false, false>(p, n_cu, s) : launch_t<false, true, false, false>(p, n_cu, s);
     }
     if (p.sq_wfrag) return hipErrorInvalidValue;         // W8A8 SFT convs in front of an fp16 conv: no kernel (no shipped recipe has it)
     if (planar) return sft ? hipErrorInvalidValue : launch_t<false, false, false, true>(p, n_cu, s);
+    if (p.c3_img) return (sft && p.c3_wfrag) ? launch_t<true, false, false, false, true>(p, n_cu, s) : hipErrorInvalidValue;
     return sft ? launch_t<true, false, false, false>(p, n_cu, s) : launch_t<false, false, false, false>(p, n_cu, s);
 }

@@ -705,9 +705,10 @@ bool read_fakeq(hdrtv_ctx *c, const Pack &pk, const std::string &layer, FakeQ &f
 
 // A-fragment element of the 3-channel 3x3 convs (le_hg_misc.hip): k-step ky, lane half lh, slot j = pixel kx = 2 lh + j / 4,
 // channel j % 4; the 4th pixel and the 4th channel are padding
-static inline float c3_welem(const std::vector<float> &w, int m, int ky, int lh, int j)
+static inline float c3_welem(const std::vector<float> &w, int m, int ky, int lh, int j, const float *bias_k = nullptr)
 {
     const int kx = 2 * lh + (j >> 2), ch = j & 3;
+    if (bias_k && ky == 1 && kx == 1 && ch == 3) return bias_k[m];      // the staged pixels' 4th channel is 1 (le_hg_misc.hip)
     return (kx < 3 && ch < 3) ? w[((size_t)m * 3 + ch) * 9 + ky * 3 + kx] : 0.f;
 }
 
@@ -727,15 +728,16 @@ bool pack_c3(hdrtv_ctx *c, const Pack &pk, const std::string &key, const std::st
             const float s = g[n] / std::sqrt(var[n] + 1e-5f);
             scale[n] = s;
             shift[n] = (b[n] - mu[n]) * s + be[n];
-        } else shift[n] = b[n];
+        }                                  // no BatchNorm: the bias rides in the K axis (c3_welem), scale 1 and shift 0
     }
+    const float *bias_k = bn_name.empty() ? b.data() : nullptr;
     const int mt = co / 32;
     std::vector<f16> fr((size_t)mt * 3 * 64 * 8, (f16)0.f);
     for (int i = 0; i < mt; ++i)
         for (int ky = 0; ky < 3; ++ky)
             for (int lane = 0; lane < 64; ++lane)
                 for (int j = 0; j < 8; ++j)
-                    fr[(((size_t)i * 3 + ky) * 64 + lane) * 8 + j] = (f16)c3_welem(w, i * 32 + (lane & 31), ky, lane >> 5, j);
+                    fr[(((size_t)i * 3 + ky) * 64 + lane) * 8 + j] = (f16)c3_welem(w, i * 32 + (lane & 31), ky, lane >> 5, j, bias_k);
     C3Layer L;
     L.cout = co;
     L.wfrag = c->wts.put(fr.data(), fr.size() * sizeof(f16));
@@ -1447,7 +1449,7 @@ struct Seq {
     // persistent 32-channel 3x3 conv, optionally with the SFT layer `sft_key` fused in front (conv32p.hip)
     void conv32(const std::string &key, const f16 *src, const f16 *cond, const std::string &sft_key, int H, int W, int act,
                 int mode, f16 *dst, int dstC, int Hd, int Wd, const f16 *res1 = nullptr, const f16 *res2 = nullptr,
-                f16 *dst_planar = nullptr, const f16 *res_planar = nullptr)
+                f16 *dst_planar = nullptr, const f16 *res_planar = nullptr, const f16 *c3_img = nullptr, const std::string &c3_key = "")
     {
         if (!ok()) return;
         auto it = c->conv.find(key);
@@ -1484,17 +1486,22 @@ struct Seq {
         static const int stamp_launch = [] { const char *e = getenv("HDRTV_STAMP_LAUNCH"); return e ? atoi(e) : -1; }();
         p.dump = (stamp_launch >= 0 && c->launches == stamp_launch) ? wsp<f16>(c, "dbg.stamps") : nullptr;
         const double npx = (double)H * W;
-        const double macs = npx * 32 * 9 * L.cout + (cond ? npx * 2 * (16 * 16 + 16 * 32) : 0.0);
+        const double macs = npx * 32 * 9 * L.cout + (cond ? npx * 2 * (16 * 16 + 16 * 32) : 0.0) + (c3_img ? npx * 27 * 32 : 0.0);
         const double outb = mode == ST_PLANAR3 ? 6.0 * npx : 2.0 * npx * L.cout;
-        const double bytes = npx * (64 + (cond ? 32 : 0)) + outb * (1 + (res1 ? 1 : 0) + (res2 ? 1 : 0) + (res_planar ? 1 : 0)) +
+        const double bytes = npx * ((c3_img ? 6 : 64) + (cond ? 32 : 0)) + outb * (1 + (res1 ? 1 : 0) + (res2 ? 1 : 0) + (res_planar ? 1 : 0)) +
                              (i8 ? 1.0 : 2.0) * 9 * 32 * L.coutPad;
         p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
+        if (c3_img) {         // conv_first fused in front of SFT_layer1 + HR_conv1: src is the planar image
+            const C3Layer &L3 = c->c3.at(c3_key);
+            p.c3_img = c3_img; p.c3_wfrag = wtp<f16>(c, L3.wfrag);      // bias inside the fragments (pack_c3), no BatchNorm
+        }
         // single-pass layers run the one-barrier schedule (conv32s.hip); HDRTV_CONV32_OLD=1 is the developer A/B switch
         const char *olde = getenv("HDRTV_CONV32_OLD");      // read per launch: the bit-exactness test flips it within one process
         const bool old_sched = olde && atoi(olde) != 0;
         const bool one_barrier = L.coutPad == 32 && !old_sched;
         char tag[48];
-        snprintf(tag, sizeof tag, "conv32%c<%d,%s%s>", one_barrier ? 's' : 'p', L.coutPad / 32, cond ? (sq ? "sft-i8" : "sft") : "plain", i8 ? ",i8" : "");
+        snprintf(tag, sizeof tag, "conv32%c<%d,%s%s%s>", one_barrier ? 's' : 'p', L.coutPad / 32, c3_img ? "c3+" : "", cond ? (sq ? "sft-i8" : "sft") : "plain", i8 ? ",i8" : "");
+        if (c3_img && !one_barrier) { rc = fail(c, HDRTV_ESTATE, "conv_first fusion needs the one-barrier schedule"); return; }
         chk(one_barrier ? conv32s_launch(p, c->n_cu, s) : conv32p_launch(p, c->n_cu, s), key.c_str(), tag, macs, bytes);
     }
     // ResBlock_with_SFT (arch_util.py:89-95): y = x + conv2(sft2(relu(conv1(sft1(x,c))),c))  [+ extra]; 2 launches
@@ -1689,10 +1696,21 @@ int run_le(hdrtv_ctx *c, Seq &q, const f16 *img, f16 *out_planar)
         const QLayer &Lq = c->q8.at("LE.conv_first");
         if (q.ok()) q.chk(planar3_to_q8_launch(img, (size_t)H * W, Lq.q.inv(), Lq.q.zoff(), img32, q.s), "le.conv_first.pack", "planar3_to_q8", 0.0, 38.0 * H * W);
         q.convq8("LE.conv_first", img32, true, 32, H, W, ACT_RELU, f0a, 32, nullptr);
+        q.conv32("LE.HR_conv1", f0a, cond1, "LE.SFT_layer1", H, W, ACT_RELU, ST_NHWC, fea0, 32, H, W);
     } else {
-        q.c3("le.conv_first", img, H, W, ACT_RELU, f0a, nullptr);
+        // fp16 conv_first is computed inside HR_conv1's kernel from the three planes (conv32s.hip, C3): its 32-channel output
+        // (0.53 GB at 4K, written and read back) never exists.  HDRTV_NO_C3FUSE=1 / HDRTV_CONV32_OLD=1: the two-launch form
+        // (developer A/B switches, read per launch); a W8A8 HR_conv1 behind an fp16 conv_first has no fused kernel.
+        const char *nf = getenv("HDRTV_NO_C3FUSE"), *olds = getenv("HDRTV_CONV32_OLD");
+        const bool fuse = !(nf && atoi(nf)) && !(olds && atoi(olds)) && c->q32.find("LE.HR_conv1") == c->q32.end();
+        if (fuse) {
+            q.conv32("LE.HR_conv1", f0a, cond1, "LE.SFT_layer1", H, W, ACT_RELU, ST_NHWC, fea0, 32, H, W, nullptr, nullptr, nullptr, nullptr,
+                     img, "le.conv_first");
+        } else {
+            q.c3("le.conv_first", img, H, W, ACT_RELU, f0a, nullptr);
+            q.conv32("LE.HR_conv1", f0a, cond1, "LE.SFT_layer1", H, W, ACT_RELU, ST_NHWC, fea0, 32, H, W);
+        }
     }
-    q.conv32("LE.HR_conv1", f0a, cond1, "LE.SFT_layer1", H, W, ACT_RELU, ST_NHWC, fea0, 32, H, W);
     f16 *fea1a = wsp<f16>(c, "le.fea1a"), *fea1 = wsp<f16>(c, "le.fea1"), *l1b = wsp<f16>(c, "le.l1b");
     auto down = [&](const char *key, const f16 *src, int Hi, int Wi, f16 *dst, int Ho, int Wo) {
         if (isq8(key)) q.convq8(key, src, false, 32, Hi, Wi, ACT_RELU, dst, 32, nullptr);

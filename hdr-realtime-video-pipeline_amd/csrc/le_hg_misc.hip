@@ -5,7 +5,10 @@
 //              GEMM's K axis is (ky | kx4, c4): one k-step of 16 per kernel row = 4 pixels x 4 channels, of which the
 //              4th pixel and the 4th channel meet zero weights.  A lane's B fragment of a k-step is then 16 CONTIGUOUS
 //              bytes (pixels kx = 2*lh, 2*lh+1 of row ky) -- one ds_read2_b64 instead of eight 2-byte gathers; 3 MFMAs per
-//              32 output channels instead of 2 (K = 48 against 32: the matrix pipe is idle here anyway).  The gather was
+//              32 output channels instead of 2 (K = 48 against 32: the matrix pipe is idle here anyway).  The 4th channel of
+//              every staged pixel is 1: a layer without BatchNorm (conv_first) has its bias, rounded to f16 as the reference's
+//              fp16 model holds it, in the centre tap's 4th-channel weight and a zero shift -- which is what lets conv32s.hip
+//              fuse the layer in front of HR_conv1 without bias registers.  The gather was
 //              half of these kernels' time (4K: conv_first 0.171 -> 0.087 ms, conv1 0.222 -> 0.146 ms with it stubbed out).
 //  hg_prep     HG_Composite._make_mask + reflect pad to a multiple of 32 (HG_Composite_arch.py:78-101)
 //  hg_final_fused   the HG tail: conv1 recomputed, second half of conv10 (1x1 over cat(Up_conv5, conv1)),
@@ -53,7 +56,8 @@ __device__ __forceinline__ void c3_stage(const C3Pre &pre, f16x4 *s_px, int tid)
 #pragma unroll
     for (int i = 0; i < C3_NP; ++i) {
         const int e = tid + 256 * i;
-        if (e < C3_HH * C3_HW) s_px[(e / C3_HW) * C3_PW + e % C3_HW] = f16x4{pre.v[i][0], pre.v[i][1], pre.v[i][2], (f16)0.f};
+        // 4th channel = 1: a layer without BatchNorm carries its bias in the centre tap's (otherwise zero) 4th-channel weight
+        if (e < C3_HH * C3_HW) s_px[(e / C3_HW) * C3_PW + e % C3_HW] = f16x4{pre.v[i][0], pre.v[i][1], pre.v[i][2], (f16)1.f};
     }
 }
 

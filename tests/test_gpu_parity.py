@@ -430,16 +430,20 @@ def test_one_barrier_conv32_schedule_is_bit_identical(torch_cuda, golden_dir, mo
         for (h, w), seed in (((2160, 3840), 41), ((1080, 1920), 42), ((270, 486), 43), ((61, 103), 44)):
             f = W.synthetic_frame(h, w, seed=seed, kind="gradient" if seed % 2 else "noise")
             res = []
-            for old in ("1", None):
-                if old:
-                    monkeypatch.setenv("HDRTV_CONV32_OLD", old)
-                else:
-                    monkeypatch.delenv("HDRTV_CONV32_OLD", raising=False)
+            # old schedule (conv_first as its own launch) | new schedule, conv_first unfused | new schedule with conv_first
+            # computed inside HR_conv1's kernel (the default for fp16 HR_conv1)
+            for env in ({"HDRTV_CONV32_OLD": "1"}, {"HDRTV_NO_C3FUSE": "1"}, {}):
+                for k in ("HDRTV_CONV32_OLD", "HDRTV_NO_C3FUSE"):
+                    monkeypatch.delenv(k, raising=False)
+                for k, v in env.items():
+                    monkeypatch.setenv(k, v)
                 out, _ = p.infer(p.preprocess(f))
                 res.append([out.clone()] + [p.tap(t).clone() for t in taps])
-            for name, a, b in zip(("out",) + taps, res[0], res[1]):
-                assert torch.isfinite(a).all(), (h, w, name)
-                assert torch.equal(a, b), (h, w, name)
+            for other in res[1:]:
+                for name, a, b in zip(("out",) + taps, res[0], other):
+                    assert torch.isfinite(a).all(), (h, w, name)
+                    assert torch.equal(a, b), (h, w, name)
     finally:
-        monkeypatch.delenv("HDRTV_CONV32_OLD", raising=False)
+        for k in ("HDRTV_CONV32_OLD", "HDRTV_NO_C3FUSE"):
+            monkeypatch.delenv(k, raising=False)
         p.close()
