@@ -447,3 +447,37 @@ def test_one_barrier_conv32_schedule_is_bit_identical(torch_cuda, golden_dir, mo
         for k in ("HDRTV_CONV32_OLD", "HDRTV_NO_C3FUSE"):
             monkeypatch.delenv(k, raising=False)
         p.close()
+
+
+def test_smallest_frames_and_rejections(torch_cuda, golden_dir, hr_state):
+    """Edge sizes.  The reference accepts any frame whose condition map keeps more than one spatial element up to the
+    4th InstanceNorm of the classifier (torch's instance_norm raises below that; hdrtv_reserve mirrors it) and, with HG,
+    whose reflect padding to a multiple of 32 is smaller than the frame (F.pad reflect raises otherwise).  The smallest
+    frames that pass -- strips 8 pixels wide or high, single-tile everywhere, most lanes of every kernel masked -- against
+    the oracle (u8, +-1 as the f16 path allows), and the rejections as errors, not garbage."""
+    from hdrtv_mi355x import weights as W
+    from hdrtv_mi355x.lib import HdrtvError
+    from hdrtv_mi355x.processor import HDRTVNetMI355X
+    from oracle import hdrtvnet_oracle as O
+    path = os.path.join(golden_dir, "hr_weights.hdrw")
+    p = HDRTVNetMI355X(path, use_hg=False, warmup_passes=0)
+    try:
+        for (h, w) in ((68, 8), (8, 68), (68, 12), (9, 70), (40, 72), (33, 130)):
+            f = W.synthetic_frame(h, w, seed=3, kind="noise")
+            d = np.abs(p.process(f).astype(int) - O.process(hr_state, f).astype(int))
+            assert d.max() <= 1 and d.mean() < 0.1, (h, w, d.max(), d.mean())
+        for (h, w), what in (((4, 4), "unsupported frame size"), ((65, 9), "AGCM classifier"), ((47, 33), "AGCM classifier")):
+            with pytest.raises(HdrtvError, match=what):
+                p.process(W.synthetic_frame(h, w, seed=3, kind="noise"))
+        assert p.process(W.synthetic_frame(68, 8, seed=4, kind="noise")).shape == (68, 8, 3)     # still usable after a refusal
+    finally:
+        p.close()
+    ph = HDRTVNetMI355X(path, use_hg=True, hg_weights="seeded:1234", warmup_passes=0)
+    try:
+        with pytest.raises(HdrtvError, match="reflect padding"):
+            ph.process(W.synthetic_frame(68, 8, seed=3, kind="gradient"))
+        for (h, w) in ((33, 130), (68, 40)):
+            out = ph.process(W.synthetic_frame(h, w, seed=3, kind="gradient"))
+            assert out.shape == (h, w, 3)
+    finally:
+        ph.close()
