@@ -747,6 +747,33 @@ bool pack_c3(hdrtv_ctx *c, const Pack &pk, const std::string &key, const std::st
     return true;
 }
 
+// LE.conv_first as a W8A8 layer -> conv_c3_q8 (le_hg_misc.hip): A fragments [2 MFMAs][64 lanes][16 bytes], byte j of lane
+// (row n, half lh) = weight of pixel kx = j / 4, channel j % 4 in kernel row ky = lh (first MFMA) / 2 (second, lh = 0 only)
+bool pack_c3_q8(hdrtv_ctx *c, const Pack &pk, const std::string &key)
+{
+    QRaw r;
+    if (!read_qraw(c, pk, key, 32, 27, r)) return false;
+    std::vector<int8_t> fr((size_t)2 * 64 * 16, (int8_t)0);
+    for (int m = 0; m < 2; ++m)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 16; ++j) {
+                const int n = lane & 31, lh = lane >> 5, kx = j >> 2, ch = j & 3;
+                const int ky = m == 0 ? lh : (lh == 0 ? 2 : -1);
+                if (ky >= 0 && kx < 3 && ch < 3) fr[((size_t)m * 64 + lane) * 16 + j] = r.w[((size_t)n * 3 + ch) * 9 + ky * 3 + kx];
+            }
+    std::vector<int> rowmap(32);
+    for (int i = 0; i < 32; ++i) rowmap[i] = i;
+    std::vector<float> scale, shift;
+    q_tables(r, 32, 3, 3, 32, rowmap, scale, shift);
+    QLayer L;
+    L.q = r.q; L.cin = 3; L.cout = 32; L.coutPad = 32; L.ks = 3; L.stride = 1;
+    L.wpk8 = c->wts.put(fr.data(), fr.size());
+    L.scale = c->wts.put(scale.data(), scale.size() * 4);
+    L.shift = c->wts.put(shift.data(), shift.size() * 4);
+    c->q8[key + "#c3"] = L;
+    return true;
+}
+
 // SFTLayer: three A fragments (hidden stack natural-k; scale/shift heads k-permuted) + 96 biases
 bool pack_sft(hdrtv_ctx *c, const Pack &pk, const std::string &key, const std::string &name)
 {
@@ -987,7 +1014,8 @@ bool build_weights(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
         if (isq("LE.CondNet2.2") && !pack_tail_q8(c, hr)) return false;
     }
     if (!pack_cond_trunk(c, hr) || !pack_cond_tail(c, hr, "LE.CondNet2.2", "LE.CondNet2.4")) return false;
-    if (isq("LE.conv_first") ? !pack_conv_q8(c, hr, "LE.conv_first", 32, 32, 3, 1, 3) : !pack_c3(c, hr, "le.conv_first", "LE.conv_first", 32, ""))
+    if (isq("LE.conv_first") ? !(pack_conv_q8(c, hr, "LE.conv_first", 32, 32, 3, 1, 3) && pack_c3_q8(c, hr, "LE.conv_first"))
+                             : !pack_c3(c, hr, "le.conv_first", "LE.conv_first", 32, ""))
         return false;
     if (!c->trunk_q8 && isq("LE.CondNet1.4") && !pack_q_last(c, hr, "LE.CondNet1.4", c->q_trunk6)) return false;
     if (!c->tail_q8 && isq("LE.CondNet2.4") && !pack_q_last(c, hr, "LE.CondNet2.4", c->q_tail2)) return false;
@@ -1691,11 +1719,19 @@ int run_le(hdrtv_ctx *c, Seq &q, const f16 *img, f16 *out_planar)
     }
     // main branch: every SFT is fused into the 3x3 conv that follows it
     f16 *f0a = wsp<f16>(c, "le.f0a"), *f0b = wsp<f16>(c, "le.f0b"), *fea0 = wsp<f16>(c, "le.fea0"), *up3 = wsp<f16>(c, "le.up3");
-    if (isq8("LE.conv_first")) {      // W8A8: the 3 planes as NHWC int8 codes (3 of 32 bytes real), then the generic int8 conv
-        int8_t *img32 = wsp<int8_t>(c, "le8.img32");
-        const QLayer &Lq = c->q8.at("LE.conv_first");
-        if (q.ok()) q.chk(planar3_to_q8_launch(img, (size_t)H * W, Lq.q.inv(), Lq.q.zoff(), img32, q.s), "le.conv_first.pack", "planar3_to_q8", 0.0, 38.0 * H * W);
-        q.convq8("LE.conv_first", img32, true, 32, H, W, ACT_RELU, f0a, 32, nullptr);
+    if (isq8("LE.conv_first")) {
+        const char *g8 = getenv("HDRTV_NO_C3Q8");     // developer A/B switch (read per launch): the generic two-launch form
+        if (g8 && atoi(g8)) {     // the 3 planes as NHWC int8 codes (3 of 32 bytes real), then the generic int8 conv
+            int8_t *img32 = wsp<int8_t>(c, "le8.img32");
+            const QLayer &Lq = c->q8.at("LE.conv_first");
+            if (q.ok()) q.chk(planar3_to_q8_launch(img, (size_t)H * W, Lq.q.inv(), Lq.q.zoff(), img32, q.s), "le.conv_first.pack", "planar3_to_q8", 0.0, 38.0 * H * W);
+            q.convq8("LE.conv_first", img32, true, 32, H, W, ACT_RELU, f0a, 32, nullptr);
+        } else if (q.ok()) {      // quantised while the patch is staged, K = (ky | kx4, c4): two int8 MFMAs per 32 pixels (conv_c3_q8)
+            const QLayer &Lq = c->q8.at("LE.conv_first#c3");
+            q.chk(conv_c3_q8_launch(img, H, W, wtp<int8_t>(c, Lq.wpk8), wtp<float>(c, Lq.scale), wtp<float>(c, Lq.shift), Lq.q.inv(),
+                                    Lq.q.zoff(), ACT_RELU, f0a, c->n_cu, q.s),
+                  "LE.conv_first", "conv_c3_q8", (double)H * W * 27 * 32, (double)H * W * (6.0 + 64.0));
+        }
         q.conv32("LE.HR_conv1", f0a, cond1, "LE.SFT_layer1", H, W, ACT_RELU, ST_NHWC, fea0, 32, H, W);
     } else {
         // fp16 conv_first is computed inside HR_conv1's kernel from the three planes (conv32s.hip, C3): its 32-channel output

@@ -49,6 +49,9 @@ hipError_t agcm_mlp_launch(const f16 *in, f16 *out, size_t npix, const f16 *frag
 
 hipError_t conv_c3_launch(const f16 *in, int H, int W, const f16 *wfrag, const float *scale, const float *shift, int cout,
                           int act, f16 *out, f16 *out_pool, int n_cu, hipStream_t s, float pool_q_inv = 0.f, float pool_q_zero = 0.f);
+// LE.conv_first as a W8A8 layer: int8 A fragments [2][64 lanes][16 B] (K = (ky | kx4, c4)), scale[32], shift[16 border classes][32]
+hipError_t conv_c3_q8_launch(const f16 *in, int H, int W, const int8_t *wq, const float *scale, const float *shift, float q_inv,
+                             float q_zoff, int act, f16 *out, int n_cu, hipStream_t s);
 // pool_q_inv > 0: out_pool holds int8 codes clamp(rint(v * pool_q_inv + pool_q_zero), -128, 127), COUT bytes per pixel
 // last layer of a fused chain as a W8A8 layer: int8 weight fragments [2][64 lanes][16 B], ss = scale[32] | shift[32]
 struct QLastArgs {

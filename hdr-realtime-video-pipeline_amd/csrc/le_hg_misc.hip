@@ -34,7 +34,7 @@ __device__ __forceinline__ f16x8 c3_frag(const f16x4 *s_px, int row, int ky, int
 }
 
 // one tile's halo pixels, fetched a tile ahead into registers: thread e = tid + 256 i owns patch pixel (e / 34, e % 34)
-struct C3Pre { f16 v[C3_NP][3]; };
+struct C3Pre { f16 v[C3_NP][3]; bool ok[C3_NP]; };
 __device__ __forceinline__ void c3_fetch(C3Pre &pre, const f16 *__restrict__ in, int H, int W, int oy0, int ox0, int tid)
 {
 #pragma unroll
@@ -44,6 +44,7 @@ __device__ __forceinline__ void c3_fetch(C3Pre &pre, const f16 *__restrict__ in,
         const int iy = oy0 - 1 + r, ix = ox0 - 1 + q;
         const bool ok = e < C3_HH * C3_HW && iy >= 0 && iy < H && ix >= 0 && ix < W;
         const size_t o = ok ? (size_t)iy * W + ix : 0;
+        pre.ok[i] = ok;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             pre.v[i][c] = in[(size_t)c * H * W + o];
@@ -170,6 +171,82 @@ __global__ __launch_bounds__(256) void conv_c3_kernel(const f16 *__restrict__ in
         }
     }
     }   // tile loop
+}
+
+// ================================================================================== conv_c3_q8
+// LE.conv_first as a W8A8 layer (the full INT8 recipe; W8A8Conv2d.forward, hdrtvnet_torch.py:351-364; scheme in conv32p.hip's
+// header): the three planes are quantised while the patch is staged -- 4 int8 codes per pixel (r, g, b, pad), out-of-image
+// pixels code 0 -- and the K axis is (ky | kx4, c4) as in conv_c3: kernel rows 0 and 1 are the two 16-byte halves of ONE
+// v_mfma_i32_32x32x32_i8 (lane half lh reads pixels l31 .. l31+3 of patch row y + lh), row 2 the first half of a second one
+// whose other half meets zero weights.  Two MFMAs per 32 pixels x 32 channels; the generic path (planar3_to_q8 + conv_q8 on
+// 32-byte pixels of which 3 bytes are real) needed nine and a 265 MB intermediate.
+__global__ __launch_bounds__(256) void conv_c3_q8_kernel(const f16 *__restrict__ in, int H, int W, const i32x4 *__restrict__ wq,
+                                                         const float *__restrict__ scale, const float *__restrict__ shift,
+                                                         float q_inv, float q_zoff, int act, f16 *__restrict__ out)
+{
+    constexpr int COUT = 32, ROWB = COUT * 2 + 16;
+    __shared__ __attribute__((aligned(16))) int s_px[C3_HH * C3_PW];
+    __shared__ __attribute__((aligned(16))) char s_out[C3_TH * C3_TW * ROWB];
+    __shared__ __attribute__((aligned(16))) float s_ss[17 * COUT];          // scale[32] | shift[16 border classes][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int tiles_x = (W + C3_TW - 1) / C3_TW, ntiles = tiles_x * ((H + C3_TH - 1) / C3_TH);
+    for (int e = tid; e < 17 * COUT; e += 256) s_ss[e] = e < COUT ? scale[e] : shift[e - COUT];
+    const i32x4 w0 = wq[lane], w1 = wq[64 + lane];
+    for (int e = tid; e < C3_HH * 2; e += 256) s_px[(e >> 1) * C3_PW + C3_HW + (e & 1)] = 0;
+    C3Pre pre;
+    auto fetch = [&](int t) { c3_fetch(pre, in, H, W, (t / tiles_x) * C3_TH, (t % tiles_x) * C3_TW, tid); };
+    const float aslope = act_slope(act);
+    int t = blockIdx.x;
+    if (t < ntiles) fetch(t);
+    for (; t < ntiles; t += gridDim.x) {
+        const int ox0 = (t % tiles_x) * C3_TW, oy0 = (t / tiles_x) * C3_TH;
+        __syncthreads();                                   // the previous tile is done with s_px and s_out
+#pragma unroll
+        for (int i = 0; i < C3_NP; ++i) {
+            const int e = tid + 256 * i;
+            if (e < C3_HH * C3_HW)
+                s_px[(e / C3_HW) * C3_PW + e % C3_HW] =
+                    pre.ok[i] ? (int)quant4((float)pre.v[i][0], (float)pre.v[i][1], (float)pre.v[i][2], 0.f, q_inv, q_zoff) : 0;
+        }
+        __syncthreads();
+        if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = 2 * wave + j;
+            const int *q0 = s_px + (row + lh) * C3_PW + l31, *q1 = s_px + (row + 2) * C3_PW + l31;
+            const i32x4 b0 = {q0[0], q0[1], q0[2], q0[3]}, b1 = {q1[0], q1[1], q1[2], q1[3]};
+            i32x16 acc;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[k] = 0;
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1, b1, acc, 0, 0, 0);
+            // border class of this lane's pixel: which kernel rows / columns fall outside the image there
+            const int oy = oy0 + row, ox = ox0 + l31;
+            const int bcls = ((((oy == 0) | ((oy == H - 1) << 1)) << 2) | ((ox == 0) | ((ox == W - 1) << 1))) & 15;
+            const int q = row * C3_TW + l31;
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int cl = 8 * qd + 4 * lh;
+                const float4 sc = *reinterpret_cast<const float4 *>(s_ss + cl);
+                const float4 sh = *reinterpret_cast<const float4 *>(s_ss + COUT + bcls * COUT + cl);
+                f16x4 o;
+                o[0] = (f16)act_fast((float)acc[4 * qd + 0] * sc.x + sh.x, aslope);
+                o[1] = (f16)act_fast((float)acc[4 * qd + 1] * sc.y + sh.y, aslope);
+                o[2] = (f16)act_fast((float)acc[4 * qd + 2] * sc.z + sh.z, aslope);
+                o[3] = (f16)act_fast((float)acc[4 * qd + 3] * sc.w + sh.w, aslope);
+                *reinterpret_cast<f16x4 *>(s_out + q * ROWB + cl * 2) = o;
+            }
+        }
+        __syncthreads();
+        constexpr int CPP = COUT / 8;
+        for (int e = tid; e < C3_TH * C3_TW * CPP; e += 256) {
+            const int q = e / CPP, c8 = e % CPP;
+            const int oy = oy0 + q / C3_TW, ox = ox0 + q % C3_TW;
+            if (oy < H && ox < W)
+                *reinterpret_cast<f16x8 *>(out + ((size_t)oy * W + ox) * COUT + c8 * 8) =
+                    *reinterpret_cast<const f16x8 *>(s_out + q * ROWB + c8 * 16);
+        }
+    }
 }
 
 // ================================================================================== hg_prep
@@ -341,6 +418,21 @@ hipError_t conv_c3_launch(const f16 *in, int H, int W, const f16 *wfrag, const f
         hipLaunchKernelGGL(conv_c3_kernel<64>, grid, dim3(256), 0, s, in, H, W, wfrag, scale, shift, act, out, out_pool, pool_q_inv, pool_q_zero);
     else
         return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t conv_c3_q8_launch(const f16 *in, int H, int W, const int8_t *wq, const float *scale, const float *shift, float q_inv,
+                             float q_zoff, int act, f16 *out, int n_cu, hipStream_t s)
+{
+    const int ntiles = ((W + C3_TW - 1) / C3_TW) * ((H + C3_TH - 1) / C3_TH);
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        int nb = 0;
+        per_cu = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_c3_q8_kernel, 256, 0) == hipSuccess && nb >= 1) ? nb : 2;
+    }
+    const dim3 grid(ntiles < per_cu * n_cu ? ntiles : per_cu * n_cu);
+    hipLaunchKernelGGL(conv_c3_q8_kernel, grid, dim3(256), 0, s, in, H, W, reinterpret_cast<const i32x4 *>(wq), scale, shift, q_inv, q_zoff,
+                       act, out);
     return hipGetLastError();
 }
 

@@ -262,7 +262,7 @@ def test_full_w8a8_layers_given_device_inputs(proc_full, sd_full, golden_dir):
     mx, mean = _stats("cond2 (cond_tail_q8) given device codes", T("le.cond2"), y)
     assert mx <= 1e-2 and mean <= 5e-4
     y = O.relu(O.conv2d(a, sd["LE.conv_first.weight"], sd["LE.conv_first.bias"], 1, 1))
-    mx, _ = _stats("conv_first (planar3_to_q8 + conv_q8<32,3,1>)", T("le.f0a"), y)
+    mx, _ = _stats("conv_first (conv_c3_q8)", T("le.f0a"), y)
     assert mx <= 2e-3
     # ---- conv32p<1,sft-i8,i8>: SFT_layer1 + HR_conv1, and a whole ResBlock_with_SFT, all six convs W8A8
     y = O.relu(O.conv2d(O.sft(sd, "LE.SFT_layer1", T("le.f0a"), T("le.cond1")), sd["LE.HR_conv1.weight"], sd["LE.HR_conv1.bias"], 1, 1))
