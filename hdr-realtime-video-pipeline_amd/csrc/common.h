@@ -33,13 +33,17 @@ __device__ __forceinline__ float act_fast(float v, float slope) { return fmaxf(v
 // zoff = -x_zero / x_scale; symmetric layers: zoff = 128), code = q - 128, byte k of the result = value k.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
+// u8 codes clamp(rint(x * inv + zoff), 0, 255) of four values, as int8 codes q - 128.  v_cvt_pk_u8_f32 rounds to nearest
+// even and saturates to [0, 255] by itself: a separate v_rndne + v_med3 in front of it changes no result (tools/
+// cvt_pk_u8_probe.hip compares both forms on the GPU over every half-integer tie from -8 to 262, +-inf, +-1e9 and 200 000
+// values in between: 0 differ), so the quantiser is one FMA + one convert per value.
 __device__ __forceinline__ unsigned quant4(float a, float b, float c, float d, float inv, float zoff)
 {
     unsigned w = 0;
-    w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(__builtin_rintf(__builtin_fmaf(a, inv, zoff)), 0.f, 255.f), 0, w);
-    w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(__builtin_rintf(__builtin_fmaf(b, inv, zoff)), 0.f, 255.f), 1, w);
-    w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(__builtin_rintf(__builtin_fmaf(c, inv, zoff)), 0.f, 255.f), 2, w);
-    w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(__builtin_rintf(__builtin_fmaf(d, inv, zoff)), 0.f, 255.f), 3, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(a, inv, zoff), 0, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(b, inv, zoff), 1, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(c, inv, zoff), 2, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(d, inv, zoff), 3, w);
     return w ^ 0x80808080u;                       // u8 code q -> int8 code q - 128
 }
 
