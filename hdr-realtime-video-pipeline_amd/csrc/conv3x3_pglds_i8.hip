@@ -306,26 +306,35 @@ __global__ __launch_bounds__(512) void conv_pglds_i8_kernel(ConvI8Params p)
             float4 *d = ok ? reinterpret_cast<float4 *>(p.dst_dot + ((size_t)Y * p.Wd + X) * 4) : reinterpret_cast<float4 *>(trash);
             *d = make_float4(r.x, r.y, r.z, 0.f);
         } else {
-            // int8 codes of the output tensor's quantiser: clamp(rint(acc * scale + shift), -128, 127)
+            // int8 codes of the output tensor's quantiser: clamp(rint(acc * scale + shift), lo, 127), computed as the u8 code
+            // 128 higher: q holds max(acc * scale + shift + 128, lo + 128), still unrounded (the 2x2 max of ST_POOL commutes with
+            // the monotone quantiser), and v_cvt_pk_u8_f32 rounds to nearest even, saturates to [0, 255] and packs in one
+            // instruction (common.h quant4; tools/cvt_pk_u8_probe.hip); xor 0x80 per byte brings the code back to int8.
+            // 4 VALU operations per value where rint / min / max / cvt / mask / shift / or took 8.5.
             float q[4][4][4];
+            const float lo128 = p.lo_clamp + 128.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float4 sc = *reinterpret_cast<const float4 *>(ss + cw + i * 16);
-                const float4 sh = *reinterpret_cast<const float4 *>(ss + 128 + cw + i * 16);
+                float4 sh = *reinterpret_cast<const float4 *>(ss + 128 + cw + i * 16);
+                sh.x += 128.f; sh.y += 128.f; sh.z += 128.f; sh.w += 128.f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float4 sj = shift_of(sh, i, j);
-                    const float lo = p.lo_clamp;
-                    q[i][j][0] = fminf(fmaxf(__builtin_rintf((float)acc[i][j][0] * sc.x + sj.x), lo), 127.f);
-                    q[i][j][1] = fminf(fmaxf(__builtin_rintf((float)acc[i][j][1] * sc.y + sj.y), lo), 127.f);
-                    q[i][j][2] = fminf(fmaxf(__builtin_rintf((float)acc[i][j][2] * sc.z + sj.z), lo), 127.f);
-                    q[i][j][3] = fminf(fmaxf(__builtin_rintf((float)acc[i][j][3] * sc.w + sj.w), lo), 127.f);
+                    q[i][j][0] = fmaxf((float)acc[i][j][0] * sc.x + sj.x, lo128);
+                    q[i][j][1] = fmaxf((float)acc[i][j][1] * sc.y + sj.y, lo128);
+                    q[i][j][2] = fmaxf((float)acc[i][j][2] * sc.z + sj.z, lo128);
+                    q[i][j][3] = fmaxf((float)acc[i][j][3] * sc.w + sj.w, lo128);
                     acc[i][j] = i32x4{0, 0, 0, 0};
                 }
             }
             auto pack4 = [](const float *v) -> unsigned {
-                return ((unsigned)(int)v[0] & 0xffu) | (((unsigned)(int)v[1] & 0xffu) << 8) | (((unsigned)(int)v[2] & 0xffu) << 16) |
-                       ((unsigned)(int)v[3] << 24);
+                unsigned w = 0;
+                w = __builtin_amdgcn_cvt_pk_u8_f32(v[0], 0, w);
+                w = __builtin_amdgcn_cvt_pk_u8_f32(v[1], 1, w);
+                w = __builtin_amdgcn_cvt_pk_u8_f32(v[2], 2, w);
+                w = __builtin_amdgcn_cvt_pk_u8_f32(v[3], 3, w);
+                return w ^ 0x80808080u;
             };
             constexpr int SP = 80;                                   // strip row pitch: 64 ch x 1 B + 16
             const int s_px = lane >> 2, s_chunk = lane & 3;

@@ -130,16 +130,18 @@ __global__ __launch_bounds__(512) void conv1x1_i8_kernel(ConvI8Params p)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float4 sc = *reinterpret_cast<const float4 *>(p.scale + cw + i * 16);
-        const float4 sh = *reinterpret_cast<const float4 *>(p.shift + cw + i * 16);
+        float4 sh = *reinterpret_cast<const float4 *>(p.shift + cw + i * 16);
+        sh.x += 128.f; sh.y += 128.f; sh.z += 128.f; sh.w += 128.f;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const float q0 = fminf(fmaxf(__builtin_rintf((float)acc[i][j][0] * sc.x + sh.x), -128.f), 127.f);
-            const float q1 = fminf(fmaxf(__builtin_rintf((float)acc[i][j][1] * sc.y + sh.y), -128.f), 127.f);
-            const float q2 = fminf(fmaxf(__builtin_rintf((float)acc[i][j][2] * sc.z + sh.z), -128.f), 127.f);
-            const float q3 = fminf(fmaxf(__builtin_rintf((float)acc[i][j][3] * sc.w + sh.w), -128.f), 127.f);
-            const unsigned pk = ((unsigned)(int)q0 & 0xffu) | (((unsigned)(int)q1 & 0xffu) << 8) | (((unsigned)(int)q2 & 0xffu) << 16) |
-                                ((unsigned)(int)q3 << 24);
-            *reinterpret_cast<unsigned *>(stg + (j * 16 + l15) * SP + i * 16 + 4 * kg) = pk;
+            // int8 code clamp(rint(acc * scale + shift), -128, 127) as the u8 code 128 higher: v_cvt_pk_u8_f32 rounds to
+            // nearest even, saturates and packs (common.h quant4), xor 0x80 per byte brings it back to int8
+            unsigned pk = 0;
+            pk = __builtin_amdgcn_cvt_pk_u8_f32((float)acc[i][j][0] * sc.x + sh.x, 0, pk);
+            pk = __builtin_amdgcn_cvt_pk_u8_f32((float)acc[i][j][1] * sc.y + sh.y, 1, pk);
+            pk = __builtin_amdgcn_cvt_pk_u8_f32((float)acc[i][j][2] * sc.z + sh.z, 2, pk);
+            pk = __builtin_amdgcn_cvt_pk_u8_f32((float)acc[i][j][3] * sc.w + sh.w, 3, pk);
+            *reinterpret_cast<unsigned *>(stg + (j * 16 + l15) * SP + i * 16 + 4 * kg) = pk ^ 0x80808080u;
         }
     }
     const int s_px = lane >> 2, s_chunk = lane & 3;

@@ -156,13 +156,18 @@ __global__ __launch_bounds__(256) void conv_c3_kernel(const f16 *__restrict__ in
                 }
                 if (pool_q_inv > 0.f) {
                     // the pooled map as int8 codes q - 128 of a W8A8 reader (W8A8Conv2d.forward, hdrtvnet_torch.py:351-356)
+                    // clamp(rint(v * inv + zero), -128, 127) as the u8 code 128 higher (common.h quant4's convert), back by xor 0x80
                     unsigned lo = 0, hi = 0;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const float q = fminf(fmaxf(__builtin_rintf((float)v[k] * pool_q_inv + pool_q_zero), -128.f), 127.f);
-                        const unsigned b = (unsigned)(int)q & 0xffu;
-                        if (k < 4) lo |= b << (8 * k); else hi |= b << (8 * (k - 4));
-                    }
+                    const float z128 = pool_q_zero + 128.f;
+                    lo = __builtin_amdgcn_cvt_pk_u8_f32((float)v[0] * pool_q_inv + z128, 0, lo);
+                    lo = __builtin_amdgcn_cvt_pk_u8_f32((float)v[1] * pool_q_inv + z128, 1, lo);
+                    lo = __builtin_amdgcn_cvt_pk_u8_f32((float)v[2] * pool_q_inv + z128, 2, lo);
+                    lo = __builtin_amdgcn_cvt_pk_u8_f32((float)v[3] * pool_q_inv + z128, 3, lo);
+                    hi = __builtin_amdgcn_cvt_pk_u8_f32((float)v[4] * pool_q_inv + z128, 0, hi);
+                    hi = __builtin_amdgcn_cvt_pk_u8_f32((float)v[5] * pool_q_inv + z128, 1, hi);
+                    hi = __builtin_amdgcn_cvt_pk_u8_f32((float)v[6] * pool_q_inv + z128, 2, hi);
+                    hi = __builtin_amdgcn_cvt_pk_u8_f32((float)v[7] * pool_q_inv + z128, 3, hi);
+                    lo ^= 0x80808080u; hi ^= 0x80808080u;
                     *reinterpret_cast<uint2 *>(reinterpret_cast<int8_t *>(out_pool) + ((size_t)oy * Wp + ox) * COUT + c8 * 8) = make_uint2(lo, hi);
                 } else {
                     *reinterpret_cast<f16x8 *>(out_pool + ((size_t)oy * Wp + ox) * COUT + c8 * 8) = v;
