@@ -47,6 +47,17 @@ __device__ __forceinline__ unsigned quant4(float a, float b, float c, float d, f
     return w ^ 0x80808080u;                       // u8 code q -> int8 code q - 128
 }
 
+// the same for values that already are code + offset (a chain's constants have 1 / x_scale and the zero point folded in)
+__device__ __forceinline__ unsigned quant4u(float a, float b, float c, float d)
+{
+    unsigned w = 0;
+    w = __builtin_amdgcn_cvt_pk_u8_f32(a, 0, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(b, 1, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(c, 2, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(d, 3, w);
+    return w ^ 0x80808080u;
+}
+
 // K-dimension permutation that lets a 32x32 MFMA accumulator tile be re-used, packed to f16,
 // as the B operand of the next MFMA (cdna_hip_programming.md section 3, "An accumulator tile as
 // the next MFMA's operand"): operand slot p (0..15) of a 16-wide k-step holds logical k

@@ -341,8 +341,8 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
                     t[4 * g + 2] = fmaxf(u2, 0.1f * u2) + zo; t[4 * g + 3] = fmaxf(u3, 0.1f * u3) + zo;
                 }
                 i32x4 hs = {0, 0, 0, 0}, ht = {0, 0, 0, 0};
-                hs[0] = (int)quant4(t[0], t[1], t[2], t[3], 1.f, 0.f);   hs[1] = (int)quant4(t[4], t[5], t[6], t[7], 1.f, 0.f);
-                ht[0] = (int)quant4(t[8], t[9], t[10], t[11], 1.f, 0.f); ht[1] = (int)quant4(t[12], t[13], t[14], t[15], 1.f, 0.f);
+                hs[0] = (int)quant4u(t[0], t[1], t[2], t[3]);   hs[1] = (int)quant4u(t[4], t[5], t[6], t[7]);
+                ht[0] = (int)quant4u(t[8], t[9], t[10], t[11]); ht[1] = (int)quant4u(t[12], t[13], t[14], t[15]);
                 const i32x16 a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(qa1s, hs, z16, 0, 0, 0);
                 const i32x16 a2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(qa1t, ht, z16, 0, 0, 0);
 #pragma unroll

@@ -40,8 +40,8 @@ __device__ __forceinline__ i32x4 requant16(const i32x16 &acc, const float *A, co
         const float4 ka = *reinterpret_cast<const float4 *>(A + 4 * g), kb = *reinterpret_cast<const float4 *>(B + 4 * g);
         const float u0 = (float)acc[4 * g + 0] * ka.x + kb.x, u1 = (float)acc[4 * g + 1] * ka.y + kb.y,
                     u2 = (float)acc[4 * g + 2] * ka.z + kb.z, u3 = (float)acc[4 * g + 3] * ka.w + kb.w;
-        o[g] = (int)quant4(fmaxf(u0, slope * u0) + zoff, fmaxf(u1, slope * u1) + zoff, fmaxf(u2, slope * u2) + zoff,
-                           fmaxf(u3, slope * u3) + zoff, 1.f, 0.f);
+        o[g] = (int)quant4u(fmaxf(u0, slope * u0) + zoff, fmaxf(u1, slope * u1) + zoff, fmaxf(u2, slope * u2) + zoff,
+                           fmaxf(u3, slope * u3) + zoff);
     }
     return o;
 }
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void le_cond_trunk_q8_kernel(TrunkQ8Params 
             const int e = tid + 256 * i;
             const int c = e / (T_HH * T_HW), r = (e / T_HW) % T_HH, q = e % T_HW;
             if (e < 3 * T_HH * T_HW) {
-                const unsigned code = quant4((float)pre[i], 0.f, 0.f, 0.f, p.q1_inv, p.q1_zoff) & 255u;
+                const unsigned code = (__builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)pre[i], p.q1_inv, p.q1_zoff), 0, 0u) ^ 0x80u) & 255u;
                 s_in[(c * T_HH + r) * T_PITCH + q] = pre_ok[i] ? (unsigned char)code : (unsigned char)0;   // out-of-image: code 0
             }
         }
