@@ -132,7 +132,9 @@ __global__ __launch_bounds__(512) void conv_pglds_kernel(ConvParams p)
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float aslope = act_slope(p.act);
+    // ReLU or none (the launcher refuses anything else): one v_max against 0 or -inf instead of max(v, slope * v)
+    // (A/B on one box, four builds: 6.89 -> 6.82 ms over the 14 launches)
+    const float act_lb = p.act == ACT_RELU ? 0.f : -__builtin_inff();
     const int kw = l15 & 7;
     const int b_lane = (wc * 64 + l15) * PIXB;
     const int a_lane = (wp * 4 * HW + l15) * PIXB;
@@ -232,10 +234,10 @@ __global__ __launch_bounds__(512) void conv_pglds_kernel(ConvParams p)
             const float4 sh = *reinterpret_cast<const float4 *>(ss + 128 + cw + i * 16);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                o[i][j][0] = (f16)act_fast(acc[i][j][0] * sc.x + sh.x, aslope);
-                o[i][j][1] = (f16)act_fast(acc[i][j][1] * sc.y + sh.y, aslope);
-                o[i][j][2] = (f16)act_fast(acc[i][j][2] * sc.z + sh.z, aslope);
-                o[i][j][3] = (f16)act_fast(acc[i][j][3] * sc.w + sh.w, aslope);
+                o[i][j][0] = (f16)fmaxf(acc[i][j][0] * sc.x + sh.x, act_lb);
+                o[i][j][1] = (f16)fmaxf(acc[i][j][1] * sc.y + sh.y, act_lb);
+                o[i][j][2] = (f16)fmaxf(acc[i][j][2] * sc.z + sh.z, act_lb);
+                o[i][j][3] = (f16)fmaxf(acc[i][j][3] * sc.w + sh.w, act_lb);
                 acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
@@ -363,7 +365,7 @@ hipError_t launch_mode(const ConvParams &p, int grid, hipStream_t stream)
 hipError_t conv_pglds_launch(ConvParams p, int n_cu, hipStream_t stream)
 {
     if ((p.c0 % CT) || (p.c1 % CT) || p.c0 + p.c1 < CT || (p.CoutPad % BN) || p.Cout != p.CoutPad || p.res1 || p.res2 ||
-        p.dst_full || !p.zeros || !p.trash || n_cu < 8 ||
+        p.dst_full || !p.zeros || !p.trash || n_cu < 8 || (p.act != ACT_RELU && p.act != ACT_NONE) ||
         (p.mode != ST_NHWC && p.mode != ST_PS && p.mode != ST_POOL && p.mode != ST_PS_DOT3) ||
         (p.mode == ST_PS && (p.dstC % 64)) || (p.mode == ST_PS_DOT3 && (p.dstC != 64 || !p.dotw || !p.dst_dot)))
         return hipErrorInvalidValue;
