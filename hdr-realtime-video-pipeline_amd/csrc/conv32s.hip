@@ -105,15 +105,19 @@ struct Lay {
 // s_waitcnt immediate of gfx9: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14
 constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 15) | (7 << 4) | ((lgkm & 15) << 8) | ((vm >> 4) << 14); }
 
-template <bool SFT, bool I8, bool SQ, bool PLANAR, bool C3 = false>
+template <bool SFT, bool I8, bool SQ, bool PLANAR, bool C3 = false, bool SPLIT = false>
 __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
 {
     static_assert(!SQ || (SFT && I8), "W8A8 SFT convs come with a W8A8 conv behind them");
     static_assert(!C3 || (SFT && !I8 && !PLANAR), "conv_first is fused in front of SFT_layer1 + HR_conv1 (fp16) only");
+    static_assert(!SPLIT || SFT || I8, "the role split needs a P pass to give to waves 4-7");
     using L = Lay<SFT, I8, SQ, C3>;
     constexpr bool PREP = SFT || I8;
     constexpr int NA = L::NA;
-    constexpr int NSTORE = PLANAR ? 3 : 2;             // stores per wave and tile, issued unconditionally
+    // SPLIT: waves 0-3 are conv waves (R M E over 64 output pixels = two 32-pixel groups each), waves 4-7 prep waves (the
+    // LDS-DMA and the P pass, three halo groups each).  Otherwise every wave does both (one conv group; two or one halo groups).
+    constexpr int NQ = SPLIT ? 2 : 1;                  // 32-pixel conv groups of a conv wave
+    constexpr int NSTORE = (PLANAR ? 3 : 2) * NQ;      // stores per conv wave and tile, issued unconditionally
         extern __shared__ __attribute__((aligned(16))) char smem[];
     // scale / shift (and the W8A8 SFT constants) live in STATIC LDS arrays: hipcc's waitcnt pass makes every LDS read
     // that may alias an LDS-DMA destination wait vmcnt(0) -- a read of these tables in the epilogue would wait for the
@@ -130,7 +134,13 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
-    char *strip = smem + L::OFF_OUT + wave * STRIP;
+    char *strip = smem + L::OFF_OUT + wave * (NQ * STRIP);           // SPLIT: waves 0-3 only, 64 pixels each
+    const int iw = wave & 3;                                          // index among the four DMA-issuing waves
+    // who issues the LDS-DMA: without the split waves 0-3.  With it the prep waves -- a conv wave that issues DMA pays for it
+    // in its epilogue, where hipcc's vmcnt(0) in front of the residuals then also waits for the pieces it has just issued
+    // (measured: condition tile on the conv waves = the 17 SFT launches 0.98 -> 1.02 ms) -- except with conv_first fused in,
+    // where the prep waves carry the extra conv and only the three condition pieces exist (0.385 -> 0.37 ms on the conv waves)
+    const bool issue_a = SPLIT ? wave >= 4 : wave < NWI, issue_c = (SPLIT && !C3) ? wave >= 4 : wave < NWI;
     const int ntiles = p.tiles_x * p.tiles_y;
     const unsigned uH = (unsigned)p.H, uW = (unsigned)p.W;
     const unsigned src_guard = (unsigned)p.H * p.W * 64u;     // byte offset of the zero guard behind src (32 ch f16)
@@ -140,7 +150,7 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
     int a_pos[A_PW], a_off[A_PW], c_pos[C_PW], c_off[C_PW];
 #pragma unroll
     for (int it = 0; it < A_PW; ++it) {
-        const int hp = (wave + it * NWI) * 16 + (lane >> 2), slot = lane & 3;
+        const int hp = (iw + it * NWI) * 16 + (lane >> 2), slot = lane & 3;
         const int hy = hp / HW, hx = hp - hy * HW;
         a_pos[it] = (hp < NPIX && hx < HC) ? (hy | (hx << 8)) : -1;
         a_off[it] = (hy * p.W + hx) * 64 + ((slot ^ swz32(hx)) << 4);
@@ -148,7 +158,7 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
     if (SFT) {
 #pragma unroll
         for (int it = 0; it < C_PW; ++it) {
-            const int hp = (wave + it * NWI) * 32 + (lane >> 1), half = lane & 1;
+            const int hp = (iw + it * NWI) * 32 + (lane >> 1), half = lane & 1;
             const int hy = hp / HW, hx = hp - hy * HW;
             c_pos[it] = (hp < NPIX && hx < HC) ? (hy | (hx << 8)) : -1;
             c_off[it] = (hy * p.W + hx) * 32 + (half << 4);
@@ -160,20 +170,20 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
         const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
         const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
         const int pix0 = iy0 * p.W + ix0;                      // may be negative; valid lanes land >= 0
-        if constexpr (!C3) {
+        if (!C3 && issue_a) {
 #pragma unroll
             for (int it = 0; it < A_PW; ++it) {
                 const bool ok = a_pos[it] >= 0 && (unsigned)(iy0 + (a_pos[it] & 255)) < uH && (unsigned)(ix0 + (a_pos[it] >> 8)) < uW;
                 const unsigned off = ok ? (unsigned)(pix0 * 64 + a_off[it]) : src_guard + ((lane & 3) << 4);
-                glds16(reinterpret_cast<const char *>(p.src) + off, abuf + (wave + it * NWI) * 1024);
+                glds16(reinterpret_cast<const char *>(p.src) + off, abuf + (iw + it * NWI) * 1024);
             }
         }
-        if (SFT) {
+        if (SFT && issue_c) {
 #pragma unroll
             for (int it = 0; it < C_PW; ++it) {
                 const bool ok = c_pos[it] >= 0 && (unsigned)(iy0 + (c_pos[it] & 255)) < uH && (unsigned)(ix0 + (c_pos[it] >> 8)) < uW;
                 const unsigned off = ok ? (unsigned)(pix0 * 32 + c_off[it]) : cond_guard + ((lane & 1) << 4);
-                glds16(reinterpret_cast<const char *>(p.cond) + off, cbuf + (wave + it * NWI) * 1024);
+                glds16(reinterpret_cast<const char *>(p.cond) + off, cbuf + (iw + it * NWI) * 1024);
             }
         }
     };
@@ -230,11 +240,12 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
     }
 
     // ---- SFT / quantise pass: lane constants of this wave's 32-slot groups, fragments and biases
-    constexpr int G_PW = 2;
-    const int gid[G_PW] = {wave >= 4 ? wave - 4 : 8 + wave, wave};     // waves 4-7: groups w-4 and w; waves 0-3: group 8+w
+    constexpr int G_PW = SPLIT ? 3 : 2;
+    // SPLIT: prep wave w takes groups w-4, w, w+4.  Otherwise waves 4-7: groups w-4 and w; waves 0-3: group 8+w
+    const int gid[3] = {SPLIT ? iw : (wave >= 4 ? wave - 4 : 8 + wave), SPLIT ? iw + 4 : wave, iw + 8};
     f16x8 sa0, sa1s, sa1t;
     f32x16 sbh, sbs, sbt;
-    int g_pos[G_PW], g_c[G_PW], g_x[G_PW], g_q[G_PW], g_p3[G_PW];
+    int g_pos[3], g_c[3], g_x[3], g_q[3], g_p3[3];
     i32x4 qa0, qa1s, qa1t;
     float cq_inv = 0.f, cq_zoff = 0.f;
     if constexpr (SQ) {
@@ -264,8 +275,8 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
     }
     // y = x*(scale+1)+shift in place on a landed halo tile (arch_util.py:68-72), three sweeps over the wave's groups:
     // every LDS read, the MLPs, modulate / quantise and write (see conv32p.hip)
-    auto sft_groups = [&](auto ngc, int tt, char *a, const char *cbuf, char *qbuf, const f16x4 *p3) __attribute__((always_inline)) {
-        constexpr int N = decltype(ngc)::value;
+    auto sft_groups = [&](auto ngc, auto g0c, int tt, char *a, const char *cbuf, char *qbuf, const f16x4 *p3) __attribute__((always_inline)) {
+        constexpr int N = decltype(ngc)::value, G0 = decltype(g0c)::value;    // this call: groups G0 .. G0 + N - 1 of the wave
         const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
         const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
         bool inimg[N];
@@ -274,13 +285,13 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
         f32x16 sc[N], sh[N];
 #pragma unroll
         for (int gi = 0; gi < N; ++gi) {
-            inimg[gi] = g_pos[gi] >= 0 && (unsigned)(iy0 + (g_pos[gi] & 255)) < uH && (unsigned)(ix0 + (g_pos[gi] >> 8)) < uW;
+            inimg[gi] = g_pos[G0 + gi] >= 0 && (unsigned)(iy0 + (g_pos[G0 + gi] & 255)) < uH && (unsigned)(ix0 + (g_pos[G0 + gi] >> 8)) < uW;
             if constexpr (SQ) {
-                const char *crow = cbuf + g_c[gi] - lh * 16;
+                const char *crow = cbuf + g_c[G0 + gi] - lh * 16;
                 c0[gi] = *reinterpret_cast<const f16x8 *>(crow);
                 c1[gi] = *reinterpret_cast<const f16x8 *>(crow + 16);
             } else if constexpr (SFT) {
-                c0[gi] = *reinterpret_cast<const f16x8 *>(cbuf + g_c[gi]);
+                c0[gi] = *reinterpret_cast<const f16x8 *>(cbuf + g_c[G0 + gi]);
             }
         }
         f16x8 xc3[N][3];
@@ -289,13 +300,13 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
             if constexpr (C3) {
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
-                    const f16x4 *q = p3 + g_p3[gi] + ky * P3_PW;
+                    const f16x4 *q = p3 + g_p3[G0 + gi] + ky * P3_PW;
                     const f16x4 u = q[0], v = q[1];
                     xc3[gi][ky] = f16x8{u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
                 }
             } else {
 #pragma unroll
-                for (int qd = 0; qd < 4; ++qd) yv[gi][qd] = *reinterpret_cast<const f16x4 *>(a + (g_x[gi] ^ (qd << 4)));
+                for (int qd = 0; qd < 4; ++qd) yv[gi][qd] = *reinterpret_cast<const f16x4 *>(a + (g_x[G0 + gi] ^ (qd << 4)));
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -381,27 +392,40 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
                     yv[gi][qd] = y;
                 }
             }
-            if (g_pos[gi] >= 0) {
+            if (g_pos[G0 + gi] >= 0) {
                 if constexpr (I8) {
-                    *reinterpret_cast<i32x4 *>(qbuf + g_q[gi]) = codes;
+                    *reinterpret_cast<i32x4 *>(qbuf + g_q[G0 + gi]) = codes;
                 } else {
 #pragma unroll
-                    for (int qd = 0; qd < 4; ++qd) *reinterpret_cast<f16x4 *>(a + (g_x[gi] ^ (qd << 4))) = yv[gi][qd];
+                    for (int qd = 0; qd < 4; ++qd) *reinterpret_cast<f16x4 *>(a + (g_x[G0 + gi] ^ (qd << 4))) = yv[gi][qd];
                 }
             }
         }
     };
     auto prep_tile = [&](int tt, char *a, const char *cbuf, char *qbuf, const f16x4 *p3) __attribute__((always_inline)) {
-        if (wave >= 4) sft_groups(std::integral_constant<int, 2>{}, tt, a, cbuf, qbuf, p3);  // wave-uniform
-        else sft_groups(std::integral_constant<int, 1>{}, tt, a, cbuf, qbuf, p3);
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        if constexpr (SPLIT) {
+            if (wave >= 4) {          // three groups as 2 + 1 (W8A8 SFT convs, conv_first fused: 1 + 1 + 1): three at once do not fit the register file
+                if constexpr (SQ || C3) {
+                    sft_groups(I1{}, I0{}, tt, a, cbuf, qbuf, p3);
+                    sft_groups(I1{}, I1{}, tt, a, cbuf, qbuf, p3);
+                } else {
+                    sft_groups(I2{}, I0{}, tt, a, cbuf, qbuf, p3);
+                }
+                sft_groups(I1{}, I2{}, tt, a, cbuf, qbuf, p3);
+            }
+        } else {
+            if (wave >= 4) sft_groups(I2{}, I0{}, tt, a, cbuf, qbuf, p3);  // wave-uniform
+            else sft_groups(I1{}, I0{}, tt, a, cbuf, qbuf, p3);
+        }
     };
 
     // ---- prologue: tiles 0 and 1 in flight, tile 0 landed and transformed
     const int t0 = blockIdx.x, step = gridDim.x;
-    if (wave < NWI) {
-        issue_tile(t0, sA, sC);
-        issue_tile(t0 + step, sA + A_BYTES, sC + C_BYTES);
-    }
+    issue_tile(t0, sA, sC);
+    issue_tile(t0 + step, sA + A_BYTES, sC + C_BYTES);
     if constexpr (C3) {
         p3_fetch(t0); p3_stage(0);
         p3_fetch(t0 + step); p3_stage(1);
@@ -415,16 +439,20 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
     }
 
     // ---- conv fragment addresses (lane constants)
-    const int q = wave * 32 + l31;                       // this lane's output pixel in the tile
-    const int qy = q / TW, qx = q % TW;
-    int xoff[3], qoff[3];
+    // this lane's output pixels in the tile: q = (conv wave) * 32 NQ + 32 g + l31, i.e. rows 2 NQ w + 2 g + (l31 >> 4)
+    int qy[NQ], xoff[NQ][3], qoff[NQ][3];
+    const int qx = l31 % TW;
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-        xoff[kx] = (qy * HW + qx + kx) * 64 + ((lh ^ swz32(qx + kx)) << 4);
-        qoff[kx] = (qy * HW + qx + kx) * 32 + ((lh ^ (qy & 1)) << 4);
+    for (int g = 0; g < NQ; ++g) {
+        qy[g] = (wave * NQ + g) * 2 + l31 / TW;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            xoff[g][kx] = (qy[g] * HW + qx + kx) * 64 + ((lh ^ swz32(qx + kx)) << 4);
+            qoff[g][kx] = (qy[g] * HW + qx + kx) * 32 + ((lh ^ (qy[g] & 1)) << 4);
+        }
     }
     const int woff = I8 ? l31 * 32 + ((lh ^ ((l31 >> 3) & 1)) << 4) : l31 * 64 + ((lh ^ swz32(l31)) << 4);
-    // this lane's two 16-byte output chunks: pixel (2*wave + it, lane >> 2) of the tile, channel chunk c8
+    // this lane's 2 NQ 16-byte output chunks: pixel (2 NQ wave + it, lane >> 2) of the tile, channel chunk c8
     const int c8 = lane & 3, spx = lane >> 2;
     const float aslope = act_slope(p.act);
     char *trash = reinterpret_cast<char *>(p.trash) + tid * 16;
@@ -436,90 +464,112 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
         const int nb = ab + 1 == NA ? 0 : ab + 1, db = NA == 2 ? ab : (nb + 1 == NA ? 0 : nb + 1);
         const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
         const int oy0 = ty * TH, ox0 = tx * TW;
-        const int bcls = I8 ? ((((oy0 + qy == 0) | ((oy0 + qy == p.H - 1) << 1)) << 2) | ((ox0 + qx == 0) | ((ox0 + qx == p.W - 1) << 1))) & 15 : 0;
+        const bool conv_wave = !SPLIT || wave < 4;           // wave-uniform
+        int bcls[NQ];
+#pragma unroll
+        for (int g = 0; g < NQ; ++g)
+            bcls[g] = I8 ? ((((oy0 + qy[g] == 0) | ((oy0 + qy[g] == p.H - 1) << 1)) << 2) | ((ox0 + qx == 0) | ((ox0 + qx == p.W - 1) << 1))) & 15 : 0;
 
         // R: destination addresses and residuals (masked lanes: trash line / zero line), loads issued unconditionally
-        f16 *dptr[2];
-        i32x4 rs1[2], rs2[2];                            // raw bits of 8 f16 each
-        f16 *pl_dst[3];
-        f16 pl_res[3];
-        if constexpr (PLANAR) {
-            const int oy = oy0 + qy, ox = ox0 + qx;
-            const bool in = lh == 0 && oy < p.H && ox < p.W;
+        f16 *dptr[2 * NQ];
+        i32x4 rs1[2 * NQ], rs2[2 * NQ];                  // raw bits of 8 f16 each
+        f16 *pl_dst[NQ][3];
+        f16 pl_res[NQ][3];
+        if (conv_wave) {
+            if constexpr (PLANAR) {
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                const size_t e = (size_t)ch * p.H * p.W + (size_t)oy * p.W + ox;
-                pl_dst[ch] = in ? p.dst_planar + e : reinterpret_cast<f16 *>(trash);
-                pl_res[ch] = *((in && p.res_planar) ? p.res_planar + e : p.zeros);
-            }
-        } else {
+                for (int g = 0; g < NQ; ++g) {
+                    const int oy = oy0 + qy[g], ox = ox0 + qx;
+                    const bool in = lh == 0 && oy < p.H && ox < p.W;
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int oy = oy0 + 2 * wave + it, ox = ox0 + spx;
-                const bool in = c8 * 8 < p.Cout && oy < p.H && ox < p.W;
-                const size_t off = ((size_t)oy * p.W + ox) * p.dstC + c8 * 8;
-                dptr[it] = in ? p.dst + off : reinterpret_cast<f16 *>(trash);
-                rs1[it] = *reinterpret_cast<const i32x4 *>((in && p.res1) ? p.res1 + off : p.zeros);
-                rs2[it] = *reinterpret_cast<const i32x4 *>((in && p.res2) ? p.res2 + off : p.zeros);
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const size_t e = (size_t)ch * p.H * p.W + (size_t)oy * p.W + ox;
+                        pl_dst[g][ch] = in ? p.dst_planar + e : reinterpret_cast<f16 *>(trash);
+                        pl_res[g][ch] = *((in && p.res_planar) ? p.res_planar + e : p.zeros);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < 2 * NQ; ++it) {
+                    const int oy = oy0 + 2 * NQ * wave + it, ox = ox0 + spx;
+                    const bool in = c8 * 8 < p.Cout && oy < p.H && ox < p.W;
+                    const size_t off = ((size_t)oy * p.W + ox) * p.dstC + c8 * 8;
+                    dptr[it] = in ? p.dst + off : reinterpret_cast<f16 *>(trash);
+                    rs1[it] = *reinterpret_cast<const i32x4 *>((in && p.res1) ? p.res1 + off : p.zeros);
+                    rs2[it] = *reinterpret_cast<const i32x4 *>((in && p.res2) ? p.res2 + off : p.zeros);
+                }
             }
         }
         if constexpr (C3) p3_fetch(t + 2 * step);              // R: this thread's pixel of the patch of tile t+2
         // X: tile t+2 in flight
-        if (wave < NWI) issue_tile(t + 2 * step, sA + db * A_BYTES, sC + cb * C_BYTES);
+        issue_tile(t + 2 * step, sA + db * A_BYTES, sC + cb * C_BYTES);
         __builtin_amdgcn_sched_barrier(0);
         STAMP(0);      // addresses, residual loads, DMA issue
 
-        f32x16 acc;
+        f32x16 acc[NQ];
+        // the wave's NQ pixel groups share every weight fragment: 1 + NQ LDS reads per NQ MFMAs
         auto conv_mfma = [&]() __attribute__((always_inline)) {
             if constexpr (I8) {
                 const char *qa = sQ + cb * L::Q_BYTES;
-                i32x16 iacc;
+                i32x16 iacc[NQ];
 #pragma unroll
-                for (int k = 0; k < 16; ++k) iacc[k] = 0;
-                i32x4 wq[9], xq[9];
+                for (int g = 0; g < NQ; ++g)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) iacc[g][k] = 0;
+                i32x4 wq[9], xq[NQ][9];
                 auto ldq = [&](int tap) {
                     wq[tap] = *reinterpret_cast<const i32x4 *>(sW + woff + tap * 32 * 32);
-                    xq[tap] = *reinterpret_cast<const i32x4 *>(qa + ((qoff[tap % 3] + (tap / 3) * HW * 32) ^ (((tap / 3) & 1) << 4)));
+#pragma unroll
+                    for (int g = 0; g < NQ; ++g)
+                        xq[g][tap] = *reinterpret_cast<const i32x4 *>(qa + ((qoff[g][tap % 3] + (tap / 3) * HW * 32) ^ (((tap / 3) & 1) << 4)));
                 };
                 ldq(0); ldq(1); ldq(2);
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     if (tap + 3 < 9) ldq(tap + 3);
-                    iacc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wq[tap], xq[tap], iacc, 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < NQ; ++g) iacc[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wq[tap], xq[g][tap], iacc[g], 0, 0, 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 3 * (1 + NQ), 0);
 #pragma unroll
                 for (int st = 0; st < 6; ++st) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, NQ, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1 + NQ, 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * NQ, 0);
 #pragma unroll
-                for (int k = 0; k < 16; ++k) acc[k] = (float)iacc[k];
+                for (int g = 0; g < NQ; ++g)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) acc[g][k] = (float)iacc[g][k];
             } else {
                 const char *a = sA + ab * A_BYTES;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) acc[k] = 0.f;
-                f16x8 wfr[18], xfr[18];
+                for (int g = 0; g < NQ; ++g)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) acc[g][k] = 0.f;
+                f16x8 wfr[18], xfr[NQ][18];
                 auto ldfrag = [&](int st) {
                     const int tap = st >> 1, ks = st & 1;
                     wfr[st] = *reinterpret_cast<const f16x8 *>(sW + (woff ^ (ks << 5)) + tap * 32 * 64);
-                    xfr[st] = *reinterpret_cast<const f16x8 *>(a + (xoff[tap % 3] ^ (ks << 5)) + (tap / 3) * HW * 64);
+#pragma unroll
+                    for (int g = 0; g < NQ; ++g)
+                        xfr[g][st] = *reinterpret_cast<const f16x8 *>(a + (xoff[g][tap % 3] ^ (ks << 5)) + (tap / 3) * HW * 64);
                 };
                 ldfrag(0); ldfrag(1); ldfrag(2);
 #pragma unroll
                 for (int st = 0; st < 18; ++st) {
                     if (st + 3 < 18) ldfrag(st + 3);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfr[st], xfr[st], acc, 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < NQ; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfr[st], xfr[g][st], acc[g], 0, 0, 0);
                 }
-                // pin the interleave: 6 reads up front, then {1 MFMA, 2 reads} x 15, then 3 MFMAs
-                __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                // pin the interleave: three steps of reads up front, then {NQ MFMAs, 1 + NQ reads} x 15, then 3 NQ MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x100, 3 * (1 + NQ), 0);
 #pragma unroll
                 for (int st = 0; st < 15; ++st) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, NQ, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1 + NQ, 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * NQ, 0);
             }
         };
         // Epilogue, last thing in the tile on both phase orders.  hipcc waits vmcnt(0) in front of the residuals' first use
@@ -531,34 +581,40 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
             if constexpr (PLANAR) {
                 // conv_last: channels 0..2 of pixel l31 sit in registers 0..2 of the lanes with lh == 0; the conv result
                 // is rounded to f16, the residual added in fp32 and the sum rounded again (as the staged path did)
-                const float4 sc4 = *reinterpret_cast<const float4 *>(sSS), sh4 = *reinterpret_cast<const float4 *>(sSS + 32 + (I8 ? bcls * 32 : 0));
-                const float sc[3] = {sc4.x, sc4.y, sc4.z}, sh[3] = {sh4.x, sh4.y, sh4.z};
-                const float o[3] = {act_fast(acc[0] * sc[0] + sh[0], aslope), act_fast(acc[1] * sc[1] + sh[1], aslope), act_fast(acc[2] * sc[2] + sh[2], aslope)};
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch) {
-                    const float v = (float)(f16)o[ch] + (p.res_planar ? (float)pl_res[ch] : 0.f);
-                    *pl_dst[ch] = (f16)v;
+                for (int g = 0; g < NQ; ++g) {
+                    const float4 sc4 = *reinterpret_cast<const float4 *>(sSS), sh4 = *reinterpret_cast<const float4 *>(sSS + 32 + (I8 ? bcls[g] * 32 : 0));
+                    const float sc[3] = {sc4.x, sc4.y, sc4.z}, sh[3] = {sh4.x, sh4.y, sh4.z};
+                    const float o[3] = {act_fast(acc[g][0] * sc[0] + sh[0], aslope), act_fast(acc[g][1] * sc[1] + sh[1], aslope),
+                                        act_fast(acc[g][2] * sc[2] + sh[2], aslope)};
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const float v = (float)(f16)o[ch] + (p.res_planar ? (float)pl_res[g][ch] : 0.f);
+                        *pl_dst[g][ch] = (f16)v;
+                    }
                 }
             } else {
 #pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                    const int cl = 8 * qd + 4 * lh;
-                    const float4 s4 = *reinterpret_cast<const float4 *>(sSS + cl);
-                    const float4 h4 = *reinterpret_cast<const float4 *>(sSS + 32 + (I8 ? bcls * 32 : 0) + cl);
-                    const float sc[4] = {s4.x, s4.y, s4.z, s4.w}, sh[4] = {h4.x, h4.y, h4.z, h4.w};
-                    f16x4 o;
-                    o[0] = (f16)act_fast(acc[4 * qd + 0] * sc[0] + sh[0], aslope);
-                    o[1] = (f16)act_fast(acc[4 * qd + 1] * sc[1] + sh[1], aslope);
-                    o[2] = (f16)act_fast(acc[4 * qd + 2] * sc[2] + sh[2], aslope);
-                    o[3] = (f16)act_fast(acc[4 * qd + 3] * sc[3] + sh[3], aslope);
-                    *reinterpret_cast<f16x4 *>(strip + l31 * OUT_ROWB + cl * 2) = o;
-                }
-                // this wave's 32 pixels back as 16-byte channel chunks (LDS operations of one wave complete in order)
-                f16x8 v[2];
+                for (int g = 0; g < NQ; ++g)
 #pragma unroll
-                for (int it = 0; it < 2; ++it) v[it] = *reinterpret_cast<const f16x8 *>(strip + (it * 16 + spx) * OUT_ROWB + c8 * 16);
+                    for (int qd = 0; qd < 4; ++qd) {
+                        const int cl = 8 * qd + 4 * lh;
+                        const float4 s4 = *reinterpret_cast<const float4 *>(sSS + cl);
+                        const float4 h4 = *reinterpret_cast<const float4 *>(sSS + 32 + (I8 ? bcls[g] * 32 : 0) + cl);
+                        const float sc[4] = {s4.x, s4.y, s4.z, s4.w}, sh[4] = {h4.x, h4.y, h4.z, h4.w};
+                        f16x4 o;
+                        o[0] = (f16)act_fast(acc[g][4 * qd + 0] * sc[0] + sh[0], aslope);
+                        o[1] = (f16)act_fast(acc[g][4 * qd + 1] * sc[1] + sh[1], aslope);
+                        o[2] = (f16)act_fast(acc[g][4 * qd + 2] * sc[2] + sh[2], aslope);
+                        o[3] = (f16)act_fast(acc[g][4 * qd + 3] * sc[3] + sh[3], aslope);
+                        *reinterpret_cast<f16x4 *>(strip + (g * 32 + l31) * OUT_ROWB + cl * 2) = o;
+                    }
+                // this wave's 32 NQ pixels back as 16-byte channel chunks (LDS operations of one wave complete in order)
+                f16x8 v[2 * NQ];
 #pragma unroll
-                for (int it = 0; it < 2; ++it) {
+                for (int it = 0; it < 2 * NQ; ++it) v[it] = *reinterpret_cast<const f16x8 *>(strip + (it * 16 + spx) * OUT_ROWB + c8 * 16);
+#pragma unroll
+                for (int it = 0; it < 2 * NQ; ++it) {
                     // residual adds in packed f16, one rounding per add as the reference's fp16 model does
                     // (x + conv2(..) then + skip, arch_util.py:95, HDRUNet3T1_arch.py:186-198)
                     v[it] = (v[it] + __builtin_bit_cast(f16x8, rs1[it])) + __builtin_bit_cast(f16x8, rs2[it]);
@@ -567,22 +623,40 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
             }
         };
         const int cn = cb ^ 1;
-        if (wave < 4) {
-            conv_mfma();
-            STAMP(1);  // conv MFMAs
-            if (PREP && t + step < ntiles) prep_tile(t + step, sA + nb * A_BYTES, sC + cn * C_BYTES, sQ + cn * L::Q_BYTES, sP3 + cn * (P3_BYTES / 8));
-            STAMP(2);  // SFT / quantise pass of the next tile
+        if constexpr (SPLIT) {
+            if (wave < 4) {                                    // conv wave: 64 output pixels
+                conv_mfma();
+                STAMP(1);
+                epilogue();
+                STAMP(3);
+            } else {                                           // prep wave: three halo groups of the next tile
+                if (t + step < ntiles) prep_tile(t + step, sA + nb * A_BYTES, sC + cn * C_BYTES, sQ + cn * L::Q_BYTES, sP3 + cn * (P3_BYTES / 8));
+                STAMP(2);
+            }
+            if constexpr (C3) p3_stage(cb);
+            // prep waves: their DMA of tile t+2 has landed and their LDS writes are done; conv waves: their LDS reads are done
+            // (and with conv_first fused their condition-tile pieces have landed: older than the NSTORE stores, which are
+            // never waited for)
+            if (wave < 4) __builtin_amdgcn_s_waitcnt(waitcnt_imm(C3 ? NSTORE : 63, 0));     // C3: their condition-tile pieces are older than the stores
+            else __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));
         } else {
-            if (PREP && t + step < ntiles) prep_tile(t + step, sA + nb * A_BYTES, sC + cn * C_BYTES, sQ + cn * L::Q_BYTES, sP3 + cn * (P3_BYTES / 8));
-            STAMP(2);
-            conv_mfma();
-            STAMP(1);
+            if (wave < 4) {
+                conv_mfma();
+                STAMP(1);  // conv MFMAs
+                if (PREP && t + step < ntiles) prep_tile(t + step, sA + nb * A_BYTES, sC + cn * C_BYTES, sQ + cn * L::Q_BYTES, sP3 + cn * (P3_BYTES / 8));
+                STAMP(2);  // SFT / quantise pass of the next tile
+            } else {
+                if (PREP && t + step < ntiles) prep_tile(t + step, sA + nb * A_BYTES, sC + cn * C_BYTES, sQ + cn * L::Q_BYTES, sP3 + cn * (P3_BYTES / 8));
+                STAMP(2);
+                conv_mfma();
+                STAMP(1);
+            }
+            epilogue();
+            if constexpr (C3) p3_stage(cb);                    // patch of tile t+2 (its parity is this tile's)
+            STAMP(3);      // epilogue incl. hipcc's vmcnt(0) (residuals + the DMA of tile t+2)
+            // the DMA of tile t+2 is older than this tile's NSTORE stores: landed once at most NSTORE operations are pending
+            __builtin_amdgcn_s_waitcnt(waitcnt_imm(NSTORE, 0));
         }
-        epilogue();
-        if constexpr (C3) p3_stage(cb);                        // patch of tile t+2 (read by P in the next iteration but one... of parity cb)
-        STAMP(3);      // epilogue incl. hipcc's vmcnt(0) (residuals + the DMA of tile t+2)
-        // the DMA of tile t+2 is older than this tile's NSTORE stores: landed once at most NSTORE operations are pending
-        __builtin_amdgcn_s_waitcnt(waitcnt_imm(NSTORE, 0));
         STAMP(4);      // closing wait
         __builtin_amdgcn_s_barrier();
         STAMP(5);      // barrier
@@ -595,12 +669,12 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
 #endif
 }
 
-template <bool SFT, bool I8, bool SQ, bool PLANAR, bool C3 = false>
-hipError_t launch_t(const Conv32Params &p, int n_cu, hipStream_t s)
+template <bool SFT, bool I8, bool SQ, bool PLANAR, bool C3 = false, bool SPLIT = false>
+hipError_t launch_k(const Conv32Params &p, int n_cu, hipStream_t s)
 {
     using L = Lay<SFT, I8, SQ, C3>;
     static DevOnce attr_once;   // hipFuncSetAttribute is per (function, device)
-    auto kern = conv32s_kernel<SFT, I8, SQ, PLANAR, C3>;
+    auto kern = conv32s_kernel<SFT, I8, SQ, PLANAR, C3, SPLIT>;
     if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L::SMEM);
         if (e != hipSuccess) return e;
@@ -610,6 +684,18 @@ hipError_t launch_t(const Conv32Params &p, int n_cu, hipStream_t s)
     const int grid = ntiles < n_cu ? ntiles : n_cu;        // persistent: one workgroup per CU
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), L::SMEM, s, p);
     return hipGetLastError();
+}
+
+// layers with a P pass run the role split (waves 0-3 convolve, waves 4-7 prepare the next tile) unless HDRTV_CONV32_NOSPLIT=1
+// (developer A/B switch, read per launch)
+template <bool SFT, bool I8, bool SQ, bool PLANAR, bool C3 = false>
+hipError_t launch_t(const Conv32Params &p, int n_cu, hipStream_t s)
+{
+    if constexpr ((SFT || I8) && !SQ) {        // W8A8 SFT convs: their P pass is too heavy for four waves (1.52 -> 1.82 ms split)
+        const char *e = getenv("HDRTV_CONV32_NOSPLIT");
+        if (!(e && atoi(e))) return launch_k<SFT, I8, SQ, PLANAR, C3, true>(p, n_cu, s);
+    }
+    return launch_k<SFT, I8, SQ, PLANAR, C3, false>(p, n_cu, s);
 }
 
 }  // namespace

@@ -433,8 +433,10 @@ def test_one_barrier_conv32_schedule_is_bit_identical(torch_cuda, golden_dir, mo
             # old schedule (conv_first as its own launch) | new schedule, conv_first unfused | new schedule with conv_first
             # computed inside HR_conv1's kernel (the default for fp16 HR_conv1)
             # (int8-full: HDRTV_NO_C3Q8 = the generic planar3_to_q8 + conv_q8 form of the W8A8 conv_first against conv_c3_q8)
-            for env in ({"HDRTV_CONV32_OLD": "1", "HDRTV_NO_C3Q8": "1"}, {"HDRTV_NO_C3FUSE": "1"}, {}):
-                for k in ("HDRTV_CONV32_OLD", "HDRTV_NO_C3FUSE", "HDRTV_NO_C3Q8"):
+            # HDRTV_CONV32_NOSPLIT: every wave convolves and prepares (conv32s's first form) against the role split
+            for env in ({"HDRTV_CONV32_OLD": "1", "HDRTV_NO_C3Q8": "1"}, {"HDRTV_NO_C3FUSE": "1", "HDRTV_CONV32_NOSPLIT": "1"},
+                        {"HDRTV_CONV32_NOSPLIT": "1"}, {"HDRTV_NO_C3FUSE": "1"}, {}):
+                for k in ("HDRTV_CONV32_OLD", "HDRTV_NO_C3FUSE", "HDRTV_NO_C3Q8", "HDRTV_CONV32_NOSPLIT"):
                     monkeypatch.delenv(k, raising=False)
                 for k, v in env.items():
                     monkeypatch.setenv(k, v)
@@ -445,7 +447,7 @@ def test_one_barrier_conv32_schedule_is_bit_identical(torch_cuda, golden_dir, mo
                     assert torch.isfinite(a).all(), (h, w, name)
                     assert torch.equal(a, b), (h, w, name)
     finally:
-        for k in ("HDRTV_CONV32_OLD", "HDRTV_NO_C3FUSE", "HDRTV_NO_C3Q8"):
+        for k in ("HDRTV_CONV32_OLD", "HDRTV_NO_C3FUSE", "HDRTV_NO_C3Q8", "HDRTV_CONV32_NOSPLIT"):
             monkeypatch.delenv(k, raising=False)
         p.close()
 

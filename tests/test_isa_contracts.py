@@ -102,10 +102,10 @@ def test_conv32s_counted_waits(tmp_path):
     kernels = _asm("conv32s.hip", tmp_path)
     seen = 0
     for name, body in kernels.items():
-        m = re.search(r"conv32s_kernelILb(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)E", name)
+        m = re.search(r"conv32s_kernelILb(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)E", name)
         if not m:
             continue
-        sft, i8, sq, planar, c3 = (int(v) for v in m.groups())
+        sft, i8, sq, planar, c3, split = (int(v) for v in m.groups())
         # DMA pieces of an issuing wave (0-3): halo tile (not with conv_first fused in: computed in the kernel) + condition tile
         npieces, nstore = (0 if c3 else 6) + (3 if sft else 0), 3 if planar else 2
         assert "scratch_" not in body, name
@@ -125,6 +125,15 @@ def test_conv32s_counted_waits(tmp_path):
         assert len([ln for ln in loop if "global_load_lds_dwordx4" in ln]) == npieces, name
         # NSTORE per phase order; the epilogue is shared by both orders
         nst = len([ln for ln in loop if re.match(r"\s*global_store", ln)])
+        if split:
+            # role split: waves 0-3 convolve two 32-pixel groups (twice the stores), waves 4-7 issue the DMA and run the P pass.
+            # The conv waves close the tile on lgkmcnt(0) only (they issue no DMA, stores are never waited for), the prep
+            # waves on vmcnt(0) lgkmcnt(0) (their DMA has landed)
+            assert nst == 2 * nstore, (name, nst)
+            closing = [ln for ln in loop if re.search(r"s_waitcnt vmcnt\(0\) lgkmcnt\(0\)", ln)]
+            assert closing, name
+            seen += 1
+            continue
         assert nst == nstore, (name, nst)
         bar = max(i for i, ln in enumerate(loop) if re.match(r"\s*s_barrier", ln))
         loop = loop[bar + 1:] + loop[:bar + 1]        # hipcc may rotate the loop: read it from behind the barrier to the barrier
@@ -134,4 +143,4 @@ def test_conv32s_counted_waits(tmp_path):
         assert len(w0) == 1 and w0[0] < bar, (name, w0)
         assert not any("v_mfma" in ln for ln in loop[w0[0]:bar]), name
         seen += 1
-    assert seen == 8
+    assert seen == 13

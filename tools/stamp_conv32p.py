@@ -38,8 +38,9 @@ if os.environ.get("HDRTV_CONV32_OLD"):
     names = ["0 offsets+resid", "1 conv MFMA", "2 staging write", "3 wait vmcnt", "4 barrier1", "5 DMA issue+stores", "6 SFT(t+1)", "7 barrier2+loop"]
 else:       # conv32s.hip
     names = ["0 addr+resid+DMA issue", "1 conv MFMA", "2 SFT(t+1)", "3 epilogue+vmcnt(0)", "4 closing wait", "5 barrier", "6 -", "7 loop"]
-for sel, rows in (("all waves", st), ("waves 0-3 (MFMA first)", st.reshape(-1, 8, 8)[:, :4].reshape(-1, 8) if len(st) % 8 == 0 else st),
-                  ("waves 4-7 (SFT first)", st.reshape(-1, 8, 8)[:, 4:].reshape(-1, 8) if len(st) % 8 == 0 else st)):
+    # (role split: waves 0-3 have no phase 2, waves 4-7 no phases 1 and 3)
+for sel, rows in (("all waves", st), ("waves 0-3 (conv waves / MFMA first)", st.reshape(-1, 8, 8)[:, :4].reshape(-1, 8) if len(st) % 8 == 0 else st),
+                  ("waves 4-7 (prep waves / SFT first)", st.reshape(-1, 8, 8)[:, 4:].reshape(-1, 8) if len(st) % 8 == 0 else st)):
     tot = rows.sum(1).mean()
     print(f"{sel}: sampled {len(rows)}, mean cycles per wave {tot:.0f}")
     for i, n in enumerate(names):
