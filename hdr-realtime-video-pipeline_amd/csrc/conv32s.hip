@@ -170,20 +170,39 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
         const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
         const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
         const int pix0 = iy0 * p.W + ix0;                      // may be negative; valid lanes land >= 0
+        // a tile whose halo lies inside the image (all but the border tiles) needs no per-lane image test: two instructions
+        // per piece instead of eight (stamps: the issue was a quarter of a prep wave's tile time)
+        const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + TH + 2 <= p.H && ix0 + HC <= p.W;     // wave-uniform
         if (!C3 && issue_a) {
+            if (interior) {
 #pragma unroll
-            for (int it = 0; it < A_PW; ++it) {
-                const bool ok = a_pos[it] >= 0 && (unsigned)(iy0 + (a_pos[it] & 255)) < uH && (unsigned)(ix0 + (a_pos[it] >> 8)) < uW;
-                const unsigned off = ok ? (unsigned)(pix0 * 64 + a_off[it]) : src_guard + ((lane & 3) << 4);
-                glds16(reinterpret_cast<const char *>(p.src) + off, abuf + (iw + it * NWI) * 1024);
+                for (int it = 0; it < A_PW; ++it) {
+                    const unsigned off = a_pos[it] >= 0 ? (unsigned)(pix0 * 64 + a_off[it]) : src_guard + ((lane & 3) << 4);
+                    glds16(reinterpret_cast<const char *>(p.src) + off, abuf + (iw + it * NWI) * 1024);
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < A_PW; ++it) {
+                    const bool ok = a_pos[it] >= 0 && (unsigned)(iy0 + (a_pos[it] & 255)) < uH && (unsigned)(ix0 + (a_pos[it] >> 8)) < uW;
+                    const unsigned off = ok ? (unsigned)(pix0 * 64 + a_off[it]) : src_guard + ((lane & 3) << 4);
+                    glds16(reinterpret_cast<const char *>(p.src) + off, abuf + (iw + it * NWI) * 1024);
+                }
             }
         }
         if (SFT && issue_c) {
+            if (interior) {
 #pragma unroll
-            for (int it = 0; it < C_PW; ++it) {
-                const bool ok = c_pos[it] >= 0 && (unsigned)(iy0 + (c_pos[it] & 255)) < uH && (unsigned)(ix0 + (c_pos[it] >> 8)) < uW;
-                const unsigned off = ok ? (unsigned)(pix0 * 32 + c_off[it]) : cond_guard + ((lane & 1) << 4);
-                glds16(reinterpret_cast<const char *>(p.cond) + off, cbuf + (iw + it * NWI) * 1024);
+                for (int it = 0; it < C_PW; ++it) {
+                    const unsigned off = c_pos[it] >= 0 ? (unsigned)(pix0 * 32 + c_off[it]) : cond_guard + ((lane & 1) << 4);
+                    glds16(reinterpret_cast<const char *>(p.cond) + off, cbuf + (iw + it * NWI) * 1024);
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < C_PW; ++it) {
+                    const bool ok = c_pos[it] >= 0 && (unsigned)(iy0 + (c_pos[it] & 255)) < uH && (unsigned)(ix0 + (c_pos[it] >> 8)) < uW;
+                    const unsigned off = ok ? (unsigned)(pix0 * 32 + c_off[it]) : cond_guard + ((lane & 1) << 4);
+                    glds16(reinterpret_cast<const char *>(p.cond) + off, cbuf + (iw + it * NWI) * 1024);
+                }
             }
         }
     };
@@ -283,6 +302,14 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
         f16x4 yv[N][4];
         f16x8 c0[N], c1[N];
         f32x16 sc[N], sh[N];
+        f16x4 s1p[N][4], s0p[N][4];                        // scale + 1 and shift rounded to f16 as soon as their MFMAs are done: a
+                                                           // third of the registers of the fp32 tiles, so three groups fit at once
+        auto pack_ss = [&](int gi) __attribute__((always_inline)) {
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { s1p[gi][qd][k] = (f16)sc[gi][4 * qd + k]; s0p[gi][qd][k] = (f16)sh[gi][4 * qd + k]; }
+        };
 #pragma unroll
         for (int gi = 0; gi < N; ++gi) {
             inimg[gi] = g_pos[G0 + gi] >= 0 && (unsigned)(iy0 + (g_pos[G0 + gi] & 255)) < uH && (unsigned)(ix0 + (g_pos[G0 + gi] >> 8)) < uW;
@@ -371,7 +398,9 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
                 sc[gi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa1s, hs, sbs, 0, 0, 0);
                 sh[gi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa1t, ht, sbt, 0, 0, 0);
             }
+            if constexpr (SFT) { if (gi > 0) pack_ss(gi - 1); }     // behind the next group's MFMAs: its results have landed
         }
+        if constexpr (SFT) pack_ss(N - 1);
 #pragma unroll
         for (int gi = 0; gi < N; ++gi) {
             i32x4 codes;
@@ -379,10 +408,7 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
             for (int qd = 0; qd < 4; ++qd) {
                 f16x4 y = yv[gi][qd];
                 if constexpr (SFT) {
-                    f16x4 s1, s0;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { s1[k] = (f16)sc[gi][4 * qd + k]; s0[k] = (f16)sh[gi][4 * qd + k]; }
-                    y = y * s1 + s0;
+                    y = y * s1p[gi][qd] + s0p[gi][qd];
                 }
                 if constexpr (I8) {
                     const unsigned w = quant4((float)y[0], (float)y[1], (float)y[2], (float)y[3], p.q_inv, p.q_zoff);
@@ -407,14 +433,15 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
         using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>;
         if constexpr (SPLIT) {
-            if (wave >= 4) {          // three groups as 2 + 1 (W8A8 SFT convs, conv_first fused: 1 + 1 + 1): three at once do not fit the register file
-                if constexpr (SQ || C3) {
+            if (wave >= 4) {          // three groups as 2 + 1 (W8A8 layers, conv_first fused: one by one): more at once do not fit the register file
+                if constexpr (SQ || C3 || I8) {
                     sft_groups(I1{}, I0{}, tt, a, cbuf, qbuf, p3);
                     sft_groups(I1{}, I1{}, tt, a, cbuf, qbuf, p3);
+                    sft_groups(I1{}, I2{}, tt, a, cbuf, qbuf, p3);
                 } else {
                     sft_groups(I2{}, I0{}, tt, a, cbuf, qbuf, p3);
+                    sft_groups(I1{}, I2{}, tt, a, cbuf, qbuf, p3);
                 }
-                sft_groups(I1{}, I2{}, tt, a, cbuf, qbuf, p3);
             }
         } else {
             if (wave >= 4) sft_groups(I2{}, I0{}, tt, a, cbuf, qbuf, p3);  // wave-uniform

@@ -122,7 +122,9 @@ def test_conv32s_counted_waits(tmp_path):
         main = [g for g in groups.values() if any(re.match(r"\s*s_barrier", ln) for ln in g)]
         assert len(main) == 1, (name, len(main))
         loop = main[0]
-        assert len([ln for ln in loop if "global_load_lds_dwordx4" in ln]) == npieces, name
+        # the issue exists twice in the code, for interior tiles (no per-lane image test) and for border tiles; a wave runs one
+        # (hipcc may merge the tails of the two paths: between one and two copies of every piece in the text)
+        assert npieces <= len([ln for ln in loop if "global_load_lds_dwordx4" in ln]) <= 2 * npieces, name
         # NSTORE per phase order; the epilogue is shared by both orders
         nst = len([ln for ln in loop if re.match(r"\s*global_store", ln)])
         if split:
