@@ -10,25 +10,32 @@
 // all eight waves are in the MFMA phase together and in the VALU / LDS-latency phase (SFT) together, two waves per
 // SIMD, so the matrix pipe idles through one phase and the vector pipe through the other (stamps: conv 14 %, SFT 39 %,
 // barriers 15 % of the wave cycles).  Here the two phases of a tile period overlap:
-//   * the per-tile work of a wave is  R: residual loads   X: LDS-DMA of tile t+2 (waves 0-3)   M: the conv MFMAs of tile t
-//     P: SFT (or quantise) pass over this wave's share of tile t+1   E: epilogue + stores of tile t;  waves 0-3 run
-//     R X M P E, waves 4-7 run R P M E -- the two waves of a SIMD are in opposite phases, one feeding the MFMA pipe while
-//     the other is in the VALU / LDS-latency part;
+//   * the per-tile work is  R: residual loads   X: LDS-DMA of tile t+2   M: the conv MFMAs of tile t   P: SFT (or quantise)
+//     pass over tile t+1's halo   E: epilogue + stores of tile t, split by ROLE (template SPLIT; every layer with a P pass
+//     except those with W8A8 SFT convs): waves 0-3 are conv waves -- R M E over 64 output pixels each, two 32-pixel groups
+//     that share every weight fragment -- and waves 4-7 prep waves -- X and P, three 32-slot halo groups each.  A SIMD holds
+//     one of each: the conv wave feeds the MFMA pipe while the prep wave is in the VALU / LDS-latency part, and neither
+//     waits for the other's memory operations (a conv wave issues no DMA, a prep wave no loads or stores).  Without the
+//     split (layers without a P pass; W8A8 SFT convs, whose P pass is too heavy for four waves; HDRTV_CONV32_NOSPLIT=1) every
+//     wave does both: waves 0-3 run R X M P E, waves 4-7 R P M E, one conv group each, two halo groups on waves 4-7 and one
+//     on waves 0-3;
 //   * ONE barrier per tile.  That takes (a) three halo buffers for fp16 layers: the conv reads A[t], P rewrites A[t+1]
 //     in place, the DMA lands in A[t+2] (W8A8 layers: the conv reads the code tile, two of each suffice); (b) an epilogue
-//     that needs no workgroup synchronisation: a wave transposes ITS 32 pixels x 32 channels through a wave-private
+//     that needs no workgroup synchronisation: a wave transposes ITS pixels x 32 channels through a wave-private
 //     strip (LDS operations of one wave complete in order) and stores them itself, 16 B per lane, 64 B runs per pixel;
 //   * vmcnt: hipcc does not count across LDS-DMA -- it waits vmcnt(0) in front of the first use of a plain load issued
 //     around a DMA and in front of the first LDS read it can name while a DMA is in flight (here: the scale / shift
-//     tables).  Both are therefore kept in E, the last thing in the tile, a few instructions in front of the closing
-//     wait for the same DMA; the closing wait is vmcnt(NSTORE): every wave issues exactly NSTORE stores per tile,
-//     unconditionally (masked-off lanes store to a trash line, their residual loads read a zero line), and the DMA is
-//     older than them, so the stores themselves are never waited for.  (Inline-asm loads with hand-counted waits were
-//     tried for the residuals: hipcc copied the destination registers in front of the wait -- a read of data that
-//     had not landed, visible as sporadic wrong half-waves at 1080p; tests/test_isa_contracts.py pins the structure.)
-// SFT share per wave: 12 groups of 32 halo slots; waves 4-7 (P first) take two, waves 0-3 one and all of the DMA issue
-// (stamps: with the DMA spread over all eight waves the critical path of a tile sat in waves 4-7 and every wave queued in
-// the address unit right behind the barrier).
+//     tables).  Both are therefore kept in E, the last thing in the tile; a wave that has issued DMA closes the tile with
+//     vmcnt(NSTORE) (every wave issues exactly NSTORE stores per tile, unconditionally -- masked-off lanes store to a trash
+//     line, their residual loads read a zero line -- and the DMA is older than them, so stores are never waited for), a
+//     prep wave of the split with vmcnt(0), a conv wave of the split with no vector-memory wait at all.  (Inline-asm
+//     loads with hand-counted waits were tried for the residuals: hipcc copied the destination registers in front of the
+//     wait -- a read of data that had not landed, visible as sporadic wrong half-waves at 1080p; tests/test_isa_contracts.py
+//     pins the structure.)
+// Stamps (make STAMP=1, profiles/r02_conv32s_stamps.txt) drove the steps: first form (every wave issues DMA, does M and P) ->
+// the tile's critical path sat in waves 4-7 and every wave queued in the address unit behind the barrier -> DMA issue on
+// waves 0-3 -> role split (the prep waves are now the critical path: DMA issue 26 %, P 64 % of their cycles; the conv waves
+// wait 20 % of theirs at the barrier).
 #include <cstdlib>
 #include <type_traits>
 
