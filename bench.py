@@ -413,8 +413,11 @@ def main():
                    "conv_pglds_i8<nhwc>": "conv_pglds_i8_kernel<0, false>", "conv_pglds_i8<ps>": "conv_pglds_i8_kernel<1, false>",
                    "conv_pglds_i8<pool>": "conv_pglds_i8_kernel<2, false>", "conv_pglds_i8<nhwc,c64>": "conv_pglds_i8_kernel<0, true>",
                    "conv_pglds_i8<ps_dot3,c64>": "conv_pglds_i8_kernel<4, true>", "conv1x1_i8": "conv1x1_i8_kernel<false>",
-                   "conv1x1_i8<f16>": "conv1x1_i8_kernel<true>", "conv32s<1,sft>": "conv32s_kernel<true, false, false, false>",
-                   "conv32p<4,plain>": "conv32p_kernel<4, false, 8>", "conv32s<1,plain>": "conv32s_kernel<false, false, false, true>",
+                   "conv1x1_i8<f16>": "conv1x1_i8_kernel<true>", "conv32s<1,sft>": "conv32s_kernel<true, false, false, false, false, true>",
+                   "conv32s<1,c3+sft>": "conv32s_kernel<true, false, false, false, true, true>",
+                   "conv32s<1,sft-i8,i8>": "conv32s_kernel<true, true, true, false, false, false>",
+                   "conv32s<1,sft,i8>": "conv32s_kernel<true, true, false, false, false, true>",
+                   "conv32p<4,plain>": "conv32p_kernel<4, false, 8>", "conv32s<1,plain>": "conv32s_kernel<false, false, false, true, false, false>",
                    "conv3x3s2_preg<192>": "conv3x3s2_preg_kernel<12>", "conv3x3s2_preg<64>": "conv3x3s2_preg_kernel<4>"}.get(kern, kern)
             if (H, Wd) == (2160, 3840) and use_hg and key in pmc:
                 traffic = pmc[key]["hbm_bytes_per_launch"]
