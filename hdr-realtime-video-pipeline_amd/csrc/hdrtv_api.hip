@@ -1407,7 +1407,7 @@ struct Seq {
         bytes += 2.0 * outel * (1 + (res1 ? 1 : 0) + (res2 ? 1 : 0) + (res_planar ? 1 : 0));
         chk(t16 ? conv_t16_launch(p, s) : s2g ? conv3x3s2_preg_launch(p, c->n_cu, s)
                 : (pglds ? conv_pglds_launch(p, c->n_cu, s)
-                         : (glds1 ? conv_glds1_launch(p, s) : conv_igemm_launch(p, L.cin_t, L.bn, L.ks, L.stride, s))),
+                         : (glds1 ? conv_glds1_launch(p, s, c->n_cu) : conv_igemm_launch(p, L.cin_t, L.bn, L.ks, L.stride, s))),
             key.c_str(), tag, macs, bytes);
     }
     // W8A8 HG layer on int8 MFMA: 3x3 (conv3x3_pglds_i8.hip) or 1x1 (conv_i8_misc.hip)

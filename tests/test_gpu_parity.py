@@ -484,3 +484,31 @@ def test_smallest_frames_and_rejections(torch_cuda, golden_dir, hr_state):
             assert out.shape == (h, w, 3)
     finally:
         ph.close()
+
+
+def test_persistent_1x1_matches_tile_kernel(torch_cuda, golden_dir, monkeypatch):
+    """conv_glds1p (the HG fuse convs conv6..conv9 as one persistent stream of (tile, chunk) iterations, wave-private
+    epilogue strips, counted vmcnt waits across tile boundaries) against the one-tile-per-workgroup kernel it replaces
+    (HDRTV_GLDS1_OLD=1): same accumulation order, so every tap must agree bit for bit -- at 1080p (32 tiles per workgroup
+    on conv9) and at a size with ragged tiles."""
+    from hdrtv_mi355x import weights as W
+    from hdrtv_mi355x.processor import HDRTVNetMI355X
+    torch = torch_cuda
+    p = HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), use_hg=True, hg_weights="seeded:1234", warmup_passes=0)
+    try:
+        for (h, w), seed in (((1080, 1920), 51), ((270, 486), 52)):
+            f = W.synthetic_frame(h, w, seed=seed, kind="gradient")
+            res = []
+            for old in ("1", None):
+                if old:
+                    monkeypatch.setenv("HDRTV_GLDS1_OLD", old)
+                else:
+                    monkeypatch.delenv("HDRTV_GLDS1_OLD", raising=False)
+                out, _ = p.infer(p.preprocess(f))
+                res.append([out.clone()] + [p.tap(t).clone() for t in ("hg.conv6", "hg.conv7", "hg.conv8", "hg.conv9")])
+            for name, a, b in zip(("out", "conv6", "conv7", "conv8", "conv9"), res[0], res[1]):
+                assert torch.isfinite(a).all(), (h, w, name)
+                assert torch.equal(a, b), (h, w, name)
+    finally:
+        monkeypatch.delenv("HDRTV_GLDS1_OLD", raising=False)
+        p.close()

@@ -146,3 +146,17 @@ def test_conv32s_counted_waits(tmp_path):
         assert not any("v_mfma" in ln for ln in loop[w0[0]:bar]), name
         seen += 1
     assert seen == 13
+
+
+def test_glds1p_store_count_matches_the_counted_wait(tmp_path):
+    """conv_glds1p (persistent 1x1 fuse convs) waits vmcnt(6 + P_NST) at a tile's first chunk: P_NST stores per wave and tile."""
+    kernels = _asm("conv1x1_glds.hip", tmp_path)
+    src = open(os.path.join(CSRC, "conv1x1_glds.hip")).read()
+    nst = int(re.search(r"constexpr int P_NST = (\d+);", src).group(1))
+    body = [b for n, b in kernels.items() if "conv_glds1p_kernel" in n]
+    assert len(body) == 1
+    body = body[0]
+    assert len(re.findall(r"^\s*(?:global|buffer|flat)_store", body, re.M)) == nst
+    waits = set(int(v) for v in re.findall(r"s_waitcnt vmcnt\((\d+)\)", body))
+    assert {6, 6 + nst} <= waits, sorted(waits)
+    assert "scratch_" not in body
