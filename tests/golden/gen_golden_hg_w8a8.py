@@ -79,10 +79,12 @@ def calibrate():
     return ranges
 
 
-def main():
+def main(integer_zero=True):
+    """integer_zero: x_zero rounded to a whole number of steps (the round-1 table) or the calibration's float minimum (what
+    the reference's calibrate_w8a8 produces: x_zero = running min)."""
     ranges = calibrate()
     print(ranges)
-    qstate = W.hg_w8a8_state(W.seeded_hg_state(SEED), ranges)
+    qstate = W.hg_w8a8_state(W.seeded_hg_state(SEED), ranges, integer_zero=integer_zero)
 
     from models.hdrtvnet_torch import W8A8Conv2d   # the reference's layer
     hg_state = W.seeded_hg_state(SEED)
@@ -114,9 +116,10 @@ def main():
         r[k] = r[k][::step].copy()
     for k in ("tensor", "cond", "rgb48"):
         r.pop(k)
-    np.savez_compressed(os.path.join(HERE, "hg_w8a8_96x128_gradient_s3.npz"), **r)
-    print("saved", {k: getattr(v, "shape", None) for k, v in r.items()})
+    name = "hg_w8a8_96x128_gradient_s3.npz" if integer_zero else "hg_w8a8_floatzero_96x128_gradient_s3.npz"
+    np.savez_compressed(os.path.join(HERE, name), **r)
+    print("saved", name, {k: getattr(v, "shape", None) for k, v in r.items()})
 
 
 if __name__ == "__main__":
-    main()
+    main(integer_zero="--float-zero" not in sys.argv)

@@ -157,9 +157,8 @@ def test_w8a8_layers_exact_given_device_inputs(proc_q, qstate, hw, seed):
 
 def test_w8a8_hg_vs_reference_golden(proc_q, golden_dir, zero_style):
     """Against the reference's own run (W8A8Conv2d swapped into its HG_Composite; tests/golden/gen_golden_hg_w8a8.py)."""
-    if zero_style != "integer-zero":
-        pytest.skip("the committed reference run used the integer-zero calibration table")
-    d = np.load(os.path.join(golden_dir, "hg_w8a8_96x128_gradient_s3.npz"))
+    d = np.load(os.path.join(golden_dir, "hg_w8a8_96x128_gradient_s3.npz" if zero_style == "integer-zero"
+                             else "hg_w8a8_floatzero_96x128_gradient_s3.npz"))
     out, _ = proc_q.infer(proc_q.preprocess(d["frame"]))
     out = out.cpu().numpy()[0]
     e = np.abs(out - d["out"])

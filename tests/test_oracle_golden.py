@@ -197,22 +197,28 @@ def test_int8_fake_quant_execution(golden_dir, tag):
         assert emax <= 3e-2 and emean <= 1.5e-3 and mae <= 0.5
 
 
-def test_hg_w8a8_fake_quant_execution(golden_dir):
+@pytest.mark.parametrize("integer_zero", [True, False])
+def test_hg_w8a8_fake_quant_execution(golden_dir, integer_zero):
     """The W8A8 HG head (18 layers of weights.HG_W8A8_GROUPS on the reference's W8A8Conv2d, asymmetric u8 activations
-    with integer zero points; the recipe and the calibration table are the product's).  Golden:
+    with integer zero points, or with the calibration's float minimum as x_zero -- what the reference's calibrate_w8a8
+    leaves in a checkpoint; the recipe and the calibration table are the product's).  Golden:
     tests/golden/gen_golden_hg_w8a8.py swapped the reference's own W8A8Conv2d into its HG_Composite and ran it on CPU.
     With ATen's conv under the oracle's graph the restatement is bit-exact against that run; with the plain-C
     operators isolated quantisation steps flip (see test_int8_fake_quant_execution)."""
     from hdrtv_mi355x import weights as W
-    d = _load(golden_dir, "hg_w8a8_96x128_gradient_s3.npz")
+    d = _load(golden_dir, "hg_w8a8_96x128_gradient_s3.npz" if integer_zero else "hg_w8a8_floatzero_96x128_gradient_s3.npz")
     hr = {k: np.asarray(v, np.float32) for k, v in W.load_pack(os.path.join(golden_dir, "hr_weights.hdrw")).items()}
-    qs = W.seeded_hg_w8a8_state(1234)
+    qs = W.seeded_hg_w8a8_state(1234, integer_zero=integer_zero)
+    fractional = 0
     for layers in W.HG_W8A8_GROUPS.values():
         for name in layers:
             s, z = float(qs[name + ".x_scale"]), float(qs[name + ".x_zero"])
             k = -z / s
-            assert k == round(k) and 0 <= k <= 255 and qs[name + ".weight_int8"].dtype == np.int8, name
+            assert 0 <= k <= 255 and qs[name + ".weight_int8"].dtype == np.int8, name
+            assert not integer_zero or k == round(k), name
+            fractional += k != round(k)
             assert all(float(qs[n + ".x_scale"]) == s and float(qs[n + ".x_zero"]) == z for n in layers)
+    assert integer_zero or fractional >= 4            # the four fuse convs (signed outputs) have zero points between codes
     q = O.w8a8_state(qs)
     assert sum(1 for v in q.values() if getattr(v, "x_scale", None) is not None) == 18
     steps = (("hg.conv2", 16), ("hg.conv3_2", 16), ("hg.conv5_2", 4), ("hg.conv_code2", 4), ("hg.conv6", 4),
