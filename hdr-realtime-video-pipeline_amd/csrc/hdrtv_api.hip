@@ -2119,8 +2119,7 @@ static bool letterbox_setup(hdrtv_ctx *c, int sh, int sw, int dh, int dw)
     }
     const size_t bytes = ints.size() * 4 + flts.size() * 4 + 16;
     if (bytes > c->lb_cap) {
-        if (c->pq_bnd) (void)hipFree(c->pq_bnd);
-    if (c->lb_dev) (void)hipFree(c->lb_dev);
+        if (c->lb_dev) (void)hipFree(c->lb_dev);
         c->lb_dev = nullptr; c->lb_cap = 0;
         if (hipMalloc(&c->lb_dev, bytes) != hipSuccess) { c->lb_dev = nullptr; return false; }
         c->lb_cap = bytes;

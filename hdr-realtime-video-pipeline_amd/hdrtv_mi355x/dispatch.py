@@ -8,18 +8,28 @@ frame index before the sink sees a frame -- the ``preserve_order`` behaviour of 
 
 Data path per frame and GPU (3840x2160: 24.9 MB in, 49.8 MB out):
 
-    parent: memcpy frame -> input slot (shared memory, page-locked by the worker with hipHostRegister)
-    worker: hipMemcpyAsync H2D -> pre + infer + post_rgb48 -> hipMemcpyAsync D2H into an output slot (same mapping) -> event
+    parent: frame -> input slot (shared memory the worker has page-locked with hipHostRegister); a producer that can
+            write in place uses ``reserve()`` / ``commit()`` and skips the memcpy
+    worker: hipMemcpyAsync H2D straight from the slot on an upload stream -> hipEvent -> pre + infer + post_rgb48 on the
+            compute stream -> hipEvent -> hipMemcpyAsync D2H straight into an output slot on a copy stream -> hipEvent
+            (the hand-off of ``feeders.py:440-496``, with HIP events where the reference uses CUDA events)
     parent: reorder stage hands slot views to the sink in index order, then returns the slot to its worker
 
-Slots are the hand-off unit in both directions (``slots`` per worker, default 3 like the reference's
+A worker keeps ``depth`` (2) frames in flight: frame *i + 1* is uploaded and queued behind frame *i* on the device before
+the worker waits for frame *i*'s download event, so upload, compute and download overlap and the device never idles
+between frames.  Slots are the hand-off unit in both directions (``slots`` per worker, default 3 like the reference's
 ``HDRTVNET_FEEDER_GPU_RGB48_RING_FRAMES``): ``submit`` blocks while worker *i mod N* has no free input slot, a worker
-blocks while all its output slots are still with the sink.  The worker body is a plain function
-``make_worker(rank, device_index, init_args) -> process(frame_u8[H,W,3]) -> u16[H,W,3]``: the product's is
-``mi355x_worker`` below (one ``HDRTVNetMI355X`` per process); tests substitute a CPU stand-in.
+holds back while all its output slots are still with the sink.
+
+The worker body comes from ``make_worker(rank, device_index, init_args)``.  It is either a plain function
+``process(frame_u8[H,W,3], out_u16[H,W,3])`` (synchronous: tests substitute CPU stand-ins of this form) or an object with
+``begin(frame, out) -> token`` / ``finish(token)`` (+ optional ``depth``, ``pin(buffer)``, ``close()``): the product's
+``mi355x_worker`` below, one ``HDRTVNetMI355X`` context per process.
 """
 from __future__ import annotations
 
+import collections
+import gc
 import multiprocessing as mp
 import queue as _queue
 import threading
@@ -30,77 +40,193 @@ from multiprocessing import shared_memory
 import numpy as np
 
 
-def mi355x_worker(rank, device_index, init_args):
-    """The product's worker body: one processor on ``cuda:<device_index>``, pinned shared slots, RGB48 out."""
-    import ctypes as C
+class _Mi355xWorker:
+    """One processor on ``cuda:<device_index>``; two frames in flight over three streams."""
 
-    import torch
+    depth = 2
 
-    from . import lib as L
-    from .processor import HDRTVNetMI355X
-    kw = dict(init_args)
-    model = kw.pop("model_path")
-    torch.cuda.set_device(device_index)
-    proc = HDRTVNetMI355X(model, device=f"cuda:{device_index}", warmup_passes=0, **kw)
-    state = {"dev_u16": None}
+    def __init__(self, rank, device_index, init_args):
+        import ctypes as C
 
-    def pin(buf):          # page-lock the shared-memory slots so that both copies are DMA transfers
-        rt = torch.cuda.cudart()
+        import torch
+
+        from . import lib as L
+        from .processor import HDRTVNetMI355X
+        self._C, self._torch, self._L = C, torch, L
+        kw = dict(init_args)
+        model = kw.pop("model_path")
+        torch.cuda.set_device(device_index)
+        self.proc = HDRTVNetMI355X(model, device=f"cuda:{device_index}", warmup_passes=0, **kw)
+        self.dev = self.proc.device
+        hip = C.CDLL("libamdhip64.so")          # torch's copy: already loaded under this SONAME (lib.load imports torch first)
+        hip.hipHostRegister.argtypes = [C.c_void_p, C.c_size_t, C.c_uint]
+        hip.hipHostUnregister.argtypes = [C.c_void_p]
+        hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        for f in (hip.hipHostRegister, hip.hipHostUnregister, hip.hipMemcpyAsync):
+            f.restype = C.c_int
+        self._hip = hip
+        self._registered = None
+        self._up, self._dn = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
+        self._hw = None
+        self._n = 0
+
+    def pin(self, buf):
+        """Page-lock the shared-memory slots so that both copies are DMA transfers straight from / into them."""
         a = np.frombuffer(buf, dtype=np.uint8)
-        rt.cudaHostRegister(a.ctypes.data, a.nbytes, 0)
+        ptr, n = a.ctypes.data, a.nbytes
+        del a
+        rc = self._hip.hipHostRegister(ptr, n, 0)
+        if rc != 0:
+            raise RuntimeError(f"hipHostRegister({n} bytes of shared slots) failed with {rc}: the dispatcher's copies would be "
+                               "pageable transfers")
+        self._registered = ptr
 
-    def process(frame, out):
+    def _buffers(self, h, w):
+        torch = self._torch
+        if self._hw != (h, w):
+            self.proc._ensure_buffers(h, w)
+            self._raw = [torch.empty((h, w, 3), dtype=torch.uint8, device=self.dev) for _ in range(self.depth)]
+            self._u16 = [torch.empty((h, w, 3), dtype=torch.uint16, device=self.dev) for _ in range(self.depth)]
+            self._up_ev = [torch.cuda.Event() for _ in range(self.depth)]
+            self._comp_ev = [None] * self.depth
+            self._dn_ev = [None] * self.depth
+            self._hw = (h, w)
+
+    def begin(self, frame, out):
+        C, torch, L, p = self._C, self._torch, self._L, self.proc
         h, w = frame.shape[:2]
-        if state["dev_u16"] is None or tuple(state["dev_u16"].shape) != (h, w, 3):
-            state["dev_u16"] = torch.empty((h, w, 3), dtype=torch.uint16, device=proc.device)
-        t, c = proc.preprocess(frame)
-        o, _ = proc.infer((t, c))
-        st = C.c_void_p(torch.cuda.current_stream(proc.device).cuda_stream)
-        proc._chk(proc._lib.hdrtv_post_rgb48(proc._ctx, st, o.data_ptr(), L.F32 if o.dtype == torch.float32 else L.F16, h, w,
-                                             state["dev_u16"].data_ptr()), "hdrtv_post_rgb48")
-        torch.from_numpy(out).copy_(state["dev_u16"], non_blocking=True)
-        torch.cuda.current_stream(proc.device).synchronize()
+        self._buffers(h, w)
+        k = self._n % self.depth
+        self._n += 1
+        main = torch.cuda.current_stream(self.dev)
+        if self._comp_ev[k] is not None:
+            self._up.wait_event(self._comp_ev[k])              # the frame that last used raw[k] has been unpacked
+        rc = self._hip.hipMemcpyAsync(self._raw[k].data_ptr(), frame.ctypes.data, frame.nbytes, 1, self._up.cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"hipMemcpyAsync H2D failed with {rc}")
+        self._up_ev[k].record(self._up)
+        main.wait_event(self._up_ev[k])
+        if self._dn_ev[k] is not None:
+            main.wait_event(self._dn_ev[k])                    # u16[k]'s previous frame has left the device
+        st = C.c_void_p(main.cuda_stream)
+        p._chk(p._lib.hdrtv_preprocess(p._ctx, st, self._raw[k].data_ptr(), h, w, p._gpu_input.data_ptr(),
+                                       p._gpu_cond.data_ptr()), "hdrtv_preprocess")
+        dt = L.F32 if p._use_hg else L.F16
+        p._chk(p._lib.hdrtv_infer(p._ctx, st, p._gpu_input.data_ptr(), p._gpu_cond.data_ptr(), h, w, p._gpu_out.data_ptr(), dt,
+                                  p._gpu_agcm.data_ptr()), "hdrtv_infer")
+        p._chk(p._lib.hdrtv_post_rgb48(p._ctx, st, p._gpu_out.data_ptr(), dt, h, w, self._u16[k].data_ptr()), "hdrtv_post_rgb48")
+        self._comp_ev[k] = torch.cuda.Event()
+        self._comp_ev[k].record(main)
+        self._dn.wait_event(self._comp_ev[k])
+        rc = self._hip.hipMemcpyAsync(out.ctypes.data, self._u16[k].data_ptr(), out.nbytes, 2, self._dn.cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"hipMemcpyAsync D2H failed with {rc}")
+        self._dn_ev[k] = torch.cuda.Event()
+        self._dn_ev[k].record(self._dn)
+        return k
 
-    process.pin = pin
-    process.close = proc.close
-    return process
+    def finish(self, token):
+        self._dn_ev[token].synchronize()
+
+    def close(self):
+        self._torch.cuda.synchronize(self.dev)
+        self.proc.close()
+        if self._registered is not None:
+            self._hip.hipHostUnregister(self._registered)
+            self._registered = None
+
+
+def mi355x_worker(rank, device_index, init_args):
+    """The product's worker body (see the module docstring)."""
+    return _Mi355xWorker(rank, device_index, init_args)
+
+
+class _SyncBody:
+    """Adapter: a plain ``process(frame, out)`` function as a depth-1 begin / finish body."""
+
+    depth = 1
+
+    def __init__(self, fn):
+        self._fn = fn
+        for name in ("pin", "close"):
+            if hasattr(fn, name):
+                setattr(self, name, getattr(fn, name))
+
+    def begin(self, frame, out):
+        self._fn(frame, out)
+        return None
+
+    def finish(self, token):
+        return None
 
 
 def _worker_main(rank, device_index, make_worker, init_args, shm_name, geom, task_q, done_q):
-    shm = None
+    shm, ins, outs, body = None, None, None, None
+    code = 0
     try:
         h, w, slots = geom
         in_b, out_b = h * w * 3, h * w * 6
         shm = shared_memory.SharedMemory(name=shm_name)
-        process = make_worker(rank, device_index, init_args)
-        if hasattr(process, "pin"):
-            process.pin(shm.buf)
+        body = make_worker(rank, device_index, init_args)
+        if not hasattr(body, "begin"):
+            body = _SyncBody(body)
+        if hasattr(body, "pin"):
+            body.pin(shm.buf)
         ins = [np.ndarray((h, w, 3), np.uint8, shm.buf, offset=s * in_b) for s in range(slots)]
         outs = [np.ndarray((h, w, 3), np.uint16, shm.buf, offset=slots * in_b + s * out_b) for s in range(slots)]
+        depth = max(1, int(getattr(body, "depth", 1)))
         free_out = list(range(slots))
+        backlog = collections.deque()
+        inflight = collections.deque()
+        stopping = False
         done_q.put(("ready", rank, None, None))
-        backlog = []
         while True:
-            msg = task_q.get() if not backlog or not free_out else (task_q.get_nowait() if not task_q.empty() else None)
-            if msg is not None:
-                if msg[0] == "stop":
+            # messages: block only when there is nothing else to do
+            block = not stopping and not inflight and not (backlog and free_out)
+            while True:
+                try:
+                    msg = task_q.get(block=block)
+                except _queue.Empty:
                     break
-                if msg[0] == "release":
+                block = False
+                if msg[0] == "stop":
+                    stopping = True
+                elif msg[0] == "release":
                     free_out.append(msg[1])
                 else:
                     backlog.append(msg)
-            if backlog and free_out:
-                _, idx, in_slot = backlog.pop(0)
+            if stopping:
+                backlog.clear()
+            # queue frames behind the ones in flight before waiting for any of them
+            while backlog and free_out and len(inflight) < depth:
+                _, idx, in_slot = backlog.popleft()
                 out_slot = free_out.pop(0)
-                process(ins[in_slot], outs[out_slot])
+                inflight.append((body.begin(ins[in_slot], outs[out_slot]), idx, in_slot, out_slot))
+            if inflight:
+                token, idx, in_slot, out_slot = inflight.popleft()
+                body.finish(token)
                 done_q.put(("frame", rank, idx, (in_slot, out_slot)))
-        if hasattr(process, "close"):
-            process.close()
+            elif stopping:
+                break
     except BaseException:  # noqa: BLE001  (reported to the parent, which raises it from submit / flush)
         done_q.put(("error", rank, None, traceback.format_exc()))
+        code = 1
     finally:
+        try:
+            if body is not None and hasattr(body, "close"):
+                body.close()
+        except BaseException:  # noqa: BLE001
+            code = code or 1
+        # the numpy views export shm.buf: drop them before the mapping goes away (BufferError otherwise)
+        ins = outs = body = None
+        gc.collect()
         if shm is not None:
-            shm.close()
+            try:
+                shm.close()
+            except BufferError:
+                pass
+    if code:
+        raise SystemExit(code)
 
 
 class FrameDispatcher:
@@ -118,6 +244,7 @@ class FrameDispatcher:
         self._task = [ctx.Queue() for _ in range(self.n)]
         self._done = ctx.Queue()
         devices = list(devices) if devices is not None else list(range(self.n))
+        self._stop = False
         self._procs = [ctx.Process(target=_worker_main, daemon=True,
                                    args=(r, devices[r], make_worker, dict(init_args or {}), self._shm[r].name,
                                          (self.h, self.w, self.slots), self._task[r], self._done)) for r in range(self.n)]
@@ -132,6 +259,7 @@ class FrameDispatcher:
             for s in range(self.slots):
                 self._free_in[r].put(s)
         self._next_submit = 0
+        self._reserved = None
         self._next_emit = 0
         self._held = {}
         self._error = None
@@ -140,21 +268,27 @@ class FrameDispatcher:
         ready, t_end = 0, time.monotonic() + start_timeout
         while ready < self.n:
             try:
-                kind, rank, _, payload = self._done.get(timeout=max(0.1, t_end - time.monotonic()))
+                kind, rank, _, payload = self._done.get(timeout=0.5)
             except _queue.Empty:
-                self.close()
-                raise RuntimeError("dispatcher workers did not come up") from None
+                dead = self._dead_worker()
+                if dead or time.monotonic() > t_end:
+                    self.close()
+                    raise RuntimeError(dead or "dispatcher workers did not come up") from None
+                continue
             if kind == "error":
                 self.close()
                 raise RuntimeError(f"dispatcher worker {rank} failed to start:\n{payload}")
             ready += 1
-        self._stop = False
         self._thread = threading.Thread(target=self._reorder, name="dispatch-reorder", daemon=True)
         self._thread.start()
 
     # ---------------------------------------------------------------- parent side
-    def submit(self, frame):
-        """Frame ``i`` (the i-th call) -> worker ``i mod N``.  Blocks while that worker's input slots are all in flight."""
+    def reserve(self):
+        """Zero-copy submission, step 1: ``(index, view)`` of the input slot frame ``index`` will be read from -- a decoder
+        writes the u8 BGR frame straight into ``view`` and then calls ``commit()``.  Blocks while worker ``index mod N`` has
+        no free input slot.  One reservation at a time."""
+        if self._reserved is not None:
+            raise RuntimeError("reserve() called twice without commit()")
         self._raise_if_failed()
         i = self._next_submit
         r = i % self.n
@@ -164,10 +298,30 @@ class FrameDispatcher:
                 break
             except _queue.Empty:
                 self._raise_if_failed()
-        np.copyto(self._ins[r][s], frame)
+        self._reserved = (i, r, s)
+        return i, self._ins[r][s]
+
+    def commit(self):
+        """Zero-copy submission, step 2: hand the reserved slot to its worker."""
+        if self._reserved is None:
+            raise RuntimeError("commit() without reserve()")
+        i, r, s = self._reserved
+        self._reserved = None
         self._task[r].put(("frame", i, s))
         self._next_submit = i + 1
         return i
+
+    def submit(self, frame):
+        """Frame ``i`` (the i-th call) -> worker ``i mod N``.  Blocks while that worker's input slots are all in flight."""
+        _, view = self.reserve()
+        try:
+            np.copyto(view, frame)
+        except BaseException:
+            i, r, s = self._reserved
+            self._reserved = None
+            self._free_in[r].put(s)
+            raise
+        return self.commit()
 
     def flush(self, timeout=600.0):
         """Wait until every submitted frame has been handed to the sink."""
@@ -179,7 +333,20 @@ class FrameDispatcher:
                     raise TimeoutError("dispatcher flush timed out")
         self._raise_if_failed()
 
+    def _dead_worker(self):
+        """A worker that is gone without having been asked to stop (GPU fault, abort, OOM kill, SIGSEGV: it posts nothing)."""
+        if self._stop:
+            return None
+        for r, p in enumerate(getattr(self, "_procs", [])):
+            if not p.is_alive() and p.exitcode is not None:
+                return f"dispatcher worker {r} died with exit code {p.exitcode}"
+        return None
+
     def _raise_if_failed(self):
+        if self._error is None:
+            dead = self._dead_worker()
+            if dead:
+                self._error = dead
         if self._error is not None:
             raise RuntimeError(f"dispatcher worker failed:\n{self._error}")
 
@@ -188,6 +355,12 @@ class FrameDispatcher:
             try:
                 kind, rank, idx, payload = self._done.get(timeout=0.1)
             except _queue.Empty:
+                if self._error is None:
+                    dead = self._dead_worker()
+                    if dead:
+                        self._error = dead
+                        with self._emitted:
+                            self._emitted.notify_all()
                 continue
             if kind == "error":
                 self._error = payload
@@ -211,6 +384,8 @@ class FrameDispatcher:
                     self._emitted.notify_all()
 
     def close(self):
+        """Stops the workers (frames still queued are dropped) and releases the shared slots.  ``exit_codes`` afterwards
+        holds every worker's exit code: 0 for a clean stop."""
         self._stop = True
         for q in getattr(self, "_task", []):
             try:
@@ -218,16 +393,22 @@ class FrameDispatcher:
             except Exception:  # noqa: BLE001
                 pass
         for p in getattr(self, "_procs", []):
-            p.join(timeout=10.0)
+            p.join(timeout=20.0)
             if p.is_alive():
                 p.terminate()
+                p.join(timeout=5.0)
+        self.exit_codes = [p.exitcode for p in getattr(self, "_procs", [])]
         t = getattr(self, "_thread", None)
         if t is not None:
             t.join(timeout=2.0)
         self._ins = self._outs = None
+        gc.collect()
         for s in getattr(self, "_shm", []):
             try:
                 s.close()
+            except Exception:  # noqa: BLE001
+                pass
+            try:
                 s.unlink()
             except Exception:  # noqa: BLE001
                 pass

@@ -88,6 +88,7 @@ class HDRTVNetMI355X:
         self._fast_zero_condition = env_true("HDRTVNET_ZERO_COND")
         self._use_cuda_graphs = bool(use_cuda_graphs)
         self._graphs = {}
+        self._profiling = False
         self.device = self._resolve_device(device)
         self.precision = self._resolve_precision(precision)
         self._use_cuda = True
@@ -325,7 +326,7 @@ class HDRTVNetMI355X:
         cond = cond.contiguous()
         if tuple(cond.shape[2:]) != (max(1, h // 4), max(1, w // 4)):
             raise ValueError("cond must be [1,3,H//4,W//4]")
-        if self._use_cuda_graphs:
+        if self._use_cuda_graphs and not self._profiling:
             return self._infer_graph(tensor, cond, h, w)
         self._chk(self._lib.hdrtv_infer(self._ctx, self._stream(), tensor.data_ptr(), cond.data_ptr(), h, w,
                                         self._gpu_out.data_ptr(), _L.F32 if self._use_hg else _L.F16,
@@ -492,10 +493,14 @@ class HDRTVNetMI355X:
     def set_hg_mask_r(self, r=0.75):
         """``HG_Composite(mask_r=...)`` (HG_Composite_arch.py:21): threshold base of the highlight mask."""
         self._chk(self._lib.hdrtv_set_hg_mask_r(self._ctx, float(r)), "hdrtv_set_hg_mask_r")
+        self._graphs.clear()          # a captured hipGraph has the old threshold baked into its kernel arguments
 
     def profile_enable(self, on=True):
-        """Per-launch HIP-event timing of subsequent infer() calls (bench.py roofline)."""
+        """Per-launch HIP-event timing of subsequent infer() calls (bench.py roofline).  While it is on, infer() launches
+        eagerly even with ``use_cuda_graphs``: a graph replay records no events, and a graph captured with profiling on
+        would carry the event records."""
         self._chk(self._lib.hdrtv_profile_enable(self._ctx, 1 if on else 0), "hdrtv_profile_enable")
+        self._profiling = bool(on)
 
     def profile_read(self):
         """[(layer, kernel, ms, macs, bytes)] of the last infer(); synchronises on its events."""

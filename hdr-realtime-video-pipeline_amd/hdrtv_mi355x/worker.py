@@ -348,6 +348,9 @@ class HeadlessPipelineWorker:
                 pass
             self._hdr_thread.join(timeout=10.0)
             if self._hdr_thread.is_alive():
+                # the stop flag and the sentinel are already set: the thread exits as soon as it unblocks and nothing will
+                # drain the queue afterwards -- make the next _process_frame raise instead of queueing into the void
+                self._hdr_error = RuntimeError("HDR feeder did not stop within 10 s; frames are no longer being delivered")
                 return False
         self._hdr_thread, self._hdr_queue = None, None
         if not keep_sink:

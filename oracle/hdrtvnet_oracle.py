@@ -461,7 +461,7 @@ def hg_generator(hg, img, mask, taps=None):
     c9 = tap("hg.conv9", fuse("conv9", _hg_up(hg, "Up_conv4", c8), c2))
     up5 = tap("hg.up5", _hg_up(hg, "Up_conv5", c9))
     c10 = tap("hg.conv10", fuse("conv10", up5, c1))
-    out = fuse("conv_last", c10, img)
+    out = tap("hg.tail", fuse("conv_last", c10, img))          # before the mask blend: lets a test re-blend with any mask
     return (mask * out + img).astype(np.float32)
 
 

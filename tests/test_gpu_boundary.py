@@ -228,3 +228,70 @@ def test_dispatcher_on_the_device(golden_dir):
     assert sorted(got) == list(range(n))
     for i in range(n):
         assert np.array_equal(got[i], want[i]), i
+
+
+def test_pq_table_survives_letterbox_growth(golden_dir):
+    """One context: post_pq_rgb48 (builds the PQ boundary table), two letterbox calls of growing geometry (the second
+    re-allocates the letterbox tables), post_pq_rgb48 again -- bit for bit the oracle both times; then close().  (Round 2's
+    letterbox_setup freed the PQ table in its grow branch and left the pointer set: ADVICE r02.)"""
+    import ctypes as C
+    import torch
+    from hdrtv_mi355x import lib as L
+    from oracle import hdrtvnet_oracle as O
+    from oracle import letterbox_oracle as LB
+    p = _hr(golden_dir)
+    try:
+        h, w = 72, 128
+        x = np.random.default_rng(9).uniform(-0.05, 1.05, (3, h, w)).astype(np.float32)
+        xin = torch.from_numpy(x).cuda()
+        u16 = torch.empty((h, w, 3), dtype=torch.uint16, device="cuda")
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        want = O.post_pq_rgb48(x, 1000.0)
+
+        def pq():
+            u16.zero_()
+            p._chk(p._lib.hdrtv_post_pq_rgb48(p._ctx, st, xin.data_ptr(), L.F32, h, w, C.c_float(1000.0), u16.data_ptr()),
+                   "hdrtv_post_pq_rgb48")
+            torch.cuda.synchronize()
+            return u16.cpu().numpy()
+
+        assert np.array_equal(pq(), want)
+        for (sh, sw), (dh, dw) in (((57, 76), (96, 96)), ((270, 480), (1080, 1920))):
+            f = np.random.default_rng(sh).integers(0, 256, (sh, sw, 3), dtype=np.uint8)
+            src = torch.from_numpy(f).cuda()
+            dst = torch.empty((dh, dw, 3), dtype=torch.uint8, device="cuda")
+            p._chk(p._lib.hdrtv_letterbox_u8(p._ctx, st, src.data_ptr(), sh, sw, dst.data_ptr(), dh, dw), "hdrtv_letterbox_u8")
+            torch.cuda.synchronize()
+            assert np.array_equal(dst.cpu().numpy(), LB.letterbox_bgr(f, dw, dh))
+            assert np.array_equal(pq(), want)
+    finally:
+        p.close()
+
+
+def test_hip_graph_follows_mask_r_and_profiling(golden_dir):
+    """set_hg_mask_r() after a capture must take effect on the next infer (the captured graph baked the old threshold in),
+    and profile_enable() must time real launches, not a replay that records nothing."""
+    import torch
+    from hdrtv_mi355x import weights as W
+    f = W.synthetic_frame(96, 128, seed=3, kind="gradient")
+    res = {}
+    for graphs in (False, True):
+        p = _hr(golden_dir, use_hg=True, hg_weights="seeded:1234", use_cuda_graphs=graphs)
+        try:
+            t, c = p.preprocess(f)
+            a = p.infer((t, c))[0].clone()
+            a2 = p.infer((t, c))[0].clone()                   # replay
+            p.set_hg_mask_r(0.3)
+            b = p.infer((t, c))[0].clone()
+            p.profile_enable(True)
+            p.infer((t, c))
+            prof = p.profile_read()
+            p.profile_enable(False)
+            b2 = p.infer((t, c))[0].clone()
+            assert torch.equal(a, a2) and torch.equal(b, b2)
+            assert len(prof) == p.infer_stats()[0] and all(ms > 0 for _, _, ms, _, _ in prof)
+            res[graphs] = (a, b)
+        finally:
+            p.close()
+    assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
+    assert not torch.equal(res[True][0], res[True][1])        # the dense mask blends the HG residual into far more pixels

@@ -1,0 +1,258 @@
+"""Parity evidence for the BASELINE.json configurations as they are benchmarked ("next round" item 1):
+
+  * configs[2]: the HG head at 3840x2160 (2176 padded rows, the 8160-tile schedules of conv_pglds) against the oracle on
+    the device's own LE output, once with the reference's mask (mask_r = 0.75) and once dense (0.3);
+  * end-to-end RGB48 integers against the ``rgb48`` vectors the reference itself produced for every HR / HG golden
+    (gui_pipeline_worker_feeders.py:223-227 applied to the reference's fp32 output), with the LSB histogram SURVEY
+    section 7 asks for.  Bit-exactness of the final integers through an fp16 network against an fp32 reference is not
+    attainable; the asserted bounds are the float bars of test_gpu_parity.py in u16 LSB;
+  * configs[0]'s size, 960x540 (the 135 -> 68 -> 136 ``_align_to`` crop), on the device;
+  * configs[4] as benchmarked: native-int8 HR together with the int8 HG head against the oracle's fake-quant composite.
+
+All tests need a real MI355X (``pytest -m gpu``) and call through the C ABI."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+OUT_MAX, OUT_MEAN = 6e-3, 5e-4              # test_gpu_parity.py's float bars for the final output
+LSB_MAX, LSB_MEAN = int(OUT_MAX * 65535) + 1, OUT_MEAN * 65535
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU; torch.cuda.is_available() is False")
+    return torch
+
+
+def _stats(name, got, want):
+    d = np.abs(np.asarray(got, np.float64) - np.asarray(want, np.float64))
+    print(f"  {name}: max_abs={d.max():.3e} mean_abs={d.mean():.3e} ref_absmean={np.abs(want).mean():.3e}")
+    return d.max(), d.mean()
+
+
+def _rgb48(proc, out):
+    """RGB48 of ``out`` through hdrtv_post_rgb48 (the feeder's quantiser) -> u16 [H,W,3]."""
+    import torch
+    from hdrtv_mi355x import lib as L
+    out = out.contiguous()
+    h, w = int(out.shape[-2]), int(out.shape[-1])
+    u16 = torch.empty((h, w, 3), dtype=torch.uint16, device=out.device)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = proc._lib.hdrtv_post_rgb48(proc._ctx, st, out.data_ptr(), L.F32 if out.dtype == torch.float32 else L.F16, h, w,
+                                    u16.data_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    return u16.cpu().numpy()
+
+
+def _lsb_histogram(name, got, want, keep=None):
+    d = np.abs(got.astype(np.int64) - want.astype(np.int64))
+    if keep is not None:
+        d = d[keep]
+    edges = [0, 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 65536]
+    hist = [(int(((d >= lo) & (d < hi)).sum())) for lo, hi in zip(edges[:-1], edges[1:])]
+    cells = " ".join(f"[{lo},{hi}):{n}" for lo, hi, n in zip(edges[:-1], edges[1:], hist) if n)
+    print(f"  RGB48 |LSB error| {name}: n={d.size} exact={hist[0] / d.size:.3%} max={int(d.max())} mean={d.mean():.2f} "
+          f"p99={np.percentile(d, 99):.0f}  histogram {cells}")
+    return int(d.max()), float(d.mean())
+
+
+# ------------------------------------------------------------------------------------------ RGB48 vs the reference's vectors
+@pytest.mark.parametrize("name", ["hr_64x96_noise_s0", "hr_60x100_noise_s2", "hr_52x76_gradient_s5", "hr_32x96_gradient_s1_taps"])
+def test_rgb48_end_to_end_vs_reference_hr(torch_cuda, golden_dir, name):
+    from hdrtv_mi355x.processor import HDRTVNetMI355X
+    d = np.load(os.path.join(golden_dir, name + ".npz"))
+    p = HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), use_hg=False, warmup_passes=0)
+    try:
+        out, _ = p.infer(p.preprocess(d["frame"]))
+        got = _rgb48(p, out)
+    finally:
+        p.close()
+    assert got.shape == d["rgb48"].shape and got.dtype == np.uint16
+    mx, mean = _lsb_histogram(name, got, d["rgb48"])
+    assert mx <= LSB_MAX and mean <= LSB_MEAN
+
+
+@pytest.mark.parametrize("name", ["hg_96x128_gradient_s3", "hg_80x112_gradient_s4"])
+def test_rgb48_end_to_end_vs_reference_hg(torch_cuda, golden_dir, name):
+    from hdrtv_mi355x.processor import HDRTVNetMI355X
+    from oracle import hdrtvnet_oracle as O
+    d = np.load(os.path.join(golden_dir, name + ".npz"))
+    p = HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), use_hg=True, hg_weights="seeded:1234", warmup_passes=0)
+    try:
+        out, _ = p.infer(p.preprocess(d["frame"]))
+        got = _rgb48(p, out)
+        base = p.tap("le.out").numpy()
+    finally:
+        p.close()
+    # the highlight mask is a hard threshold on the LE output: a pixel whose bit flipped under fp16 gets (or loses) the whole
+    # HG residual, which is not a rounding error; such pixels are counted, bounded, and excluded from the LSB bars
+    same = (O.hg_mask(base) == d["mask"])[0]
+    print(f"  mask flips vs the reference run: {int((~same).sum())} of {same.size}")
+    assert (~same).mean() <= 0.002
+    _lsb_histogram(name + " (all pixels)", got, d["rgb48"])
+    mx, mean = _lsb_histogram(name + " (mask bit equal)", got, d["rgb48"], keep=same)
+    assert mx <= int(8e-3 * 65535) + 1 and mean <= 6e-4 * 65535          # test_hg_golden's float bars in LSB
+
+
+@pytest.mark.parametrize("tag,prec", [("full_qat", "int8-full"), ("mixed_qat", "int8-mixed")])
+def test_rgb48_end_to_end_vs_reference_int8_storage(torch_cuda, golden_dir, tag, prec):
+    """The INT8 checkpoints as the reference executes them on ROCm (pre-dequantised at load)."""
+    from hdrtv_mi355x.processor import HDRTVNetMI355X
+    d = np.load(os.path.join(golden_dir, f"int8_{tag}_64x96_gradient_s6.npz"))
+    p = HDRTVNetMI355X(os.path.join(golden_dir, f"hr_int8_{tag}.hdrw"), precision=prec, use_hg=False, warmup_passes=0)
+    try:
+        out, _ = p.infer(p.preprocess(d["frame"]))
+        got = _rgb48(p, out)
+    finally:
+        p.close()
+    mx, mean = _lsb_histogram(f"int8 {tag} (pre-dequantised)", got, d["rgb48"])
+    assert mx <= LSB_MAX and mean <= LSB_MEAN
+
+
+# ------------------------------------------------------------------------------------------ configs[0]: 960x540 on the device
+def test_540p_on_the_device(torch_cuda, golden_dir, hr_state):
+    """BASELINE.json configs[0]'s frame (960x540: the condition map is 135x240, LE's 1/8 level 68 rows -> 136 after the
+    up-convs, cropped back to 135 by ``_align_to``) through the device: AGCM against the reference run's vectors, the
+    whole HR forward against the oracle."""
+    from hdrtv_mi355x.processor import HDRTVNetMI355X
+    from oracle import hdrtvnet_oracle as O
+    d = np.load(os.path.join(golden_dir, "agcm_540x960_s0.npz"))
+    frame = np.random.default_rng(0).integers(0, 256, (540, 960, 3), dtype=np.uint8)
+    p = HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), use_hg=False, warmup_passes=0)
+    try:
+        t, c = p.preprocess(frame)
+        out, agcm = p.infer((t, c))
+        cond = c.float().cpu().numpy()[0]
+        agcm_np, out_np = agcm.float().cpu().numpy()[0], out.float().cpu().numpy()[0]
+        fea6 = p.tap("agcm.bias").numpy().ravel()[160:166]
+        u8 = p.postprocess(out).copy()
+    finally:
+        p.close()
+    mx, _ = _stats("cond (subsampled) vs reference", cond[:, ::9, ::16], d["cond_sub"])
+    assert mx <= 1.2e-3
+    mx, _ = _stats("fea6 vs reference", fea6, d["fea6"])
+    assert mx <= 2e-3
+    mx, _ = _stats("agcm_out (subsampled) vs reference", agcm_np[:, ::9, ::16], d["agcm_sub"])
+    assert mx <= 2e-3
+    assert np.abs(agcm_np.mean((1, 2)) - d["agcm_mean"]).max() <= 5e-4
+    rt, rc = O.preprocess(frame)
+    rout, ragcm = O.hr_forward(hr_state, rt, rc)
+    mx, mean = _stats("out 540x960 vs O.hr_forward", out_np, rout)
+    assert mx <= OUT_MAX and mean <= OUT_MEAN
+    du8 = np.abs(u8.astype(int) - O.postprocess_u8(rout).astype(int))
+    print(f"  u8: max={du8.max()} mean={du8.mean():.3f}")
+    assert du8.max() <= 3 and du8.mean() <= 0.6
+
+
+# ------------------------------------------------------------------------------------------ configs[2]: HG at 3840x2160
+def test_uhd_hg_vs_oracle(torch_cuda, golden_dir, hg_state):
+    """Full AGCM + LE + HG at 3840x2160.  The oracle (PyTorch's CPU kernels under the oracle's graph: ~40 s on the GPU
+    box's cores) evaluates the HG generator once on the DEVICE's LE output padded to 2176 rows; ``hg.tail`` (conv_last's
+    output before the blend) lets both masks be applied to that one run with the reference's arithmetic
+    ``mask * out + img``.  Checked: conv2, conv5_2 (1/16 resolution: the 540-tile layers), conv9 (input of Up_conv5),
+    the ps_dot3 partial sums over all padded pixels, and the final output at mask_r = 0.75 and 0.3."""
+    from hdrtv_mi355x import weights as W
+    from hdrtv_mi355x.processor import HDRTVNetMI355X
+    from oracle import hdrtvnet_oracle as O
+    h, w = 2160, 3840
+    f = W.synthetic_frame(h, w, seed=61, kind="gradient")
+    p = HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), use_hg=True, hg_weights="seeded:1234", warmup_passes=0)
+    try:
+        out, _ = p.infer(p.preprocess(f))
+        out75 = out.cpu().numpy()[0]
+        base = p.tap("le.out").numpy()
+        dev = {n: p.tap(n).numpy() for n in ("hg.conv2", "hg.conv5_2", "hg.conv9")}
+        part = p.tap("hg.part").numpy().reshape(-1).reshape(2176, w, 4)[:, :, :3].transpose(2, 0, 1)
+        mask75_dev = p.tap("hg.mask").numpy()[:, :h, :w]
+        p.set_hg_mask_r(0.3)
+        out, _ = p.infer(p.preprocess(f))
+        out30 = out.cpu().numpy()[0]
+        mask30_dev = p.tap("hg.mask").numpy()[:, :h, :w]
+        assert np.array_equal(p.tap("le.out").numpy(), base)
+    finally:
+        p.close()
+    ph = (32 - h % 32) % 32
+    assert ph == 16
+    bp = np.pad(base, ((0, 0), (0, ph), (0, 0)), mode="reflect")
+    taps = {}
+    O.use_backend("aten")
+    try:
+        O.hg_generator(hg_state, bp, np.zeros((1, h + ph, w), np.float32), taps)
+    finally:
+        O.use_backend("c")
+    for name, tol in (("hg.conv2", 1e-2), ("hg.conv5_2", 3e-2), ("hg.conv9", 6e-3)):
+        mx, mean = _stats(name + " 2176x3840", dev[name], taps[name])
+        assert mx <= tol and mean <= tol / 20, name
+    w10 = np.asarray(hg_state["conv10.weight"], np.float32).reshape(3, 128)[:, :64]
+    want_part = np.einsum("ok,khw->ohw", w10, taps["hg.up5"]).astype(np.float32)
+    mx, mean = _stats("hg.part (ps_dot3 epilogue) 2176x3840", part, want_part)
+    assert mx <= 6e-3 and mean <= 4e-4
+    tail = taps["hg.tail"][:, :h, :w]
+    for r, got, dev_mask in ((0.75, out75, mask75_dev), (0.3, out30, mask30_dev)):
+        mask = O.hg_mask(base, r=r)
+        assert np.array_equal(dev_mask, mask)
+        ref = (mask * tail + base).astype(np.float32)                       # Hallucination_arch.py:136
+        mx, mean = _stats(f"hg out 2160x3840, mask_r={r} (mask fraction {mask.mean():.4f})", got, ref)
+        assert mx <= 3e-3 and mean <= 2e-4
+        if r == 0.3:
+            assert mask.mean() >= 0.2
+            inside = mask[0] > 0
+            dd = np.abs(got - ref)[:, inside]
+            print(f"  masked-in pixels only ({int(inside.sum())}): max_abs={dd.max():.3e} mean_abs={dd.mean():.3e}")
+            assert dd.max() <= 3e-3
+
+
+# ------------------------------------------------------------------------------------------ configs[4]: int8 HR + int8 HG
+@pytest.mark.parametrize("tag", ["full", "mixed"])
+def test_native_int8_hr_with_int8_hg_vs_fake_quant_oracle(torch_cuda, golden_dir, tag):
+    """The configuration ``bench.py --int8`` / ``config4_int8`` times: the shipped QAT checkpoint with its W8A8 layers on
+    int8 MFMA (``predequantize="off"``) feeding the W8A8 HG head (reference-style min/max calibration), at 272x480, against
+    the oracle's fake-quant composite (fp32, ATen convolutions: the arithmetic of the reference's CPU run).  Bars: the
+    reference's own for a re-quantised graph (float MAE <= 0.02, u8 MAE <= 5, scripts/validate_tensorrt_sources.py:598-609)
+    end to end; the HG head alone, on the device's own LE output, the bars of test_gpu_int8_hg.py."""
+    from hdrtv_mi355x import weights as W
+    from hdrtv_mi355x.processor import HDRTVNetMI355X
+    from oracle import hdrtvnet_oracle as O
+    h, w = 272, 480
+    f = W.synthetic_frame(h, w, seed=11, kind="gradient")
+    qstate = W.seeded_hg_w8a8_state(1234, integer_zero=False)
+    p = HDRTVNetMI355X(os.path.join(golden_dir, f"hr_int8_{tag}_qat.hdrw"), precision=f"int8-{tag}", predequantize="off",
+                       use_hg=True, hg_weights="seeded-w8a8-minmax:1234", warmup_passes=0)
+    try:
+        assert p._is_w8_model and p._hg_int8
+        out, agcm = p.infer(p.preprocess(f))
+        out_np = out.cpu().numpy()[0]
+        base = p.tap("le.out").numpy()
+        u8 = p.postprocess(out).copy()
+    finally:
+        p.close()
+    sd = O.w8a8_state(W.load_pack(os.path.join(golden_dir, f"hr_int8_{tag}_qat.hdrw")))
+    hq = O.w8a8_state(qstate)
+    O.use_backend("aten")
+    try:
+        rt, rc = O.preprocess(f)
+        taps = {}
+        ref, _ = O.hg_composite(sd, hq, rt, rc, taps)
+        ph = (32 - h % 32) % 32
+        mask = O.hg_mask(base)
+        ref_on_base = O.hg_generator(hq, np.pad(base, ((0, 0), (0, ph), (0, 0)), mode="reflect"),
+                                     np.pad(mask, ((0, 0), (0, ph), (0, 0)), mode="reflect"))[:, :h, :w]
+    finally:
+        O.use_backend("c")
+    mx, mean = _stats(f"int8-{tag} LE out vs fake-quant oracle", base, taps["base"])
+    mx, mean = _stats(f"int8-{tag} HR + int8 HG, final out vs fake-quant composite", out_np, ref)
+    du8 = np.abs(u8.astype(int) - O.postprocess_u8(ref).astype(int))
+    flips = float((O.hg_mask(base) != taps["mask"]).mean())
+    print(f"  u8: max={du8.max()} MAE={du8.mean():.4f} (reference bar: MAE <= 5); mask flips {flips:.4%}")
+    assert mean <= 0.02 and du8.mean() <= 5.0
+    assert mean <= (1.5e-2 if tag == "full" else 3e-3)              # ~2-3x the measured level (printed above)
+    e = np.abs(out_np - ref_on_base)
+    print(f"  HG head on the device's own LE output: max {e.max():.3e} mean {e.mean():.3e}")
+    assert e.max() <= 2e-2 and e.mean() <= 5e-4

@@ -81,6 +81,40 @@ def _failing_worker(rank, device_index, init_args):
     return process
 
 
+def _dying_worker(rank, device_index, init_args):
+    """A worker that is killed mid-stream without a Python exception (what a GPU fault, an abort or the OOM killer does)."""
+    count = {"n": 0}
+
+    def process(frame, out):
+        count["n"] += 1
+        if rank == 1 and count["n"] == 2:
+            os._exit(3)
+        out[...] = 1
+    return process
+
+
+class _PipelinedStandin:
+    """begin / finish stand-in with two frames in flight: the work of a frame happens in finish(), so a correct worker
+    loop must have begun frame i + 1 before it finishes frame i (recorded in the output for the test to see)."""
+    depth = 2
+
+    def __init__(self):
+        self.begun = 0
+
+    def begin(self, frame, out):
+        self.begun += 1
+        return (frame, out, self.begun)
+
+    def finish(self, token):
+        frame, out, seq = token
+        np.multiply(frame, 257, out=out, dtype=np.uint16, casting="unsafe")
+        out[0, 0, 2] = self.begun - seq            # frames begun after this one at the time it is finished
+
+
+def _pipelined_worker(rank, device_index, init_args):
+    return _PipelinedStandin()
+
+
 def test_dispatcher_round_robin_restores_order():
     """The product's multi-GPU dispatcher (hdrtv_mi355x/dispatch.py) with two stand-in workers: frame i is processed by
     worker i mod 2, completions arrive out of order, the sink sees indices 0, 1, 2, ... with the right contents."""
@@ -97,6 +131,7 @@ def test_dispatcher_round_robin_restores_order():
             d.submit(f)
         d.flush(timeout=60)
         depth = d.max_reorder_depth
+    assert d.exit_codes == [0, 0]                                       # a clean stop is exit code 0 (no BufferError at shm.close)
     assert [s[0] for s in seen] == list(range(n))                       # presentation order = source order
     assert [s[1] for s in seen] == [i % 2 for i in range(n)]            # frame i ran on worker i mod N
     for i, (_, _, got) in enumerate(seen):
@@ -117,3 +152,41 @@ def test_dispatcher_reports_worker_failure():
             d.flush(timeout=30)
     finally:
         d.close()
+
+
+def test_dispatcher_detects_a_dead_worker():
+    """A worker process that disappears posts nothing: submit / flush must still fail (not spin), naming the exit code."""
+    from hdrtv_mi355x.dispatch import FrameDispatcher
+    import pytest
+    import time
+    d = FrameDispatcher(2, 8, 8, lambda i, v: None, make_worker=_dying_worker, init_args={}, slots=2)
+    t0 = time.monotonic()
+    try:
+        with pytest.raises(RuntimeError, match="worker 1 died with exit code 3"):
+            for _ in range(12):
+                d.submit(np.zeros((8, 8, 3), np.uint8))
+            d.flush(timeout=30)
+        assert time.monotonic() - t0 < 20
+    finally:
+        d.close()
+    assert d.exit_codes[1] == 3
+
+
+def test_dispatcher_keeps_two_frames_in_flight_and_zero_copy_submit():
+    """begin / finish bodies: the worker loop begins frame i + 1 before it waits for frame i whenever a frame is queued
+    (the overlap the product's worker gets from its three streams), and reserve() / commit() feed slots in place."""
+    from hdrtv_mi355x.dispatch import FrameDispatcher
+    h, w, n = 8, 16, 20
+    seen = {}
+    with FrameDispatcher(1, h, w, lambda i, v: seen.__setitem__(i, v.copy()), make_worker=_pipelined_worker, init_args={}, slots=3) as d:
+        for i in range(n):
+            idx, view = d.reserve()
+            assert idx == i
+            view[...] = i + 1
+            d.commit()
+        d.flush(timeout=60)
+    assert sorted(seen) == list(range(n))
+    for i in range(n):
+        assert seen[i][1, 1, 0] == (i + 1) * 257
+    overlapped = sum(int(seen[i][0, 0, 2]) >= 1 for i in range(n))
+    assert overlapped >= n // 2, overlapped          # the parent submits ahead, so most frames had a successor queued behind them
