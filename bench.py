@@ -4,6 +4,10 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Started plainly with --gpus N > 1 (no WORLD_SIZE in the environment) it launches the N ranks itself as fresh child
+processes (python -m torch.distributed.run, before this process has imported torch or touched a GPU) and relays rank 0's
+JSON line.
+
 A step = one pass of the hot path over one batch of synthetic frames: one 3840x2160 frame
 per GPU (BASELINE.json configs[2]: full HDRTVNet++ AGCM+LE+HG fp16 + fused RGB48 post;
 at N > 1 frame i goes to GPU i mod N = configs[3], no data-path collective).  The u8 frames
@@ -26,6 +30,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -60,9 +66,14 @@ def parse():
                     help="skip the extra BASELINE configs[4] measurement (INT8-QAT, HG on int8 MFMA) reported beside the headline at N=1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="960x540", help="WxH of the plain-C oracle's extra sample")
-    ap.add_argument("--cpu-protocol", default="bounded", choices=("bounded", "full"),
+    ap.add_argument("--cpu-protocol", default="bounded", choices=("bounded", "full", "quick"),
                     help="cpu_baseline: 'full' = SURVEY 8d to the letter (5 warm-up + 20 timed frames at 960x540 and 1920x1080, 2 timed "
-                         "frames at the workload size: minutes); 'bounded' = the same measurement on 3 + 1 timed frames")
+                         "frames at the workload size: ~6 minutes); 'bounded' (default, ~2.5 minutes) = 5 + 20 frames at 960x540, 1 + 5 at "
+                         "1920x1080 and ONE unscaled frame at the workload size as `value`; 'quick' = 1 + 3 / 0 + 1 frames, scaled")
+    ap.add_argument("--no-dispatcher", action="store_true",
+                    help="skip the host-fed in-product dispatcher measurement (hdrtv_mi355x/dispatch.py, one worker process) reported "
+                         "beside value_pcie_inclusive at N=1")
+    ap.add_argument("--dispatcher", action="store_true", help="only the host-fed dispatcher measurement (its own JSON line)")
     ap.add_argument("--layers", action="store_true", help="print the per-layer profile to stderr")
     return ap.parse_args()
 
@@ -107,10 +118,11 @@ def cpu_baseline(args, use_hg):
     O.set_threads(cores)
     hr = W.load_pack(os.path.join(REPO, "tests", "golden", "hr_weights.hdrw"))
     hg = W.seeded_hg_state(1234) if use_hg else None
-    full = args.cpu_protocol == "full"
-    plan = [(540, 960, 5 if full else 1, 20 if full else 3), (1080, 1920, 5 if full else 0, 20 if full else 1)]
-    if full:
-        plan.append((args.height, args.width, 0, 2))
+    plan = {"full": [(540, 960, 5, 20), (1080, 1920, 5, 20), (args.height, args.width, 0, 2)],
+            "bounded": [(540, 960, 5, 20), (1080, 1920, 1, 5), (args.height, args.width, 0, 1)],
+            "quick": [(540, 960, 1, 3), (1080, 1920, 0, 1)]}[args.cpu_protocol]
+    seen = set()
+    plan = [p for p in plan if not (p[:2] in seen or seen.add(p[:2]))]         # --height/--width equal to a fixed size: once
 
     def stages(frame):
         t0 = time.perf_counter()
@@ -199,8 +211,89 @@ def int8_extra(args, dev, dev_frames, steps=20, warmup=3):
         return {"error": f"{type(exc).__name__}: {exc}"}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the N ranks as fresh child processes -- this
+    process has not imported torch or touched a GPU, and it never replaces itself with another program -- wait for them and
+    relay rank 0's JSON line.  Returns the launcher's exit code."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {args.gpus} without WORLD_SIZE: launching {' '.join(cmd)}", file=sys.stderr, flush=True)
+    child = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)          # stderr passes through
+    lines = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
+    for ln in child.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    return child.returncode if child.returncode else (0 if lines else 1)
+
+
+def rank_stub():
+    """HDRTV_BENCH_RANK_STUB=1 (tests/test_bench_contract.py, CPU): the rank-side protocol without a GPU -- rendezvous over
+    gloo, barrier, max-over-ranks of a wall time, rank 0 prints one JSON line carrying n_gpus = WORLD_SIZE."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"stub": True, "n_gpus": world, "max_over_ranks": float(t.item())}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def dispatcher_host_fed(args, frames, device_index, use_hg, steps, warmup=5):
+    """The in-product N = 1 form of the host-fed path (hdrtv_mi355x/dispatch.py): this process only fills shared-memory slots
+    (a 24.9 MB memcpy per 4K frame) and consumes RGB48 views in order; ONE worker process owns the GPU context, DMAs straight
+    from / into the page-locked slots and keeps two frames in flight.  Comparable with value_pcie_inclusive; never `value`."""
+    from hdrtv_mi355x.dispatch import FrameDispatcher
+    H, Wd = args.height, args.width
+    seen = {"n": 0, "sum": 0}
+
+    def sink(i, view):
+        seen["n"] += 1
+        seen["sum"] += int(view[H // 2, Wd // 2, 1])            # touch the frame: the view is only valid during the call
+
+    init = {"model_path": os.path.join(REPO, "tests", "golden", "hr_weights.hdrw"), "use_hg": use_hg,
+            "hg_weights": "seeded:1234" if use_hg else None}
+    try:
+        with FrameDispatcher(1, H, Wd, sink, init_args=init, devices=[device_index], slots=3) as d:
+            for i in range(warmup):
+                d.submit(frames[i % len(frames)])
+            d.flush(timeout=300)
+            t0 = time.perf_counter()
+            for i in range(steps):
+                d.submit(frames[i % len(frames)])
+            d.flush(timeout=300)
+            el = time.perf_counter() - t0
+        return {"value": round(steps / el, 3), "unit": "frames/s", "frames": steps, "workers": 1, "slots": 3, "frames_in_flight": 2,
+                "ms_per_frame": round(el / steps * 1e3, 3), "worker_exit_codes": d.exit_codes,
+                "what": "FrameDispatcher: parent memcpy into a pinned shared slot -> worker hipMemcpyAsync H2D -> pre + infer + post_rgb48 "
+                        "-> hipMemcpyAsync D2H into a pinned shared slot -> hipEvent -> in-order sink"}
+    except Exception as exc:  # noqa: BLE001  (an extra: never take the headline line down with it)
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
+    if os.environ.get("HDRTV_BENCH_RANK_STUB"):
+        return rank_stub()
+    if args.dispatcher:
+        from hdrtv_mi355x import weights as W
+        frames = [W.synthetic_frame(args.height, args.width, seed=1234 + i, kind="noise" if i % 2 == 0 else "gradient") for i in range(4)]
+        print(json.dumps({"dispatcher_host_fed": dispatcher_host_fed(args, frames, 0, not args.no_hg, max(40, args.steps))}), flush=True)
+        return None
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -317,9 +410,10 @@ def main():
         tt = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        pp = torch.tensor([p50], device=red_dev, dtype=torch.float64)
+        # per-frame statistics: the slowest rank's p50 / p99 and the lowest rank's 1 % low
+        pp = torch.tensor([p50, p99, -one_pct_low], device=red_dev, dtype=torch.float64)
         dist.all_reduce(pp, op=dist.ReduceOp.MAX)
-        p50 = float(pp.item())
+        p50, p99, one_pct_low = float(pp[0].item()), float(pp[1].item()), -float(pp[2].item())
     value = world * args.steps / elapsed
     lib.hdrtv_ring_destroy(ctx)
 
@@ -475,6 +569,8 @@ def main():
         }
         if world == 1 and use_hg and not args.int8 and not args.no_int8_extra:
             line["config4_int8"] = int8_extra(args, dev, dev_frames)
+        if world == 1 and not args.int8 and not args.no_dispatcher:
+            line["dispatcher_host_fed"] = dispatcher_host_fed(args, frames, local_rank, use_hg, max(40, args.steps))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, use_hg)
         print(json.dumps(line), flush=True)

@@ -45,3 +45,21 @@ def test_bench_defaults_are_the_headline_configuration():
     assert spec is not None
     for needle in ('"--gpus", type=int, default=1', '"--height", type=int, default=2160', '"--width", type=int, default=3840'):
         assert needle in src, needle
+
+
+def test_bench_self_launches_its_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment starts two ranks itself (torch.distributed.run in a
+    child process) and relays rank 0's line with n_gpus = 2.  HDRTV_BENCH_RANK_STUB=1 replaces the GPU work of a rank by the
+    rendezvous / barrier / max-over-ranks skeleton (gloo), so this runs without a GPU."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HDRTV_BENCH_RANK_STUB"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["max_over_ranks"] == 2.0
+    assert "torch.distributed.run" in r.stderr and "--nproc-per-node=2" in r.stderr

@@ -203,12 +203,14 @@ def test_ring_exhaustion_falls_back_and_feeder_errors_surface(golden_dir, tmp_pa
 
 def test_dispatcher_on_the_device(golden_dir):
     """hdrtv_mi355x/dispatch.py with the product's worker body: two worker processes (both on this box's one GPU), frames
-    round-robin, RGB48 frames back in order and bit-identical to an in-process processor's."""
+    round-robin, two frames in flight per worker (upload / compute / download on three streams, DMA straight from and into
+    the page-locked shared slots), RGB48 frames back in order and bit-identical to an in-process processor's -- at 1920x1080,
+    where the persistent kernels walk many tiles and the copies are long enough to overlap compute."""
     import ctypes as C
     import torch
     from hdrtv_mi355x import lib as L, weights as W
     from hdrtv_mi355x.dispatch import FrameDispatcher
-    h, w, n = 64, 96, 9
+    h, w, n = 1080, 1920, 9
     frames = [W.synthetic_frame(h, w, seed=200 + i, kind="gradient" if i % 2 else "noise") for i in range(n)]
     p = _hr(golden_dir, use_hg=True, hg_weights="seeded:1234")
     want = []
@@ -225,6 +227,7 @@ def test_dispatcher_on_the_device(golden_dir):
         for f in frames:
             d.submit(f)
         d.flush(timeout=120)
+    assert d.exit_codes == [0, 0]
     assert sorted(got) == list(range(n))
     for i in range(n):
         assert np.array_equal(got[i], want[i]), i
