@@ -1,0 +1,321 @@
+// conv3x3_prw.hip -- HG 3x3 convolutions (Hallucination_arch.py:97-137), "private weights" schedule.
+//
+// GEMM view as conv3x3_pglds.hip (M = output channels, N = a 16x16-pixel tile, K = 64-channel chunk x tap, halo tile
+// with its 18x18 pixels x 128 B staged once per chunk by LDS-DMA and re-read for all nine taps), but the work of a tile
+// is cut the other way: the block covers 256 output channels and wave w owns channels 32w .. 32w+31 for ALL 256 pixels
+// (2 x 16 accumulator tiles of 16x16 = 128 VGPRs).  A wave therefore needs only ITS 32 weight rows of a tap (4 KiB),
+// which it DMAs into a wave-private two-slot ring one tap ahead and waits for with its own vmcnt:
+//   * no weight traffic is shared between waves, so there is no barrier per tap -- one s_barrier per 64-channel chunk
+//     (576 MFMAs per wave) orders the shared halo buffers, where conv_pglds has nine;
+//   * a wave's waits are for DMAs it issued a whole tap (~2000 cycles) earlier, so they are free in steady state, and the
+//     eight waves drift apart instead of reaching the DMA issue / wait / barrier / MFMA phases together: the two waves
+//     of a SIMD fill each other's gaps on the matrix pipe;
+//   * per MFMA: 0.56 ds_read_b128 (conv_pglds: 0.5), 0.06 LDS-DMA pieces (0.08), the same L2 -> CU weight bytes.
+// Accumulation order per output element is conv_pglds's (chunk, tap, k-step), so results are bit-identical to it.
+//
+// LDS: 2 x 41 KiB halo + 8 x 2 x 4 KiB weight rings + 2 x 2 KiB scale/shift + 1 KiB DMA trash + 1 KiB dot weights = 152 KiB.
+#include "launchers.h"
+
+namespace {
+
+constexpr int TH = 16, TW = 16, HW = 18, NPIX = HW * HW;
+constexpr int CT = 64, PIXB = CT * 2;                    // 64-channel chunk = 128 B per pixel
+constexpr int BN = 256, WCH = 32;                        // block / wave output channels
+constexpr int A_PIECES = 41, A_PIECES_PER_WAVE = 6;      // 324 halo px = 40.5 KiB; pieces 41..47 go to the trash KiB
+constexpr int A_BYTES = A_PIECES * 1024;
+constexpr int W_SLOT = WCH * PIXB;                       // 4 KiB: 32 rows x 64 K
+constexpr int W_OFF = 2 * A_BYTES;
+constexpr int SS_OFF = W_OFF + 8 * 2 * W_SLOT;           // two slots of {scale[256], shift[256]}
+constexpr int TRASH_OFF = SS_OFF + 2 * 2048;
+constexpr int DOTW_OFF = TRASH_OFF + 1024;
+constexpr int SMEM = DOTW_OFF + 1024;                    // 155 648 B
+
+template <int MODE> struct NStores { static constexpr int N = MODE == ST_POOL ? 4 : 16; };
+
+template <int OFF> __device__ __forceinline__ void glds16(const void *g, void *lds)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds, 16, OFF, 0);
+}
+
+template <int N> __device__ __forceinline__ void wait_vm()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+struct Tile { int n0, oy0, ox0; };
+
+template <int MODE>
+__global__ __launch_bounds__(512) void conv_prw_kernel(ConvParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *sA = smem;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kg = lane >> 4;
+    char *sW = smem + W_OFF + wave * (2 * W_SLOT);
+
+    // ---- this block's run of tiles: XCD x owns a contiguous range, its blocks interleave in it (as conv_pglds) --
+    const int ntn = p.CoutPad / BN;
+    const int total = p.tiles_x * p.tiles_y * ntn;
+    int t_first, t_step, ntile;
+    {
+        const int G = gridDim.x, b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+        const int nslots = (G - xcd + 7) >> 3;
+        const int q = total >> 3, r = total & 7;
+        const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        const int len = q + (xcd < r ? 1 : 0);
+        t_first = base + slot;
+        t_step = nslots;
+        ntile = slot < len ? (len - slot + nslots - 1) / nslots : 0;
+    }
+    if (ntile == 0) return;
+    auto decode = [&](int t) {
+        Tile o;
+        const int nsp = p.tiles_x * p.tiles_y;
+        const int nt_i = p.nt_slow ? t / nsp : t % ntn, sp = p.nt_slow ? t - nt_i * nsp : t / ntn;
+        const int ty = sp / p.tiles_x, tx = sp - ty * p.tiles_x;
+        o.n0 = nt_i * BN; o.oy0 = ty * TH; o.ox0 = tx * TW;
+        return o;
+    };
+
+    const int nchunk = (p.c0 + p.c1) / CT, nchunk0 = p.c0 / CT;
+
+    // ---- LDS-DMA issue helpers (wave-uniform LDS base, per-lane swizzled source) ------------
+    // (the per-lane address arithmetic of the rare DMA issues and of the epilogue is recomputed from an opaque copy of the
+    // lane id each time: hoisted out of the tile loop it would sit in ~40 VGPRs across the MFMA stream, which has none to spare)
+    auto opaque_lane = [&]() { int v = lane; asm volatile("" : "+v"(v)); return v; };
+    auto issue_A = [&](int cc, int buf, const Tile &T) {
+        const int ln = opaque_lane();
+        const int l_row = ln >> 3, l_slot = ln & 7;
+        const f16 *src;
+        int cs, coff;
+        if (cc < nchunk0) { src = p.src0; cs = p.s0_stride; coff = cc * CT; }
+        else { src = p.src1; cs = p.s1_stride; coff = (cc - nchunk0) * CT; }
+#pragma unroll
+        for (int it = 0; it < A_PIECES_PER_WAVE; ++it) {
+            const int piece = wave + it * 8;
+            const int hp = piece * 8 + l_row;
+            const int hy = hp / HW, hx = hp - hy * HW;
+            const int iy = T.oy0 - 1 + hy, ix = T.ox0 - 1 + hx;
+            // branch-free: one select between the pixel's address and the zero line
+            const bool ok = (hp < NPIX) & ((unsigned)iy < (unsigned)p.Hi) & ((unsigned)ix < (unsigned)p.Wi);
+            const long off = ((long)iy * p.Wi + ix) * cs + coff + ((l_slot ^ (hx & 7)) << 3);
+            const f16 *g = ok ? src + off : p.zeros + (l_slot << 3);
+            glds16<0>(g, piece < A_PIECES ? sA + buf * A_BYTES + piece * 1024 : smem + TRASH_OFF);
+        }
+    };
+    // this wave's 32 weight rows of (chunk cc, tap): four 1-KiB pieces = one address + four immediates
+    const int w_lane = (lane >> 3) * CT + (((lane & 7) ^ (lane >> 3)) << 3);
+    auto issue_W = [&](int cc, int tap, int n0, int slot) {
+        const f16 *g = p.wpk + ((size_t)(tap * nchunk + cc) * p.CoutPad + n0 + wave * WCH) * CT + w_lane;
+        char *d = sW + slot * W_SLOT;
+        glds16<0>(g, d); glds16<1024>(g, d); glds16<2048>(g, d); glds16<3072>(g, d);
+    };
+    auto issue_SS = [&](int n0, int slot) {      // wave 0: scale[256], wave 1: shift[256]; the others keep the piece count equal
+        const float *g = (wave == 1 ? p.shift : p.scale) + n0 + opaque_lane() * 4;
+        glds16<0>(g, wave < 2 ? smem + SS_OFF + slot * 2048 + wave * 1024 : smem + TRASH_OFF);
+    };
+
+    f32x4 acc[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float act_lb = p.act == ACT_RELU ? 0.f : -__builtin_inff();
+    const int kw = l15 & 7;
+    const int w_rd = l15 * PIXB;
+    const int a_lane = l15 * PIXB;
+
+    // ---- prologue ------------------------------------------------------------------------------
+    Tile cur = decode(t_first), nxt = cur;
+    issue_A(0, 0, cur);
+    issue_SS(cur.n0, 0);
+    issue_W(0, 0, cur.n0, 0);
+
+    int gch = 0;                                  // chunks done so far: halo buffer parity
+    int ws = 0;                                   // taps done so far: weight slot parity
+    for (int k = 0; k < ntile; ++k) {
+        const bool has_next = k + 1 < ntile;
+        if (has_next) nxt = decode(t_first + (k + 1) * t_step);
+        for (int cc = 0; cc < nchunk; ++cc, ++gch) {
+            const char *a = sA + (gch & 1) * A_BYTES + a_lane;
+            const bool last_chunk = cc + 1 == nchunk;
+            const bool pfA = !last_chunk || has_next;    // a halo tile is staged during this chunk's tap 1
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap, ++ws) {
+                // weights of this tap: issued a tap ago.  vmcnt retires in issue order, so the halo of this chunk
+                // (issued eight taps ago) has landed with them; younger operations may stay in flight.
+                if (tap == 2 && pfA) {
+                    if (last_chunk) wait_vm<A_PIECES_PER_WAVE + 1>(); else wait_vm<A_PIECES_PER_WAVE>();
+                } else if (tap == 0 && cc == 0 && k > 0) {
+                    wait_vm<NStores<MODE>::N>();         // the previous tile's stores are younger than weights(0)
+                } else {
+                    wait_vm<0>();
+                }
+                if (tap == 0) __builtin_amdgcn_s_barrier();   // every wave's halo pieces have landed; the other buffer is free
+                if (tap < 8) issue_W(cc, tap + 1, cur.n0, (ws + 1) & 1);
+                else if (!last_chunk) issue_W(cc + 1, 0, cur.n0, (ws + 1) & 1);
+                else if (has_next) issue_W(0, 0, nxt.n0, (ws + 1) & 1);
+                if (tap == 1 && pfA) {
+                    if (!last_chunk) issue_A(cc + 1, (gch + 1) & 1, cur);
+                    else { issue_A(0, (gch + 1) & 1, nxt); issue_SS(nxt.n0, (k + 1) & 1); }
+                }
+
+                const char *bw = sW + (ws & 1) * W_SLOT + w_rd;
+                const char *ax = a + ((tap / 3) * HW + tap % 3) * PIXB;
+                const int kx = (l15 + tap % 3) & 7;
+                f16x8 wf[2][2];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        wf[ks][i] = *reinterpret_cast<const f16x8 *>(bw + i * 16 * PIXB + (((ks * 4 + kg) ^ kw) << 4));
+                auto ldx = [&](int j, int ks) {
+                    return *reinterpret_cast<const f16x8 *>(ax + j * HW * PIXB + (((ks * 4 + kg) ^ kx) << 4));
+                };
+                // pixel-row fragments run two rows ahead of their MFMAs; program order is the schedule
+                f16x8 xf[3][2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { xf[j][0] = ldx(j, 0); xf[j][1] = ldx(j, 1); }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    if (j + 2 < 16) { xf[(j + 2) % 3][0] = ldx(j + 2, 0); xf[(j + 2) % 3][1] = ldx(j + 2, 1); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0][0], xf[j % 3][0], acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0][1], xf[j % 3][0], acc[1][j], 0, 0, 0);
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1][0], xf[j % 3][1], acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1][1], xf[j % 3][1], acc[1][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+
+        // ------------------------------------------------------------ epilogue, from registers
+        // lane: pixel (row j, column l15), channels n0 + 32 wave + i*16 + 4*kg + {0..3}
+        const float *ss = reinterpret_cast<const float *>(smem + SS_OFF + (k & 1) * 2048);
+        const int eln = opaque_lane();
+        const int l15 = eln & 15, kg = eln >> 4;
+        char *trash = reinterpret_cast<char *>(p.trash) + eln * 16;
+        const int cw = wave * WCH + 4 * kg;
+        // The strip is the weight slot this wave has just finished with (the other one is receiving the next tile's first
+        // tap): wave-private, so no synchronisation.  A pixel's 32 channels are 64 B = four 16-B slots, xor-swizzled by
+        // pixel so that the 8-byte quad writes of 16 pixels spread over the banks.
+        char *stg = sW + ((ws - 1) & 1) * W_SLOT;
+        const int s_px = eln >> 2, s_slot = eln & 3;
+        float4 sc[2], sh[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            sc[i] = *reinterpret_cast<const float4 *>(ss + cw + i * 16);
+            sh[i] = *reinterpret_cast<const float4 *>(ss + 256 + cw + i * 16);
+        }
+        auto outv = [&](int i, int j) {
+            f16x4 o;
+            o[0] = (f16)fmaxf(acc[i][j][0] * sc[i].x + sh[i].x, act_lb);
+            o[1] = (f16)fmaxf(acc[i][j][1] * sc[i].y + sh[i].y, act_lb);
+            o[2] = (f16)fmaxf(acc[i][j][2] * sc[i].z + sh[i].z, act_lb);
+            o[3] = (f16)fmaxf(acc[i][j][3] * sc[i].w + sh[i].w, act_lb);
+            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            return o;
+        };
+        auto st_off = [&](int px, int slot16, int half) {       // byte offset of an 8-byte quad in the strip
+            return px * 64 + ((slot16 ^ ((px >> 1) & 3)) << 4) + half * 8;
+        };
+        if constexpr (MODE == ST_NHWC || MODE == ST_PS) {
+            const int cps = p.dstC;
+            const int chw = cur.n0 + wave * WCH;
+            const int sub = MODE == ST_PS ? chw / cps : 0;
+            const int cbase = (MODE == ST_PS ? chw - sub * cps : chw) + s_slot * 8;
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {              // four pixel rows per pass = the 4 KiB strip
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        *reinterpret_cast<f16x4 *>(stg + st_off(jj * 16 + l15, i * 2 + (kg >> 1), kg & 1)) = outv(i, pass * 4 + jj);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int px = rr * 16 + s_px;
+                    const f16x8 v = *reinterpret_cast<const f16x8 *>(stg + px * 64 + ((s_slot ^ ((px >> 1) & 3)) << 4));
+                    const int oy = cur.oy0 + pass * 4 + rr;
+                    const int oxx = cur.ox0 + s_px;
+                    f16 *d;
+                    if constexpr (MODE == ST_NHWC) {
+                        const bool ok = oy < p.Ho && oxx < p.Wo;
+                        d = ok ? p.dst + ((size_t)oy * p.Wo + oxx) * p.dstC + cbase : reinterpret_cast<f16 *>(trash);
+                    } else {
+                        const int Y = 2 * oy + (sub >> 1), X = 2 * oxx + (sub & 1);
+                        const bool ok = oy < p.Ho && oxx < p.Wo && Y < p.Hd && X < p.Wd;
+                        d = ok ? p.dst + ((size_t)Y * p.Wd + X) * cps + cbase : reinterpret_cast<f16 *>(trash);
+                    }
+                    *reinterpret_cast<f16x8 *>(d) = v;
+                }
+            }
+        } else {   // ST_POOL: 2x2 max; rows j, j+1 are in this lane, columns 2c, 2c+1 meet in the strip
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {              // four pooled rows per pass
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const f16x4 u = outv(i, pass * 8 + 2 * jj), v = outv(i, pass * 8 + 2 * jj + 1);
+                        f16x4 m;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) m[r] = u[r] > v[r] ? u[r] : v[r];
+                        *reinterpret_cast<f16x4 *>(stg + st_off(jj * 16 + l15, i * 2 + (kg >> 1), kg & 1)) = m;
+                    }
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {                // 16 pooled pixels (2 rows x 8) per store
+                    const int prow = rr * 2 + (s_px >> 3), pcol = s_px & 7;
+                    const int px0 = prow * 16 + 2 * pcol, px1 = px0 + 1;
+                    f16x8 v = *reinterpret_cast<const f16x8 *>(stg + px0 * 64 + ((s_slot ^ ((px0 >> 1) & 3)) << 4));
+                    const f16x8 v1 = *reinterpret_cast<const f16x8 *>(stg + px1 * 64 + ((s_slot ^ ((px1 >> 1) & 3)) << 4));
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] = v[r] > v1[r] ? v[r] : v1[r];
+                    const int py = (cur.oy0 >> 1) + pass * 4 + prow, pxx = (cur.ox0 >> 1) + pcol;
+                    const bool ok = py < p.Hd && pxx < p.Wd;
+                    f16 *d = ok ? p.dst + ((size_t)py * p.Wd + pxx) * p.dstC + cur.n0 + wave * WCH + s_slot * 8 : reinterpret_cast<f16 *>(trash);
+                    *reinterpret_cast<f16x8 *>(d) = v;
+                }
+            }
+        }
+        cur = nxt;
+    }
+}
+
+template <int MODE>
+hipError_t launch_mode(const ConvParams &p, int grid, hipStream_t stream)
+{
+    static DevOnce attr_once;   // hipFuncSetAttribute is per (function, device)
+    auto kern = conv_prw_kernel<MODE>;
+    if (attr_once.need()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) return e;
+        attr_once.done();
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), SMEM, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// 3x3, stride 1, pad 1, Cin (src0 [+ src1 concat]) multiple of 64, Cout == CoutPad multiple of 256, no residuals;
+// store modes NHWC / PS / POOL.  One block per CU (n_cu), each walking tiles.  hipErrorInvalidValue otherwise.
+hipError_t conv_prw_launch(ConvParams p, int n_cu, hipStream_t stream)
+{
+    if ((p.c0 % CT) || (p.c1 % CT) || p.c0 + p.c1 < CT || (p.CoutPad % BN) || p.Cout != p.CoutPad || p.res1 || p.res2 ||
+        p.dst_full || !p.zeros || !p.trash || n_cu < 8 || (p.act != ACT_RELU && p.act != ACT_NONE) ||
+        (p.mode != ST_NHWC && p.mode != ST_PS && p.mode != ST_POOL) || (p.mode == ST_PS && (p.dstC % 64)))
+        return hipErrorInvalidValue;
+    p.tiles_x = (p.Wo + TW - 1) / TW;
+    p.tiles_y = (p.Ho + TH - 1) / TH;
+    const int total = p.tiles_x * p.tiles_y * (p.CoutPad / BN);
+    const int grid = total < n_cu ? total : n_cu;
+    switch (p.mode) {
+    case ST_NHWC: return launch_mode<ST_NHWC>(p, grid, stream);
+    case ST_PS: return launch_mode<ST_PS>(p, grid, stream);
+    default: return launch_mode<ST_POOL>(p, grid, stream);
+    }
+}

@@ -1393,10 +1393,13 @@ struct Seq {
         const bool s2g = L.ks == 3 && L.stride == 2 && L.cin_t == 64 && L.bn == L.coutPad && (L.coutPad == 64 || L.coutPad == 192);
         static const bool no_t16 = getenv("HDRTV_NO_T16") != nullptr;       // developer A/B: the generic implicit-GEMM kernel
         const bool t16 = !no_t16 && L.ks == 3 && L.stride == 2 && L.cin == 32 && L.coutPad == 32 && !src1 && mode == ST_NHWC && !res1 && !res2;
+        // HG 3x3 convs with Cout a multiple of 256: the private-weight schedule (conv3x3_prw.hip); HDRTV_PRW=0: conv_pglds
+        static const bool use_prw = [] { const char *e = getenv("HDRTV_PRW"); return e ? atoi(e) != 0 : true; }();
+        const bool prw = pglds && use_prw && (L.coutPad % 256) == 0 && mode != ST_PS_DOT3;
         char tag[64];
         if (t16) snprintf(tag, sizeof tag, "conv_t16<32,3,2>");
         else if (s2g) snprintf(tag, sizeof tag, "conv3x3s2_preg<%d>", L.coutPad);
-        else if (pglds) snprintf(tag, sizeof tag, "conv_pglds<%s>", mode == ST_POOL ? "pool" : (mode == ST_PS ? "ps" : (mode == ST_PS_DOT3 ? "ps_dot3" : "nhwc")));
+        else if (pglds) snprintf(tag, sizeof tag, "%s<%s>", prw ? "conv_prw" : "conv_pglds", mode == ST_POOL ? "pool" : (mode == ST_PS ? "ps" : (mode == ST_PS_DOT3 ? "ps_dot3" : "nhwc")));
         else if (glds1) snprintf(tag, sizeof tag, "conv_glds1");
         else snprintf(tag, sizeof tag, "conv_igemm<%d,%d,%d,%d>", L.cin_t, L.bn, L.ks, L.stride);
         const double macs = (double)p.Ho * p.Wo * L.cin * L.ks * L.ks * L.cout;
@@ -1406,7 +1409,7 @@ struct Seq {
                                                                     : (mode == ST_PS_DOT3 ? 8.0 * Hd * Wd : (double)p.Ho * p.Wo * L.cout));
         bytes += 2.0 * outel * (1 + (res1 ? 1 : 0) + (res2 ? 1 : 0) + (res_planar ? 1 : 0));
         chk(t16 ? conv_t16_launch(p, s) : s2g ? conv3x3s2_preg_launch(p, c->n_cu, s)
-                : (pglds ? conv_pglds_launch(p, c->n_cu, s)
+                : (pglds ? (prw ? conv_prw_launch(p, c->n_cu, s) : conv_pglds_launch(p, c->n_cu, s))
                          : (glds1 ? conv_glds1_launch(p, s, c->n_cu) : conv_igemm_launch(p, L.cin_t, L.bn, L.ks, L.stride, s))),
             key.c_str(), tag, macs, bytes);
     }

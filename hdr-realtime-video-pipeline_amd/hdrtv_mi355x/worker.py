@@ -29,13 +29,21 @@ from .processor import HDRTVNetMI355X
 _RING_FRAMES = max(2, min(8, int(os.environ.get("HDRTVNET_FEEDER_GPU_RGB48_RING_FRAMES", "3") or 3)))
 
 # preset table: the subset of gui_config.PRECISIONS (src/gui_config.py:19-160) this backend serves
+def _int8_preset(recipe, suffix):
+    return {"precision": f"int8-{recipe}", "model": f"original/pytorch_int8/hg/HR_HG_original_int8_{recipe}{suffix}.pt",
+            "model_nohg": f"original/pytorch_int8/hr/HR_original_int8_{recipe}{suffix}.pt"}
+
+
 PRECISIONS = {
     "FP16": {"precision": "fp16", "model": "original/HR.pt", "model_nohg": "original/HR.pt",
              "hg_weights": "original/HG.pt"},
-    "INT8 Full (QAT)": {"precision": "int8-full", "model": "original/pytorch_int8/hg/HR_HG_original_int8_full_qat.pt",
-                        "model_nohg": "original/pytorch_int8/hr/HR_original_int8_full_qat.pt"},
-    "INT8 Mixed (QAT)": {"precision": "int8-mixed", "model": "original/pytorch_int8/hg/HR_HG_original_int8_mixed_qat.pt",
-                         "model_nohg": "original/pytorch_int8/hr/HR_original_int8_mixed_qat.pt"},
+    # the six INT8 presets (all of gui_config.py's); "FP32" and the TensorRT-only FP8 presets are not served by this backend
+    "INT8 Mixed (PTQ)": _int8_preset("mixed", ""),
+    "INT8 Mixed (QAT)": _int8_preset("mixed", "_qat"),
+    "INT8 Mixed (QAT) (Film)": _int8_preset("mixed", "_qat_film"),
+    "INT8 Full (PTQ)": _int8_preset("full", ""),
+    "INT8 Full (QAT)": _int8_preset("full", "_qat"),
+    "INT8 Full (QAT) (Film)": _int8_preset("full", "_qat_film"),
 }
 
 
