@@ -30,8 +30,6 @@ constexpr int TRASH_OFF = SS_OFF + 2 * 2048;
 constexpr int DOTW_OFF = TRASH_OFF + 1024;
 constexpr int SMEM = DOTW_OFF + 1024;                    // 155 648 B
 
-template <int MODE> struct NStores { static constexpr int N = MODE == ST_POOL ? 4 : 16; };
-
 template <int OFF> __device__ __forceinline__ void glds16(const void *g, void *lds)
 {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
@@ -53,7 +51,6 @@ __global__ __launch_bounds__(512) void conv_prw_kernel(ConvParams p)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15, kg = lane >> 4;
     char *sW = smem + W_OFF + wave * (2 * W_SLOT);
 
     // ---- this block's run of tiles: XCD x owns a contiguous range, its blocks interleave in it (as conv_pglds) --
@@ -124,15 +121,58 @@ __global__ __launch_bounds__(512) void conv_prw_kernel(ConvParams p)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float act_lb = p.act == ACT_RELU ? 0.f : -__builtin_inff();
-    const int kw = l15 & 7;
-    const int w_rd = l15 * PIXB;
-    const int a_lane = l15 * PIXB;
+
+    // ---- the MFMA stream -------------------------------------------------------------------------
+    // A tap is eight groups of two pixel rows: group g's four fragment reads are issued in front of group g-1's eight MFMAs,
+    // so the compiler's wait for them (always lgkmcnt(0): with global_load_lds in the kernel its waitcnt pass never counts)
+    // finds nothing younger outstanding.  The pipeline runs across taps, chunks and tiles: group 7 of a tap reads the next
+    // tap's weight fragments and its first group, behind the vmcnt wait for those weights (issued at the top of this tap)
+    // and, in front of a new chunk, the barrier that says every wave's halo pieces have landed.
+    f16x8 wf[2][2], xa[2][2], xb[2][2];
+    // (fragment addresses are rebuilt from an opaque lane id at every tap: kept loop-invariant they cost a dozen VGPRs)
+    auto rd_w = [&](f16x8 (&w)[2][2], int slot, int ln) {
+        const int q15 = ln & 15, qg = ln >> 4;
+        const char *bw = sW + slot * W_SLOT + q15 * PIXB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                w[ks][i] = *reinterpret_cast<const f16x8 *>(bw + i * 16 * PIXB + (((ks * 4 + qg) ^ (q15 & 7)) << 4));
+    };
+    // ax: the tap's halo origin (buffer + tap offset, wave-uniform); dx = tap % 3
+    auto rd_x = [&](f16x8 (&x)[2][2], const char *ax, int dx, int row0, int ln) {
+        const int q15 = ln & 15, qg = ln >> 4, kx = (q15 + dx) & 7;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                x[r][ks] = *reinterpret_cast<const f16x8 *>(ax + q15 * PIXB + (row0 + r) * HW * PIXB + (((ks * 4 + qg) ^ kx) << 4));
+    };
+    // "these fragments are needed now": makes the compiler put its (uncounted) LDS wait HERE, in front of the next group's
+    // reads, instead of behind them in front of the first MFMA
+    auto touch = [&](const f16x8 (&x)[2][2]) {
+        asm volatile("" ::"v"(x[0][0]), "v"(x[0][1]), "v"(x[1][0]), "v"(x[1][1]));
+    };
+    auto mm = [&](const f16x8 (&x)[2][2], int row0) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int j = row0 + r;
+            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0][0], x[r][0], acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0][1], x[r][0], acc[1][j], 0, 0, 0);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1][0], x[r][1], acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1][1], x[r][1], acc[1][j], 0, 0, 0);
+        }
+    };
 
     // ---- prologue ------------------------------------------------------------------------------
     Tile cur = decode(t_first), nxt = cur;
     issue_A(0, 0, cur);
     issue_SS(cur.n0, 0);
     issue_W(0, 0, cur.n0, 0);
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    rd_w(wf, 0, lane);
+    rd_x(xa, sA, 0, 0, lane);
 
     int gch = 0;                                  // chunks done so far: halo buffer parity
     int ws = 0;                                   // taps done so far: weight slot parity
@@ -140,21 +180,13 @@ __global__ __launch_bounds__(512) void conv_prw_kernel(ConvParams p)
         const bool has_next = k + 1 < ntile;
         if (has_next) nxt = decode(t_first + (k + 1) * t_step);
         for (int cc = 0; cc < nchunk; ++cc, ++gch) {
-            const char *a = sA + (gch & 1) * A_BYTES + a_lane;
+            const char *a = sA + (gch & 1) * A_BYTES;
+            const char *a_nc = sA + ((gch + 1) & 1) * A_BYTES;
             const bool last_chunk = cc + 1 == nchunk;
             const bool pfA = !last_chunk || has_next;    // a halo tile is staged during this chunk's tap 1
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap, ++ws) {
-                // weights of this tap: issued a tap ago.  vmcnt retires in issue order, so the halo of this chunk
-                // (issued eight taps ago) has landed with them; younger operations may stay in flight.
-                if (tap == 2 && pfA) {
-                    if (last_chunk) wait_vm<A_PIECES_PER_WAVE + 1>(); else wait_vm<A_PIECES_PER_WAVE>();
-                } else if (tap == 0 && cc == 0 && k > 0) {
-                    wait_vm<NStores<MODE>::N>();         // the previous tile's stores are younger than weights(0)
-                } else {
-                    wait_vm<0>();
-                }
-                if (tap == 0) __builtin_amdgcn_s_barrier();   // every wave's halo pieces have landed; the other buffer is free
+                // weights of the next tap into the slot whose fragments have been in registers since the end of the last tap
                 if (tap < 8) issue_W(cc, tap + 1, cur.n0, (ws + 1) & 1);
                 else if (!last_chunk) issue_W(cc + 1, 0, cur.n0, (ws + 1) & 1);
                 else if (has_next) issue_W(0, 0, nxt.n0, (ws + 1) & 1);
@@ -162,33 +194,41 @@ __global__ __launch_bounds__(512) void conv_prw_kernel(ConvParams p)
                     if (!last_chunk) issue_A(cc + 1, (gch + 1) & 1, cur);
                     else { issue_A(0, (gch + 1) & 1, nxt); issue_SS(nxt.n0, (k + 1) & 1); }
                 }
-
-                const char *bw = sW + (ws & 1) * W_SLOT + w_rd;
                 const char *ax = a + ((tap / 3) * HW + tap % 3) * PIXB;
-                const int kx = (l15 + tap % 3) & 7;
-                f16x8 wf[2][2];
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        wf[ks][i] = *reinterpret_cast<const f16x8 *>(bw + i * 16 * PIXB + (((ks * 4 + kg) ^ kw) << 4));
-                auto ldx = [&](int j, int ks) {
-                    return *reinterpret_cast<const f16x8 *>(ax + j * HW * PIXB + (((ks * 4 + kg) ^ kx) << 4));
-                };
-                // pixel-row fragments run two rows ahead of their MFMAs; program order is the schedule
-                f16x8 xf[3][2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) { xf[j][0] = ldx(j, 0); xf[j][1] = ldx(j, 1); }
+                const int tl = opaque_lane();
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    if (j + 2 < 16) { xf[(j + 2) % 3][0] = ldx(j + 2, 0); xf[(j + 2) % 3][1] = ldx(j + 2, 1); }
+                for (int g = 0; g < 7; ++g) {
+                    if (g & 1) touch(xb); else touch(xa);
                     __builtin_amdgcn_sched_barrier(0);
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0][0], xf[j % 3][0], acc[0][j], 0, 0, 0);
-                    acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0][1], xf[j % 3][0], acc[1][j], 0, 0, 0);
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1][0], xf[j % 3][1], acc[0][j], 0, 0, 0);
-                    acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1][1], xf[j % 3][1], acc[1][j], 0, 0, 0);
+                    if (g & 1) rd_x(xa, ax, tap % 3, 2 * g + 2, tl); else rd_x(xb, ax, tap % 3, 2 * g + 2, tl);
                     __builtin_amdgcn_sched_barrier(0);
+                    if (g & 1) mm(xb, 2 * g); else mm(xa, 2 * g);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // the next tap's weights, issued at the top of this one, have had seven groups to land; only this tap's halo
+                // pieces are younger.  vmcnt retires in issue order: a halo staged at tap 1 has landed long before tap 8.
+                if (tap == 1 && pfA) {
+                    if (last_chunk) wait_vm<A_PIECES_PER_WAVE + 1>(); else wait_vm<A_PIECES_PER_WAVE>();
+                } else {
+                    wait_vm<0>();
+                }
+                if (tap == 8) __builtin_amdgcn_s_barrier();   // every wave's pieces of the next halo are in; this chunk's buffer is done with
+                {
+                    const int tnx = (tap + 1) % 9;
+                    const char *axn = (tap == 8 ? a_nc : a) + ((tnx / 3) * HW + tnx % 3) * PIXB;
+                    f16x8 wn[2][2];
+                    touch(xb);
+                    __builtin_amdgcn_sched_barrier(0);
+                    rd_x(xa, axn, tnx % 3, 0, tl);
+                    rd_w(wn, (ws + 1) & 1, tl);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(xb, 14);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) wf[ks][i] = wn[ks][i];
                 }
             }
         }
@@ -200,10 +240,10 @@ __global__ __launch_bounds__(512) void conv_prw_kernel(ConvParams p)
         const int l15 = eln & 15, kg = eln >> 4;
         char *trash = reinterpret_cast<char *>(p.trash) + eln * 16;
         const int cw = wave * WCH + 4 * kg;
-        // The strip is the weight slot this wave has just finished with (the other one is receiving the next tile's first
-        // tap): wave-private, so no synchronisation.  A pixel's 32 channels are 64 B = four 16-B slots, xor-swizzled by
+        // The strip is the weight slot whose fragments (the next tile's first tap) are already in registers; the next DMA into
+        // it is a whole tap away (the other slot receives weights at the top of the next tap): wave-private, no synchronisation.  A pixel's 32 channels are 64 B = four 16-B slots, xor-swizzled by
         // pixel so that the 8-byte quad writes of 16 pixels spread over the banks.
-        char *stg = sW + ((ws - 1) & 1) * W_SLOT;
+        char *stg = sW + (ws & 1) * W_SLOT;
         const int s_px = eln >> 2, s_slot = eln & 3;
         float4 sc[2], sh[2];
 #pragma unroll

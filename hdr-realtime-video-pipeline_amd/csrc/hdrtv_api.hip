@@ -1394,8 +1394,20 @@ struct Seq {
         static const bool no_t16 = getenv("HDRTV_NO_T16") != nullptr;       // developer A/B: the generic implicit-GEMM kernel
         const bool t16 = !no_t16 && L.ks == 3 && L.stride == 2 && L.cin == 32 && L.coutPad == 32 && !src1 && mode == ST_NHWC && !res1 && !res2;
         // HG 3x3 convs with Cout a multiple of 256: the private-weight schedule (conv3x3_prw.hip); HDRTV_PRW=0: conv_pglds
-        static const bool use_prw = [] { const char *e = getenv("HDRTV_PRW"); return e ? atoi(e) != 0 : true; }();
-        const bool prw = pglds && use_prw && (L.coutPad % 256) == 0 && mode != ST_PS_DOT3;
+        // HDRTV_PRW: 0 = never, 1 (default) = where its coarser tiles fill the chip, 2 = wherever it applies
+        // (read per launch: the A/B test flips it inside one process)
+        const char *prw_env = getenv("HDRTV_PRW");
+        const int use_prw_mode = prw_env ? atoi(prw_env) : 1;
+        const bool use_prw = use_prw_mode != 0;
+        bool prw = pglds && use_prw && (L.coutPad % 256) == 0 && mode != ST_PS_DOT3;
+        if (prw && use_prw_mode == 1) {
+            // its tiles are twice as large (256 output channels): keep conv_pglds where the coarser grain costs more of the
+            // last round on n_cu workgroups than the schedule gains (~1.1x measured on full rounds)
+            const long tsp = (long)((p.Wo + 15) / 16) * ((p.Ho + 15) / 16);
+            const long t2 = tsp * (L.coutPad / 256), t1 = tsp * (L.coutPad / 128), n = c->n_cu;
+            const double e2 = (double)t2 / (double)(((t2 + n - 1) / n) * n), e1 = (double)t1 / (double)(((t1 + n - 1) / n) * n);
+            prw = e2 * 1.10 >= e1;
+        }
         char tag[64];
         if (t16) snprintf(tag, sizeof tag, "conv_t16<32,3,2>");
         else if (s2g) snprintf(tag, sizeof tag, "conv3x3s2_preg<%d>", L.coutPad);

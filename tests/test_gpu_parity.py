@@ -512,3 +512,38 @@ def test_persistent_1x1_matches_tile_kernel(torch_cuda, golden_dir, monkeypatch)
     finally:
         monkeypatch.delenv("HDRTV_GLDS1_OLD", raising=False)
         p.close()
+
+
+def test_private_weight_conv_schedule_is_bit_identical(torch_cuda, golden_dir, monkeypatch):
+    """conv_prw (csrc/conv3x3_prw.hip: 256 output channels per workgroup, a wave owns 32 of them for the whole 16x16 tile
+    and keeps its weight rows in a private LDS ring; one barrier per 64-channel chunk) against conv_pglds (HDRTV_PRW=0):
+    same accumulation order per output element, so every HG tensor and the final output agree bit for bit -- at 4K (the
+    steady state of the cross-tile software pipeline), at 1080p, and at sizes with ragged right / bottom tiles and with
+    fewer tiles than workgroups.  HDRTV_PRW=2 forces the new schedule onto every layer it can run (the default, 1, leaves
+    the low-resolution layers on conv_pglds)."""
+    from hdrtv_mi355x import weights as W
+    from hdrtv_mi355x.processor import HDRTVNetMI355X
+    torch = torch_cuda
+    taps = ("hg.conv2", "hg.conv3_2", "hg.conv4_2", "hg.conv5_2", "hg.conv_code2", "hg.conv6", "hg.conv7", "hg.conv8", "hg.conv9")
+    p = HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), use_hg=True, hg_weights="seeded:1234", warmup_passes=0)
+    try:
+        for (h, w), seed in (((2160, 3840), 71), ((1080, 1920), 72), ((270, 486), 73), ((97, 131), 74)):
+            f = W.synthetic_frame(h, w, seed=seed, kind="gradient")
+            res = []
+            for mode in ("0", "1", "2"):
+                monkeypatch.setenv("HDRTV_PRW", mode)
+                out, _ = p.infer(p.preprocess(f))
+                res.append([out.clone()] + [p._tap_device(t).clone() for t in taps] + [p._tap_device("hg.part").clone()])
+                if mode != "0":
+                    p.profile_enable(True)
+                    p.infer(p.preprocess(f))
+                    kern = [k for _, k, _, _, _ in p.profile_read()]
+                    p.profile_enable(False)
+                    assert (sum("conv_prw" in k for k in kern) >= 7) if (mode == "2" or h >= 1080) else True
+            for other in res[1:]:
+                for name, a, b in zip(("out",) + taps + ("hg.part",), res[0], other):
+                    assert torch.isfinite(a.float()).all(), (h, w, name)
+                    assert torch.equal(a, b), (h, w, name)
+    finally:
+        monkeypatch.delenv("HDRTV_PRW", raising=False)
+        p.close()

@@ -160,3 +160,23 @@ def test_glds1p_store_count_matches_the_counted_wait(tmp_path):
     waits = set(int(v) for v in re.findall(r"s_waitcnt vmcnt\((\d+)\)", body))
     assert {6, 6 + nst} <= waits, sorted(waits)
     assert "scratch_" not in body
+
+
+def test_prw_has_no_scratch_and_the_waits_it_counts_on(tmp_path):
+    """conv3x3_prw.hip sits at ~250 VGPRs with LDS-DMA in flight all the time: a single spill puts scratch loads (and the
+    vmcnt(0) hipcc guards them with) into the MFMA stream.  Its only counted waits are for the halo pieces of tap 1
+    (A_PIECES_PER_WAVE, + 1 with the scale/shift piece): pin them, the DMA piece counts and the MFMA count per kernel."""
+    kernels = _asm("conv3x3_prw.hip", tmp_path)
+    src = open(os.path.join(CSRC, "conv3x3_prw.hip")).read()
+    per_wave = int(re.search(r"A_PIECES_PER_WAVE = (\d+)", src).group(1))
+    seen = 0
+    for name, body in kernels.items():
+        if "conv_prw_kernel" not in name:
+            continue
+        assert "scratch_" not in body, name
+        assert len(re.findall(r"v_mfma_f32_16x16x32_f16", body)) == 9 * 64, name                              # nine unrolled taps x 64 MFMAs
+        waits = set(int(v) for v in re.findall(r"s_waitcnt vmcnt\((\d+)\)", body))
+        assert waits == {0, per_wave, per_wave + 1}, (name, sorted(waits))
+        assert len(re.findall(r"s_barrier", body)) == 2, name                               # prologue + one per chunk (tap 8)
+        seen += 1
+    assert seen == 3
