@@ -58,6 +58,22 @@ __device__ __forceinline__ unsigned quant4u(float a, float b, float c, float d)
     return w ^ 0x80808080u;
 }
 
+// ---- LDS-DMA as a BUFFER load (buffer_load_dwordx4 ... lds).  Not global_load_lds: that one is a FLAT-encoded instruction,
+// which hipcc's waitcnt pass books as "may access LDS and memory"; from then on it never counts -- every wait it inserts is
+// lgkmcnt(0) / vmcnt(0).  With the buffer form LDS reads get counted waits.  A lane whose byte offset lies outside the
+// resource's num_records writes ZEROS to LDS (tools/lds_dma_oob_probe.hip), so image borders need no zero line: DMA_OOB.
+// dma16<OFF>: OFF is an immediate (<= 4095) added to both the memory and the LDS address; voff per lane, soff wave-uniform.
+typedef __amdgpu_buffer_rsrc_t dma_rsrc_t;
+constexpr unsigned DMA_OOB = 0x80000000u;                // beyond every tensor here (all < 2 GiB)
+__device__ __forceinline__ dma_rsrc_t dma_rsrc(const void *base, unsigned bytes = 0x80000000u)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), (short)0, (int)bytes, 0x00020000);
+}
+template <int OFF = 0> __device__ __forceinline__ void dma16(dma_rsrc_t r, void *lds, unsigned voff, unsigned soff = 0)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds, 16, voff, soff, OFF, 0);
+}
+
 // K-dimension permutation that lets a 32x32 MFMA accumulator tile be re-used, packed to f16,
 // as the B operand of the next MFMA (cdna_hip_programming.md section 3, "An accumulator tile as
 // the next MFMA's operand"): operand slot p (0..15) of a 16-wide k-step holds logical k

@@ -28,11 +28,6 @@ static_assert(NPIX * OUT_ROWB <= SMEM, "epilogue tile must fit");
 // every ds_read_b128 lane group of a 32x32x16 fragment hits 16 distinct 16-byte slots of the 256-byte bank row)
 __device__ __forceinline__ int swz64(int row) { return (row >> 1) & 7; }
 
-__device__ __forceinline__ void glds16(const void *g, void *lds)
-{
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                     (__attribute__((address_space(3))) void *)lds, 16, 0, 0);
-}
 
 __global__ __launch_bounds__(512) void conv_glds1_kernel(ConvParams p)
 {
@@ -65,25 +60,26 @@ __global__ __launch_bounds__(512) void conv_glds1_kernel(ConvParams p)
         int cs, coff;
         if (cc < nchunk0) { src = p.src0; cs = p.s0_stride; coff = cc * CT; }
         else { src = p.src1; cs = p.s1_stride; coff = (cc - nchunk0) * CT; }
+        const dma_rsrc_t ra = dma_rsrc(src, (unsigned)p.Hi * (unsigned)p.Wi * (unsigned)cs * 2u);
 #pragma unroll
         for (int it = 0; it < A_PIECES_PER_WAVE; ++it) {
             const int piece = wave + it * 8;
             const int hp = piece * 8 + l_row;
             const int hy = hp / TW, hx = hp - hy * TW;
             const int iy = oy0 + hy, ix = ox0 + hx;
-            const bool ok = iy < p.Hi && ix < p.Wi;
-            const f16 *g = ok ? src + ((size_t)iy * p.Wi + ix) * cs + coff + ((l_slot ^ swz64(hx)) << 3)
-                              : p.zeros + (l_slot << 3);
-            glds16(g, sA + buf * A_BYTES + piece * 1024);
+            const bool ok = (iy < p.Hi) & (ix < p.Wi);
+            const unsigned off = ((unsigned)(iy * p.Wi + ix) * (unsigned)cs + (unsigned)(coff + ((l_slot ^ swz64(hx)) << 3))) * 2u;
+            dma16(ra, sA + buf * A_BYTES + piece * 1024, ok ? off : DMA_OOB);         // out of the image: zeros
         }
     };
     auto issue_B = [&](int cc, int slot) {
-        const f16 *base = p.wpk + ((size_t)cc * p.CoutPad + n0) * CT;
+        const dma_rsrc_t rb = dma_rsrc(p.wpk, (unsigned)nchunk * (unsigned)p.CoutPad * (unsigned)(CT * 2));
+        const unsigned so = (unsigned)(cc * p.CoutPad + n0) * (unsigned)(CT * 2);
 #pragma unroll
         for (int k = 0; k < B_PIECES_PER_WAVE; ++k) {
             const int piece = wave * B_PIECES_PER_WAVE + k;
             const int n = piece * 8 + l_row;
-            glds16(base + (size_t)n * CT + ((l_slot ^ swz64(n)) << 3), sB + slot * B_BYTES + piece * 1024);
+            dma16(rb, sB + slot * B_BYTES + piece * 1024, (unsigned)(n * CT + ((l_slot ^ swz64(n)) << 3)) * 2u, so);
         }
     };
 
@@ -233,23 +229,24 @@ __global__ __launch_bounds__(512) void conv_glds1p_kernel(ConvParams p)
         int cs, coff;
         if (cc < nchunk0) { src = p.src0; cs = p.s0_stride; coff = cc * CT; }
         else { src = p.src1; cs = p.s1_stride; coff = (cc - nchunk0) * CT; }
+        const dma_rsrc_t ra = dma_rsrc(src, (unsigned)p.Hi * (unsigned)p.Wi * (unsigned)cs * 2u);
 #pragma unroll
         for (int it = 0; it < A_PIECES_PER_WAVE; ++it) {
             const int piece = wave + it * 8;
             const int hp = piece * 8 + l_row;
             const int hy = hp / TW, hx = hp - hy * TW;
             const int iy = T.oy0 + hy, ix = T.ox0 + hx;
-            const bool ok = iy < p.Hi && ix < p.Wi;
-            const f16 *g = ok ? src + ((size_t)iy * p.Wi + ix) * cs + coff + ((l_slot ^ swz64(hx)) << 3)
-                              : p.zeros + (l_slot << 3);
-            glds16(g, sA + slot * A_BYTES + piece * 1024);
+            const bool ok = (iy < p.Hi) & (ix < p.Wi);
+            const unsigned off = ((unsigned)(iy * p.Wi + ix) * (unsigned)cs + (unsigned)(coff + ((l_slot ^ swz64(hx)) << 3))) * 2u;
+            dma16(ra, sA + slot * A_BYTES + piece * 1024, ok ? off : DMA_OOB);      // out of the image: zeros
         }
-        const f16 *base = p.wpk + ((size_t)cc * p.CoutPad + T.n0) * CT;
+        const dma_rsrc_t rb = dma_rsrc(p.wpk, (unsigned)nchunk * (unsigned)p.CoutPad * (unsigned)(CT * 2));
+        const unsigned so = (unsigned)(cc * p.CoutPad + T.n0) * (unsigned)(CT * 2);
 #pragma unroll
         for (int k = 0; k < B_PIECES_PER_WAVE; ++k) {
             const int piece = wave * B_PIECES_PER_WAVE + k;
             const int n = piece * 8 + l_row;
-            glds16(base + (size_t)n * CT + ((l_slot ^ swz64(n)) << 3), sB + slot * B_BYTES + piece * 1024);
+            dma16(rb, sB + slot * B_BYTES + piece * 1024, (unsigned)(n * CT + ((l_slot ^ swz64(n)) << 3)) * 2u, so);
         }
     };
 

@@ -34,11 +34,17 @@ constexpr int SMEM = DOTW_OFF + 1024;                    // 147 KiB
 // stores per wave and tile, by store mode (see the epilogues)
 template <int MODE> struct NStores { static constexpr int N = MODE == ST_POOL ? 2 : (MODE == ST_PS_DOT3 ? 1 : 8); };
 
-__device__ __forceinline__ void glds16(const void *g, void *lds)
+// LDS-DMA as a buffer load (see conv3x3_prw.hip): counted waits from hipcc, zeros for out-of-range lanes
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *base, unsigned bytes)
 {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                     (__attribute__((address_space(3))) void *)lds, 16, 0, 0);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), (short)0, (int)bytes, 0x00020000);
 }
+__device__ __forceinline__ void bdma16(rsrc_t r, void *lds, unsigned voff, unsigned soff)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds, 16, voff, soff, 0, 0);
+}
+constexpr unsigned OOB = 0x80000000u;
 
 template <int N> __device__ __forceinline__ void wait_vm()
 {
@@ -92,31 +98,34 @@ __global__ __launch_bounds__(512) void conv_pglds_kernel(ConvParams p)
         int cs, coff;
         if (cc < nchunk0) { src = p.src0; cs = p.s0_stride; coff = cc * CT; }
         else { src = p.src1; cs = p.s1_stride; coff = (cc - nchunk0) * CT; }
+        const rsrc_t rs = make_rsrc(src, (unsigned)p.Hi * (unsigned)p.Wi * (unsigned)cs * 2u);
 #pragma unroll
         for (int it = 0; it < A_PIECES_PER_WAVE; ++it) {
             const int piece = wave + it * 8;
             const int hp = piece * 8 + l_row;
             const int hy = hp / HW, hx = hp - hy * HW;
             const int iy = T.oy0 - 1 + hy, ix = T.ox0 - 1 + hx;
-            const bool ok = hp < NPIX && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
-            const f16 *g = ok ? src + ((size_t)iy * p.Wi + ix) * cs + coff + ((l_slot ^ (hx & 7)) << 3)
-                              : p.zeros + (l_slot << 3);
-            glds16(g, sA + buf * A_BYTES + piece * 1024);
+            const bool ok = (hp < NPIX) & ((unsigned)iy < (unsigned)p.Hi) & ((unsigned)ix < (unsigned)p.Wi);
+            const unsigned off = ((unsigned)(iy * p.Wi + ix) * (unsigned)cs + (unsigned)(coff + ((l_slot ^ (hx & 7)) << 3))) * 2u;
+            bdma16(rs, sA + buf * A_BYTES + piece * 1024, ok ? off : OOB, 0);
         }
     };
     auto issue_B = [&](int it_i, int n0, int slot) {
         const int cc = it_i / 9, tap = it_i - cc * 9;
-        const f16 *base = p.wpk + ((size_t)(tap * nchunk + cc) * p.CoutPad + n0) * CT;
+        const rsrc_t rs = make_rsrc(p.wpk, 9u * (unsigned)nchunk * (unsigned)p.CoutPad * (unsigned)PIXB);
+        const unsigned so = (unsigned)((tap * nchunk + cc) * p.CoutPad + n0) * (unsigned)PIXB;
 #pragma unroll
         for (int k = 0; k < B_PIECES_PER_WAVE; ++k) {
             const int piece = wave * B_PIECES_PER_WAVE + k;
             const int n = piece * 8 + l_row;
-            glds16(base + (size_t)n * CT + ((l_slot ^ (n & 7)) << 3), sB + slot * B_BYTES + piece * 1024);
+            bdma16(rs, sB + slot * B_BYTES + piece * 1024, (unsigned)(n * CT + ((l_slot ^ (n & 7)) << 3)) * 2u, so);
         }
     };
     auto issue_SS = [&](int n0, int slot) {      // every wave writes the same 1 KiB: {scale[128], shift[128]}
-        const float *g = (lane < 32 ? p.scale : p.shift - 128) + n0 + lane * 4;
-        glds16(g, smem + SS_OFF + slot * 1024);
+        const char *sc = reinterpret_cast<const char *>(p.scale), *sh = reinterpret_cast<const char *>(p.shift);
+        const char *lo = sc < sh ? sc : sh;                      // one (wave-uniform) resource over both arrays
+        const rsrc_t rs = make_rsrc(lo, 0xffffffffu);
+        bdma16(rs, smem + SS_OFF + slot * 1024, (unsigned)((lane < 32 ? sc : sh) - lo) + (unsigned)(lane & 31) * 16u, (unsigned)n0 * 4u);
     };
 
     if constexpr (MODE == ST_PS_DOT3) {          // before any DMA is in flight (ordinary loads drain the queue)

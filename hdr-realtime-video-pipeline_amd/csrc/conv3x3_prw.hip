@@ -18,11 +18,15 @@
 
 namespace {
 
-constexpr int TH = 16, TW = 16, HW = 18, NPIX = HW * HW;
+constexpr int TW = 16, HW = 18;
 constexpr int CT = 64, PIXB = CT * 2;                    // 64-channel chunk = 128 B per pixel
 constexpr int BN = 256, WCH = 32;                        // block / wave output channels
-constexpr int A_PIECES = 41, A_PIECES_PER_WAVE = 6;      // 324 halo px = 40.5 KiB; pieces 41..47 go to the trash KiB
-constexpr int A_BYTES = A_PIECES * 1024;
+// Tile height TH = 16 (324 halo px = 40.5 KiB: 41 pieces, 6 per wave, pieces 41..47 go to the trash KiB) or, for layers with
+// too few 16x16 tiles to fill the chip's last round, TH = 8 (180 halo px: 23 pieces, 3 per wave; twice the weight bytes per MAC)
+template <int TH> struct Geo {
+    static constexpr int NPIX = (TH + 2) * HW, A_PIECES = (NPIX * PIXB + 1023) / 1024, A_PIECES_PER_WAVE = (A_PIECES + 7) / 8;
+};
+constexpr int A_BYTES = Geo<16>::A_PIECES * 1024;        // LDS layout is the TH = 16 one for both
 constexpr int W_SLOT = WCH * PIXB;                       // 4 KiB: 32 rows x 64 K
 constexpr int W_OFF = 2 * A_BYTES;
 constexpr int SS_OFF = W_OFF + 8 * 2 * W_SLOT;           // two slots of {scale[256], shift[256]}
@@ -30,11 +34,21 @@ constexpr int TRASH_OFF = SS_OFF + 2 * 2048;
 constexpr int DOTW_OFF = TRASH_OFF + 1024;
 constexpr int SMEM = DOTW_OFF + 1024;                    // 155 648 B
 
-template <int OFF> __device__ __forceinline__ void glds16(const void *g, void *lds)
+// LDS-DMA as a BUFFER load (buffer_load_dwordx4 ... lds), not global_load_lds: the global form is a FLAT-encoded
+// instruction that hipcc's waitcnt pass treats as "may touch LDS and memory", after which it never counts again -- every
+// later wait becomes lgkmcnt(0) / vmcnt(0) (tools/lds_dma_oob_probe.hip and the ISA of this file show the difference).
+// Lanes whose byte offset lies outside the resource's num_records write zeros to LDS: the image border needs no zero line.
+// OFF is an immediate added to both the memory and the LDS address.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *base, unsigned bytes)
 {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                     (__attribute__((address_space(3))) void *)lds, 16, OFF, 0);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), (short)0, (int)bytes, 0x00020000);
 }
+template <int OFF> __device__ __forceinline__ void bdma16(rsrc_t r, void *lds, unsigned voff, unsigned soff)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds, 16, voff, soff, OFF, 0);
+}
+constexpr unsigned OOB = 0x80000000u;                    // beyond any tensor here (all < 2 GiB)
 
 template <int N> __device__ __forceinline__ void wait_vm()
 {
@@ -43,9 +57,11 @@ template <int N> __device__ __forceinline__ void wait_vm()
 
 struct Tile { int n0, oy0, ox0; };
 
-template <int MODE>
+template <int MODE, int TH>
 __global__ __launch_bounds__(512) void conv_prw_kernel(ConvParams p)
 {
+    constexpr int NPIX = Geo<TH>::NPIX, A_PIECES = Geo<TH>::A_PIECES, A_PIECES_PER_WAVE = Geo<TH>::A_PIECES_PER_WAVE;
+    constexpr int NG = TH / 2;                               // groups of two pixel rows per tap
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *sA = smem;
 
@@ -90,42 +106,41 @@ __global__ __launch_bounds__(512) void conv_prw_kernel(ConvParams p)
         int cs, coff;
         if (cc < nchunk0) { src = p.src0; cs = p.s0_stride; coff = cc * CT; }
         else { src = p.src1; cs = p.s1_stride; coff = (cc - nchunk0) * CT; }
+        const rsrc_t rs = make_rsrc(src, (unsigned)p.Hi * (unsigned)p.Wi * (unsigned)cs * 2u);
 #pragma unroll
         for (int it = 0; it < A_PIECES_PER_WAVE; ++it) {
             const int piece = wave + it * 8;
             const int hp = piece * 8 + l_row;
             const int hy = hp / HW, hx = hp - hy * HW;
             const int iy = T.oy0 - 1 + hy, ix = T.ox0 - 1 + hx;
-            // branch-free: one select between the pixel's address and the zero line
             const bool ok = (hp < NPIX) & ((unsigned)iy < (unsigned)p.Hi) & ((unsigned)ix < (unsigned)p.Wi);
-            const long off = ((long)iy * p.Wi + ix) * cs + coff + ((l_slot ^ (hx & 7)) << 3);
-            const f16 *g = ok ? src + off : p.zeros + (l_slot << 3);
-            glds16<0>(g, piece < A_PIECES ? sA + buf * A_BYTES + piece * 1024 : smem + TRASH_OFF);
+            const unsigned off = ((unsigned)(iy * p.Wi + ix) * (unsigned)cs + (unsigned)(coff + ((l_slot ^ (hx & 7)) << 3))) * 2u;
+            bdma16<0>(rs, piece < A_PIECES ? sA + buf * A_BYTES + piece * 1024 : smem + TRASH_OFF, ok ? off : OOB, 0);
         }
     };
-    // this wave's 32 weight rows of (chunk cc, tap): four 1-KiB pieces = one address + four immediates
-    const int w_lane = (lane >> 3) * CT + (((lane & 7) ^ (lane >> 3)) << 3);
+    // this wave's 32 weight rows of (chunk cc, tap): four 1-KiB pieces = one scalar offset + four immediates
+    const unsigned w_lane = (unsigned)((lane >> 3) * CT + (((lane & 7) ^ (lane >> 3)) << 3)) * 2u;
     auto issue_W = [&](int cc, int tap, int n0, int slot) {
-        const f16 *g = p.wpk + ((size_t)(tap * nchunk + cc) * p.CoutPad + n0 + wave * WCH) * CT + w_lane;
+        const rsrc_t rs = make_rsrc(p.wpk, 9u * (unsigned)nchunk * (unsigned)p.CoutPad * (unsigned)PIXB);
+        const unsigned so = (unsigned)((tap * nchunk + cc) * p.CoutPad + n0 + wave * WCH) * (unsigned)PIXB;
         char *d = sW + slot * W_SLOT;
-        glds16<0>(g, d); glds16<1024>(g, d); glds16<2048>(g, d); glds16<3072>(g, d);
+        bdma16<0>(rs, d, w_lane, so); bdma16<1024>(rs, d, w_lane, so); bdma16<2048>(rs, d, w_lane, so); bdma16<3072>(rs, d, w_lane, so);
     };
     auto issue_SS = [&](int n0, int slot) {      // wave 0: scale[256], wave 1: shift[256]; the others keep the piece count equal
-        const float *g = (wave == 1 ? p.shift : p.scale) + n0 + opaque_lane() * 4;
-        glds16<0>(g, wave < 2 ? smem + SS_OFF + slot * 2048 + wave * 1024 : smem + TRASH_OFF);
+        const rsrc_t rs = make_rsrc(wave == 1 ? p.shift : p.scale, (unsigned)p.CoutPad * 4u);
+        bdma16<0>(rs, wave < 2 ? smem + SS_OFF + slot * 2048 + wave * 1024 : smem + TRASH_OFF, (unsigned)opaque_lane() * 16u, (unsigned)n0 * 4u);
     };
 
-    f32x4 acc[2][16];
+    f32x4 acc[2][TH];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TH; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float act_lb = p.act == ACT_RELU ? 0.f : -__builtin_inff();
 
     // ---- the MFMA stream -------------------------------------------------------------------------
-    // A tap is eight groups of two pixel rows: group g's four fragment reads are issued in front of group g-1's eight MFMAs,
-    // so the compiler's wait for them (always lgkmcnt(0): with global_load_lds in the kernel its waitcnt pass never counts)
-    // finds nothing younger outstanding.  The pipeline runs across taps, chunks and tiles: group 7 of a tap reads the next
+    // A tap is TH/2 groups of two pixel rows: group g's four fragment reads are issued in front of group g-1's eight MFMAs
+    // (the compiler's counted lgkmcnt waits leave them in flight).  The pipeline runs across taps, chunks and tiles: group 7 of a tap reads the next
     // tap's weight fragments and its first group, behind the vmcnt wait for those weights (issued at the top of this tap)
     // and, in front of a new chunk, the barrier that says every wave's halo pieces have landed.
     f16x8 wf[2][2], xa[2][2], xb[2][2];
@@ -147,11 +162,6 @@ __global__ __launch_bounds__(512) void conv_prw_kernel(ConvParams p)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
                 x[r][ks] = *reinterpret_cast<const f16x8 *>(ax + q15 * PIXB + (row0 + r) * HW * PIXB + (((ks * 4 + qg) ^ kx) << 4));
-    };
-    // "these fragments are needed now": makes the compiler put its (uncounted) LDS wait HERE, in front of the next group's
-    // reads, instead of behind them in front of the first MFMA
-    auto touch = [&](const f16x8 (&x)[2][2]) {
-        asm volatile("" ::"v"(x[0][0]), "v"(x[0][1]), "v"(x[1][0]), "v"(x[1][1]));
     };
     auto mm = [&](const f16x8 (&x)[2][2], int row0) {
 #pragma unroll
@@ -198,9 +208,7 @@ __global__ __launch_bounds__(512) void conv_prw_kernel(ConvParams p)
                 const int tl = opaque_lane();
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int g = 0; g < 7; ++g) {
-                    if (g & 1) touch(xb); else touch(xa);
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int g = 0; g < NG - 1; ++g) {
                     if (g & 1) rd_x(xa, ax, tap % 3, 2 * g + 2, tl); else rd_x(xb, ax, tap % 3, 2 * g + 2, tl);
                     __builtin_amdgcn_sched_barrier(0);
                     if (g & 1) mm(xb, 2 * g); else mm(xa, 2 * g);
@@ -218,12 +226,10 @@ __global__ __launch_bounds__(512) void conv_prw_kernel(ConvParams p)
                     const int tnx = (tap + 1) % 9;
                     const char *axn = (tap == 8 ? a_nc : a) + ((tnx / 3) * HW + tnx % 3) * PIXB;
                     f16x8 wn[2][2];
-                    touch(xb);
-                    __builtin_amdgcn_sched_barrier(0);
                     rd_x(xa, axn, tnx % 3, 0, tl);
                     rd_w(wn, (ws + 1) & 1, tl);
                     __builtin_amdgcn_sched_barrier(0);
-                    mm(xb, 14);
+                    mm(xb, TH - 2);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks)
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(512) void conv_prw_kernel(ConvParams p)
             const int sub = MODE == ST_PS ? chw / cps : 0;
             const int cbase = (MODE == ST_PS ? chw - sub * cps : chw) + s_slot * 8;
 #pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {              // four pixel rows per pass = the 4 KiB strip
+            for (int pass = 0; pass < TH / 4; ++pass) {         // four pixel rows per pass = the 4 KiB strip
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(512) void conv_prw_kernel(ConvParams p)
             }
         } else {   // ST_POOL: 2x2 max; rows j, j+1 are in this lane, columns 2c, 2c+1 meet in the strip
 #pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {              // four pooled rows per pass
+            for (int pass = 0; pass < TH / 8; ++pass) {         // four pooled rows per pass
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
@@ -325,11 +331,11 @@ __global__ __launch_bounds__(512) void conv_prw_kernel(ConvParams p)
     }
 }
 
-template <int MODE>
+template <int MODE, int TH>
 hipError_t launch_mode(const ConvParams &p, int grid, hipStream_t stream)
 {
     static DevOnce attr_once;   // hipFuncSetAttribute is per (function, device)
-    auto kern = conv_prw_kernel<MODE>;
+    auto kern = conv_prw_kernel<MODE, TH>;
     if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return e;
@@ -342,20 +348,28 @@ hipError_t launch_mode(const ConvParams &p, int grid, hipStream_t stream)
 }  // namespace
 
 // 3x3, stride 1, pad 1, Cin (src0 [+ src1 concat]) multiple of 64, Cout == CoutPad multiple of 256, no residuals;
-// store modes NHWC / PS / POOL.  One block per CU (n_cu), each walking tiles.  hipErrorInvalidValue otherwise.
-hipError_t conv_prw_launch(ConvParams p, int n_cu, hipStream_t stream)
+// store modes NHWC / PS / POOL; th = pixel rows per tile (16 or 8).  One block per CU (n_cu), each walking tiles.
+// hipErrorInvalidValue otherwise.
+hipError_t conv_prw_launch(ConvParams p, int th, int n_cu, hipStream_t stream)
 {
     if ((p.c0 % CT) || (p.c1 % CT) || p.c0 + p.c1 < CT || (p.CoutPad % BN) || p.Cout != p.CoutPad || p.res1 || p.res2 ||
-        p.dst_full || !p.zeros || !p.trash || n_cu < 8 || (p.act != ACT_RELU && p.act != ACT_NONE) ||
+        p.dst_full || !p.zeros || !p.trash || n_cu < 8 || (p.act != ACT_RELU && p.act != ACT_NONE) || (th != 8 && th != 16) ||
         (p.mode != ST_NHWC && p.mode != ST_PS && p.mode != ST_POOL) || (p.mode == ST_PS && (p.dstC % 64)))
         return hipErrorInvalidValue;
     p.tiles_x = (p.Wo + TW - 1) / TW;
-    p.tiles_y = (p.Ho + TH - 1) / TH;
+    p.tiles_y = (p.Ho + th - 1) / th;
     const int total = p.tiles_x * p.tiles_y * (p.CoutPad / BN);
     const int grid = total < n_cu ? total : n_cu;
+    if (th == 16) {
+        switch (p.mode) {
+        case ST_NHWC: return launch_mode<ST_NHWC, 16>(p, grid, stream);
+        case ST_PS: return launch_mode<ST_PS, 16>(p, grid, stream);
+        default: return launch_mode<ST_POOL, 16>(p, grid, stream);
+        }
+    }
     switch (p.mode) {
-    case ST_NHWC: return launch_mode<ST_NHWC>(p, grid, stream);
-    case ST_PS: return launch_mode<ST_PS>(p, grid, stream);
-    default: return launch_mode<ST_POOL>(p, grid, stream);
+    case ST_NHWC: return launch_mode<ST_NHWC, 8>(p, grid, stream);
+    case ST_PS: return launch_mode<ST_PS, 8>(p, grid, stream);
+    default: return launch_mode<ST_POOL, 8>(p, grid, stream);
     }
 }

@@ -28,11 +28,6 @@ constexpr int A_PIECES = (NPIX + 7) / 8;                            // 71 one-Ki
 constexpr int A_BYTES = 72 * 1024;
 constexpr int SMEM = 2 * A_BYTES;
 
-__device__ __forceinline__ void glds16(const void *g, void *lds)
-{
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                     (__attribute__((address_space(3))) void *)lds, 16, 0, 0);
-}
 
 template <int NW>   // waves = 16-channel tiles: Cout = 16 * NW
 __global__ __launch_bounds__(64 * NW, 1) void conv3x3s2_preg_kernel(ConvParams p)   // 1 block per CU: LDS-limited anyway
@@ -61,14 +56,15 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3s2_preg_kernel(ConvParams p
     auto issue_tile = [&](int t, int buf) {
         const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
         const int iy0 = 2 * ty * TH - 1, ix0 = 2 * tx * TW - 1;
+        const dma_rsrc_t ra = dma_rsrc(p.src0, (unsigned)p.Hi * (unsigned)p.Wi * (unsigned)p.s0_stride * 2u);
         for (int piece = wave; piece < A_PIECES; piece += NW) {
             const int q = piece * 8 + l_row;
             const int hy = q / HWD, col = q - hy * HWD;
             const int hx = col < NEVEN ? 2 * col : 2 * (col - NEVEN) + 1;
             const int iy = iy0 + hy, ix = ix0 + hx;
-            const bool ok = q < NPIX && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
-            const f16 *g = ok ? p.src0 + ((size_t)iy * p.Wi + ix) * p.s0_stride + ((l_slot ^ l_row) << 3) : p.zeros + (l_slot << 3);
-            glds16(g, smem + buf * A_BYTES + piece * 1024);
+            const bool ok = (q < NPIX) & ((unsigned)iy < (unsigned)p.Hi) & ((unsigned)ix < (unsigned)p.Wi);
+            const unsigned off = ((unsigned)(iy * p.Wi + ix) * (unsigned)p.s0_stride + (unsigned)((l_slot ^ l_row) << 3)) * 2u;
+            dma16(ra, smem + buf * A_BYTES + piece * 1024, ok ? off : DMA_OOB);       // out of the image: zeros
         }
     };
 

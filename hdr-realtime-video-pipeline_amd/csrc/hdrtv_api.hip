@@ -1394,24 +1394,31 @@ struct Seq {
         static const bool no_t16 = getenv("HDRTV_NO_T16") != nullptr;       // developer A/B: the generic implicit-GEMM kernel
         const bool t16 = !no_t16 && L.ks == 3 && L.stride == 2 && L.cin == 32 && L.coutPad == 32 && !src1 && mode == ST_NHWC && !res1 && !res2;
         // HG 3x3 convs with Cout a multiple of 256: the private-weight schedule (conv3x3_prw.hip); HDRTV_PRW=0: conv_pglds
-        // HDRTV_PRW: 0 = never, 1 (default) = where its coarser tiles fill the chip, 2 = wherever it applies
+        // HDRTV_PRW: 0 = never, 1 (default) = the cheapest shape per layer, 2 / 3 = 16-row / 8-row tiles wherever it applies
         // (read per launch: the A/B test flips it inside one process)
         const char *prw_env = getenv("HDRTV_PRW");
         const int use_prw_mode = prw_env ? atoi(prw_env) : 1;
         const bool use_prw = use_prw_mode != 0;
         bool prw = pglds && use_prw && (L.coutPad % 256) == 0 && mode != ST_PS_DOT3;
+        int prw_th = 16;
         if (prw && use_prw_mode == 1) {
-            // its tiles are twice as large (256 output channels): keep conv_pglds where the coarser grain costs more of the
-            // last round on n_cu workgroups than the schedule gains (~1.1x measured on full rounds)
-            const long tsp = (long)((p.Wo + 15) / 16) * ((p.Ho + 15) / 16);
-            const long t2 = tsp * (L.coutPad / 256), t1 = tsp * (L.coutPad / 128), n = c->n_cu;
-            const double e2 = (double)t2 / (double)(((t2 + n - 1) / n) * n), e1 = (double)t1 / (double)(((t1 + n - 1) / n) * n);
-            prw = e2 * 1.10 >= e1;
+            // Its tiles cover 256 output channels (conv_pglds: 128).  Pick the shape whose tile count wastes least of the last
+            // round on n_cu workgroups: relative cost per unit of work 1.0 (16-row tiles), 1.09 (8-row tiles: twice the weight
+            // bytes per MAC, 1.11x the halo), 1.15 - 1.22 (conv_pglds) -- measured on full rounds, profiles/r03_prw_ab.txt
+            const long tx = (p.Wo + 15) / 16, n = c->n_cu;
+            auto cost = [&](long tiles, double rel) { return (double)(((tiles + n - 1) / n) * n) / (double)tiles * rel; };
+            const double c16 = cost(tx * ((p.Ho + 15) / 16) * (L.coutPad / 256), 1.0);
+            const double c8 = cost(tx * ((p.Ho + 7) / 8) * (L.coutPad / 256), 1.09);
+            const double c0 = cost(tx * ((p.Ho + 15) / 16) * (L.coutPad / 128), 1.22);
+            if (c0 <= c16 && c0 <= c8) prw = false;
+            else prw_th = c8 < c16 ? 8 : 16;
+        } else if (prw && use_prw_mode == 3) {
+            prw_th = 8;
         }
         char tag[64];
         if (t16) snprintf(tag, sizeof tag, "conv_t16<32,3,2>");
         else if (s2g) snprintf(tag, sizeof tag, "conv3x3s2_preg<%d>", L.coutPad);
-        else if (pglds) snprintf(tag, sizeof tag, "%s<%s>", prw ? "conv_prw" : "conv_pglds", mode == ST_POOL ? "pool" : (mode == ST_PS ? "ps" : (mode == ST_PS_DOT3 ? "ps_dot3" : "nhwc")));
+        else if (pglds) snprintf(tag, sizeof tag, "%s<%s>", prw ? (prw_th == 8 ? "conv_prw8" : "conv_prw") : "conv_pglds", mode == ST_POOL ? "pool" : (mode == ST_PS ? "ps" : (mode == ST_PS_DOT3 ? "ps_dot3" : "nhwc")));
         else if (glds1) snprintf(tag, sizeof tag, "conv_glds1");
         else snprintf(tag, sizeof tag, "conv_igemm<%d,%d,%d,%d>", L.cin_t, L.bn, L.ks, L.stride);
         const double macs = (double)p.Ho * p.Wo * L.cin * L.ks * L.ks * L.cout;
@@ -1421,7 +1428,7 @@ struct Seq {
                                                                     : (mode == ST_PS_DOT3 ? 8.0 * Hd * Wd : (double)p.Ho * p.Wo * L.cout));
         bytes += 2.0 * outel * (1 + (res1 ? 1 : 0) + (res2 ? 1 : 0) + (res_planar ? 1 : 0));
         chk(t16 ? conv_t16_launch(p, s) : s2g ? conv3x3s2_preg_launch(p, c->n_cu, s)
-                : (pglds ? (prw ? conv_prw_launch(p, c->n_cu, s) : conv_pglds_launch(p, c->n_cu, s))
+                : (pglds ? (prw ? conv_prw_launch(p, prw_th, c->n_cu, s) : conv_pglds_launch(p, c->n_cu, s))
                          : (glds1 ? conv_glds1_launch(p, s, c->n_cu) : conv_igemm_launch(p, L.cin_t, L.bn, L.ks, L.stride, s))),
             key.c_str(), tag, macs, bytes);
     }

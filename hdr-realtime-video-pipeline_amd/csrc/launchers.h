@@ -14,7 +14,7 @@ struct DevOnce {
 hipError_t conv_igemm_launch(ConvParams p, int cin_t, int bn, int ks, int stride, hipStream_t stream);
 hipError_t conv_glds1_launch(ConvParams p, hipStream_t stream, int n_cu = 0);   // n_cu >= 8: the persistent form
 hipError_t conv_pglds_launch(ConvParams p, int n_cu, hipStream_t stream);
-hipError_t conv_prw_launch(ConvParams p, int n_cu, hipStream_t stream);      // Cout % 256 == 0, modes NHWC / PS / POOL
+hipError_t conv_prw_launch(ConvParams p, int th, int n_cu, hipStream_t stream);   // Cout % 256 == 0, modes NHWC / PS / POOL; th = 16 | 8
 hipError_t conv_pglds_i8_launch(ConvI8Params p, int n_cu, hipStream_t stream);
 hipError_t conv1x1_i8_launch(ConvI8Params p, hipStream_t stream);
 hipError_t conv32p_launch(Conv32Params p, int n_cu, hipStream_t stream);

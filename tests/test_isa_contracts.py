@@ -168,15 +168,23 @@ def test_prw_has_no_scratch_and_the_waits_it_counts_on(tmp_path):
     (A_PIECES_PER_WAVE, + 1 with the scale/shift piece): pin them, the DMA piece counts and the MFMA count per kernel."""
     kernels = _asm("conv3x3_prw.hip", tmp_path)
     src = open(os.path.join(CSRC, "conv3x3_prw.hip")).read()
-    per_wave = int(re.search(r"A_PIECES_PER_WAVE = (\d+)", src).group(1))
+    assert "A_PIECES_PER_WAVE = (A_PIECES + 7) / 8" in src and "(TH + 2) * HW" in src
     seen = 0
     for name, body in kernels.items():
-        if "conv_prw_kernel" not in name:
+        km = re.search(r"conv_prw_kernelILi(\d+)ELi(\d+)E", name)
+        if not km:
             continue
+        th = int(km.group(2))
+        per_wave = (((th + 2) * 18 * 128 + 1023) // 1024 + 7) // 8        # halo pieces per wave: 6 (16-row tiles) or 3
         assert "scratch_" not in body, name
-        assert len(re.findall(r"v_mfma_f32_16x16x32_f16", body)) == 9 * 64, name                              # nine unrolled taps x 64 MFMAs
+        assert len(re.findall(r"v_mfma_f32_16x16x32_f16", body)) == 9 * 4 * th, name      # nine unrolled taps x (2 x TH x 2 k-steps)
         waits = set(int(v) for v in re.findall(r"s_waitcnt vmcnt\((\d+)\)", body))
         assert waits == {0, per_wave, per_wave + 1}, (name, sorted(waits))
         assert len(re.findall(r"s_barrier", body)) == 2, name                               # prologue + one per chunk (tap 8)
+        # LDS-DMA must be the BUFFER form: with the FLAT-encoded global_load_lds in a kernel hipcc stops counting and every
+        # wait becomes lgkmcnt(0) / vmcnt(0)
+        assert "global_load_lds" not in body and len(re.findall(r"buffer_load_dwordx4 .* lds", body)) >= 36 + per_wave, name
+        counted = [int(v) for v in re.findall(r"lgkmcnt\((\d+)\)", body)]
+        assert sum(v > 0 for v in counted) > sum(v == 0 for v in counted), name
         seen += 1
-    assert seen == 3
+    assert seen == 6

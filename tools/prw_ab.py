@@ -40,22 +40,27 @@ if __name__ == "__main__":
         child(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
         sys.exit(0)
     h, w = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (2160, 3840)
+    modes = sys.argv[3].split(",") if len(sys.argv) > 3 else ["0", "2", "3", "1"]
     import torch
     outs = []
-    for v in ("0", "1"):
+    for v in modes:
         path = f"/tmp/prw_ab_{v}.pt"
         env = dict(os.environ, HDRTV_PRW=v)
         subprocess.run([sys.executable, __file__, "--child", str(h), str(w), path], env=env, check=True, stdout=subprocess.DEVNULL)
         outs.append(torch.load(path, weights_only=False))
-    a, b = outs
-    for n in ("out",) + TAPS:
-        same = torch.equal(a[n], b[n])
-        extra = "" if same else f"  max|d|={float((a[n].float() - b[n].float()).abs().max()):.3e} n_diff={int((a[n] != b[n]).sum())}"
-        print(f"{n:16s} {'bit-identical' if same else 'DIFFERENT'}{extra}")
-    tot = [0.0, 0.0]
+    a = outs[0]
+    for v, b in zip(modes[1:], outs[1:]):
+        bad = [n for n in ("out",) + TAPS if not torch.equal(a[n], b[n])]
+        print(f"HDRTV_PRW={v} vs {modes[0]}: {'all taps bit-identical' if not bad else 'DIFFERENT: ' + ' '.join(bad)}")
+    tot = [0.0] * len(modes)
+    print(f"{'layer':14s} " + " | ".join(f"PRW={v:1s} kernel              ms     TF" for v in modes))
     for layer, (kern, ms, macs) in a["prof"].items():
-        kb, msb, _ = b["prof"][layer]
         if "hg." in layer and ("pglds" in kern or "prw" in kern):
-            tot[0] += ms; tot[1] += msb
-            print(f"{layer:14s} {kern:22s} {ms:7.3f} ms {2 * macs / ms / 1e9:7.1f} TF | {kb:22s} {msb:7.3f} ms {2 * macs / msb / 1e9:7.1f} TF  x{ms / msb:.3f}")
-    print(f"HG 3x3 total: {tot[0]:.3f} -> {tot[1]:.3f} ms;  frame: {sum(v[1] for v in a['prof'].values()):.3f} -> {sum(v[1] for v in b['prof'].values()):.3f} ms")
+            cells = []
+            for i, o in enumerate(outs):
+                kb, msb, _ = o["prof"][layer]
+                tot[i] += msb
+                cells.append(f"{kb:20s} {msb:6.3f} {2 * macs / msb / 1e9:6.0f}")
+            print(f"{layer:14s} " + " | ".join(cells))
+    print("HG 3x3 total ms: " + "  ".join(f"PRW={v}: {t:.3f}" for v, t in zip(modes, tot)))
+    print("frame ms:        " + "  ".join(f"PRW={v}: {sum(x[1] for x in o['prof'].values()):.3f}" for v, o in zip(modes, outs)))
