@@ -73,11 +73,6 @@ template <int NW> struct Til {
 
 __device__ __forceinline__ int swz32(int v) { return (v >> 2) & 3; }   // weight rows: by row; halo: by column
 
-__device__ __forceinline__ void glds16(const void *g, void *lds)
-{
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                     (__attribute__((address_space(3))) void *)lds, 16, 0, 0);
-}
 
 __device__ __forceinline__ f32x16 tile16(const float *b, int lh)
 {
@@ -167,14 +162,14 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
         for (int it = 0; it < T::A_PW; ++it) {
             const bool ok = a_pos[it] >= 0 && (unsigned)(iy0 + (a_pos[it] & 255)) < uH && (unsigned)(ix0 + (a_pos[it] >> 8)) < uW;
             const unsigned off = ok ? (unsigned)(pix0 * 64 + a_off[it]) : src_guard + ((lane & 3) << 4);
-            glds16(reinterpret_cast<const char *>(p.src) + off, sA + buf * A_BYTES + (wave + it * NW) * 1024);
+            dma16(dma_rsrc(p.src), sA + buf * A_BYTES + (wave + it * NW) * 1024, off);
         }
         if (SFT) {
 #pragma unroll
             for (int it = 0; it < T::C_PW; ++it) {
                 const bool ok = c_pos[it] >= 0 && (unsigned)(iy0 + (c_pos[it] & 255)) < uH && (unsigned)(ix0 + (c_pos[it] >> 8)) < uW;
                 const unsigned off = ok ? (unsigned)(pix0 * 32 + c_off[it]) : cond_guard + ((lane & 1) << 4);
-                glds16(reinterpret_cast<const char *>(p.cond) + off, sC + buf * C_BYTES + (wave + it * NW) * 1024);
+                dma16(dma_rsrc(p.cond), sC + buf * C_BYTES + (wave + it * NW) * 1024, off);
             }
         }
     };
@@ -186,14 +181,14 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
         for (int piece = wave; piece < 9 * L::COUTP / 32; piece += NW) {
             const int r = piece * 32 + (lane >> 1), half = lane & 1;
             const int n = r % L::COUTP;
-            glds16(p.wpk8 + (size_t)r * 32 + ((half ^ ((n >> 3) & 1)) << 4), sW + piece * 1024);
+            dma16(dma_rsrc(p.wpk8), sW + piece * 1024, (unsigned)(r * 32 + ((half ^ ((n >> 3) & 1)) << 4)));
         }
         for (int e = tid; e < 17 * L::COUTP; e += NT) sSS[e] = e < L::COUTP ? p.scale[e] : p.shift[e - L::COUTP];
     } else {
         for (int piece = wave; piece < 9 * L::COUTP / 16; piece += NW) {
             const int r = piece * 16 + (lane >> 2), slot = lane & 3;     // r = tap*COUTP + n
             const int n = r % L::COUTP;
-            glds16(p.wpk + (size_t)r * 32 + ((slot ^ swz32(n)) << 3), sW + piece * 1024);
+            dma16(dma_rsrc(p.wpk), sW + piece * 1024, (unsigned)(r * 32 + ((slot ^ swz32(n)) << 3)) * 2u);
         }
         for (int e = tid; e < L::COUTP; e += NT) {
             sSS[e] = p.scale[e];

@@ -65,11 +65,6 @@ static_assert(NWI * A_PW * 16 >= NPIX && NWI * C_PW * 32 >= NPIX && NG * 32 * 64
 
 __device__ __forceinline__ int swz32(int v) { return (v >> 2) & 3; }
 
-__device__ __forceinline__ void glds16(const void *g, void *lds)
-{
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                     (__attribute__((address_space(3))) void *)lds, 16, 0, 0);
-}
 
 __device__ __forceinline__ f32x16 tile16(const float *b, int lh)
 {
@@ -185,14 +180,14 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
 #pragma unroll
                 for (int it = 0; it < A_PW; ++it) {
                     const unsigned off = a_pos[it] >= 0 ? (unsigned)(pix0 * 64 + a_off[it]) : src_guard + ((lane & 3) << 4);
-                    glds16(reinterpret_cast<const char *>(p.src) + off, abuf + (iw + it * NWI) * 1024);
+                    dma16(dma_rsrc(p.src), abuf + (iw + it * NWI) * 1024, off);
                 }
             } else {
 #pragma unroll
                 for (int it = 0; it < A_PW; ++it) {
                     const bool ok = a_pos[it] >= 0 && (unsigned)(iy0 + (a_pos[it] & 255)) < uH && (unsigned)(ix0 + (a_pos[it] >> 8)) < uW;
                     const unsigned off = ok ? (unsigned)(pix0 * 64 + a_off[it]) : src_guard + ((lane & 3) << 4);
-                    glds16(reinterpret_cast<const char *>(p.src) + off, abuf + (iw + it * NWI) * 1024);
+                    dma16(dma_rsrc(p.src), abuf + (iw + it * NWI) * 1024, off);
                 }
             }
         }
@@ -201,14 +196,14 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
 #pragma unroll
                 for (int it = 0; it < C_PW; ++it) {
                     const unsigned off = c_pos[it] >= 0 ? (unsigned)(pix0 * 32 + c_off[it]) : cond_guard + ((lane & 1) << 4);
-                    glds16(reinterpret_cast<const char *>(p.cond) + off, cbuf + (iw + it * NWI) * 1024);
+                    dma16(dma_rsrc(p.cond), cbuf + (iw + it * NWI) * 1024, off);
                 }
             } else {
 #pragma unroll
                 for (int it = 0; it < C_PW; ++it) {
                     const bool ok = c_pos[it] >= 0 && (unsigned)(iy0 + (c_pos[it] & 255)) < uH && (unsigned)(ix0 + (c_pos[it] >> 8)) < uW;
                     const unsigned off = ok ? (unsigned)(pix0 * 32 + c_off[it]) : cond_guard + ((lane & 1) << 4);
-                    glds16(reinterpret_cast<const char *>(p.cond) + off, cbuf + (iw + it * NWI) * 1024);
+                    dma16(dma_rsrc(p.cond), cbuf + (iw + it * NWI) * 1024, off);
                 }
             }
         }
@@ -221,14 +216,14 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
         for (int piece = wave; piece < 9; piece += NW) {
             const int r = piece * 32 + (lane >> 1), half = lane & 1;
             const int n = r % 32;
-            glds16(p.wpk8 + (size_t)r * 32 + ((half ^ ((n >> 3) & 1)) << 4), sW + piece * 1024);
+            dma16(dma_rsrc(p.wpk8), sW + piece * 1024, (unsigned)(r * 32 + ((half ^ ((n >> 3) & 1)) << 4)));
         }
         for (int e = tid; e < 17 * 32; e += NT) sSS[e] = e < 32 ? p.scale[e] : p.shift[e - 32];
     } else {
         for (int piece = wave; piece < 18; piece += NW) {
             const int r = piece * 16 + (lane >> 2), slot = lane & 3;     // r = tap*32 + n
             const int n = r % 32;
-            glds16(p.wpk + (size_t)r * 32 + ((slot ^ swz32(n)) << 3), sW + piece * 1024);
+            dma16(dma_rsrc(p.wpk), sW + piece * 1024, (unsigned)(r * 32 + ((slot ^ swz32(n)) << 3)) * 2u);
         }
         for (int e = tid; e < 32; e += NT) {
             sSS[e] = p.scale[e];

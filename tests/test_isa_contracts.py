@@ -96,7 +96,7 @@ def test_conv32p_asm_loads_are_read_only_after_the_wait(tmp_path):
 
 def test_conv32s_counted_waits(tmp_path):
     """conv32s.hip (one barrier per tile) waits for the next tile's LDS-DMA by COUNT: per tile and wave it issues exactly
-    NPIECES global_load_lds and then, on each of the two phase orders, NSTORE global stores, and the loop's closing wait is
+    NPIECES LDS-DMA pieces (buffer_load_dwordx4 ... lds) and then, on each of the two phase orders, NSTORE global stores, and the loop's closing wait is
     vmcnt(NSTORE).  hipcc's own vmcnt(0) (residuals, first nameable LDS read with a DMA in flight) must sit in the epilogue,
     behind every MFMA of the tile -- in the MFMA or SFT phase it would stall the wave on the DMA it has just issued."""
     kernels = _asm("conv32s.hip", tmp_path)
@@ -124,7 +124,7 @@ def test_conv32s_counted_waits(tmp_path):
         loop = main[0]
         # the issue exists twice in the code, for interior tiles (no per-lane image test) and for border tiles; a wave runs one
         # (hipcc may merge the tails of the two paths: between one and two copies of every piece in the text)
-        assert npieces <= len([ln for ln in loop if "global_load_lds_dwordx4" in ln]) <= 2 * npieces, name
+        assert npieces <= len([ln for ln in loop if re.search(r"buffer_load_dwordx4 .* lds", ln)]) <= 2 * npieces, name
         # NSTORE per phase order; the epilogue is shared by both orders
         nst = len([ln for ln in loop if re.match(r"\s*global_store", ln)])
         if split:
