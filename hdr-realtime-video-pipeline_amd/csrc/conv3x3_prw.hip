@@ -131,6 +131,17 @@ __global__ __launch_bounds__(512) void conv_prw_kernel(ConvParams p)
         bdma16<0>(rs, wave < 2 ? smem + SS_OFF + slot * 2048 + wave * 1024 : smem + TRASH_OFF, (unsigned)opaque_lane() * 16u, (unsigned)n0 * 4u);
     };
 
+    // ST_PS_DOT3 (Up_conv5: Cout = 256 = four pixel-shuffle positions x 64 channels): the 64 -> 3 dot products behind the
+    // shuffle run over TWO waves' channels (wave 2s: channels 0-31 of position s, wave 2s+1: 32-63).  The odd wave leaves its
+    // partial sums in its strip and raises flag[s] = tile count; the even wave adds them to its own and stores; ack[s] tells
+    // the odd wave that the strip may be overwritten (by its weight DMA at tap 1 of the next tile).  Both counters live in LDS.
+    volatile int *s_flag = reinterpret_cast<volatile int *>(smem + DOTW_OFF + 768);     // [4] flag, [4] ack
+    if constexpr (MODE == ST_PS_DOT3) {
+        float *s_w = reinterpret_cast<float *>(smem + DOTW_OFF);
+        for (int e = tid; e < 3 * 64; e += 512) s_w[e] = p.dotw[e];
+        if (tid < 8) s_flag[tid] = 0;
+    }
+
     f32x4 acc[2][TH];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -196,6 +207,11 @@ __global__ __launch_bounds__(512) void conv_prw_kernel(ConvParams p)
             const bool pfA = !last_chunk || has_next;    // a halo tile is staged during this chunk's tap 1
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap, ++ws) {
+                if constexpr (MODE == ST_PS_DOT3) {
+                    // this tap's DMA goes into the slot that was the last tile's strip: the partner must have read it
+                    if (tap == 1 && cc == 0 && k > 0 && (wave & 1))
+                        while (s_flag[4 + (wave >> 1)] < k) __builtin_amdgcn_s_sleep(2);
+                }
                 // weights of the next tap into the slot whose fragments have been in registers since the end of the last tap
                 if (tap < 8) issue_W(cc, tap + 1, cur.n0, (ws + 1) & 1);
                 else if (!last_chunk) issue_W(cc + 1, 0, cur.n0, (ws + 1) & 1);
@@ -299,6 +315,67 @@ __global__ __launch_bounds__(512) void conv_prw_kernel(ConvParams p)
                     *reinterpret_cast<f16x8 *>(d) = v;
                 }
             }
+        } else if constexpr (MODE == ST_PS_DOT3) {
+            // pixel shuffle, ReLU, then this wave's half of the 64 -> 3 dot products: only 3 partial sums per pixel leave the CU.
+            // fp32 arithmetic as conv_pglds's; the sum over a pixel's channels is associated differently (per wave, then the
+            // pair), so the results agree with it to rounding, not bit for bit.
+            const float *s_w = reinterpret_cast<const float *>(smem + DOTW_OFF) + (wave & 1) * 32 + 4 * kg;
+            float4 w0[2], w1[2], w2[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                w0[i] = *reinterpret_cast<const float4 *>(s_w + i * 16);
+                w1[i] = *reinterpret_cast<const float4 *>(s_w + 64 + i * 16);
+                w2[i] = *reinterpret_cast<const float4 *>(s_w + 128 + i * 16);
+            }
+            float4 R[TH / 4];                                    // this lane's pixels: (row 4 * pass + kg, column l15)
+#pragma unroll
+            for (int pass = 0; pass < TH / 4; ++pass) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const f16x4 o = outv(i, pass * 4 + jj);
+                        const float x0 = (float)o[0], x1 = (float)o[1], x2 = (float)o[2], x3 = (float)o[3];
+                        a0 += w0[i].x * x0 + w0[i].y * x1 + w0[i].z * x2 + w0[i].w * x3;
+                        a1 += w1[i].x * x0 + w1[i].y * x1 + w1[i].z * x2 + w1[i].w * x3;
+                        a2 += w2[i].x * x0 + w2[i].y * x1 + w2[i].z * x2 + w2[i].w * x3;
+                    }
+                    // the four k-groups of a pixel meet in the strip (ordinary LDS writes and reads: wave-private, in order)
+                    *reinterpret_cast<float4 *>(stg + jj * 1024 + kg * 256 + l15 * 16) = make_float4(a0, a1, a2, 0.f);
+                }
+                float4 r = *reinterpret_cast<const float4 *>(stg + kg * 1024 + l15 * 16);
+#pragma unroll
+                for (int q = 1; q < 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4 *>(stg + kg * 1024 + q * 256 + l15 * 16);
+                    r.x += v.x; r.y += v.y; r.z += v.z;
+                }
+                R[pass] = r;
+            }
+            const int pair = wave >> 1;
+            if (wave & 1) {
+#pragma unroll
+                for (int pass = 0; pass < TH / 4; ++pass) *reinterpret_cast<float4 *>(stg + pass * 1024 + eln * 16) = R[pass];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // the partial sums are in LDS before the flag is
+                s_flag[pair] = k + 1;
+            } else {
+                const char *pst = stg + 2 * W_SLOT;                          // the partner's strip: same slot parity, next wave's ring
+                while (s_flag[pair] < k + 1) __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+                for (int pass = 0; pass < TH / 4; ++pass) {
+                    const float4 v = *reinterpret_cast<const float4 *>(pst + pass * 1024 + eln * 16);
+                    R[pass].x += v.x; R[pass].y += v.y; R[pass].z += v.z;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // (the reads have returned)
+                s_flag[4 + pair] = k + 1;
+#pragma unroll
+                for (int pass = 0; pass < TH / 4; ++pass) {
+                    const int oy = cur.oy0 + pass * 4 + kg, ox = cur.ox0 + l15;
+                    const int Y = 2 * oy + (pair >> 1), X = 2 * ox + (pair & 1);
+                    if (oy < p.Ho && ox < p.Wo && Y < p.Hd && X < p.Wd)
+                        *reinterpret_cast<float4 *>(p.dst_dot + ((size_t)Y * p.Wd + X) * 4) = make_float4(R[pass].x, R[pass].y, R[pass].z, 0.f);
+                }
+            }
         } else {   // ST_POOL: 2x2 max; rows j, j+1 are in this lane, columns 2c, 2c+1 meet in the strip
 #pragma unroll
             for (int pass = 0; pass < TH / 8; ++pass) {         // four pooled rows per pass
@@ -348,13 +425,14 @@ hipError_t launch_mode(const ConvParams &p, int grid, hipStream_t stream)
 }  // namespace
 
 // 3x3, stride 1, pad 1, Cin (src0 [+ src1 concat]) multiple of 64, Cout == CoutPad multiple of 256, no residuals;
-// store modes NHWC / PS / POOL; th = pixel rows per tile (16 or 8).  One block per CU (n_cu), each walking tiles.
+// store modes NHWC / PS / POOL (th = pixel rows per tile: 16 or 8) and PS_DOT3 (Cout = 256, th = 16).  One block per CU (n_cu), each walking tiles.
 // hipErrorInvalidValue otherwise.
 hipError_t conv_prw_launch(ConvParams p, int th, int n_cu, hipStream_t stream)
 {
     if ((p.c0 % CT) || (p.c1 % CT) || p.c0 + p.c1 < CT || (p.CoutPad % BN) || p.Cout != p.CoutPad || p.res1 || p.res2 ||
         p.dst_full || !p.zeros || !p.trash || n_cu < 8 || (p.act != ACT_RELU && p.act != ACT_NONE) || (th != 8 && th != 16) ||
-        (p.mode != ST_NHWC && p.mode != ST_PS && p.mode != ST_POOL) || (p.mode == ST_PS && (p.dstC % 64)))
+        (p.mode != ST_NHWC && p.mode != ST_PS && p.mode != ST_POOL && p.mode != ST_PS_DOT3) || (p.mode == ST_PS && (p.dstC % 64)) ||
+        (p.mode == ST_PS_DOT3 && (p.CoutPad != 256 || p.dstC != 64 || !p.dotw || !p.dst_dot || th != 16)))
         return hipErrorInvalidValue;
     p.tiles_x = (p.Wo + TW - 1) / TW;
     p.tiles_y = (p.Ho + th - 1) / th;
@@ -364,6 +442,7 @@ hipError_t conv_prw_launch(ConvParams p, int th, int n_cu, hipStream_t stream)
         switch (p.mode) {
         case ST_NHWC: return launch_mode<ST_NHWC, 16>(p, grid, stream);
         case ST_PS: return launch_mode<ST_PS, 16>(p, grid, stream);
+        case ST_PS_DOT3: return launch_mode<ST_PS_DOT3, 16>(p, grid, stream);
         default: return launch_mode<ST_POOL, 16>(p, grid, stream);
         }
     }

@@ -1399,9 +1399,11 @@ struct Seq {
         const char *prw_env = getenv("HDRTV_PRW");
         const int use_prw_mode = prw_env ? atoi(prw_env) : 1;
         const bool use_prw = use_prw_mode != 0;
-        bool prw = pglds && use_prw && (L.coutPad % 256) == 0 && mode != ST_PS_DOT3;
+        const bool prw_dot3 = mode == ST_PS_DOT3 && L.coutPad == 256;                // Up_conv5: always the 16-row shape
+        bool prw = pglds && use_prw && (L.coutPad % 256) == 0 && (mode != ST_PS_DOT3 || prw_dot3);
         int prw_th = 16;
-        if (prw && use_prw_mode == 1) {
+        if (prw && prw_dot3) {
+        } else if (prw && use_prw_mode == 1) {
             // Its tiles cover 256 output channels (conv_pglds: 128).  Pick the shape whose tile count wastes least of the last
             // round on n_cu workgroups: relative cost per unit of work 1.0 (16-row tiles), 1.09 (8-row tiles: twice the weight
             // bytes per MAC, 1.11x the halo), 1.15 - 1.22 (conv_pglds) -- measured on full rounds, profiles/r03_prw_ab.txt

@@ -187,4 +187,4 @@ def test_prw_has_no_scratch_and_the_waits_it_counts_on(tmp_path):
         counted = [int(v) for v in re.findall(r"lgkmcnt\((\d+)\)", body)]
         assert sum(v > 0 for v in counted) > sum(v == 0 for v in counted), name
         seen += 1
-    assert seen == 6
+    assert seen == 7          # NHWC / PS / POOL x {16, 8}-row tiles + PS_DOT3

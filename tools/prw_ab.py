@@ -51,6 +51,8 @@ if __name__ == "__main__":
     a = outs[0]
     for v, b in zip(modes[1:], outs[1:]):
         bad = [n for n in ("out",) + TAPS if not torch.equal(a[n], b[n])]
+        for n in bad:
+            print(f"   {n}: max|d| = {float((a[n].float() - b[n].float()).abs().max()):.3e}")
         print(f"HDRTV_PRW={v} vs {modes[0]}: {'all taps bit-identical' if not bad else 'DIFFERENT: ' + ' '.join(bad)}")
     tot = [0.0] * len(modes)
     print(f"{'layer':14s} " + " | ".join(f"PRW={v:1s} kernel              ms     TF" for v in modes))
