@@ -29,11 +29,6 @@ constexpr int SMEM = DOTW_OFF + 1024;                    // 147 KiB
 // stores per wave and tile, by store mode (see the epilogues)
 template <int MODE> struct NStores { static constexpr int N = (MODE == ST_POOL || MODE == ST_PS_DOT3) ? 1 : 4; };
 
-__device__ __forceinline__ void glds16(const void *g, void *lds)
-{
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                     (__attribute__((address_space(3))) void *)lds, 16, 0, 0);
-}
 
 template <int N> __device__ __forceinline__ void wait_vm()
 {
@@ -93,38 +88,45 @@ __global__ __launch_bounds__(512) void conv_pglds_i8_kernel(ConvI8Params p)
         int cs, coff;
         if (cc < nchunk0) { src = p.src0; cs = p.c0; coff = cc * CT; }
         else { src = p.src1; cs = p.c1; coff = (cc - nchunk0) * CT; }
+        // LDS-DMA as a buffer load (common.h): lanes outside the image write zeros = code 0, whose share of the sum the
+        // epilogue's border-class constants take back out
+        const dma_rsrc_t ra = dma_rsrc(src, (unsigned)p.Hi * (unsigned)p.Wi * (unsigned)(C64 ? 64 : cs));
 #pragma unroll
         for (int it = 0; it < A_PIECES_PER_WAVE; ++it) {
             const int piece = wave + it * 8;
             const int hp = piece * 8 + l_row;
             const int hy = hp / HW, hx = hp - hy * HW;
             const int iy = T.oy0 - 1 + hy, ix = T.ox0 - 1 + hx;
-            const bool ok = hp < NPIX && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
-            const int8_t *g;
+            unsigned off;
+            bool ok;
             if constexpr (C64) {
                 const int sc = l_slot ^ (hx & 7);            // source chunk 0..3: this pixel, 4..7: its right neighbour
                 const int ixx = ix + (sc >> 2);
-                const bool ok2 = hp < NPIX && iy >= 0 && iy < p.Hi && ixx >= 0 && ixx < p.Wi;
-                g = ok2 ? src + ((size_t)iy * p.Wi + ixx) * 64 + ((sc & 3) << 4) : p.padline + (l_slot << 4);
+                ok = (hp < NPIX) & ((unsigned)iy < (unsigned)p.Hi) & ((unsigned)ixx < (unsigned)p.Wi);
+                off = (unsigned)(iy * p.Wi + ixx) * 64u + (unsigned)((sc & 3) << 4);
             } else {
-                g = ok ? src + ((size_t)iy * p.Wi + ix) * cs + coff + ((l_slot ^ (hx & 7)) << 4) : p.padline + (l_slot << 4);
+                ok = (hp < NPIX) & ((unsigned)iy < (unsigned)p.Hi) & ((unsigned)ix < (unsigned)p.Wi);
+                off = (unsigned)(iy * p.Wi + ix) * (unsigned)cs + (unsigned)(coff + ((l_slot ^ (hx & 7)) << 4));
             }
-            glds16(g, sA + buf * A_BYTES + piece * 1024);
+            dma16(ra, sA + buf * A_BYTES + piece * 1024, ok ? off : DMA_OOB);
         }
     };
     auto issue_B = [&](int it_i, int n0, int slot) {
         const int cc = it_i / NT, tap = it_i - cc * NT;
-        const int8_t *base = p.wpk + ((size_t)(tap * nchunk + cc) * p.Cout + n0) * CT;
+        const dma_rsrc_t rb = dma_rsrc(p.wpk, (unsigned)NT * (unsigned)nchunk * (unsigned)p.Cout * (unsigned)CT);
+        const unsigned so = (unsigned)((tap * nchunk + cc) * p.Cout + n0) * (unsigned)CT;
 #pragma unroll
         for (int k = 0; k < B_PIECES_PER_WAVE; ++k) {
             const int piece = wave * B_PIECES_PER_WAVE + k;
             const int n = piece * 8 + l_row;
-            glds16(base + (size_t)n * CT + ((l_slot ^ (n & 7)) << 4), sB + slot * B_BYTES + piece * 1024);
+            dma16(rb, sB + slot * B_BYTES + piece * 1024, (unsigned)(n * CT + ((l_slot ^ (n & 7)) << 4)), so);
         }
     };
     auto issue_SS = [&](int n0, int slot) {      // every wave writes the same 1 KiB: {scale[128], shift[128]}
-        const float *g = (lane < 32 ? p.scale : p.shift - 128) + n0 + lane * 4;
-        glds16(g, smem + SS_OFF + slot * 1024);
+        const char *sc = reinterpret_cast<const char *>(p.scale), *sh = reinterpret_cast<const char *>(p.shift);
+        const char *lo = sc < sh ? sc : sh;                      // one (wave-uniform) resource over both arrays
+        dma16(dma_rsrc(lo, 0xffffffffu), smem + SS_OFF + slot * 1024, (unsigned)((lane < 32 ? sc : sh) - lo) + (unsigned)(lane & 31) * 16u,
+              (unsigned)n0 * 4u);
     };
 
     if constexpr (MODE == ST_PS_DOT3) {          // before any DMA is in flight (ordinary loads drain the queue)

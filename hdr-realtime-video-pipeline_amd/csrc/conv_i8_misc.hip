@@ -16,11 +16,6 @@ constexpr int A_BYTES = TP * CT, B_BYTES = BN * CT;   // 16 KiB + 16 KiB per sta
 constexpr int STAGE = A_BYTES + B_BYTES, NSTAGE = 2;
 constexpr int SMEM = NSTAGE * STAGE;                  // 64 KiB
 
-__device__ __forceinline__ void glds16(const void *g, void *lds)
-{
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                     (__attribute__((address_space(3))) void *)lds, 16, 0, 0);
-}
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <bool OUTF16>
@@ -43,20 +38,22 @@ __global__ __launch_bounds__(512) void conv1x1_i8_kernel(ConvI8Params p)
         if (cc < nchunk0) { src = p.src0; cs = p.c0; coff = cc * CT; }
         else { src = p.src1; cs = p.c1; coff = (cc - nchunk0) * CT; }
         char *sa = smem + stage * STAGE, *sb = sa + A_BYTES;
+        // LDS-DMA as buffer loads (common.h); pixels past the end of the tensor are zeros (their results are never stored)
+        const dma_rsrc_t ra = dma_rsrc(src, (unsigned)npx * (unsigned)cs);
 #pragma unroll
         for (int it = 0; it < 2; ++it) {              // 16 pieces of 8 pixel rows
             const int piece = wave * 2 + it;
             const int r = piece * 8 + l_row;
             const size_t px = px0 + r;
-            const int8_t *g = px < npx ? src + px * cs + coff + ((l_slot ^ (r & 7)) << 4) : p.padline + (l_slot << 4);
-            glds16(g, sa + piece * 1024);
+            dma16(ra, sa + piece * 1024, px < npx ? (unsigned)px * (unsigned)cs + (unsigned)(coff + ((l_slot ^ (r & 7)) << 4)) : DMA_OOB);
         }
-        const int8_t *wb = p.wpk + ((size_t)cc * p.Cout + n0) * CT;
+        const dma_rsrc_t rb = dma_rsrc(p.wpk, (unsigned)nchunk * (unsigned)p.Cout * (unsigned)CT);
+        const unsigned so = (unsigned)(cc * p.Cout + n0) * (unsigned)CT;
 #pragma unroll
         for (int it = 0; it < 2; ++it) {              // 16 pieces of 8 weight rows
             const int piece = wave * 2 + it;
             const int n = piece * 8 + l_row;
-            glds16(wb + (size_t)n * CT + ((l_slot ^ (n & 7)) << 4), sb + piece * 1024);
+            dma16(rb, sb + piece * 1024, (unsigned)(n * CT + ((l_slot ^ (n & 7)) << 4)), so);
         }
     };
 

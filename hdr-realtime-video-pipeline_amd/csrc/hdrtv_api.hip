@@ -372,7 +372,10 @@ bool pack_conv_i8(hdrtv_ctx *c, const Pack &pk, const std::string &key, const st
     std::vector<int8_t> wp((size_t)(c64 ? 6 : taps) * nch * coP * 128, (int8_t)0);
     std::vector<float> scale(coP, 0.f), shift(coP, 0.f), delta;
     std::vector<int> delta_acc;
-    const bool need_delta = !in.integer && ks == 3;
+    // Out-of-image halo pixels are ZEROS (what an LDS-DMA lane outside its buffer resource writes), i.e. code 0 = the value
+    // x_scale * (128 - k), not 0.0: a 3x3 layer takes the padded taps' share back out through a per-channel constant for each of
+    // the 16 border classes.  k = 128 needs none.  (Round 2 staged a line of code k - 128 for integer zero points instead.)
+    const bool need_delta = ks == 3 && in.kf != 128.0;
     if (need_delta) { delta.assign((size_t)16 * coP, 0.f); delta_acc.assign((size_t)16 * coP, 0); }
     for (int np = 0; np < co; ++np) {
         const int n = ps_cps > 0 ? 4 * (np % ps_cps) + np / ps_cps : np;
@@ -416,7 +419,7 @@ bool pack_conv_i8(hdrtv_ctx *c, const Pack &pk, const std::string &key, const st
                 delta_acc[(size_t)cls * coP + np] = (int)std::nearbyint(-(128.0 - in.kf) * (double)miss);
             }
     }
-    std::vector<int8_t> pad(128, (int8_t)(in.integer ? in.k - 128 : 0));
+    std::vector<int8_t> pad(128, (int8_t)0);
     ConvI8Layer L;
     if (need_delta) {
         L.delta = c->wts.put(delta.data(), delta.size() * 4);
