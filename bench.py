@@ -501,7 +501,10 @@ def main():
         try:
             pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic_int8.json" if args.int8 else "pmc_traffic.json")))["kernels"]
             # profile tag -> kernel name in the rocprofv3 counter CSV (template argument = store mode, common.h)
-            key = {"conv_pglds<nhwc>": "conv_pglds_kernel<0>", "conv_pglds<ps>": "conv_pglds_kernel<1>",
+            key = {"conv_prw<nhwc>": "conv_prw_kernel<0, 16>", "conv_prw<ps>": "conv_prw_kernel<1, 16>", "conv_prw<pool>": "conv_prw_kernel<2, 16>",
+                   "conv_prw<ps_dot3>": "conv_prw_kernel<4, 16>", "conv_prw8<nhwc>": "conv_prw_kernel<0, 8>", "conv_prw8<ps>": "conv_prw_kernel<1, 8>",
+                   "conv_prw8<pool>": "conv_prw_kernel<2, 8>",
+                   "conv_pglds<nhwc>": "conv_pglds_kernel<0>", "conv_pglds<ps>": "conv_pglds_kernel<1>",
                    "conv_pglds<pool>": "conv_pglds_kernel<2>", "conv_pglds<ps_dot3>": "conv_pglds_kernel<4>",
                    "conv_glds1": "conv_glds1_kernel",
                    "conv_pglds_i8<nhwc>": "conv_pglds_i8_kernel<0, false>", "conv_pglds_i8<ps>": "conv_pglds_i8_kernel<1, false>",
