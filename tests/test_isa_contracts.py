@@ -188,3 +188,20 @@ def test_prw_has_no_scratch_and_the_waits_it_counts_on(tmp_path):
         assert sum(v > 0 for v in counted) > sum(v == 0 for v in counted), name
         seen += 1
     assert seen == 7          # NHWC / PS / POOL x {16, 8}-row tiles + PS_DOT3
+
+
+@pytest.mark.parametrize("src", ["conv3x3_prw.hip", "conv3x3_pglds.hip", "conv3x3_pglds_i8.hip", "conv1x1_glds.hip", "conv_i8_misc.hip",
+                                 "conv3x3s2_preg.hip", "conv32s.hip", "conv32p.hip"])
+def test_lds_dma_kernels_spill_nothing_and_use_the_buffer_form(src, tmp_path):
+    """Every kernel that stages through LDS-DMA: (1) no scratch -- a scratch load with a DMA in flight is guarded by
+    vmcnt(0), i.e. it drains the DMA queue in the middle of the pipeline (round 2's conv3x3s2_preg<12> spilled 3 VGPRs);
+    (2) the DMA is `buffer_load_dwordx4 ... lds`, never the FLAT-encoded global_load_lds, after which hipcc's waitcnt pass
+    stops counting."""
+    out = tmp_path / (src + ".s")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", str(out)],
+                   check=True, capture_output=True)
+    text = out.read_text()
+    spills = [int(v) for v in re.findall(r"\.vgpr_spill_count:\s*(\d+)", text)]
+    assert spills and max(spills) == 0, (src, spills)
+    assert "global_load_lds" not in text and re.search(r"buffer_load_dwordx4 .* lds", text), src
+    assert not re.search(r"^\s*scratch_", text, re.M), src
