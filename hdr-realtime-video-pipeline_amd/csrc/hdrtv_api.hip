@@ -1464,7 +1464,28 @@ struct Seq {
         const double outel = mode == ST_POOL ? (double)Hd * Wd * L.cout_real : (double)Hi * Wi * L.cout_real;
         const double bytes = (double)Hi * Wi * L.cin + (double)L.ks * L.ks * L.cin * L.cout +
                              (mode == ST_PS_DOT3 ? 16.0 * Hd * Wd : outel * (L.out_f16 ? 2.0 : 1.0));
-        chk(L.ks == 3 ? conv_pglds_i8_launch(p, c->n_cu, s) : conv1x1_i8_launch(p, s), key.c_str(), tag, macs, bytes);
+        // the private-weight schedule (conv3x3_prw_i8.hip) and its tile shape, picked as for the fp16 layers (Seq::conv)
+        const char *prw_env = getenv("HDRTV_PRW");
+        const int prw_mode = prw_env ? atoi(prw_env) : 1;
+        bool prw = prw_mode != 0 && L.ks == 3 && c0 != 64 && (L.cout % 256) == 0 && mode != ST_PS_DOT3 && !L.out_f16;
+        int prw_th = 16;
+        if (prw && prw_mode == 1) {
+            const long tx = (Wi + 15) / 16, n = c->n_cu;
+            auto cost = [&](long tiles, double rel) { return (double)(((tiles + n - 1) / n) * n) / (double)tiles * rel; };
+            const double c16 = cost(tx * ((Hi + 15) / 16) * (L.cout / 256), 1.0), c8 = cost(tx * ((Hi + 7) / 8) * (L.cout / 256), 1.09);
+            const double c0c = cost(tx * ((Hi + 15) / 16) * (L.cout / 128), 1.22);
+            if (c0c <= c16 && c0c <= c8) prw = false;
+            else prw_th = c8 < c16 ? 8 : 16;
+        } else if (prw && prw_mode == 3) {
+            prw_th = 8;
+        }
+        // HDRTV_PRW_I8: 0 = never, 1 = only where the 8-row tiles win (the low-resolution layers), 2 = wherever HDRTV_PRW selects it
+        const char *i8_env = getenv("HDRTV_PRW_I8");
+        const int i8_mode = i8_env ? atoi(i8_env) : 1;
+        if (i8_mode == 0 || (i8_mode == 1 && prw_th != 8)) prw = false;
+        if (prw) snprintf(tag, sizeof tag, "conv_prw%s_i8<%s>", prw_th == 8 ? "8" : "", mode == ST_POOL ? "pool" : (mode == ST_PS ? "ps" : "nhwc"));
+        chk(L.ks == 3 ? (prw ? conv_prw_i8_launch(p, prw_th, c->n_cu, s) : conv_pglds_i8_launch(p, c->n_cu, s)) : conv1x1_i8_launch(p, s),
+            key.c_str(), tag, macs, bytes);
     }
     // W8A8 LE layer on int8 MFMA (conv_q8.hip).  src: f16 NHWC (quantised on load) or this layer's int8 codes; dst: f16, or
     // (oq != nullptr) the int8 codes of the reading layer's quantiser *oq

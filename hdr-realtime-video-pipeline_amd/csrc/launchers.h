@@ -16,6 +16,7 @@ hipError_t conv_glds1_launch(ConvParams p, hipStream_t stream, int n_cu = 0);   
 hipError_t conv_pglds_launch(ConvParams p, int n_cu, hipStream_t stream);
 hipError_t conv_prw_launch(ConvParams p, int th, int n_cu, hipStream_t stream);   // Cout % 256 == 0, modes NHWC / PS / POOL; th = 16 | 8
 hipError_t conv_pglds_i8_launch(ConvI8Params p, int n_cu, hipStream_t stream);
+hipError_t conv_prw_i8_launch(ConvI8Params p, int th, int n_cu, hipStream_t stream);   // Cin % 128 == 0, Cout % 256 == 0, int8 out
 hipError_t conv1x1_i8_launch(ConvI8Params p, hipStream_t stream);
 hipError_t conv32p_launch(Conv32Params p, int n_cu, hipStream_t stream);
 hipError_t conv32s_launch(Conv32Params p, int n_cu, hipStream_t stream);   // the single-pass (CoutPad == 32) layers

