@@ -266,14 +266,15 @@ def dispatcher_host_fed(args, frames, device_index, use_hg, steps, warmup=5):
     init = {"model_path": os.path.join(REPO, "tests", "golden", "hr_weights.hdrw"), "use_hg": use_hg,
             "hg_weights": "seeded:1234" if use_hg else None}
     try:
-        with FrameDispatcher(1, H, Wd, sink, init_args=init, devices=[device_index], slots=3) as d:
+        # (bounded waits: an extra must never push a default run past the driver's limit)
+        with FrameDispatcher(1, H, Wd, sink, init_args=init, devices=[device_index], slots=3, start_timeout=150.0) as d:
             for i in range(warmup):
                 d.submit(frames[i % len(frames)])
-            d.flush(timeout=300)
+            d.flush(timeout=100)
             t0 = time.perf_counter()
             for i in range(steps):
                 d.submit(frames[i % len(frames)])
-            d.flush(timeout=300)
+            d.flush(timeout=100)
             el = time.perf_counter() - t0
         return {"value": round(steps / el, 3), "unit": "frames/s", "frames": steps, "workers": 1, "slots": 3, "frames_in_flight": 2,
                 "ms_per_frame": round(el / steps * 1e3, 3), "worker_exit_codes": d.exit_codes,
