@@ -505,6 +505,9 @@ def main():
             key = {"conv_prw<nhwc>": "conv_prw_kernel<0, 16>", "conv_prw<ps>": "conv_prw_kernel<1, 16>", "conv_prw<pool>": "conv_prw_kernel<2, 16>",
                    "conv_prw<ps_dot3>": "conv_prw_kernel<4, 16>", "conv_prw8<nhwc>": "conv_prw_kernel<0, 8>", "conv_prw8<ps>": "conv_prw_kernel<1, 8>",
                    "conv_prw8<pool>": "conv_prw_kernel<2, 8>",
+                   "conv_prw_i8<nhwc>": "conv_prw_i8_kernel<0, 16>", "conv_prw_i8<ps>": "conv_prw_i8_kernel<1, 16>",
+                   "conv_prw_i8<pool>": "conv_prw_i8_kernel<2, 16>", "conv_prw8_i8<nhwc>": "conv_prw_i8_kernel<0, 8>",
+                   "conv_prw8_i8<ps>": "conv_prw_i8_kernel<1, 8>", "conv_prw8_i8<pool>": "conv_prw_i8_kernel<2, 8>",
                    "conv_pglds<nhwc>": "conv_pglds_kernel<0>", "conv_pglds<ps>": "conv_pglds_kernel<1>",
                    "conv_pglds<pool>": "conv_pglds_kernel<2>", "conv_pglds<ps_dot3>": "conv_pglds_kernel<4>",
                    "conv_glds1": "conv_glds1_kernel",
