@@ -1225,6 +1225,10 @@ int do_reserve(hdrtv_ctx *c, int H, int W)
     const Shapes s = shapes_for(H, W);
     // InstanceNorm2d needs more than one spatial element at the 4th classifier block (the reference raises
     // ValueError there too: torch/nn/functional.py _verify_spatial_size)
+    // LDS-DMA (buffer loads) addresses a tensor with 32-bit byte offsets below 2 GiB: the widest tensors are 128 bytes per
+    // (padded) pixel -> 16.7 Mpixel (5120 x 2880 fits; 7680 x 4320 does not)
+    if ((size_t)((H + 31) / 32 * 32) * (size_t)((W + 31) / 32 * 32) * 128 >= ((size_t)1 << 31))
+        return fail(c, HDRTV_EINVAL, "unsupported frame size %dx%d: more than 16.7 Mpixel (32-bit LDS-DMA offsets)", W, H);
     if (s.ch[4] * s.cw[4] < 2) return fail(c, HDRTV_EINVAL, "frame %dx%d too small for the AGCM classifier", W, H);
     // F.pad(mode="reflect") (HG_Composite_arch.py:97-103) needs the padding to be smaller than the dimension; torch raises
     if (c->has_hg && (s.Hp - H >= H || s.Wp - W >= W))

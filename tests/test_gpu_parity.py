@@ -472,6 +472,8 @@ def test_smallest_frames_and_rejections(torch_cuda, golden_dir, hr_state):
         for (h, w), what in (((4, 4), "unsupported frame size"), ((65, 9), "AGCM classifier"), ((47, 33), "AGCM classifier")):
             with pytest.raises(HdrtvError, match=what):
                 p.process(W.synthetic_frame(h, w, seed=3, kind="noise"))
+        with pytest.raises(HdrtvError, match="16.7 Mpixel"):          # 32-bit LDS-DMA offsets: refused, not wrapped around
+            p.process(np.zeros((4400, 7800, 3), np.uint8))
         assert p.process(W.synthetic_frame(68, 8, seed=4, kind="noise")).shape == (68, 8, 3)     # still usable after a refusal
     finally:
         p.close()
