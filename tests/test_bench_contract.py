@@ -9,9 +9,9 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("name", ["r01_final_bench_default.json", "r01_int8_bench.json", "r02_bench_default.json",
-                                  "r02_bench_cpu_full_protocol.json"])
+                                  "r02_bench_cpu_full_protocol.json", "r03_bench_default.json"])
 def test_committed_bench_lines_follow_the_contract(name):
-    d = json.load(open(os.path.join(REPO, "profiles", name)))
+    d = json.loads(open(os.path.join(REPO, "profiles", name)).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -28,7 +28,14 @@ def test_committed_bench_lines_follow_the_contract(name):
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and 0 < c["value"] < d["value"]
-    if name.startswith("r02"):          # round-2 protocol: ring-inclusive value, 1 % low, eager-CPU baseline per stage
+    if name.startswith("r03"):          # round 3: traffic measured for the new dominant kernel, the in-product dispatcher beside the headline,
+        # the bounded CPU protocol ending in one unscaled frame at the workload size
+        assert d["roofline"]["kernel"].startswith("conv_prw") and d["roofline"]["traffic"] > d["roofline"]["algorithmic_bytes_per_launch"]
+        disp = d["dispatcher_host_fed"]
+        assert disp["worker_exit_codes"] == [0] and abs(disp["value"] / d["value_pcie_inclusive"] - 1.0) <= 0.03
+        assert [(r["size"], r["warmup"], r["timed_frames"]) for r in c["runs"]] == [("960x540", 5, 20), ("1920x1080", 1, 5), ("3840x2160", 0, 1)]
+        assert "scaled" not in c["sample"] and d["p99_ms"] >= d["p50_ms"]
+    if name.startswith("r02") or name.startswith("r03"):          # round-2 protocol: ring-inclusive value, 1 % low, eager-CPU baseline per stage
         assert d["one_percent_low_fps"] <= 1000.0 / d["p50_ms"] * 1.001 and d["value_device_only"] > 0 and "pinned host" in d["metric"]
         assert c["cores"] <= c["physical_cores_available"] and c["cpu_model"] and c["backend"].startswith("PyTorch CPU eager")
         for r in c["runs"]:
