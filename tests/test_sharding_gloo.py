@@ -106,7 +106,9 @@ class _PipelinedStandin:
         return (frame, out, self.begun)
 
     def finish(self, token):
+        import time
         frame, out, seq = token
+        time.sleep(0.01)                           # the "device" is slower than the producer: frames queue up behind it
         np.multiply(frame, 257, out=out, dtype=np.uint16, casting="unsafe")
         out[0, 0, 2] = self.begun - seq            # frames begun after this one at the time it is finished
 
@@ -189,4 +191,4 @@ def test_dispatcher_keeps_two_frames_in_flight_and_zero_copy_submit():
     for i in range(n):
         assert seen[i][1, 1, 0] == (i + 1) * 257
     overlapped = sum(int(seen[i][0, 0, 2]) >= 1 for i in range(n))
-    assert overlapped >= n // 2, overlapped          # the parent submits ahead, so most frames had a successor queued behind them
+    assert overlapped >= n - 4, overlapped          # the parent submits ahead: all but the first / last frames had a successor begun
