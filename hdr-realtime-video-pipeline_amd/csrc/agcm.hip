@@ -32,7 +32,9 @@ __device__ __forceinline__ float fake_q(float x, const FakeQ &q)
     return c * q.scale + q.zero;      // q.zero = x_zero (asymmetric) or -128 * x_scale (symmetric: the u8 code is x / x_scale + 128)
 }
 
-template <bool IN_F16>
+// PX output pixels per workgroup: 16, or 4 for the small maps of the last blocks (four times the workgroups, a quarter of
+// the dependent FMA chain per thread: block 5 at 4K is 510 pixels)
+template <bool IN_F16, int PX>
 __global__ __launch_bounds__(256) void cls_block_kernel(const void *__restrict__ in_, int Ci, int Hi, int Wi,
                                                         const float *__restrict__ nmean, const float *__restrict__ nrstd,
                                                         const float *__restrict__ ngamma, const float *__restrict__ nbeta,
@@ -40,13 +42,14 @@ __global__ __launch_bounds__(256) void cls_block_kernel(const void *__restrict__
                                                         float *__restrict__ out, int Ho, int Wo, float2 *__restrict__ part,
                                                         FakeQ qin, FakeQ qstat)
 {
-    __shared__ float s_sum[128][17];
-    __shared__ float s_cnt[16];
+    constexpr int NCG = 256 / PX;                 // channel lanes per pixel
+    __shared__ float s_sum[128][PX + 1];
+    __shared__ float s_cnt[PX];
     const int npix = Ho * Wo;
-    const int p0 = blockIdx.x * 16;
-    // phase 1: windowed sums of the (normalised) input, 16 pixels x Ci channels
-    for (int e = threadIdx.x; e < Ci * 16; e += 256) {
-        const int px = e & 15, ci = e >> 4;
+    const int p0 = blockIdx.x * PX;
+    // phase 1: windowed sums of the (normalised) input, PX pixels x Ci channels
+    for (int e = threadIdx.x; e < Ci * PX; e += 256) {
+        const int px = e % PX, ci = e / PX;
         const int p = p0 + px;
         float s = 0.f;
         int cnt = 0;
@@ -77,10 +80,10 @@ __global__ __launch_bounds__(256) void cls_block_kernel(const void *__restrict__
         if (ci == 0) s_cnt[px] = (float)cnt;
     }
     __syncthreads();
-    const int px = threadIdx.x & 15, cg = threadIdx.x >> 4;
+    const int px = threadIdx.x % PX, cg = threadIdx.x / PX;
     const int p = p0 + px;
     const bool ok = p < npix;
-    for (int co = cg; co < Co; co += 16) {
+    for (int co = cg; co < Co; co += NCG) {
         const float *w = Wt + (size_t)co * Ci;
         float acc = 0.f;
         for (int ci = 0; ci < Ci; ++ci) acc += w[ci] * s_sum[ci][px];
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256) void cls_block_kernel(const void *__restrict__
         const float vs = qstat.on ? fake_q(v, qstat) : v;
         float s1 = ok ? vs : 0.f, s2 = ok ? vs * vs : 0.f;
 #pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
+        for (int o = 1; o < PX; o <<= 1) {
             s1 += __shfl_xor(s1, o);
             s2 += __shfl_xor(s2, o);
         }
@@ -338,22 +341,25 @@ __global__ __launch_bounds__(256) void agcm_mlp_kernel(const f16 *__restrict__ i
 
 }  // namespace
 
+// returns the number of workgroups (= partials per channel) through *nblk
 hipError_t cls_block_launch(const void *in, int in_f16, int Ci, int Hi, int Wi, const float *nmean, const float *nrstd,
                             const float *ngamma, const float *nbeta, const float *Wt, const float *bias, int Co, float *out,
-                            int Ho, int Wo, float *part, hipStream_t s, const FakeQ *qin, const FakeQ *qstat)
+                            int Ho, int Wo, float *part, hipStream_t s, const FakeQ *qin, const FakeQ *qstat, int *nblk)
 {
-    const int grid = (Ho * Wo + 15) / 16;
     const FakeQ off{0, 0.f, 0.f, 0.f, 0.f};
     const FakeQ qi = qin ? *qin : off, qs = qstat ? *qstat : off;
-    if (in_f16)
-        hipLaunchKernelGGL(cls_block_kernel<true>, dim3(grid), dim3(256), 0, s, in, Ci, Hi, Wi, nmean, nrstd, ngamma, nbeta, Wt,
-                           bias, Co, out, Ho, Wo, reinterpret_cast<float2 *>(part), qi, qs);
-    else
-        hipLaunchKernelGGL(cls_block_kernel<false>, dim3(grid), dim3(256), 0, s, in, Ci, Hi, Wi, nmean, nrstd, ngamma, nbeta,
-                           Wt, bias, Co, out, Ho, Wo, reinterpret_cast<float2 *>(part), qi, qs);
+    float2 *pt = reinterpret_cast<float2 *>(part);
+    const int npix = Ho * Wo;
+    const bool small = npix <= 4096;
+    const int grid = small ? (npix + 3) / 4 : (npix + 15) / 16;
+    if (nblk) *nblk = grid;
+#define CLS_LAUNCH(F16, PXV) hipLaunchKernelGGL((cls_block_kernel<F16, PXV>), dim3(grid), dim3(256), 0, s, in, Ci, Hi, Wi, nmean, nrstd, \
+                                                 ngamma, nbeta, Wt, bias, Co, out, Ho, Wo, pt, qi, qs)
+    if (small) { if (in_f16) CLS_LAUNCH(true, 4); else CLS_LAUNCH(false, 4); }
+    else { if (in_f16) CLS_LAUNCH(true, 16); else CLS_LAUNCH(false, 16); }
+#undef CLS_LAUNCH
     return hipGetLastError();
 }
-
 hipError_t cls_stats_launch(const float *part, int C, int nblk, int n, float eps, float *mean, float *rstd, hipStream_t s)
 {
     hipLaunchKernelGGL(cls_stats_kernel, dim3(C), dim3(256), 0, s, reinterpret_cast<const float2 *>(part), nblk, n, eps, mean,

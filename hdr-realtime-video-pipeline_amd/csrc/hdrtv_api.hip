@@ -1258,7 +1258,7 @@ int do_reserve(hdrtv_ctx *c, int H, int W)
         snprintf(nm, sizeof nm, "agcm.rstd%d", i + 1);
         ws_add(c, nm, cls_co[i], 1, 1, 3);
     }
-    ws_add(c, "agcm.part", 2 * 128 * ((s.ch[1] * s.cw[1] + 15) / 16), 1, 1, 3);   // per-block (sum, sumsq) partials
+    ws_add(c, "agcm.part", 2 * 128 * ((s.ch[1] * s.cw[1] + 15) / 16) + 2 * 128 * 1024, 1, 1, 3);   // per-workgroup (sum, sumsq) partials
     ws_add(c, "agcm.frags", 14 * 64 * 8 / 2, 1, 1, 3);   // f16 elements stored in an f32-sized slot
     ws_add(c, "agcm.bias", 168, 1, 1, 3);
     ws_add(c, "agcm.out", 3, H, W, 1);
@@ -1615,10 +1615,10 @@ int run_agcm(hdrtv_ctx *c, Seq &q, const f16 *rgb, const f16 *cond, f16 *agcm_ou
         const float *w = wtp<float>(c, c->f32v.at(b));
         snprintf(b, sizeof b, "cls%d.b", i);
         const float *bias = wtp<float>(c, c->f32v.at(b));
-        const int nblk = (s.ch[i + 1] * s.cw[i + 1] + 15) / 16;
+        int nblk = 0;
         q.chk(cls_block_launch(in, i == 0, cls_ci[i], s.ch[i], s.cw[i], nm, nr, ng, nb, w, bias, cls_co[i], out, s.ch[i + 1],
                                s.cw[i + 1], wsp<float>(c, "agcm.part"), q.s, c->cls_q[i].on ? &c->cls_q[i] : nullptr,
-                               (i == 4 && c->cls_q[5].on) ? &c->cls_q[5] : nullptr),
+                               (i == 4 && c->cls_q[5].on) ? &c->cls_q[5] : nullptr, &nblk),
               "cls_block", c->cls_q[i].on ? "cls_block<fq>" : "cls_block", (double)s.ch[i] * s.cw[i] * cls_ci[i] * cls_co[i]);
         snprintf(a, sizeof a, "agcm.mean%d", i + 1);
         snprintf(b, sizeof b, "agcm.rstd%d", i + 1);

@@ -38,7 +38,8 @@ hipError_t post_rgb48_launch(const void *in, int is_f32, int H, int W, uint16_t 
 struct FakeQ { int on; float inv, zoff, scale, zero; };
 hipError_t cls_block_launch(const void *in, int in_f16, int Ci, int Hi, int Wi, const float *nmean, const float *nrstd,
                             const float *ngamma, const float *nbeta, const float *Wt, const float *bias, int Co, float *out,
-                            int Ho, int Wo, float *part, hipStream_t s, const FakeQ *qin = nullptr, const FakeQ *qstat = nullptr);
+                            int Ho, int Wo, float *part, hipStream_t s, const FakeQ *qin = nullptr, const FakeQ *qstat = nullptr,
+                            int *nblk = nullptr);
 hipError_t cls_stats_launch(const float *part, int C, int nblk, int n, float eps, float *mean, float *rstd, hipStream_t s);
 struct AgcmFoldArgs {
     const float *mean5;
