@@ -171,7 +171,7 @@ def cpu_baseline(args, use_hg):
     return out
 
 
-def int8_extra(args, dev, dev_frames, steps=20, warmup=3):
+def int8_extra(args, dev, dev_frames, steps=20, warmup=3, recipe="full"):
     """BASELINE configs[4] beside the headline, same frames, same timing method (never `value`): HR from the INT8-QAT
     checkpoint (int8 storage, fp16 compute), HG head W8A8 on int8 MFMA.  `python bench.py --int8` is the full run."""
     import contextlib
@@ -181,8 +181,8 @@ def int8_extra(args, dev, dev_frames, steps=20, warmup=3):
     try:
         H, Wd = args.height, args.width
         with contextlib.redirect_stdout(sys.stderr):
-            proc = HDRTVNetMI355X(os.path.join(REPO, "tests", "golden", "hr_int8_full_qat.hdrw"), device=str(dev),
-                                  precision="int8-full", predequantize="off", use_hg=True, hg_weights="seeded-w8a8:1234", warmup_passes=0)
+            proc = HDRTVNetMI355X(os.path.join(REPO, "tests", "golden", f"hr_int8_{recipe}_qat.hdrw"), device=str(dev),
+                                  precision=f"int8-{recipe}", predequantize="off", use_hg=True, hg_weights="seeded-w8a8:1234", warmup_passes=0)
         proc._ensure_buffers(H, Wd)
         lib, ctx = proc._lib, proc._ctx
         rgb48 = torch.empty((H, Wd, 3), dtype=torch.uint16, device=dev)
@@ -204,7 +204,7 @@ def int8_extra(args, dev, dev_frames, steps=20, warmup=3):
         torch.cuda.synchronize(dev)
         el = time.perf_counter() - t0
         proc.close()
-        return {"metric": "frames/sec, INT8-QAT HDRTVNet++ (HR: the shipped full-QAT checkpoint, W8A8 layers on int8 MFMA; HG W8A8 on int8 MFMA), same frames",
+        return {"metric": f"frames/sec, INT8-QAT HDRTVNet++ (HR: the shipped {recipe}-QAT checkpoint, W8A8 layers on int8 MFMA; HG W8A8 on int8 MFMA), same frames",
                 "value": round(steps / el, 3), "unit": "frames/s", "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
                 "dtype": "i8+f16"}
     except Exception as exc:  # noqa: BLE001  (an extra: never take the headline line down with it)
@@ -576,6 +576,8 @@ def main():
         }
         if world == 1 and use_hg and not args.int8 and not args.no_int8_extra:
             line["config4_int8"] = int8_extra(args, dev, dev_frames)
+            # the reference's default preset is the mixed recipe (gui_config.py: DEFAULT_PRECISION_KEY = "INT8 Mixed (QAT)")
+            line["config4_int8_mixed"] = int8_extra(args, dev, dev_frames, recipe="mixed")
         if world == 1 and not args.int8 and not args.no_dispatcher:
             line["dispatcher_host_fed"] = dispatcher_host_fed(args, frames, local_rank, use_hg, max(40, args.steps))
         if world == 1 and not args.no_cpu_baseline:
