@@ -29,9 +29,11 @@ The worker body comes from ``make_worker(rank, device_index, init_args)``.  It i
 from __future__ import annotations
 
 import collections
+import contextlib
 import gc
 import multiprocessing as mp
 import queue as _queue
+import sys
 import threading
 import time
 import traceback
@@ -56,7 +58,8 @@ class _Mi355xWorker:
         kw = dict(init_args)
         model = kw.pop("model_path")
         torch.cuda.set_device(device_index)
-        self.proc = HDRTVNetMI355X(model, device=f"cuda:{device_index}", warmup_passes=0, **kw)
+        with contextlib.redirect_stdout(sys.stderr):   # a worker's banner must not land on the parent's stdout (bench.py's one JSON line)
+            self.proc = HDRTVNetMI355X(model, device=f"cuda:{device_index}", warmup_passes=0, **kw)
         self.dev = self.proc.device
         hip = C.CDLL("libamdhip64.so")          # torch's copy: already loaded under this SONAME (lib.load imports torch first)
         hip.hipHostRegister.argtypes = [C.c_void_p, C.c_size_t, C.c_uint]

@@ -298,3 +298,20 @@ def test_hip_graph_follows_mask_r_and_profiling(golden_dir):
             p.close()
     assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
     assert not torch.equal(res[True][0], res[True][1])        # the dense mask blends the HG residual into far more pixels
+
+
+@pytest.mark.gpu
+def test_bench_prints_exactly_one_line_on_stdout():
+    """The driver parses bench.py's stdout as ONE JSON line: nothing else (processor banners of the dispatcher's worker processes,
+    warnings, progress) may land there.  Small frame, dispatcher leg included, everything else at its default."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--height", "270", "--width", "480", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-int8-extra"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["dispatcher_host_fed"]["value"] > 0
