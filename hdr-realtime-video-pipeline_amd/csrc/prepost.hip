@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void cond_resize_kernel(const f16 *__restrict_
 // coordinate 4d + 1.5, i.e. the mean of pixels (4d+1, 4d+2) in each direction (hdrtvnet_torch.py:2269-2276).
 // mode 2: HDRTVNET_ZERO_COND -- the condition map is zero (hdrtvnet_torch.py:2265-2267).
 constexpr int PF_OW = 32, PF_OH = 8, PF_IW = 140, PF_IH = 44, PF_ROWDW = 107;   // 107 dwords cover 420 B at any alignment
+constexpr int PF_PITCH = 144;
 
 __global__ __launch_bounds__(256) void pre_fused_kernel(const uint8_t *__restrict__ bgr, f16 *__restrict__ out, f16 *__restrict__ cond,
                                                         int H, int W, int Ho, int Wo, const float *__restrict__ wx,
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256) void pre_fused_kernel(const uint8_t *__restric
                                                         const float *__restrict__ wy, const int *__restrict__ ymn,
                                                         const int *__restrict__ yns, int mode)
 {
-    __shared__ f16 s_in[3][PF_IH][PF_IW + 2];
+    __shared__ __attribute__((aligned(16))) f16 s_in[3][PF_IH][PF_PITCH];     // 288-byte rows: 16-byte reads at columns 8k
     __shared__ float s_h[3][PF_IH][PF_OW + 1];
     __shared__ float s_wx[PF_OW][AA_TAPS], s_wy[PF_OH][AA_TAPS];      // this tile's tap tables (pitch 17: conflict-free across outputs)
     __shared__ int s_xb[PF_OW], s_xn[PF_OW], s_yb[PF_OH], s_yn[PF_OH];
@@ -189,8 +190,16 @@ __global__ __launch_bounds__(256) void pre_fused_kernel(const uint8_t *__restric
         f16 *dst = out + c * npix + (size_t)y * W + x;
         if (x + 8 <= wx1) {
             f16x8 v;
+            if (((x - ix0) & 1) == 0) {            // (always, for the 0.25x tables: xmn is even) four dword reads
+                const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
+                i32x4 u;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = src[i];
+                for (int i = 0; i < 4; ++i) u[i] = (int)s32[i];
+                v = __builtin_bit_cast(f16x8, u);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = src[i];
+            }
             *reinterpret_cast<f16x8 *>(dst) = v;
         } else {
             for (int i = 0; x + i < wx1; ++i) dst[i] = src[i];
@@ -219,22 +228,61 @@ __global__ __launch_bounds__(256) void pre_fused_kernel(const uint8_t *__restric
         }
         return;
     }
-    for (int e = tid; e < 3 * PF_IH * PF_OW; e += 256) {
-        const int c = e / (PF_IH * PF_OW), r = (e / PF_OW) % PF_IH, o = e % PF_OW;
-        float sacc = 0.f;
-        if (iy0 + r < H) {
-            // all 16 taps unrolled (a counted loop serialises on LDS latency): taps beyond this output's count have weight 0 in
-            // the table and re-read the last valid sample, so they add exactly +0
-            const int base = s_xb[o], n1 = s_xn[o] - 1;     // n1 < 0 for outputs beyond the image
-            if (n1 >= 0) {
-                float xv[16], wv[16];
+    // horizontal pass: a thread owns the four adjacent outputs o0 .. o0 + 3 (o0 = 4 * (tid % 8), the same in every trip: their
+    // 4 x 16 weights stay in registers) of one row per trip.  Interior outputs -- 16 taps each, windows 4 samples apart -- read
+    // their 28 samples as four 16-byte LDS reads instead of 64 two-byte gathers; anything else (image borders) goes tap by tap.
+    // Either way: fp32, taps in order, separate multiply and add (ATen's _upsample_bicubic2d_aa, as cond_resize_kernel).
+    {
+        const int o0 = 4 * (tid & 7);
+        float wv[4][16];
+        int xb[4], xn1[4];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) { xv[j] = (float)s_in[c][r][base + (j < n1 ? j : n1)]; wv[j] = s_wx[o][j]; }
+        for (int i = 0; i < 4; ++i) {
+            xb[i] = s_xb[o0 + i]; xn1[i] = s_xn[o0 + i] - 1;     // n1 < 0 for outputs beyond the image
 #pragma unroll
-                for (int j = 0; j < 16; ++j) sacc = __fadd_rn(sacc, __fmul_rn(wv[j], xv[j]));
-            }
+            for (int j = 0; j < 16; ++j) wv[i][j] = s_wx[o0 + i][j];
         }
-        s_h[c][r][o] = sacc;
+        const int wstart = xb[0] & ~7, d = xb[0] - wstart;
+        const bool fast = (d == 0 || d == 2) && xn1[0] == 15 && xn1[1] == 15 && xn1[2] == 15 && xn1[3] == 15 &&
+                          xb[1] == xb[0] + 4 && xb[2] == xb[0] + 8 && xb[3] == xb[0] + 12;
+        for (int e = tid >> 3; e < 3 * PF_IH; e += 32) {
+            const int c = e / PF_IH, r = e - c * PF_IH;
+            float sacc[4] = {0.f, 0.f, 0.f, 0.f};
+            if (iy0 + r < H) {
+                if (fast) {
+                    const f16x8 *src = reinterpret_cast<const f16x8 *>(&s_in[c][r][wstart]);
+                    const f16x8 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+                    float xv[32];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { xv[k] = (float)q0[k]; xv[8 + k] = (float)q1[k]; xv[16 + k] = (float)q2[k]; xv[24 + k] = (float)q3[k]; }
+                    if (d == 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 16; ++j) sacc[i] = __fadd_rn(sacc[i], __fmul_rn(wv[i][j], xv[4 * i + j]));
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 16; ++j) sacc[i] = __fadd_rn(sacc[i], __fmul_rn(wv[i][j], xv[2 + 4 * i + j]));
+                    }
+                } else {
+                    // taps beyond an output's count have weight 0 in the table and re-read the last valid sample: they add exactly +0
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (xn1[i] >= 0) {
+                            float xv[16];
+#pragma unroll
+                            for (int j = 0; j < 16; ++j) xv[j] = (float)s_in[c][r][xb[i] + (j < xn1[i] ? j : xn1[i])];
+#pragma unroll
+                            for (int j = 0; j < 16; ++j) sacc[i] = __fadd_rn(sacc[i], __fmul_rn(wv[i][j], xv[j]));
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_h[c][r][o0 + i] = sacc[i];
+        }
     }
     __syncthreads();
     for (int e = tid; e < 3 * PF_OH * PF_OW; e += 256) {
