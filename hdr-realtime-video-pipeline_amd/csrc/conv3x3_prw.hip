@@ -137,8 +137,23 @@ __global__ __launch_bounds__(512) void conv_prw_kernel(ConvParams p)
     // the odd wave that the strip may be overwritten (by its weight DMA at tap 1 of the next tile).  Both counters live in LDS.
     volatile int *s_flag = reinterpret_cast<volatile int *>(smem + DOTW_OFF + 768);     // [4] flag, [4] ack
     if constexpr (MODE == ST_PS_DOT3) {
-        float *s_w = reinterpret_cast<float *>(smem + DOTW_OFF);
-        for (int e = tid; e < 3 * 64; e += 512) s_w[e] = p.dotw[e];
+        // The dot products run on the matrix pipe (epilogue below).  Table entry ((half * 3 + o) * 4 + kg): the A-operand
+        // fragment of output o for the lanes of k-group kg of a wave that owns channel half `half` -- K slot e of the group is
+        // channel 4 kg + e (e < 4, accumulator block 0) or 16 + 4 kg + e - 4 (block 1), i.e. exactly the order in which a
+        // lane's two f16x4 results of a pixel row form a B fragment without any data movement.  An fp32 weight is carried as
+        // hi + lo * 2^-10 (two f16 values, lo scaled into the normal range): products exact, 22 bits of the weight kept.
+        if (tid < 24) {
+            const int kgq = tid & 3, o = (tid >> 2) % 3, half = tid / 12;
+            f16x8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float w = p.dotw[o * 64 + half * 32 + (e < 4 ? 4 * kgq + e : 16 + 4 * kgq + e - 4)];
+                hi[e] = (f16)w;
+                lo[e] = (f16)((w - (float)hi[e]) * 1024.f);
+            }
+            *reinterpret_cast<f16x8 *>(smem + DOTW_OFF + tid * 32) = hi;
+            *reinterpret_cast<f16x8 *>(smem + DOTW_OFF + tid * 32 + 16) = lo;
+        }
         if (tid < 8) s_flag[tid] = 0;
     }
 
@@ -317,40 +332,30 @@ __global__ __launch_bounds__(512) void conv_prw_kernel(ConvParams p)
             }
         } else if constexpr (MODE == ST_PS_DOT3) {
             // pixel shuffle, ReLU, then this wave's half of the 64 -> 3 dot products: only 3 partial sums per pixel leave the CU.
-            // fp32 arithmetic as conv_pglds's; the sum over a pixel's channels is associated differently (per wave, then the
-            // pair), so the results agree with it to rounding, not bit for bit.
-            const float *s_w = reinterpret_cast<const float *>(smem + DOTW_OFF) + (wave & 1) * 32 + 4 * kg;
-            float4 w0[2], w1[2], w2[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                w0[i] = *reinterpret_cast<const float4 *>(s_w + i * 16);
-                w1[i] = *reinterpret_cast<const float4 *>(s_w + 64 + i * 16);
-                w2[i] = *reinterpret_cast<const float4 *>(s_w + 128 + i * 16);
-            }
+            // The f16 results of a pixel row (as the reference's fp16 graph holds Up_conv5's output) are the B operand of one
+            // v_mfma_f32_16x16x32_f16 per weight half (hi, lo): K = the wave's 32 channels, output rows 4 q + o carry output o of
+            // pixel row 4 pass + q, so after four rows lane (kg, l15) holds the three sums of pixel (4 pass + kg, l15) in
+            // registers 0..2 -- the layout the pair hand-off below expects.  fp32 accumulation as conv_pglds's, associated
+            // differently (and the weights to 22 bits): the results agree with it to rounding, not bit for bit.
+            const int orow = l15 & 3, qrow = l15 >> 2;
+            const char *tb = smem + DOTW_OFF + ((((wave & 1) * 3 + (orow < 3 ? orow : 0)) * 4 + kg) << 5);
+            const f16x8 zero8 = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+            f16x8 fh = *reinterpret_cast<const f16x8 *>(tb), fl = *reinterpret_cast<const f16x8 *>(tb + 16);
+            if (orow == 3) { fh = zero8; fl = zero8; }
             float4 R[TH / 4];                                    // this lane's pixels: (row 4 * pass + kg, column l15)
 #pragma unroll
             for (int pass = 0; pass < TH / 4; ++pass) {
+                f32x4 ah = {0.f, 0.f, 0.f, 0.f}, al = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const f16x4 o = outv(i, pass * 4 + jj);
-                        const float x0 = (float)o[0], x1 = (float)o[1], x2 = (float)o[2], x3 = (float)o[3];
-                        a0 += w0[i].x * x0 + w0[i].y * x1 + w0[i].z * x2 + w0[i].w * x3;
-                        a1 += w1[i].x * x0 + w1[i].y * x1 + w1[i].z * x2 + w1[i].w * x3;
-                        a2 += w2[i].x * x0 + w2[i].y * x1 + w2[i].z * x2 + w2[i].w * x3;
-                    }
-                    // the four k-groups of a pixel meet in the strip (ordinary LDS writes and reads: wave-private, in order)
-                    *reinterpret_cast<float4 *>(stg + jj * 1024 + kg * 256 + l15 * 16) = make_float4(a0, a1, a2, 0.f);
+                    const f16x4 o0 = outv(0, pass * 4 + jj), o1 = outv(1, pass * 4 + jj);
+                    const f16x8 b = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
+                    const bool mine = qrow == jj;
+                    ah = __builtin_amdgcn_mfma_f32_16x16x32_f16(mine ? fh : zero8, b, ah, 0, 0, 0);
+                    al = __builtin_amdgcn_mfma_f32_16x16x32_f16(mine ? fl : zero8, b, al, 0, 0, 0);
                 }
-                float4 r = *reinterpret_cast<const float4 *>(stg + kg * 1024 + l15 * 16);
-#pragma unroll
-                for (int q = 1; q < 4; ++q) {
-                    const float4 v = *reinterpret_cast<const float4 *>(stg + kg * 1024 + q * 256 + l15 * 16);
-                    r.x += v.x; r.y += v.y; r.z += v.z;
-                }
-                R[pass] = r;
+                constexpr float k = 1.f / 1024.f;
+                R[pass] = make_float4(ah[0] + al[0] * k, ah[1] + al[1] * k, ah[2] + al[2] * k, 0.f);
             }
             const int pair = wave >> 1;
             if (wave & 1) {
