@@ -1290,6 +1290,7 @@ int do_reserve(hdrtv_ctx *c, int H, int W)
         const int Hp = s.Hp, Wp = s.Wp;
         ws_add(c, "hg.img", 3, Hp, Wp, 1); ws_add(c, "hg.mask", 1, Hp, Wp, 4);
         ws_add(c, "hg.part", 4, Hp, Wp, 3);
+        ws_add(c, "hg.part2", 4, Hp, Wp, 3);        // conv10's second half (over conv1), left by conv1's kernel
         if (!c->hg_i8) {
             ws_add(c, "hg.p1", 64, Hp / 2, Wp / 2, 0);
             ws_add(c, "hg.conv2", 128, Hp / 2, Wp / 2, 0); ws_add(c, "hg.up4", 128, Hp / 2, Wp / 2, 0);
@@ -1518,13 +1519,14 @@ struct Seq {
         chk(conv_q8_launch(p, s), key.c_str(), tag, macs, bytes);
     }
     void c3(const std::string &key, const f16 *in, int H, int W, int act, f16 *out, f16 *out_pool, float pool_q_inv = 0.f,
-            float pool_q_zero = 0.f)
+            float pool_q_zero = 0.f, const f16 *w2frag = nullptr, float *part2 = nullptr)
     {
         if (!ok()) return;
         const C3Layer &L = c->c3.at(key);
         chk(conv_c3_launch(in, H, W, wtp<f16>(c, L.wfrag), wtp<float>(c, L.scale), wtp<float>(c, L.shift), L.cout, act, out,
-                           out_pool, c->n_cu, s, pool_q_inv, pool_q_zero), key.c_str(), L.cout == 64 ? "conv_c3<64>" : "conv_c3<32>", (double)H * W * 27 * L.cout,
-            (double)H * W * (6.0 + 2.0 * L.cout * (out_pool ? 1.25 : 1.0)));
+                           out_pool, c->n_cu, s, pool_q_inv, pool_q_zero, w2frag, part2), key.c_str(),
+            part2 ? "conv_c3<64,dot3>" : (L.cout == 64 ? "conv_c3<64>" : "conv_c3<32>"), (double)H * W * (27 * L.cout + (part2 ? 192 : 0)),
+            (double)H * W * (6.0 + (out ? 2.0 * L.cout : 0.0) + (out_pool ? (pool_q_inv > 0.f ? 0.25 : 0.5) * L.cout : 0.0) + (part2 ? 16.0 : 0.0)));
     }
     // persistent 32-channel 3x3 conv, optionally with the SFT layer `sft_key` fused in front (conv32p.hip)
     void conv32(const std::string &key, const f16 *src, const f16 *cond, const std::string &sft_key, int H, int W, int act,
@@ -1837,11 +1839,17 @@ int run_hg(hdrtv_ctx *c, Seq &q, const f16 *base, void *out, int out_f32)
     uint8_t *mask = wsp<uint8_t>(c, "hg.mask");
     q.chk(hg_prep_launch(base, s.H, s.W, Hp, Wp, img, mask, c->mask_r, 0.1f, q.s), "hg_prep", "hg_prep", 0.0, 13.0 * Hp * Wp);
     float *part = wsp<float>(c, "hg.part");
-    // conv1: only the pooled map is kept (conv1_out is recomputed in hg_final_fused)
+    // conv1: only the pooled map is kept; its kernel also leaves conv10's second half (the 64 -> 3 sums over conv1's channels) per
+    // pixel, so the tail is a per-pixel kernel.  HDRTV_FINAL_RECOMPUTE=1 (developer A/B switch, read per launch): the tail
+    // recomputes conv1 instead (hg_final_fused) -- same arithmetic, same results.
+    const char *fr_env = getenv("HDRTV_FINAL_RECOMPUTE");
+    const bool light = !(fr_env && atoi(fr_env));
+    float *part2 = light ? wsp<float>(c, "hg.part2") : nullptr;
+    const f16 *w2frag = light ? wtp<f16>(c, c->hgf_wfrag) + 6 * 64 * 8 : nullptr;      // fragments 6..9 of the tail's set
     if (c->hg_i8) {
         int8_t *p1q = wsp<int8_t>(c, "hg8.p1");
         // the fp16 -> int8 boundary costs no pass of its own: conv1 stores the codes its reader conv2 wants
-        q.c3("hg.conv1", img, Hp, Wp, ACT_RELU, nullptr, reinterpret_cast<f16 *>(p1q), c->hg_q0_inv, c->hg_q0_zero);
+        q.c3("hg.conv1", img, Hp, Wp, ACT_RELU, nullptr, reinterpret_cast<f16 *>(p1q), c->hg_q0_inv, c->hg_q0_zero, w2frag, part2);
         // W8A8 checkpoint: conv2 .. conv9 on int8 MFMA, every activation between conv1 and conv9 one int8 tensor
         int8_t *c2q = wsp<int8_t>(c, "hg8.conv2"), *p3 = wsp<int8_t>(c, "hg8.p3"), *c3 = wsp<int8_t>(c, "hg8.conv3_2"),
                *p4 = wsp<int8_t>(c, "hg8.p4"), *c4 = wsp<int8_t>(c, "hg8.conv4_2"), *p5 = wsp<int8_t>(c, "hg8.p5"),
@@ -1870,7 +1878,7 @@ int run_hg(hdrtv_ctx *c, Seq &q, const f16 *base, void *out, int out_f32)
         q.conv8("hg.Up_conv5", c9q, 64, nullptr, 0, Hp / 2, Wp / 2, ST_PS_DOT3, nullptr, 64, Hp, Wp, wtp<float>(c, c->hg_w10a), part);
     } else {
         f16 *p1 = wsp<f16>(c, "hg.p1"), *c2 = wsp<f16>(c, "hg.conv2"), *u4 = wsp<f16>(c, "hg.up4"), *c9 = wsp<f16>(c, "hg.conv9");
-        q.c3("hg.conv1", img, Hp, Wp, ACT_RELU, nullptr, p1);
+        q.c3("hg.conv1", img, Hp, Wp, ACT_RELU, nullptr, p1, 0.f, 0.f, w2frag, part2);
         q.conv("hg.conv2", p1, 64, nullptr, 0, Hp / 2, Wp / 2, ACT_RELU, ST_NHWC, c2, 128, Hp / 2, Wp / 2);
         f16 *p3 = wsp<f16>(c, "hg.p3"), *c3 = wsp<f16>(c, "hg.conv3_2"), *p4 = wsp<f16>(c, "hg.p4"), *c4 = wsp<f16>(c, "hg.conv4_2"),
             *p5 = wsp<f16>(c, "hg.p5"), *c5 = wsp<f16>(c, "hg.conv5_2"), *pc = wsp<f16>(c, "hg.pc"), *code = wsp<f16>(c, "hg.conv_code2");
@@ -1904,8 +1912,12 @@ int run_hg(hdrtv_ctx *c, Seq &q, const f16 *base, void *out, int out_f32)
     fa.b10 = wtp<float>(c, c->f32v.at("hg.b10"));
     fa.wl = wtp<float>(c, c->f32v.at("hg.wl")); fa.bl = wtp<float>(c, c->f32v.at("hg.bl"));
     fa.out = out; fa.out_f32 = out_f32; fa.H = s.H; fa.W = s.W; fa.Hp = Hp; fa.Wp = Wp;
-    q.chk(hg_final_fused_launch(fa, c->n_cu, q.s), "hg_final", "hg_final_fused", (double)Hp * Wp * (128 * 3 + 6 * 3),
-          (double)s.H * s.W * (6 + 1 + 16 + 3 * (out_f32 ? 4 : 2)));
+    if (light)
+        q.chk(hg_final_light_launch(fa, part2, q.s), "hg_final", "hg_final_light", (double)s.H * s.W * 6 * 3,
+              (double)s.H * s.W * (6 + 1 + 32 + 3 * (out_f32 ? 4 : 2)));
+    else
+        q.chk(hg_final_fused_launch(fa, c->n_cu, q.s), "hg_final", "hg_final_fused", (double)Hp * Wp * (128 * 3 + 6 * 3),
+              (double)s.H * s.W * (6 + 1 + 16 + 3 * (out_f32 ? 4 : 2)));
     return q.rc;
 }
 

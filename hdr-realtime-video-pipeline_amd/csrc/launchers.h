@@ -51,7 +51,8 @@ hipError_t agcm_fold_launch(const AgcmFoldArgs &a, f16 *frags, float *biasbuf, h
 hipError_t agcm_mlp_launch(const f16 *in, f16 *out, size_t npix, const f16 *frags, const float *biasbuf, hipStream_t s);
 
 hipError_t conv_c3_launch(const f16 *in, int H, int W, const f16 *wfrag, const float *scale, const float *shift, int cout,
-                          int act, f16 *out, f16 *out_pool, int n_cu, hipStream_t s, float pool_q_inv = 0.f, float pool_q_zero = 0.f);
+                          int act, f16 *out, f16 *out_pool, int n_cu, hipStream_t s, float pool_q_inv = 0.f, float pool_q_zero = 0.f,
+                          const f16 *w2frag = nullptr, float *part2 = nullptr);   // HG.conv1: + conv10's second half per pixel (f32 [H][W][4])
 // LE.conv_first as a W8A8 layer: int8 A fragments [2][64 lanes][16 B] (K = (ky | kx4, c4)), scale[32], shift[16 border classes][32]
 hipError_t conv_c3_q8_launch(const f16 *in, int H, int W, const int8_t *wq, const float *scale, const float *shift, float q_inv,
                              float q_zoff, int act, f16 *out, int n_cu, hipStream_t s);
@@ -98,6 +99,8 @@ struct HgFinalFusedArgs {
     int out_f32, H, W, Hp, Wp;
 };
 hipError_t hg_final_fused_launch(const HgFinalFusedArgs &a, int n_cu, hipStream_t s);
+// the same tail when conv_c3_launch(..., w2frag, part2) has left conv10's second half per pixel: a per-pixel kernel (a.wfrag, scale, shift unused)
+hipError_t hg_final_light_launch(const HgFinalFusedArgs &a, const float *part2, hipStream_t s);
 hipError_t letterbox_launch(const LetterboxParams &p, hipStream_t s);
 hipError_t metrics_launch(const MetricsParams &p, hipStream_t s);
 int metrics_blocks(int H, int W);

@@ -62,12 +62,18 @@ __device__ __forceinline__ void c3_stage(const C3Pre &pre, f16x4 *s_px, int tid)
     }
 }
 
-template <int COUT>
+// DOT (HG.conv1 only): besides the pooled map the kernel leaves, per pixel, the three partial sums of conv10's second half
+// (1x1 over conv1's 64 channels, Hallucination_arch.py:130-133) in part2 [H][W][4] f32 -- the f16 activations, as they lie in the
+// accumulator registers, are the B operand of four MFMAs against the k-permuted weight fragments w2frag (the chain
+// hg_final_fused recomputes conv1 for); with them the HG tail (hg_final_light) is a per-pixel kernel.
+template <int COUT, bool DOT = false>
 __global__ __launch_bounds__(256) void conv_c3_kernel(const f16 *__restrict__ in, int H, int W, const f16 *__restrict__ wfrag,
                                                       const float *__restrict__ scale, const float *__restrict__ shift,
                                                       int act, f16 *__restrict__ out, f16 *__restrict__ out_pool, float pool_q_inv,
-                                                      float pool_q_zero)
+                                                      float pool_q_zero, const f16 *__restrict__ w2frag = nullptr,
+                                                      float *__restrict__ part2 = nullptr)
 {
+    static_assert(!DOT || COUT == 64, "the fused conv10 half belongs to HG.conv1");
     constexpr int MT = COUT / 32;
     constexpr int ROWB = COUT * 2 + 16;
     __shared__ __attribute__((aligned(16))) f16x4 s_px[C3_HH * C3_PW];
@@ -76,6 +82,8 @@ __global__ __launch_bounds__(256) void conv_c3_kernel(const f16 *__restrict__ in
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int tiles_x = (W + C3_TW - 1) / C3_TW, ntiles = tiles_x * ((H + C3_TH - 1) / C3_TH);
     if (tid < COUT) { s_ss[tid] = scale[tid]; s_ss[COUT + tid] = shift[tid]; }
+    __shared__ __attribute__((aligned(16))) f16x8 s_w2[DOT ? 4 * 64 : 1];      // read at use: the kernel lives on 3 workgroups per CU
+    if constexpr (DOT) s_w2[tid] = reinterpret_cast<const f16x8 *>(w2frag)[tid];
     f16x8 wf[MT][3];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -95,6 +103,36 @@ __global__ __launch_bounds__(256) void conv_c3_kernel(const f16 *__restrict__ in
     __syncthreads();
     if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
     f32x16 acc[MT][2];
+    // one row's epilogue (DOT): its 64 f16 activations go to the staging tile and, as they lie in the registers, into the four B
+    // fragments of conv10's second half.  Run right behind the row's conv MFMAs, so that only one row of accumulators is live:
+    // the kernel must stay under 168 VGPRs for its three workgroups per CU.
+    auto dot_row = [&](int j) __attribute__((always_inline)) {
+        const int q = (2 * wave + j) * C3_TW + l31;
+        f16x8 bf[4];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int cl = i * 32 + 8 * qd + 4 * lh;
+                const float4 sc = *reinterpret_cast<const float4 *>(s_ss + cl);
+                const float4 sh = *reinterpret_cast<const float4 *>(s_ss + COUT + cl);
+                f16x4 o;
+                o[0] = (f16)act_fast(acc[i][j][4 * qd + 0] * sc.x + sh.x, aslope);
+                o[1] = (f16)act_fast(acc[i][j][4 * qd + 1] * sc.y + sh.y, aslope);
+                o[2] = (f16)act_fast(acc[i][j][4 * qd + 2] * sc.z + sh.z, aslope);
+                o[3] = (f16)act_fast(acc[i][j][4 * qd + 3] * sc.w + sh.w, aslope);
+                *reinterpret_cast<f16x4 *>(s_out + q * ROWB + cl * 2) = o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) bf[2 * i + (qd >> 1)][4 * (qd & 1) + k] = o[k];
+            }
+        f32x16 o3;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) o3[k] = 0.f;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) o3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w2[s4 * 64 + lane], bf[s4], o3, 0, 0, 0);
+        const int y = oy0 + 2 * wave + j, x = ox0 + l31;
+        if (lh == 0 && y < H && x < W) *reinterpret_cast<float4 *>(part2 + ((size_t)y * W + x) * 4) = make_float4(o3[0], o3[1], o3[2], 0.f);
+    };
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int row = 2 * wave + j;
@@ -108,25 +146,31 @@ __global__ __launch_bounds__(256) void conv_c3_kernel(const f16 *__restrict__ in
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i][ky], xf[ky], acc[i][j], 0, 0, 0);
         }
-    }
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-            const int cl = i * 32 + 8 * qd + 4 * lh;
-            const float4 sc = *reinterpret_cast<const float4 *>(s_ss + cl);
-            const float4 sh = *reinterpret_cast<const float4 *>(s_ss + COUT + cl);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int q = (2 * wave + j) * C3_TW + l31;
-                f16x4 o;
-                o[0] = (f16)act_fast(acc[i][j][4 * qd + 0] * sc.x + sh.x, aslope);
-                o[1] = (f16)act_fast(acc[i][j][4 * qd + 1] * sc.y + sh.y, aslope);
-                o[2] = (f16)act_fast(acc[i][j][4 * qd + 2] * sc.z + sh.z, aslope);
-                o[3] = (f16)act_fast(acc[i][j][4 * qd + 3] * sc.w + sh.w, aslope);
-                *reinterpret_cast<f16x4 *>(s_out + q * ROWB + cl * 2) = o;
-            }
+        if constexpr (DOT) {
+            dot_row(j);
+            __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    if constexpr (!DOT) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int cl = i * 32 + 8 * qd + 4 * lh;
+                const float4 sc = *reinterpret_cast<const float4 *>(s_ss + cl);
+                const float4 sh = *reinterpret_cast<const float4 *>(s_ss + COUT + cl);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int q = (2 * wave + j) * C3_TW + l31;
+                    f16x4 o;
+                    o[0] = (f16)act_fast(acc[i][j][4 * qd + 0] * sc.x + sh.x, aslope);
+                    o[1] = (f16)act_fast(acc[i][j][4 * qd + 1] * sc.y + sh.y, aslope);
+                    o[2] = (f16)act_fast(acc[i][j][4 * qd + 2] * sc.z + sh.z, aslope);
+                    o[3] = (f16)act_fast(acc[i][j][4 * qd + 3] * sc.w + sh.w, aslope);
+                    *reinterpret_cast<f16x4 *>(s_out + q * ROWB + cl * 2) = o;
+                }
+            }
+    }
     __syncthreads();
     constexpr int CPP = COUT / 8;
     for (int e = tid; e < C3_TH * C3_TW * CPP; e += 256) {
@@ -393,6 +437,71 @@ __global__ __launch_bounds__(256) void hg_final_fused_kernel(HgFinalFusedParams 
     }   // tile loop
 }
 
+// ============================================================================ hg_final_light
+// The HG tail when conv1's kernel has already left conv10's second half per pixel (conv_c3<64, DOT>): per pixel
+//   conv10 = f16((part2 + part) + b10), conv_last over cat(conv10, img) rounded to f16, out = mask * that + img, cropped
+// (Hallucination_arch.py:130-137, HG_Composite_arch.py:103) -- the same expressions, in the same order, as hg_final_fused.
+struct HgFinalLightParams {
+    const f16 *img;        // planar f16 [3][Hp][Wp]
+    const uint8_t *mask;   // [Hp][Wp]
+    const float *part, *part2;    // f32 [Hp][Wp][4]: conv10 over Up_conv5's / conv1's 64 channels
+    const float *b10, *wl, *bl;
+    void *out;
+    int out_f32, H, W, Hp, Wp;
+};
+
+__global__ __launch_bounds__(256) void hg_final_light_kernel(HgFinalLightParams p)
+{
+    const int nx = (p.W + 3) >> 2;
+    const size_t total = (size_t)p.H * nx, plane_i = (size_t)p.Hp * p.Wp, plane_o = (size_t)p.H * p.W;
+    float b10[3], wl[18], bl[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { b10[k] = p.b10[k]; bl[k] = p.bl[k]; }
+#pragma unroll
+    for (int k = 0; k < 18; ++k) wl[k] = p.wl[k];
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int y = (int)(e / nx), x0 = (int)(e - (size_t)y * nx) * 4;
+        const size_t pix = (size_t)y * p.Wp + x0;          // Wp is a multiple of 32: the four pixels exist in every padded tensor
+        float4 pt[4], p2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { pt[k] = reinterpret_cast<const float4 *>(p.part)[pix + k]; p2[k] = reinterpret_cast<const float4 *>(p.part2)[pix + k]; }
+        f16x4 iv[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) iv[ch] = *reinterpret_cast<const f16x4 *>(p.img + ch * plane_i + pix);
+        const uint32_t m4 = *reinterpret_cast<const uint32_t *>(p.mask + pix);
+        float res[3][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float c10[3] = {(float)(f16)(p2[k].x + pt[k].x + b10[0]), (float)(f16)(p2[k].y + pt[k].y + b10[1]),
+                                  (float)(f16)(p2[k].z + pt[k].z + b10[2])};
+            const float im[3] = {(float)iv[0][k], (float)iv[1][k], (float)iv[2][k]};
+            const float m = (float)((m4 >> (8 * k)) & 0xff);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                float v = bl[ch];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) v += wl[ch * 6 + t] * c10[t] + wl[ch * 6 + 3 + t] * im[t];
+                v = (float)(f16)v;
+                res[ch][k] = m * v + im[ch];
+            }
+        }
+        const size_t oo = (size_t)y * p.W + x0;
+        const bool vec = (p.W & 3) == 0;                    // then x0 + 3 < W and the row starts are 16-byte (f32) / 8-byte (f16) aligned
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            if (p.out_f32) {
+                float *d = reinterpret_cast<float *>(p.out) + ch * plane_o + oo;
+                if (vec) *reinterpret_cast<float4 *>(d) = make_float4(res[ch][0], res[ch][1], res[ch][2], res[ch][3]);
+                else for (int k = 0; k < 4 && x0 + k < p.W; ++k) d[k] = res[ch][k];
+            } else {
+                f16 *d = reinterpret_cast<f16 *>(p.out) + ch * plane_o + oo;
+                if (vec) *reinterpret_cast<f16x4 *>(d) = f16x4{(f16)res[ch][0], (f16)res[ch][1], (f16)res[ch][2], (f16)res[ch][3]};
+                else for (int k = 0; k < 4 && x0 + k < p.W; ++k) d[k] = (f16)res[ch][k];
+            }
+        }
+    }
+}
+
 inline int grid_for(size_t n, int per_block)
 {
     size_t g = (n + per_block - 1) / per_block;
@@ -404,23 +513,31 @@ inline int grid_for(size_t n, int per_block)
 }  // namespace
 
 hipError_t conv_c3_launch(const f16 *in, int H, int W, const f16 *wfrag, const float *scale, const float *shift, int cout,
-                          int act, f16 *out, f16 *out_pool, int n_cu, hipStream_t s, float pool_q_inv, float pool_q_zero)
+                          int act, f16 *out, f16 *out_pool, int n_cu, hipStream_t s, float pool_q_inv, float pool_q_zero,
+                          const f16 *w2frag, float *part2)
 {
+    if ((w2frag != nullptr) != (part2 != nullptr) || (part2 && cout != 64)) return hipErrorInvalidValue;
     const int ntiles = ((W + C3_TW - 1) / C3_TW) * ((H + C3_TH - 1) / C3_TH);
     // persistent: as many workgroups as are resident at once (registers: 3 / 2 per CU today), one round
-    static int occ[2] = {0, 0};
-    int &per_cu = occ[cout == 64];
+    static int occ[3] = {0, 0, 0};
+    int &per_cu = occ[part2 ? 2 : (cout == 64)];
     if (per_cu == 0) {
         int nb = 0;
         const hipError_t e = cout == 32 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_c3_kernel<32>, 256, 0)
-                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_c3_kernel<64>, 256, 0);
+                           : part2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_c3_kernel<64, true>, 256, 0)
+                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_c3_kernel<64>, 256, 0);
         per_cu = (e == hipSuccess && nb >= 1) ? nb : 2;
     }
     const dim3 grid(ntiles < per_cu * n_cu ? ntiles : per_cu * n_cu);
     if (cout == 32)
-        hipLaunchKernelGGL(conv_c3_kernel<32>, grid, dim3(256), 0, s, in, H, W, wfrag, scale, shift, act, out, out_pool, pool_q_inv, pool_q_zero);
+        hipLaunchKernelGGL(conv_c3_kernel<32>, grid, dim3(256), 0, s, in, H, W, wfrag, scale, shift, act, out, out_pool, pool_q_inv, pool_q_zero,
+                           (const f16 *)nullptr, (float *)nullptr);
+    else if (cout == 64 && part2)
+        hipLaunchKernelGGL((conv_c3_kernel<64, true>), grid, dim3(256), 0, s, in, H, W, wfrag, scale, shift, act, out, out_pool, pool_q_inv, pool_q_zero,
+                           w2frag, part2);
     else if (cout == 64)
-        hipLaunchKernelGGL(conv_c3_kernel<64>, grid, dim3(256), 0, s, in, H, W, wfrag, scale, shift, act, out, out_pool, pool_q_inv, pool_q_zero);
+        hipLaunchKernelGGL(conv_c3_kernel<64>, grid, dim3(256), 0, s, in, H, W, wfrag, scale, shift, act, out, out_pool, pool_q_inv, pool_q_zero,
+                           (const f16 *)nullptr, (float *)nullptr);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();
@@ -446,6 +563,16 @@ hipError_t hg_prep_launch(const f16 *base, int H, int W, int Hp, int Wp, f16 *im
 {
     hipLaunchKernelGGL(hg_prep_kernel, dim3(grid_for((size_t)Hp * Wp, 256)), dim3(256), 0, s, base, H, W, Hp, Wp, img_pad,
                        mask, r, thresh);
+    return hipGetLastError();
+}
+
+hipError_t hg_final_light_launch(const HgFinalFusedArgs &a, const float *part2, hipStream_t s)
+{
+    if (!part2 || (a.Wp & 31) || a.W > a.Wp || a.H > a.Hp) return hipErrorInvalidValue;
+    HgFinalLightParams p;
+    p.img = a.img; p.mask = a.mask; p.part = a.part; p.part2 = part2; p.b10 = a.b10; p.wl = a.wl; p.bl = a.bl;
+    p.out = a.out; p.out_f32 = a.out_f32; p.H = a.H; p.W = a.W; p.Hp = a.Hp; p.Wp = a.Wp;
+    hipLaunchKernelGGL(hg_final_light_kernel, dim3(grid_for((size_t)a.H * ((a.W + 3) / 4), 256)), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

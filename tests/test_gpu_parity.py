@@ -558,3 +558,37 @@ def test_private_weight_conv_schedule_is_bit_identical(torch_cuda, golden_dir, m
     finally:
         monkeypatch.delenv("HDRTV_PRW", raising=False)
         p.close()
+
+
+@pytest.mark.gpu
+def test_hg_tail_variants_are_bit_identical(torch_cuda, golden_dir, monkeypatch):
+    """The HG tail (conv10's second half over conv1, conv_last, mask blend; Hallucination_arch.py:130-137): by default conv1's
+    kernel leaves the 64 -> 3 sums per pixel (conv_c3<64,dot3>) and a per-pixel kernel finishes (hg_final_light);
+    HDRTV_FINAL_RECOMPUTE=1 recomputes conv1 inside the tail (hg_final_fused).  Same fragments, same expressions in the same order:
+    the outputs agree bit for bit -- at 4K, at 1080p, at a width that is not a multiple of 4 (scalar stores) and at a size with
+    fewer tiles than workgroups; fp16 and W8A8 HG heads."""
+    from hdrtv_mi355x import weights as W
+    from hdrtv_mi355x.processor import HDRTVNetMI355X
+    torch = torch_cuda
+    for hgw in ("seeded:1234", "seeded-w8a8:1234"):
+        p = HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), use_hg=True, hg_weights=hgw, warmup_passes=0)
+        try:
+            for (h, w), seed in (((2160, 3840), 81), ((1080, 1920), 82), ((97, 131), 83), ((64, 96), 84)):
+                f = W.synthetic_frame(h, w, seed=seed, kind="gradient")
+                res = {}
+                for mode in ("1", "0"):
+                    monkeypatch.setenv("HDRTV_FINAL_RECOMPUTE", mode)
+                    out, _ = p.infer(p.preprocess(f))
+                    p.profile_enable(True)
+                    p.infer(p.preprocess(f))
+                    kern = [k for _, k, _, _, _ in p.profile_read()]
+                    p.profile_enable(False)
+                    assert ("hg_final_fused" in kern) == (mode == "1") and ("hg_final_light" in kern) == (mode == "0"), kern
+                    assert ("conv_c3<64,dot3>" in kern) == (mode == "0"), kern
+                    res[mode] = (out.clone(), p._tap_device("hg.p1" if "w8a8" not in hgw else "hg8.p1").clone())
+                assert torch.isfinite(res["0"][0]).all()
+                assert torch.equal(res["0"][0], res["1"][0]), (hgw, h, w, (res["0"][0] - res["1"][0]).abs().max().item())
+                assert torch.equal(res["0"][1], res["1"][1]), (hgw, h, w)
+        finally:
+            monkeypatch.delenv("HDRTV_FINAL_RECOMPUTE", raising=False)
+            p.close()

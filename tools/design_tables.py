@@ -18,7 +18,9 @@ what = {'conv_prw<pool>': ('HG conv3_1, conv4_1, conv5_1 (+ 2x2 max-pool)', 'MFM
         'conv32p<4,plain>': ('LE up-convs (32→128 + PixelShuffle)', 'HBM'), 'le_cond_trunk': ('LE cond_first (3 layers) + CondNet1 (3 layers), chained in registers', 'HBM (1.3 GB of writes)'),
         'conv32s<1,c3+sft>': ('LE conv_first + SFT_layer1 + HR_conv1 in one launch', 'HBM / latency'), 'conv_t16<32,3,2>': ('LE stride-2 down-convs', 'HBM'),
         'conv32s<1,plain>': ('LE conv_last (32→3, planar out + residual)', 'HBM'), 'hg_final_fused': ('HG tail: conv1 recompute, conv10 second half, conv_last, mask blend', 'latency (LDS gathers)'),
-        'conv_c3<64>': ('HG conv1 (3→64), only the 2×2-pooled map is written (317 MB)', 'latency (LDS gathers)'), 'conv3x3s2_preg<64>': ('LE CondNet3.2 / CondNet4.2', 'HBM'),
+        'conv_c3<64>': ('HG conv1 (3→64), only the 2×2-pooled map is written (317 MB)', 'latency (LDS gathers)'),
+        'conv_c3<64,dot3>': ('HG conv1 (3→64): the 2×2-pooled map + conv10\'s second half per pixel (64→3 sums as MFMAs on the f16 activations in registers)', 'latency (LDS gathers)'),
+        'hg_final_light': ('HG tail per pixel: conv10 = f16(part + part2 + b), conv_last, mask blend', 'HBM'), 'conv3x3s2_preg<64>': ('LE CondNet3.2 / CondNet4.2', 'HBM'),
         'agcm_mlp': ('AGCM per-pixel 3→64→64→3', 'MFMA (small)'), 'cls_block': ('AGCM classifier blocks (5)', 'latency'), 'cond_tail': ('LE CondNet2.{2,4}', 'HBM'),
         'cls_stats': ('InstanceNorm statistics (5)', 'latency'), 'conv_igemm<32,32,3,2>': ('LE CondNet4.4', 'latency'), 'hg_prep': ('HG mask + reflect pad', 'HBM'),
         'conv_igemm<64,32,1,1>': ('LE CondNet3.4', 'latency'), 'agcm_fold': ('GFM fold into per-frame MLP weights', 'latency')}
