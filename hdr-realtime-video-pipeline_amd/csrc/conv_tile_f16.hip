@@ -22,14 +22,22 @@ __global__ __launch_bounds__(256, 4) void conv_t16_kernel(ConvParams p)
     char *sX = smem;                                           // [NPX][32] f16, chunk-swizzled
     float *sS = reinterpret_cast<float *>(smem + ((NPX * ROWB + 255) & ~255)); // scale[32], shift[32]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-    const int tiles_x = (p.Wo + TT_TW - 1) / TT_TW;
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int tiles_x = (p.Wo + TT_TW - 1) / TT_TW, ntiles = tiles_x * ((p.Ho + TT_TH - 1) / TT_TH);
+    // 16 of the 18 A fragments live in registers; the last tap's two sit in LDS (the same for every wave) and are read per tile:
+    // with all 72 weight registers live the kernel spills at the 128 VGPRs its four workgroups per CU allow
+    f16x8 wv[16];
+#pragma unroll
+    for (int st = 0; st < 16; ++st) wv[st] = *reinterpret_cast<const f16x8 *>(p.wpk + (size_t)((st >> 1) * 32 + l31) * TT_CIN + ((st & 1) * 2 + lh) * 8);
+    f16x8 *sW8 = reinterpret_cast<f16x8 *>(reinterpret_cast<char *>(sS) + 256);
+    if (tid < 128) sW8[tid] = *reinterpret_cast<const f16x8 *>(p.wpk + (size_t)(8 * 32 + (tid & 31)) * TT_CIN + ((tid >> 6) * 2 + ((tid >> 5) & 1)) * 8);
+    if (tid < 64) sS[tid] = tid < 32 ? p.scale[tid] : p.shift[tid - 32];
+    // persistent over tiles: the 72 weight registers are loaded once per workgroup, not once per tile (18 KiB per wave against a
+    // 36-KiB halo patch: per-tile workgroups moved twice the payload in weights)
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
     const int oy0 = ty * TT_TH, ox0 = tx * TT_TW;
     const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
-    f16x8 wv[18];
-#pragma unroll
-    for (int st = 0; st < 18; ++st) wv[st] = *reinterpret_cast<const f16x8 *>(p.wpk + (size_t)((st >> 1) * 32 + l31) * TT_CIN + ((st & 1) * 2 + lh) * 8);
-    if (tid < 64) sS[tid] = tid < 32 ? p.scale[tid] : p.shift[tid - 32];
+    if (t != (int)blockIdx.x) __syncthreads();                 // the previous tile's fragment reads are done
     for (int e = tid; e < NPX * TT_NCH; e += 256) {
         const int hp = e >> 2, ch = e & 3;
         const int hy = hp / HWD, hx = hp - hy * HWD;
@@ -53,8 +61,9 @@ __global__ __launch_bounds__(256, 4) void conv_t16_kernel(ConvParams p)
         for (int ks = 0; ks < 2; ++ks) {
             const int ch = ks * 2 + lh;
             const f16x8 xv = *reinterpret_cast<const f16x8 *>(sX + hp * ROWB + ((ch ^ tsw(hp)) << 4));
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[tap * 2 + ks], xv, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tap < 8 ? wv[(tap < 8 ? tap : 0) * 2 + ks] : sW8[ks * 64 + lane], xv, acc, 0, 0, 0);
         }
+        if (tap % 3 == 2) __builtin_amdgcn_sched_barrier(0);   // fragment reads at most a kernel row ahead: 72 weight registers are live
     }
     const int oy = oy0 + qy, ox = ox0 + qx;
     if (oy < p.Ho && ox < p.Wo) {
@@ -69,25 +78,27 @@ __global__ __launch_bounds__(256, 4) void conv_t16_kernel(ConvParams p)
             *reinterpret_cast<f16x4 *>(p.dst + ((size_t)oy * p.Wo + ox) * p.dstC + n) = o;
         }
     }
+    }   // tile loop
 }
 
 }  // namespace
 
 // 3x3 / stride 2 / pad 1, 32 -> 32 (CoutPad == 32), weights [9][32][32] f16 (pack_conv with cin_t = 32), NHWC in and out
-hipError_t conv_t16_launch(ConvParams p, hipStream_t s)
+hipError_t conv_t16_launch(ConvParams p, hipStream_t s, int n_cu)
 {
     if (p.c0 != 32 || p.c1 != 0 || p.CoutPad != 32 || (p.s0_stride % 8) || (p.dstC % 4) || p.mode != ST_NHWC || p.res1 || p.res2 ||
         p.Ho != (p.Hi - 1) / 2 + 1 || p.Wo != (p.Wi - 1) / 2 + 1)
         return hipErrorInvalidValue;
     constexpr int NPX = 17 * 33;
-    const int smem = ((NPX * 64 + 255) & ~255) + 256;
+    const int smem = ((NPX * 64 + 255) & ~255) + 256 + 2048;       // halo patch, scale / shift, the last tap's two A fragments
     static DevOnce attr_once;   // hipFuncSetAttribute is per (function, device)
     if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_t16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return e;
         attr_once.done();
     }
-    const int grid = ((p.Wo + TT_TW - 1) / TT_TW) * ((p.Ho + TT_TH - 1) / TT_TH);
+    const int ntiles = ((p.Wo + TT_TW - 1) / TT_TW) * ((p.Ho + TT_TH - 1) / TT_TH);
+    const int grid = ntiles < 4 * n_cu ? ntiles : 4 * n_cu;       // four workgroups per CU are resident (LDS 36 KiB, <= 128 VGPRs)
     hipLaunchKernelGGL(conv_t16_kernel<2>, dim3(grid), dim3(256), smem, s, p);
     return hipGetLastError();
 }

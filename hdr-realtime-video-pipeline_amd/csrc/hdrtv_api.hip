@@ -1437,7 +1437,7 @@ struct Seq {
                                               : (mode == ST_PLANAR3 ? 3.0 * Hd * Wd
                                                                     : (mode == ST_PS_DOT3 ? 8.0 * Hd * Wd : (double)p.Ho * p.Wo * L.cout));
         bytes += 2.0 * outel * (1 + (res1 ? 1 : 0) + (res2 ? 1 : 0) + (res_planar ? 1 : 0));
-        chk(t16 ? conv_t16_launch(p, s) : s2g ? conv3x3s2_preg_launch(p, c->n_cu, s)
+        chk(t16 ? conv_t16_launch(p, s, c->n_cu) : s2g ? conv3x3s2_preg_launch(p, c->n_cu, s)
                 : (pglds ? (prw ? conv_prw_launch(p, prw_th, c->n_cu, s) : conv_pglds_launch(p, c->n_cu, s))
                          : (glds1 ? conv_glds1_launch(p, s, c->n_cu) : conv_igemm_launch(p, L.cin_t, L.bn, L.ks, L.stride, s))),
             key.c_str(), tag, macs, bytes);
