@@ -20,7 +20,8 @@ __global__ __launch_bounds__(256, 4) void conv_t16_kernel(ConvParams p)
     constexpr int HH = (TT_TH - 1) * S + 3, HWD = (TT_TW - 1) * S + 3, NPX = HH * HWD, ROWB = TT_CIN * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *sX = smem;                                           // [NPX][32] f16, chunk-swizzled
-    float *sS = reinterpret_cast<float *>(smem + ((NPX * ROWB + 255) & ~255)); // scale[32], shift[32]
+    constexpr int NPIECE = (NPX * TT_NCH + 63) / 64;           // the patch as whole 1-KiB LDS-DMA pieces (the last one part-filled)
+    float *sS = reinterpret_cast<float *>(smem + NPIECE * 1024); // scale[32], shift[32]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int tiles_x = (p.Wo + TT_TW - 1) / TT_TW, ntiles = tiles_x * ((p.Ho + TT_TH - 1) / TT_TH);
     // 16 of the 18 A fragments live in registers; the last tap's two sit in LDS (the same for every wave) and are read per tile:
@@ -33,21 +34,32 @@ __global__ __launch_bounds__(256, 4) void conv_t16_kernel(ConvParams p)
     if (tid < 64) sS[tid] = tid < 32 ? p.scale[tid] : p.shift[tid - 32];
     // persistent over tiles: the 72 weight registers are loaded once per workgroup, not once per tile (18 KiB per wave against a
     // 36-KiB halo patch: per-tile workgroups moved twice the payload in weights)
+    // The halo patch is staged by LDS-DMA (buffer_load ... lds: no VGPR staging, no address arithmetic per tile beyond one
+    // base): piece = 64 consecutive 16-byte LDS slots, slot q holds chunk (q & 3) ^ tsw(q >> 2) of halo pixel q >> 2.  The
+    // Out-of-image lanes (zero padding) get an offset beyond the resource and the DMA writes zeros for them.
+    constexpr int PPW = (NPIECE + 3) / 4;
+    const dma_rsrc_t rsrc = dma_rsrc(p.src0, (unsigned)p.Hi * (unsigned)p.Wi * (unsigned)p.s0_stride * 2u);
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int ty = t / tiles_x, tx = t - ty * tiles_x;
     const int oy0 = ty * TT_TH, ox0 = tx * TT_TW;
     const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
     if (t != (int)blockIdx.x) __syncthreads();                 // the previous tile's fragment reads are done
-    for (int e = tid; e < NPX * TT_NCH; e += 256) {
-        const int hp = e >> 2, ch = e & 3;
-        const int hy = hp / HWD, hx = hp - hy * HWD;
-        const int iy = iy0 + hy, ix = ix0 + hx;
-        f16x8 v;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = (f16)0.f;           // zero padding
-        if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi)
-            v = *reinterpret_cast<const f16x8 *>(p.src0 + ((size_t)iy * p.Wi + ix) * p.s0_stride + ch * 8);
-        *reinterpret_cast<f16x8 *>(sX + hp * ROWB + ((ch ^ tsw(hp)) << 4)) = v;
+    {
+        const unsigned base = (unsigned)((iy0 * p.Wi + ix0) * p.s0_stride) * 2u;     // may wrap below zero; in-image lanes land >= 0
+        const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + HH <= p.Hi && ix0 + HWD <= p.Wi;     // workgroup-uniform
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                           // opaque copy: keeps the nine pieces' lane arithmetic inside the tile loop
+#pragma unroll 1                                               // (hoisted or interleaved, its results do not fit beside the 64 weight registers at 128 VGPRs)
+        for (int it = 0; it < PPW; ++it) {
+            if (wave + 4 * it < NPIECE) {                      // wave-uniform
+                const int q = (wave + 4 * it) * 64 + ln, hp = q >> 2;
+                const int hy = hp / HWD, hx = hp - hy * HWD;
+                const bool ok = hp < NPX && (interior || ((unsigned)(iy0 + hy) < (unsigned)p.Hi && (unsigned)(ix0 + hx) < (unsigned)p.Wi));
+                const unsigned off = (unsigned)((hy * p.Wi + hx) * p.s0_stride + (((q & 3) ^ tsw(hp)) << 3)) * 2u;
+                dma16(rsrc, sX + (wave + 4 * it) * 1024, ok ? base + off : DMA_OOB);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);                    // vmcnt(0): this wave's pieces have landed
     }
     __syncthreads();
     const int qy = 2 * wave + (l31 >> 4), qx = l31 & 15;
@@ -90,7 +102,7 @@ hipError_t conv_t16_launch(ConvParams p, hipStream_t s, int n_cu)
         p.Ho != (p.Hi - 1) / 2 + 1 || p.Wo != (p.Wi - 1) / 2 + 1)
         return hipErrorInvalidValue;
     constexpr int NPX = 17 * 33;
-    const int smem = ((NPX * 64 + 255) & ~255) + 256 + 2048;       // halo patch, scale / shift, the last tap's two A fragments
+    const int smem = ((NPX * 4 + 63) / 64) * 1024 + 256 + 2048;    // halo patch (whole DMA pieces), scale / shift, the last tap's two A fragments
     static DevOnce attr_once;   // hipFuncSetAttribute is per (function, device)
     if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_t16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);

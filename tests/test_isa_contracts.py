@@ -194,7 +194,7 @@ def test_prw_has_no_scratch_and_the_waits_it_counts_on(tmp_path):
 
 
 @pytest.mark.parametrize("src", ["conv3x3_prw.hip", "conv3x3_pglds.hip", "conv3x3_pglds_i8.hip", "conv1x1_glds.hip", "conv_i8_misc.hip",
-                                 "conv3x3s2_preg.hip", "conv32s.hip", "conv32p.hip"])
+                                 "conv3x3s2_preg.hip", "conv32s.hip", "conv32p.hip", "conv_tile_f16.hip"])
 def test_lds_dma_kernels_spill_nothing_and_use_the_buffer_form(src, tmp_path):
     """Every kernel that stages through LDS-DMA: (1) no scratch -- a scratch load with a DMA in flight is guarded by
     vmcnt(0), i.e. it drains the DMA queue in the middle of the pipeline (round 2's conv3x3s2_preg<12> spilled 3 VGPRs);
