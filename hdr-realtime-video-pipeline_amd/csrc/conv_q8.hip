@@ -36,12 +36,10 @@ __global__ __launch_bounds__(256) void conv_q8_kernel(ConvQ8Params p)
     float *sS = reinterpret_cast<float *>(sW + KS * KS * p.CoutPad * CIN);   // scale[CoutPad], shift[16][CoutPad]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-    const int tiles_x = (p.Wo + Q8_TW - 1) / Q8_TW;
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-    const int oy0 = ty * Q8_TH, ox0 = tx * Q8_TW;
-    const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
+    const int tiles_x = (p.Wo + Q8_TW - 1) / Q8_TW, ntiles = tiles_x * ((p.Ho + Q8_TH - 1) / Q8_TH);
 
-    // ---- weights, scale and the border-class shifts
+    // ---- weights, scale and the border-class shifts: once per (persistent) workgroup -- 9 .. 36 KiB that a per-tile workgroup
+    // staged again for every 18 .. 36 KiB halo patch
     const int wrows = KS * KS * p.CoutPad;
     for (int e = tid; e < wrows * NCH; e += 256) {
         const int r = e / NCH, ch = e - r * NCH;
@@ -50,6 +48,11 @@ __global__ __launch_bounds__(256) void conv_q8_kernel(ConvQ8Params p)
     }
     for (int e = tid; e < 17 * p.CoutPad; e += 256) sS[e] = e < p.CoutPad ? p.scale[e] : p.shift[e - p.CoutPad];
 
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int oy0 = ty * Q8_TH, ox0 = tx * Q8_TW;
+    const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
+    if (t != (int)blockIdx.x) __syncthreads();                 // the previous tile's fragment reads are done
     // ---- halo tile: quantise on load (f16 source) or copy (int8 source); out-of-image pixels are code 0
     for (int e = tid; e < NPX * NCH; e += 256) {
         const int hp = e / NCH, ch = e - hp * NCH;
@@ -124,6 +127,7 @@ __global__ __launch_bounds__(256) void conv_q8_kernel(ConvQ8Params p)
             }
         }
     }
+    }   // tile loop
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(256 * NG, 1) void conv_q8_multi_kernel(ConvQ8MultiP
 }
 
 template <int CIN, int KS, int S>
-hipError_t launch_q8(const ConvQ8Params &p, hipStream_t s)
+hipError_t launch_q8(const ConvQ8Params &p, int n_cu, hipStream_t s)
 {
     constexpr int HH = (Q8_TH - 1) * S + KS, HWD = (Q8_TW - 1) * S + KS, NPX = HH * HWD;
     const int smem = ((NPX * CIN + 255) & ~255) + KS * KS * p.CoutPad * CIN + 17 * p.CoutPad * 4;
@@ -290,7 +294,15 @@ hipError_t launch_q8(const ConvQ8Params &p, hipStream_t s)
         if (e != hipSuccess) return e;
         attr_once.done();
     }
-    const int grid = ((p.Wo + Q8_TW - 1) / Q8_TW) * ((p.Ho + Q8_TH - 1) / Q8_TH);
+    // persistent: as many workgroups as are resident at once with this layer's LDS footprint
+    static int per_cu_of[161];                                 // by KiB of dynamic LDS; 0 = not asked yet
+    int &per_cu = per_cu_of[(smem + 1023) / 1024];
+    if (per_cu == 0) {
+        int nb = 0;
+        per_cu = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, smem) == hipSuccess && nb >= 1) ? nb : 1;
+    }
+    const int ntiles = ((p.Wo + Q8_TW - 1) / Q8_TW) * ((p.Ho + Q8_TH - 1) / Q8_TH);
+    const int grid = ntiles < per_cu * n_cu ? ntiles : per_cu * n_cu;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, p);
     return hipGetLastError();
 }
@@ -327,17 +339,17 @@ hipError_t conv_q8_multi_launch(ConvQ8MultiParams p, int n_cu, hipStream_t s)
 
 // Cin in {32, 64}; (ks, stride) in {(3,2), (3,1), (1,1)}; CoutPad a multiple of 32, Cout a multiple of 4; src_stride and dstC
 // multiples of 16 / 4 elements so that every access is aligned.  hipErrorInvalidValue otherwise.
-hipError_t conv_q8_launch(ConvQ8Params p, hipStream_t s)
+hipError_t conv_q8_launch(ConvQ8Params p, hipStream_t s, int n_cu)
 {
     if ((p.CoutPad % 32) || (p.Cout % 4) || p.Cout > p.CoutPad || (p.src_stride % 16) || (p.dstC % 4) || !p.wpk8 || !p.scale || !p.shift)
         return hipErrorInvalidValue;
     const int pad = p.ks / 2;
     if (p.Ho != (p.Hi + 2 * pad - p.ks) / p.stride + 1 || p.Wo != (p.Wi + 2 * pad - p.ks) / p.stride + 1) return hipErrorInvalidValue;
-    if (p.Cin == 32 && p.ks == 3 && p.stride == 2) return launch_q8<32, 3, 2>(p, s);
-    if (p.Cin == 64 && p.ks == 3 && p.stride == 2) return launch_q8<64, 3, 2>(p, s);
-    if (p.Cin == 32 && p.ks == 3 && p.stride == 1) return launch_q8<32, 3, 1>(p, s);
-    if (p.Cin == 64 && p.ks == 3 && p.stride == 1) return launch_q8<64, 3, 1>(p, s);
-    if (p.Cin == 64 && p.ks == 1 && p.stride == 1) return launch_q8<64, 1, 1>(p, s);
-    if (p.Cin == 32 && p.ks == 1 && p.stride == 1) return launch_q8<32, 1, 1>(p, s);
+    if (p.Cin == 32 && p.ks == 3 && p.stride == 2) return launch_q8<32, 3, 2>(p, n_cu, s);
+    if (p.Cin == 64 && p.ks == 3 && p.stride == 2) return launch_q8<64, 3, 2>(p, n_cu, s);
+    if (p.Cin == 32 && p.ks == 3 && p.stride == 1) return launch_q8<32, 3, 1>(p, n_cu, s);
+    if (p.Cin == 64 && p.ks == 3 && p.stride == 1) return launch_q8<64, 3, 1>(p, n_cu, s);
+    if (p.Cin == 64 && p.ks == 1 && p.stride == 1) return launch_q8<64, 1, 1>(p, n_cu, s);
+    if (p.Cin == 32 && p.ks == 1 && p.stride == 1) return launch_q8<32, 1, 1>(p, n_cu, s);
     return hipErrorInvalidValue;
 }

@@ -1516,7 +1516,7 @@ struct Seq {
         const double macs = (double)p.Ho * p.Wo * L.cin * L.ks * L.ks * L.cout;
         const double bytes = (double)Hi * Wi * L.cin * (src_i8 ? 1.0 : 2.0) + (double)L.ks * L.ks * L.cin * L.coutPad +
                              (double)p.Ho * p.Wo * L.cout * (oq ? 1.0 : 2.0);
-        chk(conv_q8_launch(p, s), key.c_str(), tag, macs, bytes);
+        chk(conv_q8_launch(p, s, c->n_cu), key.c_str(), tag, macs, bytes);
     }
     void c3(const std::string &key, const f16 *in, int H, int W, int act, f16 *out, f16 *out_pool, float pool_q_inv = 0.f,
             float pool_q_zero = 0.f, const f16 *w2frag = nullptr, float *part2 = nullptr)
