@@ -303,17 +303,23 @@ __global__ __launch_bounds__(256) void agcm_mlp_kernel(const f16 *__restrict__ i
     const size_t ngrp = (npix + 31) / 32;
     const size_t wave_id = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const size_t nwave = ((size_t)gridDim.x * blockDim.x) >> 6;
+    // the three input values of a group are fetched one trip ahead: at two waves per SIMD (220 VGPRs) nothing else hides the
+    // load latency in front of the dependent MFMA chain
+    f16 nx[3] = {(f16)0.f, (f16)0.f, (f16)0.f};
+    auto fetch = [&](size_t g) {
+        const size_t pix = g * 32 + l31;
+        const size_t o = (g < ngrp && pix < npix && lh == 0) ? pix : 0;       // masked lanes read pixel 0 and drop it
+        nx[0] = in[o]; nx[1] = in[npix + o]; nx[2] = in[2 * npix + o];
+    };
+    fetch(wave_id);
     for (size_t g = wave_id; g < ngrp; g += nwave) {
         const size_t pix = g * 32 + l31;
         const bool ok = pix < npix;
         f16x8 x;
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[j] = (f16)0.f;
-        if (ok && lh == 0) {
-            x[0] = in[pix];
-            x[1] = in[npix + pix];
-            x[2] = in[2 * npix + pix];
-        }
+        if (ok && lh == 0) { x[0] = nx[0]; x[1] = nx[1]; x[2] = nx[2]; }
+        fetch(g + nwave);
         // layer 1: 3 -> 64, ReLU
         f32x16 h0 = bias_tile(s_bias + 0, lh), h1 = bias_tile(s_bias + 32, lh);
         h0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[0], x, h0, 0, 0, 0);
