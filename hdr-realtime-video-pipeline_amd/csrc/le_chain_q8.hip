@@ -289,12 +289,22 @@ __global__ __launch_bounds__(256) void agcm_mlp_q8_kernel(AgcmQ8Params p)
     for (int i = 0; i < 2; ++i) w3[i] = p.wfrag[(6 + i) * 64 + lane];
     const size_t ngrp = (p.npix + 31) / 32;
     const size_t wave_id = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwave = ((size_t)gridDim.x * blockDim.x) >> 6;
+    // a group's three input values are fetched one trip ahead (as agcm_mlp_kernel: nothing else hides the load latency in front
+    // of the dependent MFMA chain)
+    f16 nx[3] = {(f16)0.f, (f16)0.f, (f16)0.f};
+    auto fetch = [&](size_t g) {
+        const size_t pix = g * 32 + l31;
+        const size_t o = (g < ngrp && pix < p.npix && lh == 0) ? pix : 0;     // masked lanes read pixel 0 and drop it
+        nx[0] = p.in[o]; nx[1] = p.in[p.npix + o]; nx[2] = p.in[2 * p.npix + o];
+    };
+    fetch(wave_id);
     for (size_t g = wave_id; g < ngrp; g += nwave) {
         const size_t pix = g * 32 + l31;
         const bool ok = pix < p.npix;
         i32x4 x = {0, 0, 0, 0};
         if (ok && lh == 0)
-            x[0] = (int)(quant4((float)p.in[pix], (float)p.in[p.npix + pix], (float)p.in[2 * p.npix + pix], 0.f, p.q1_inv, p.q1_zoff) & 0x00ffffffu);
+            x[0] = (int)(quant4((float)nx[0], (float)nx[1], (float)nx[2], 0.f, p.q1_inv, p.q1_zoff) & 0x00ffffffu);
+        fetch(g + nwave);
         i32x4 b[2], c[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
