@@ -287,8 +287,8 @@ __device__ __forceinline__ f16x8 relu_pack(const f32x16 &a, int s)
 __global__ __launch_bounds__(256) void agcm_mlp_kernel(const f16 *__restrict__ in, f16 *__restrict__ out, size_t npix,
                                                        const f16 *__restrict__ frags, const float *__restrict__ biasbuf)
 {
-    __shared__ __attribute__((aligned(16))) float s_bias[160];
-    for (int e = threadIdx.x; e < 160; e += 256) s_bias[e] = biasbuf[e];
+    __shared__ __attribute__((aligned(16))) float s_bias0[160];
+    for (int e = threadIdx.x; e < 160; e += 256) s_bias0[e] = biasbuf[e];
     __syncthreads();
     const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
     f16x8 a1[2], a2[8], a3[4];
@@ -320,6 +320,11 @@ __global__ __launch_bounds__(256) void agcm_mlp_kernel(const f16 *__restrict__ i
         for (int j = 0; j < 8; ++j) x[j] = (f16)0.f;
         if (ok && lh == 0) { x[0] = nx[0]; x[1] = nx[1]; x[2] = nx[2]; }
         fetch(g + nwave);
+        // the five bias tiles are read from LDS in every trip: hoisted out of the loop (80 VGPRs) they cost the kernel its third
+        // wave per SIMD
+        int bo = 0;
+        asm volatile("" : "+v"(bo));
+        const float *s_bias = s_bias0 + bo;
         // layer 1: 3 -> 64, ReLU
         f32x16 h0 = bias_tile(s_bias + 0, lh), h1 = bias_tile(s_bias + 32, lh);
         h0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[0], x, h0, 0, 0, 0);

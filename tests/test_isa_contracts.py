@@ -21,7 +21,7 @@ pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not ins
 
 def _asm(src, tmp_path):
     out = tmp_path / (src + ".s")
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-S", "--cuda-device-only",
                     os.path.join(CSRC, src), "-o", str(out)], check=True, capture_output=True)
     text = out.read_text()
     kernels = {}
@@ -201,7 +201,7 @@ def test_lds_dma_kernels_spill_nothing_and_use_the_buffer_form(src, tmp_path):
     (2) the DMA is `buffer_load_dwordx4 ... lds`, never the FLAT-encoded global_load_lds, after which hipcc's waitcnt pass
     stops counting."""
     out = tmp_path / (src + ".s")
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", str(out)],
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", str(out)],
                    check=True, capture_output=True)
     text = out.read_text()
     spills = [int(v) for v in re.findall(r"\.vgpr_spill_count:\s*(\d+)", text)]
