@@ -367,12 +367,14 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
     int qoff[3];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) qoff[kx] = (qy * HW + qx + kx) * 32 + ((lh ^ (qy & 1)) << 4);
-    // this thread's two 16-byte output chunks: pixel (q2y[it], q2x) of the tile, channel chunk c8
-    const int c8 = tid & 3;
+    // this thread's two 16-byte output chunks: pixel (q2y[it], q2x) of the tile, channel chunk c8 -- pixels of the wave's OWN two
+    // rows (the ones its accumulators hold), so that the staging tile is read back by the wave that wrote it: LDS operations
+    // of one wave complete in order, and the store phase of a pass needs no workgroup barrier
+    const int c8 = lane & 3;
     int q2y[2];
-    const int q2x = ((tid >> 2) % TW);
+    const int q2x = lane >> 2;
 #pragma unroll
-    for (int it = 0; it < 2; ++it) q2y[it] = ((tid + it * NT) >> 2) / TW;
+    for (int it = 0; it < 2; ++it) q2y[it] = 2 * wave + it;
     const bool c8_ok = c8 * 8 < p.Cout;
     const float aslope = act_slope(p.act);
 
@@ -437,10 +439,45 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
             }
         }
         STAMP(0);      // offsets + residual prefetch
+        // fp16 multi-pass layers (the up-convs) run their passes two at a time: an activation fragment read from LDS feeds
+        // both passes' MFMAs (54 LDS reads per pass pair instead of 72)
+        constexpr int PB = (!I8 && NPASS % 2 == 0) ? 2 : 1;
+        f32x16 accb[PB];
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
             f32x16 acc;
-            if constexpr (I8) {
+            if constexpr (PB == 2) {
+                if ((pass & 1) == 0) {
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) accb[b][k] = 0.f;
+                    f16x8 wfr[2][18], xfr[18];
+                    auto ldfrag = [&](int st) {
+                        const int tap = st >> 1, ks = st & 1;
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+                            wfr[b][st] = *reinterpret_cast<const f16x8 *>(sW + (woff ^ (ks << 5)) + (tap * L::COUTP + (pass + b) * 32) * 64);
+                        xfr[st] = *reinterpret_cast<const f16x8 *>(a + (xoff[tap % 3] ^ (ks << 5)) + (tap / 3) * HW * 64);
+                    };
+                    ldfrag(0); ldfrag(1); ldfrag(2);
+#pragma unroll
+                    for (int st = 0; st < 18; ++st) {
+                        if (st + 3 < 18) ldfrag(st + 3);
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) accb[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfr[b][st], xfr[st], accb[b], 0, 0, 0);
+                    }
+                    // pin the interleave: 9 reads up front, then {2 MFMAs, 3 reads} x 15, then 6 MFMAs
+                    __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+#pragma unroll
+                    for (int st = 0; st < 15; ++st) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                }
+                acc = accb[pass & 1];
+            } else if constexpr (I8) {
                 // 9 k-steps (one tap = 32 input channels); fragment reads run three steps ahead of their MFMA
                 const char *qa = sQ + buf * L::Q_BYTES;
                 i32x16 iacc;
@@ -513,7 +550,9 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
             // where a vmcnt(0) in front of the second chunk would also wait for the first chunk's store to complete.
             if (pass == 0) __builtin_amdgcn_s_waitcnt(0x0f70);               // vmcnt(0), expcnt / lgkmcnt untouched
             STAMP(3);  // wait for DMA(t+1) / outstanding memory ops
-            __syncthreads();
+            // one barrier per tile here (tile t+1 has landed for everyone); the planar head reads other waves' pixels from the
+            // staging tile and needs it for that, too
+            if (pass == 0) __syncthreads();
             STAMP(4);  // barrier 1
             if (p.mode == ST_PLANAR3) {
 #pragma unroll
@@ -529,7 +568,7 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
                 // both staging chunks first (one LDS latency, not two), then the adds and the stores
                 f16x8 v[2];
 #pragma unroll
-                for (int it = 0; it < 2; ++it) v[it] = *reinterpret_cast<const f16x8 *>(sO + ((tid + it * NT) >> 2) * OUT_ROWB + c8 * 16);
+                for (int it = 0; it < 2; ++it) v[it] = *reinterpret_cast<const f16x8 *>(sO + (q2y[it] * TW + q2x) * OUT_ROWB + c8 * 16);
 #pragma unroll
                 for (int it = 0; it < 2; ++it) {
                     // residual adds in packed f16, one rounding per add as the reference's fp16 model does
@@ -539,9 +578,9 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
                     if (ooff[pass][it] >= 0) *reinterpret_cast<f16x8 *>(p.dst + ooff[pass][it]) = v[it];
                 }
             }
-            if (pass < NPASS - 1) __syncthreads();      // staging tile is reused by the next pass
             STAMP(5);  // DMA issue + stores
         }
+        __syncthreads();                                // every wave is done with this tile's halo buffer (and, planar head, the staging tile)
         // conv(t) released its halo buffer at the barrier: tile t+2 goes in flight AFTER the stores (an
         // LDS-DMA in flight makes hipcc wait vmcnt(0) at the next use of any plain load result -- the
         // prefetched residuals -- which would park the store phase on the DMA) and BEFORE the SFT of
