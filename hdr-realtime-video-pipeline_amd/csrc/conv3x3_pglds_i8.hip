@@ -130,8 +130,22 @@ __global__ __launch_bounds__(512) void conv_pglds_i8_kernel(ConvI8Params p)
     };
 
     if constexpr (MODE == ST_PS_DOT3) {          // before any DMA is in flight (ordinary loads drain the queue)
-        float *s_w = reinterpret_cast<float *>(smem + DOTW_OFF);
-        for (int e = tid; e < 3 * 64; e += 512) s_w[e] = p.dotw[e];
+        // The 64 -> 3 dot products run on the matrix pipe (epilogue; scheme in conv3x3_prw.hip).  Table entry
+        // ((khalf * 3 + o) * 4 + kg): the A fragment of output o for k-group kg over channels 32 khalf .. 32 khalf + 31 -- K slot e of
+        // the group is channel 32 khalf + 4 kg + e (e < 4) or 32 khalf + 16 + 4 kg + e - 4, the order in which a lane's f16x4 results
+        // of two accumulator blocks form a B fragment as they lie.  An fp32 weight rides as hi + lo * 2^-10 (two f16 operands).
+        if (tid < 24) {
+            const int kgq = tid & 3, o = (tid >> 2) % 3, khalf = tid / 12;
+            f16x8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float w = p.dotw[o * 64 + khalf * 32 + (e < 4 ? 4 * kgq + e : 16 + 4 * kgq + e - 4)];
+                hi[e] = (f16)w;
+                lo[e] = (f16)((w - (float)hi[e]) * 1024.f);
+            }
+            *reinterpret_cast<f16x8 *>(smem + DOTW_OFF + tid * 32) = hi;
+            *reinterpret_cast<f16x8 *>(smem + DOTW_OFF + tid * 32 + 16) = lo;
+        }
         __syncthreads();
     }
 
@@ -268,40 +282,47 @@ __global__ __launch_bounds__(512) void conv_pglds_i8_kernel(ConvI8Params p)
             }
             // Up_conv5: {scale, shift} give real values; ReLU, f16 rounding (the tensor the reference's fp16 conv10 reads),
             // pixel shuffle, then the first half of conv10 as 3 dot products per pixel (conv3x3_pglds.hip, same epilogue)
-            const float *s_w = reinterpret_cast<const float *>(smem + DOTW_OFF);
-            float a0[4], a1[4], a2[4];
+            // f16 results of pixel row j as B fragments (blocks 0|1 and 2|3), A = the three weight rows placed in rows 4 j + o: the
+            // four rows accumulate into one f32x4 whose lane (kg, l15) is pixel (wp * 4 + kg, l15)
+            const int orow = l15 & 3, qrow = l15 >> 2;
+            const f16x8 zero8 = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+            f16x8 fh[2], fl[2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a0[j] = a1[j] = a2[j] = 0.f;
+            for (int kh = 0; kh < 2; ++kh) {
+                const char *tb = smem + DOTW_OFF + (((kh * 3 + (orow < 3 ? orow : 0)) * 4 + kg) << 5);
+                fh[kh] = *reinterpret_cast<const f16x8 *>(tb);
+                fl[kh] = *reinterpret_cast<const f16x8 *>(tb + 16);
+                if (orow == 3) { fh[kh] = zero8; fl[kh] = zero8; }
+            }
+            float4 scv[4], shv[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float4 sc = *reinterpret_cast<const float4 *>(ss + cw + i * 16);
-                const float4 sh = *reinterpret_cast<const float4 *>(ss + 128 + cw + i * 16);
-                const float4 w0 = *reinterpret_cast<const float4 *>(s_w + i * 16 + 4 * kg);
-                const float4 w1 = *reinterpret_cast<const float4 *>(s_w + 64 + i * 16 + 4 * kg);
-                const float4 w2 = *reinterpret_cast<const float4 *>(s_w + 128 + i * 16 + 4 * kg);
+                scv[i] = *reinterpret_cast<const float4 *>(ss + cw + i * 16);
+                shv[i] = *reinterpret_cast<const float4 *>(ss + 128 + cw + i * 16);
+            }
+            f32x4 ah = {0.f, 0.f, 0.f, 0.f}, al = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float x0 = (float)(f16)fmaxf((float)acc[i][j][0] * sc.x + sh.x, 0.f);
-                    const float x1 = (float)(f16)fmaxf((float)acc[i][j][1] * sc.y + sh.y, 0.f);
-                    const float x2 = (float)(f16)fmaxf((float)acc[i][j][2] * sc.z + sh.z, 0.f);
-                    const float x3 = (float)(f16)fmaxf((float)acc[i][j][3] * sc.w + sh.w, 0.f);
+            for (int j = 0; j < 4; ++j) {
+                f16x4 x[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    x[i][0] = (f16)fmaxf((float)acc[i][j][0] * scv[i].x + shv[i].x, 0.f);
+                    x[i][1] = (f16)fmaxf((float)acc[i][j][1] * scv[i].y + shv[i].y, 0.f);
+                    x[i][2] = (f16)fmaxf((float)acc[i][j][2] * scv[i].z + shv[i].z, 0.f);
+                    x[i][3] = (f16)fmaxf((float)acc[i][j][3] * scv[i].w + shv[i].w, 0.f);
                     acc[i][j] = i32x4{0, 0, 0, 0};
-                    a0[j] += w0.x * x0 + w0.y * x1 + w0.z * x2 + w0.w * x3;
-                    a1[j] += w1.x * x0 + w1.y * x1 + w1.z * x2 + w1.w * x3;
-                    a2[j] += w2.x * x0 + w2.y * x1 + w2.z * x2 + w2.w * x3;
+                }
+                const bool mine = qrow == j;
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh) {
+                    const f16x8 b = {x[2 * kh][0], x[2 * kh][1], x[2 * kh][2], x[2 * kh][3], x[2 * kh + 1][0], x[2 * kh + 1][1], x[2 * kh + 1][2], x[2 * kh + 1][3]};
+                    ah = __builtin_amdgcn_mfma_f32_16x16x32_f16(mine ? fh[kh] : zero8, b, ah, 0, 0, 0);
+                    al = __builtin_amdgcn_mfma_f32_16x16x32_f16(mine ? fl[kh] : zero8, b, al, 0, 0, 0);
                 }
             }
-            // k-groups of a pixel are summed through the wave-private strip, not ds_bpermute (see conv3x3_pglds.hip)
             const int sub = cur.n0 / 64 + wc;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                *reinterpret_cast<float4 *>(stg + j * 1024 + kg * 256 + l15 * 16) = make_float4(a0[j], a1[j], a2[j], 0.f);
-            float4 r = *reinterpret_cast<const float4 *>(stg + kg * 1024 + l15 * 16);
-#pragma unroll
-            for (int kk = 1; kk < 4; ++kk) {
-                const float4 v = *reinterpret_cast<const float4 *>(stg + kg * 1024 + kk * 256 + l15 * 16);
-                r.x += v.x; r.y += v.y; r.z += v.z;
-            }
+            constexpr float kscale = 1.f / 1024.f;
+            const float4 r = make_float4(ah[0] + al[0] * kscale, ah[1] + al[1] * kscale, ah[2] + al[2] * kscale, 0.f);
             const int oy = cur.oy0 + wp * 4 + kg, ox = cur.ox0 + l15;
             const int Y = 2 * oy + (sub >> 1), X = 2 * ox + (sub & 1);
             const bool ok = oy < p.Ho && ox < p.Wo && Y < p.Hd && X < p.Wd;
