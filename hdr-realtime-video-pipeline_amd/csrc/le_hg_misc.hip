@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256) void conv_c3_kernel(const f16 *__restrict__ in
     static_assert(!DOT || COUT == 64, "the fused conv10 half belongs to HG.conv1");
     constexpr int MT = COUT / 32;
     constexpr int ROWB = COUT * 2 + 16;
-    __shared__ __attribute__((aligned(16))) f16x4 s_px[C3_HH * C3_PW];
+    __shared__ __attribute__((aligned(16))) f16x4 s_px_all[(DOT ? 2 : 1) * C3_HH * C3_PW];      // DOT: two patches, one barrier per tile
+    f16x4 *s_px = s_px_all;
     __shared__ __attribute__((aligned(16))) char s_out[C3_TH * C3_TW * ROWB];
     __shared__ __attribute__((aligned(16))) float s_ss[2 * COUT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
@@ -89,19 +90,37 @@ __global__ __launch_bounds__(256) void conv_c3_kernel(const f16 *__restrict__ in
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) wf[i][ky] = reinterpret_cast<const f16x8 *>(wfrag)[(i * 3 + ky) * 64 + lane];
-    for (int e = tid; e < C3_HH * 2; e += 256) s_px[(e >> 1) * C3_PW + C3_HW + (e & 1)] = f16x4{(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+    for (int e = tid; e < C3_HH * 2 * (DOT ? 2 : 1); e += 256)
+        s_px_all[(e / (C3_HH * 2)) * (C3_HH * C3_PW) + ((e % (C3_HH * 2)) >> 1) * C3_PW + C3_HW + (e & 1)] = f16x4{(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
     // persistent over 8x32-pixel tiles, the next tile's image patch fetched while this one computes
     C3Pre pre;
     auto fetch = [&](int t) { c3_fetch(pre, in, H, W, (t / tiles_x) * C3_TH, (t % tiles_x) * C3_TW, tid); };
     const float aslope = act_slope(act);
     int t = blockIdx.x;
     if (t < ntiles) fetch(t);
+    // DOT (HG.conv1: pooled output only): ONE barrier per tile.  The patch of tile t+1 is staged into the other buffer while tile
+    // t computes (its registers were fetched a tile earlier, the fetch of t+2 follows at once), and everything behind the MFMAs
+    // is wave-private: a wave's two pixel rows hold whole 2x2 pooling windows, so it reads back only what it staged itself
+    // (LDS operations of one wave complete in order).
+    int pbuf = 0;
+    if constexpr (DOT) {
+        if (t < ntiles) c3_stage(pre, s_px_all, tid);
+        if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
+    }
     for (; t < ntiles; t += gridDim.x) {
     const int ox0 = (t % tiles_x) * C3_TW, oy0 = (t / tiles_x) * C3_TH;
-    __syncthreads();                                   // the previous tile is done with s_px and s_out
-    c3_stage(pre, s_px, tid);
-    __syncthreads();
-    if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
+    if constexpr (DOT) {
+        __syncthreads();                               // this tile's patch is staged; the other buffer's readers (tile t-1) are done
+        s_px = s_px_all + pbuf * (C3_HH * C3_PW);
+        if (t + (int)gridDim.x < ntiles) c3_stage(pre, s_px_all + (pbuf ^ 1) * (C3_HH * C3_PW), tid);
+        if (t + 2 * (int)gridDim.x < ntiles) fetch(t + 2 * gridDim.x);
+        pbuf ^= 1;
+    } else {
+        __syncthreads();                               // the previous tile is done with s_px and s_out
+        c3_stage(pre, s_px, tid);
+        __syncthreads();
+        if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
+    }
     f32x16 acc[MT][2];
     // one row's epilogue (DOT): its 64 f16 activations go to the staging tile and, as they lie in the registers, into the four B
     // fragments of conv10's second half.  Run right behind the row's conv MFMAs, so that only one row of accumulators is live:
@@ -171,8 +190,48 @@ __global__ __launch_bounds__(256) void conv_c3_kernel(const f16 *__restrict__ in
                 }
             }
     }
-    __syncthreads();
     constexpr int CPP = COUT / 8;
+    if constexpr (DOT) {
+        // this wave's pooled row: 16 pooled pixels x 8 chunks of 8 channels = two items per lane, from its own two staged rows
+        const int Hq = H / 2, Wq = W / 2;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int e = lane + 64 * it;
+            const int px = e / CPP, c8 = e % CPP;
+            const int oy = oy0 / 2 + wave, ox = ox0 / 2 + px;
+            const int q00 = 2 * wave * C3_TW + 2 * px;
+            f16x8 v = *reinterpret_cast<const f16x8 *>(s_out + q00 * ROWB + c8 * 16);
+            const f16x8 v1 = *reinterpret_cast<const f16x8 *>(s_out + (q00 + 1) * ROWB + c8 * 16);
+            const f16x8 v2 = *reinterpret_cast<const f16x8 *>(s_out + (q00 + C3_TW) * ROWB + c8 * 16);
+            const f16x8 v3 = *reinterpret_cast<const f16x8 *>(s_out + (q00 + C3_TW + 1) * ROWB + c8 * 16);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const f16 m = v[k] > v1[k] ? v[k] : v1[k];
+                const f16 m2 = v2[k] > v3[k] ? v2[k] : v3[k];
+                v[k] = m > m2 ? m : m2;
+            }
+            if (oy < Hq && ox < Wq) {
+                if (pool_q_inv > 0.f) {        // int8 codes q - 128 of a W8A8 reader, as below
+                    unsigned lo = 0, hi = 0;
+                    const float z128 = pool_q_zero + 128.f;
+                    lo = __builtin_amdgcn_cvt_pk_u8_f32((float)v[0] * pool_q_inv + z128, 0, lo);
+                    lo = __builtin_amdgcn_cvt_pk_u8_f32((float)v[1] * pool_q_inv + z128, 1, lo);
+                    lo = __builtin_amdgcn_cvt_pk_u8_f32((float)v[2] * pool_q_inv + z128, 2, lo);
+                    lo = __builtin_amdgcn_cvt_pk_u8_f32((float)v[3] * pool_q_inv + z128, 3, lo);
+                    hi = __builtin_amdgcn_cvt_pk_u8_f32((float)v[4] * pool_q_inv + z128, 0, hi);
+                    hi = __builtin_amdgcn_cvt_pk_u8_f32((float)v[5] * pool_q_inv + z128, 1, hi);
+                    hi = __builtin_amdgcn_cvt_pk_u8_f32((float)v[6] * pool_q_inv + z128, 2, hi);
+                    hi = __builtin_amdgcn_cvt_pk_u8_f32((float)v[7] * pool_q_inv + z128, 3, hi);
+                    lo ^= 0x80808080u; hi ^= 0x80808080u;
+                    *reinterpret_cast<uint2 *>(reinterpret_cast<int8_t *>(out_pool) + ((size_t)oy * Wq + ox) * COUT + c8 * 8) = make_uint2(lo, hi);
+                } else {
+                    *reinterpret_cast<f16x8 *>(out_pool + ((size_t)oy * Wq + ox) * COUT + c8 * 8) = v;
+                }
+            }
+        }
+        continue;
+    }
+    __syncthreads();
     for (int e = tid; e < C3_TH * C3_TW * CPP; e += 256) {
         const int q = e / CPP, c8 = e % CPP;
         const int oy = oy0 + q / C3_TW, ox = ox0 + q % C3_TW;
@@ -516,7 +575,7 @@ hipError_t conv_c3_launch(const f16 *in, int H, int W, const f16 *wfrag, const f
                           int act, f16 *out, f16 *out_pool, int n_cu, hipStream_t s, float pool_q_inv, float pool_q_zero,
                           const f16 *w2frag, float *part2)
 {
-    if ((w2frag != nullptr) != (part2 != nullptr) || (part2 && cout != 64)) return hipErrorInvalidValue;
+    if ((w2frag != nullptr) != (part2 != nullptr) || (part2 && (cout != 64 || out || !out_pool))) return hipErrorInvalidValue;
     const int ntiles = ((W + C3_TW - 1) / C3_TW) * ((H + C3_TH - 1) / C3_TH);
     // persistent: as many workgroups as are resident at once (registers: 3 / 2 per CU today), one round
     static int occ[3] = {0, 0, 0};
