@@ -41,7 +41,7 @@ L = lambda n: json.loads(open(P(n)).read().strip().splitlines()[-1])
 d, i8, mx, pd = L("r03_bench_default.json"), L("r03_int8_bench.json"), L("r03_int8_mixed_bench.json"), L("r03_int8_predeq_bench.json")
 r, c = d['roofline'], d['cpu_baseline']
 stat = next(float(x["AverageNs"]) for x in csv.DictReader(open(P("r03_kernel_stats.csv"))) if "conv_prw_kernel<2, 16>" in x["Name"]) / 1e6
-para = (f"Round-3 build (`profiles/r03_bench_default.json`; the pool's boxes differ by ±4 %: this build has read 92.8–98.1 frames/s on six boxes (its mid-round state 88.7–94.9), round 2's "
+para = (f"Round-3 build (`profiles/r03_bench_default.json`; the pool's boxes differ by ±4 %: this build has read 92.8–100.7 frames/s on seven boxes (its mid-round state 88.7–94.9), round 2's "
         f"build 86–90.6): **{d['value']:.1f} frames/s ring-inclusive, {d['ms_per_step']:.2f} ms, p50 {d['p50_ms']:.2f}, 1 % low {d['one_percent_low_fps']:.1f} fps**; "
         f"device-only {d['value_device_only']:.1f}, PCIe-inclusive {d['value_pcie_inclusive']:.1f}, host-fed through the dispatcher {d['dispatcher_host_fed']['value']:.1f}; "
         f"{d['tflops_end_to_end']:.0f} TFLOP/s end to end. configs[4] on the same box (`profiles/r03_int8_*.json`): full recipe native "
