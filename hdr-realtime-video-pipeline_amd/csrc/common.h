@@ -211,6 +211,21 @@ struct ConvQ8MultiParams {
     ConvQ8Group g[3];
 };
 
+// Parameter block of the row-streaming fused ResBlock_with_SFT (le_rows.hip): y = x + conv2(sft2(relu(conv1(sft1(x, c))), c))
+struct RowsRbParams {
+    const f16 *x;          // NHWC 32 [H][W]
+    const f16 *cond;       // NHWC 16 [H][W]
+    const f16 *w1, *w2;    // [9][32][32] (pack_conv, CIN_T = 32)
+    const float *b1, *b2;  // [32] bias
+    const f16 *sft1_wfrag, *sft2_wfrag;     // pack_sft fragments
+    const float *sft1_bias, *sft2_bias;
+    f16 *dst;              // NHWC 32 [H][W]
+    char *trash;           // >= 8 KiB write-only scratch for masked-off lanes (keeps store counts exact)
+    void *dump;            // diagnostic builds (make STAMP=1): per-phase cycle sums
+    int H, W;
+    int nstrips, rows_per_seg;              // set by the launcher
+};
+
 // Letterbox (letterbox.hip): u8 BGR [sh][sw][3] -> u8 BGR [dh][dw][3], resized region [y0, y0+new_h) x [x0, x0+new_w)
 enum { LB_COPY = 0, LB_AREA_INT = 1, LB_AREA_FRAC = 2, LB_CUBIC = 3 };
 struct LetterboxParams {

@@ -242,6 +242,10 @@ struct hdrtv_ctx {
     int ring_next = 0, ring_H = 0, ring_W = 0;
     std::mutex ring_mu;
     std::condition_variable ring_cv;
+    // developer variant table (hdrtv_set_variant): which of several equivalent kernels / schedules a layer runs on.  Filled
+    // once in hdrtv_create (defaults, then HDRTV_VARIANTS="name=value,..." of the creating process); never read from the
+    // environment on the launch path.
+    std::map<std::string, int> var;
 };
 
 namespace {
@@ -255,6 +259,31 @@ int fail(hdrtv_ctx *c, int code, const char *fmt, ...)
     va_end(ap);
     if (c) c->err = buf;
     return code;
+}
+
+// ---- developer variants: name -> default.  hdrtv_set_variant changes one on a context; HDRTV_VARIANTS="a=1,b=0" seeds them at
+// hdrtv_create.  The launch path reads c->var only.
+const std::pair<const char *, int> k_variants[] = {
+    {"le_rows", 1},          // fused row-streaming LE kernels (le_rows.hip); 0 = the per-layer 16x16-tile kernels
+};
+void variants_init(hdrtv_ctx *c)
+{
+    for (const auto &kv : k_variants) c->var[kv.first] = kv.second;
+    const char *e = getenv("HDRTV_VARIANTS");
+    if (!e) return;
+    std::string str(e);
+    size_t pos = 0;
+    while (pos < str.size()) {
+        size_t nx = str.find(',', pos);
+        if (nx == std::string::npos) nx = str.size();
+        const std::string one = str.substr(pos, nx - pos);
+        const size_t eq = one.find('=');
+        if (eq != std::string::npos) {
+            auto it = c->var.find(one.substr(0, eq));
+            if (it != c->var.end()) it->second = atoi(one.c_str() + eq + 1);
+        }
+        pos = nx + 1;
+    }
 }
 
 #define HIPCHK(c, expr)                                                                         \
@@ -1586,10 +1615,46 @@ struct Seq {
         if (c3_img && !one_barrier) { rc = fail(c, HDRTV_ESTATE, "conv_first fusion needs the one-barrier schedule"); return; }
         chk(one_barrier ? conv32s_launch(p, c->n_cu, s) : conv32p_launch(p, c->n_cu, s), key.c_str(), tag, macs, bytes);
     }
+    // diagnostic builds (make STAMP=1) write per-phase cycle sums of launch number HDRTV_STAMP_LAUNCH (read once) here
+    void *stamp_buf() const
+    {
+#ifdef HDRTV_STAMP
+        static const int stamp_launch = [] { const char *e = getenv("HDRTV_STAMP_LAUNCH"); return e ? atoi(e) : -1; }();
+        return (stamp_launch >= 0 && c->launches == stamp_launch) ? (void *)wsp<f16>(c, "dbg.stamps") : nullptr;
+#else
+        return nullptr;
+#endif
+    }
+    // the row-streaming kernels (le_rows.hip) cut a map into 60-column strips x row segments, one workgroup each: worth it
+    // when a segment is long against its 4 .. 6 warm-up rows
+    bool rows_fit(int H, int W) const
+    {
+        const int nstrips = (W + 59) / 60, nseg = std::max(1, c->n_cu / nstrips);
+        return W >= 60 && (H + nseg - 1) / nseg >= 12;
+    }
     // ResBlock_with_SFT (arch_util.py:89-95): y = x + conv2(sft2(relu(conv1(sft1(x,c))),c))  [+ extra]; 2 launches
     void resblock(const std::string &base, const f16 *x, const f16 *cond, int H, int W, f16 *tb, f16 *y,
                   const f16 *extra = nullptr)
     {
+        // fp16 block without a second residual, enough rows per segment to amortise the 4-row warm-up: ONE row-streaming
+        // launch (le_rows.hip), the intermediate never leaves LDS; bit-identical to the two launches below
+        if (ok() && c->var.at("le_rows") && !extra && rows_fit(H, W) && c->conv.count(base + ".conv1") && c->conv.count(base + ".conv2") &&
+            !c->sft.at(base + ".sft1").q && !c->sft.at(base + ".sft2").q) {
+            const ConvLayer &L1 = c->conv.at(base + ".conv1"), &L2 = c->conv.at(base + ".conv2");
+            const SftLayer &S1 = c->sft.at(base + ".sft1"), &S2 = c->sft.at(base + ".sft2");
+            RowsRbParams p;
+            memset(&p, 0, sizeof p);
+            p.x = x; p.cond = cond; p.H = H; p.W = W; p.dst = y;
+            p.w1 = wtp<f16>(c, L1.wpk); p.w2 = wtp<f16>(c, L2.wpk); p.b1 = wtp<float>(c, L1.shift); p.b2 = wtp<float>(c, L2.shift);
+            p.sft1_wfrag = wtp<f16>(c, S1.wfrag); p.sft1_bias = wtp<float>(c, S1.bias);
+            p.sft2_wfrag = wtp<f16>(c, S2.wfrag); p.sft2_bias = wtp<float>(c, S2.bias);
+            p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
+            p.dump = stamp_buf();
+            const double npx = (double)H * W;
+            chk(le_rb_rows_launch(p, c->n_cu, s), base.c_str(), "le_rb_rows", npx * (2.0 * 32 * 9 * 32 + 4.0 * (16 * 16 + 16 * 32)),
+                npx * (64 + 32 + 64) + 2.0 * 2 * 9 * 32 * 32);
+            return;
+        }
         conv32(base + ".conv1", x, cond, base + ".sft1", H, W, ACT_RELU, ST_NHWC, tb, 32, H, W);
         conv32(base + ".conv2", tb, cond, base + ".sft2", H, W, ACT_NONE, ST_NHWC, y, 32, H, W, x, extra);
     }
@@ -1953,6 +2018,7 @@ int hdrtv_create(const void *hr_pack, size_t hr_bytes, const void *hg_pack, size
     // test switch: a huge value gives every persistent kernel one tile per workgroup (tests/test_gpu_parity.py
     // compares that schedule bit for bit with the real one)
     if (const char *e = getenv("HDRTV_FORCE_NCU")) { if (atoi(e) > 0) c->n_cu = atoi(e); }
+    variants_init(c);
     if (hipMalloc((void **)&c->wts.dev, c->wts.size + 256) != hipSuccess) {
         c->wts.dev = nullptr;
         return fail(c, HDRTV_ENOMEM, "weight allocation failed");
@@ -1986,6 +2052,24 @@ int hdrtv_set_cond_mode(hdrtv_ctx *c, int mode)
     if (!c) return HDRTV_EINVAL;
     if (mode < 0 || mode > 2) return fail(c, HDRTV_EINVAL, "cond mode must be 0 (bicubic-aa), 1 (bilinear) or 2 (zero)");
     c->cond_mode = mode;
+    return HDRTV_OK;
+}
+
+int hdrtv_set_variant(hdrtv_ctx *c, const char *name, int value)
+{
+    if (!c || !name) return HDRTV_EINVAL;
+    auto it = c->var.find(name);
+    if (it == c->var.end()) return fail(c, HDRTV_EINVAL, "unknown variant %s", name);
+    it->second = value;
+    return HDRTV_OK;
+}
+
+int hdrtv_get_variant(hdrtv_ctx *c, const char *name, int *value)
+{
+    if (!c || !name || !value) return HDRTV_EINVAL;
+    auto it = c->var.find(name);
+    if (it == c->var.end()) return fail(c, HDRTV_EINVAL, "unknown variant %s", name);
+    *value = it->second;
     return HDRTV_OK;
 }
 

@@ -43,6 +43,8 @@ SYMBOLS = [
     ("hdrtv_profile_enable", _I, [_VP, _I]),
     ("hdrtv_profile_get", _I, [_VP, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_float),
                                C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("hdrtv_set_variant", _I, [_VP, C.c_char_p, _I]),
+    ("hdrtv_get_variant", _I, [_VP, C.c_char_p, C.POINTER(_I)]),
     ("hdrtv_last_error", C.c_char_p, [_VP]),
 ]
 

@@ -495,6 +495,16 @@ class HDRTVNetMI355X:
         self._chk(self._lib.hdrtv_set_hg_mask_r(self._ctx, float(r)), "hdrtv_set_hg_mask_r")
         self._graphs.clear()          # a captured hipGraph has the old threshold baked into its kernel arguments
 
+    def set_variant(self, name, value):
+        """Developer / test switch (``hdrtv_set_variant``): which of several equivalent kernels a layer runs on."""
+        self._chk(self._lib.hdrtv_set_variant(self._ctx, name.encode(), int(value)), "hdrtv_set_variant")
+        self._graphs.clear()          # a captured hipGraph replays the launches it was captured with
+
+    def get_variant(self, name):
+        v = C.c_int()
+        self._chk(self._lib.hdrtv_get_variant(self._ctx, name.encode(), C.byref(v)), "hdrtv_get_variant")
+        return v.value
+
     def profile_enable(self, on=True):
         """Per-launch HIP-event timing of subsequent infer() calls (bench.py roofline).  While it is on, infer() launches
         eagerly even with ``use_cuda_graphs``: a graph replay records no events, and a graph captured with profiling on

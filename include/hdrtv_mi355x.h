@@ -154,6 +154,13 @@ int hdrtv_profile_enable(hdrtv_ctx *ctx, int on);
 int hdrtv_profile_get(hdrtv_ctx *ctx, int i, const char **layer, const char **kernel, float *ms, double *macs,
                       double *bytes);
 
+/* Developer / test switch with no reference counterpart: selects which of several equivalent kernels or schedules a
+ * layer runs on (e.g. "le_rows": 1 = the fused row-streaming LE kernels, 0 = one launch per layer).  The table is
+ * filled at hdrtv_create (defaults, then the creating process's HDRTV_VARIANTS="name=value,..."); the launch path never
+ * reads the environment.  Takes effect at the next hdrtv_infer; HDRTV_EINVAL for an unknown name. */
+int hdrtv_set_variant(hdrtv_ctx *ctx, const char *name, int value);
+int hdrtv_get_variant(hdrtv_ctx *ctx, const char *name, int *value);
+
 const char *hdrtv_last_error(const hdrtv_ctx *ctx);
 
 #ifdef __cplusplus
