@@ -6,17 +6,23 @@
 // the 32-channel intermediate written to and read back from HBM, every input halo fetched 1.27x).
 //
 // Schedule.  A workgroup owns a STRIP of 60 output columns and a SEGMENT of rows and walks down it two rows per step.
-// The stages of the chain run skewed against each other, each on rows the previous stage finished a step earlier:
-//     step s:   LDS-DMA of rows 2s+8, 2s+9 (x: 64 px x 64 B, cond: 64 px x 32 B; four steps ahead)
+// The stages of the chain run skewed against each other, each on rows the previous stage finished a step earlier
+// (DPF = 3, the conv1 -> sft2 hand-over inside a step):
+//     step s:   LDS-DMA of rows 2s+6, 2s+7 (x: 64 px x 64 B, cond: 64 px x 32 B; three steps ahead)
 //               sft1           -> Y1 rows 2s,   2s+1          (64 columns: the strip + 2 halo columns each side)
 //               conv1 + sft2   -> Y2 rows 2s-3, 2s-2          (62 columns)
 //               conv2 + x      -> out rows 2s-6, 2s-5         (60 columns; x from the ring the DMA filled)
 // so a row is fetched ONCE (plus 4 of 64 columns shared with the neighbour strips and 4 rows per segment), there is no
 // vertical recompute, and ONE s_barrier per step orders all rings (every ring slot is written and read in different steps).
 // Waves have ROLES, so that a wave's 3x3 filter bank lives in its registers for the whole launch (18 A fragments = 72
-// VGPRs; conv32s re-reads it from LDS for every 32 pixels): waves 0-3 run conv1 + sft2, waves 4-7 sft1 + conv2 + the
-// stores, one 32-pixel group (row g >> 1, column half g & 1) per stage, step and wave.  Each SIMD holds one wave of
-// either role; they meet only at the barrier.
+// VGPRs; conv32s re-reads it from LDS for every 32 pixels): waves 0-3 (role B) run sft1, conv1 and sft2 -- LDS to LDS, not
+// one memory operation -- and waves 4-7 (role C) the LDS-DMA, conv2, the residual and the stores; one 32-pixel group
+// (row g >> 1, column half g & 1) per stage, step and wave.  Each SIMD holds one wave of either role; they meet at the barrier.
+// The kernel is bound by vector-instruction issue (two waves per SIMD, ~40 MFMAs against a few hundred VALU / LDS
+// instructions per step), so the code is written for few instructions: the Y rings keep their first two rows a second
+// time behind the last (a 3-row conv window never wraps: one address per fragment column, kernel rows as immediates), an SFT
+// pass (a chain of dependent MFMA -> VALU -> MFMA steps) runs between the MFMAs of an independent conv, ReLU / LeakyReLU and the
+// residual add work on packed f16.
 // Arithmetic, operand order and rounding points are conv32s's (K order (tap, k-step) on v_mfma_f32_32x32x16_f16, SFT in
 // packed f16, bias added in fp32 behind the sum, residual add in f16): results are bit-identical to the two-launch form.
 #include "launchers.h"
@@ -35,43 +41,59 @@ namespace {
 #define STAMP_DUMP(p)
 #endif
 
+// Diagnostic builds only (make EXTRA=-DRB_ABL=n, tools/abl_rows.sh): leave parts of the kernel out to see what its time is
+// made of -- 1 no LDS-DMA, 2 no global stores, 4 no conv MFMAs, 8 no SFT passes, 16 no step barrier.  Results are garbage.
+#ifndef RB_ABL
+#define RB_ABL 0
+#endif
+
 constexpr int WS = 60;                  // output columns of a strip
 constexpr int WI = 64;                  // input columns: 2 halo columns each side
-constexpr int YP = 68;                  // pixel pitch of the Y rings (fragment reads of the two unused lanes run to slot 65)
-constexpr int DPF = 4;                  // the LDS-DMA runs DPF steps ahead
-constexpr int XR = 16, CR = 14, YR = 6; // ring rows (see header: live ranges 2 DPF + 8, 2 DPF + 5 (even), 6)
+constexpr int YP = 66;                  // pixel pitch of the Y rings (fragment reads of the two unused lanes run to slot 65)
+constexpr int YN = 6, YPH = YN + 2;     // Y ring rows; physical rows: rows 0 and 1 of a lap are kept a second time behind row 5
 constexpr int X_ROWB = WI * 64, C_ROWB = WI * 32, Y_ROWB = YP * 64;
-constexpr int OFF_X = 0, OFF_C = OFF_X + XR * X_ROWB, OFF_Y1 = OFF_C + CR * C_ROWB, OFF_Y2 = OFF_Y1 + YR * Y_ROWB;
 constexpr int OUT_ROWB = 64 + 16, STRIP = 32 * OUT_ROWB;
-constexpr int OFF_ST = OFF_Y2 + YR * Y_ROWB;
-constexpr int OFF_B = OFF_ST + 4 * STRIP;            // conv1 / conv2 bias (in the dynamic buffer: hipcc guards every read of a
-                                                     // NAMED LDS array with vmcnt(0) while an LDS-DMA is in flight)
-constexpr int SMEM_RB = OFF_B + 256;
-static_assert(SMEM_RB <= 160 * 1024, "LDS budget");
-constexpr int BIG = 336;                // multiple of every ring size: keeps (row + BIG) % ring non-negative
+constexpr int BIG = 168;                // multiple of every ring size: keeps (row + BIG) % ring non-negative
+constexpr int SFT_TILE_F = 3 * 2 * 16;  // floats of one SFT layer's three bias tiles
+// DPF: the LDS-DMA runs DPF steps ahead.  PIPE: sft2 runs one step behind its conv1 (inside the NEXT conv1's MFMA stream).
+template <int DPF, bool PIPE> struct RbGeo {
+    static constexpr int LAG = PIPE ? 8 : 6;                 // output rows trail the sft1 rows by LAG
+    static constexpr int XR = 2 * DPF + LAG + 2;             // x ring: fetched 2 DPF rows ahead, read again LAG rows later (the residual)
+    static constexpr int CR = 2 * DPF + LAG;                 // condition ring: last read by sft2, LAG - 3 rows behind
+    static constexpr int OFF_X = 0, OFF_C = OFF_X + XR * X_ROWB, OFF_Y1 = OFF_C + CR * C_ROWB, OFF_Y2 = OFF_Y1 + YPH * Y_ROWB;
+    static constexpr int OFF_ST = OFF_Y2 + YPH * Y_ROWB;
+    static constexpr int OFF_B = OFF_ST + 4 * STRIP;         // conv1 | conv2 bias, then the two SFT layers' bias tiles
+    static constexpr int SMEM = OFF_B + 256 + 2 * SFT_TILE_F * 4;
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+    static_assert(BIG % XR == 0 && BIG % CR == 0 && BIG % YN == 0, "BIG");
+};
 
 __device__ __forceinline__ int swz32(int v) { return (v >> 2) & 3; }
 
 // LDS reads while an LDS-DMA is in flight: hipcc's waitcnt pass puts s_waitcnt vmcnt(0) in front of every LDS load that
 // carries NO alias metadata -- in practice loads of HIP's struct vector types (float4 ...), which are aggregate copies
 // without a TBAA tag -- and none in front of loads of clang ext_vector types (f16x8, f32x4: TBAA-tagged; the pass then
-// consults its list of DMA stores with alias scopes, which is empty here).  With the DMA running four steps ahead a
+// consults its list of DMA stores with alias scopes, which is empty here).  With the DMA running steps ahead a
 // vmcnt(0) in the loop drains the whole prefetch queue, so: ext_vector types only for LDS reads inside the step loop
 // (tests/test_isa_contracts.py pins the loop's wait set).
 
 // s_waitcnt immediate of gfx9: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14
 constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 15) | (7 << 4) | ((lgkm & 15) << 8) | ((vm >> 4) << 14); }
 
-__device__ __forceinline__ f32x16 tile16(const float *b, int lh)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// four fp32 -> f16 (round to nearest even) as two v_cvt_pk_f16_f32
+__device__ __forceinline__ f16x4 cvt4(float a, float b, float c, float d)
 {
-    f32x16 a;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const float4 v = *reinterpret_cast<const float4 *>(b + 8 * g + 4 * lh);
-        a[4 * g + 0] = v.x; a[4 * g + 1] = v.y; a[4 * g + 2] = v.z; a[4 * g + 3] = v.w;
-    }
-    return a;
+    const f16x2 lo = __builtin_convertvector(f32x2{a, b}, f16x2), hi = __builtin_convertvector(f32x2{c, d}, f16x2);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
+// accumulator quad qd (registers 4 qd .. 4 qd + 3) + bias -> f16
+__device__ __forceinline__ f16x4 bias_cvt4(const f32x16 &acc, int qd, const f32x4 &b)
+{
+    const f32x2 lo = f32x2{acc[4 * qd], acc[4 * qd + 1]} + f32x2{b[0], b[1]}, hi = f32x2{acc[4 * qd + 2], acc[4 * qd + 3]} + f32x2{b[2], b[3]};
+    return __builtin_shufflevector(__builtin_convertvector(lo, f16x2), __builtin_convertvector(hi, f16x2), 0, 1, 2, 3);
+}
+__device__ __forceinline__ f16x4 zero4() { return f16x4{(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f}; }
 
 __device__ __forceinline__ f16x8 lrelu_pack16(const f32x16 &a, int s)
 {
@@ -91,58 +113,99 @@ __device__ __forceinline__ void load_bank(Bank &b, const f16 *wpk, int l31, int 
         b.f[st] = *reinterpret_cast<const f16x8 *>(wpk + ((st >> 1) * 32 + l31) * 32 + 16 * (st & 1) + 8 * lh);
 }
 
-// The SFT layer's operands (pack_sft, hdrtv_api.hip): hidden stack, scale head, shift head; biases as accumulator tiles
-struct Sft { f16x8 a0, a1s, a1t; f32x16 bh, bs, bt; };
-__device__ __forceinline__ void load_sft(Sft &s, const f16 *wfrag, const float *bias, int lane, int lh)
+// The SFT layer's operands (pack_sft, hdrtv_api.hip): three A fragments (hidden stack, scale head, shift head) in registers;
+// the three bias tiles (accumulator inits, (scale + 1) folded into the second) in LDS, 2 lane halves x 16 floats each
+struct SftW { f16x8 a0, a1s, a1t; };
+__device__ __forceinline__ void load_sft(SftW &s, const f16 *wfrag, int lane)
 {
     const f16x8 *fr = reinterpret_cast<const f16x8 *>(wfrag);
     s.a0 = fr[lane]; s.a1s = fr[64 + lane]; s.a1t = fr[128 + lane];
-    s.bh = tile16(bias, lh); s.bs = tile16(bias + 32, lh); s.bt = tile16(bias + 64, lh);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) s.bs[k] += 1.f;           // (scale + 1) enters through the accumulator init
 }
-// y = x * (scale + 1) + shift on one pixel's 16 channels of this lane (channel quads qd: channels 8 qd + 4 lh ..), conv32s's form
-__device__ __forceinline__ void sft_apply(const Sft &s, const f16x8 &c0, f16x4 (&y)[4])
+__device__ __forceinline__ void sft_tiles_to_lds(float *dst, const float *bias, int tid)
 {
-    const f32x16 h = __builtin_amdgcn_mfma_f32_32x32x16_f16(s.a0, c0, s.bh, 0, 0, 0);
-    const f16x8 hs = lrelu_pack16(h, 0), ht = lrelu_pack16(h, 1);
-    const f32x16 sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(s.a1s, hs, s.bs, 0, 0, 0);
-    const f32x16 sh = __builtin_amdgcn_mfma_f32_32x32x16_f16(s.a1t, ht, s.bt, 0, 0, 0);
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-        f16x4 s1, s0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { s1[k] = (f16)sc[4 * qd + k]; s0[k] = (f16)sh[4 * qd + k]; }
-        y[qd] = y[qd] * s1 + s0;
+    if (tid < SFT_TILE_F) {
+        const int t = tid >> 5, lh = (tid >> 4) & 1, j = tid & 15;
+        dst[tid] = bias[32 * t + 8 * (j >> 2) + 4 * lh + (j & 3)] + (t == 1 ? 1.f : 0.f);
     }
 }
+__device__ __forceinline__ f32x16 ld_tile(const float *t)
+{
+    f32x16 a;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(t + 4 * g);
+        a[4 * g + 0] = v[0]; a[4 * g + 1] = v[1]; a[4 * g + 2] = v[2]; a[4 * g + 3] = v[3];
+    }
+    return a;
+}
+// y = x * (scale + 1) + shift on one pixel's 16 channels of this lane (channel quads qd: channels 8 qd + 4 lh ..), in three
+// stages so that a caller can put independent work between the dependent MFMAs (conv32s's arithmetic, bit for bit)
+__device__ __forceinline__ f32x16 sft_hidden(const SftW &s, const f16x8 &c0, const float *tiles)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(s.a0, c0, ld_tile(tiles), 0, 0, 0);
+}
+__device__ __forceinline__ void sft_heads(const SftW &s, const f32x16 &h, const float *tiles, f32x16 &sc, f32x16 &sh)
+{
+    const f16x8 hs = lrelu_pack16(h, 0), ht = lrelu_pack16(h, 1);
+    sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(s.a1s, hs, ld_tile(tiles + 32), 0, 0, 0);
+    sh = __builtin_amdgcn_mfma_f32_32x32x16_f16(s.a1t, ht, ld_tile(tiles + 64), 0, 0, 0);
+}
+__device__ __forceinline__ void sft_modulate(const f32x16 &sc, const f32x16 &sh, f16x4 (&y)[4])
+{
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd)
+        y[qd] = y[qd] * cvt4(sc[4 * qd], sc[4 * qd + 1], sc[4 * qd + 2], sc[4 * qd + 3]) + cvt4(sh[4 * qd], sh[4 * qd + 1], sh[4 * qd + 2], sh[4 * qd + 3]);
+}
 
-// 3x3 conv of one 32-pixel group: rows r0..r2 are the LDS bases of the three input rows, xo[kx][ks] this lane's fragment
-// offsets inside a row.  K order (tap, k-step); reads run three steps ahead of the MFMAs.
-__device__ __forceinline__ f32x16 conv18(const Bank &w, const char *r0, const char *r1, const char *r2, const int (&xo)[3][2])
+// 3x3 conv of one 32-pixel group out of a Y ring: a[kx][ks] = this lane's fragment address (kernel column kx, k-step ks) in
+// the window's FIRST row; the window's rows are Y_ROWB apart (it never wraps, see YPH).  K order (tap, k-step); reads run
+// AHEAD steps in front of the MFMAs; hook(st) runs behind MFMA st.
+template <int AHEAD, class Hook>
+__device__ __forceinline__ f32x16 conv18(const Bank &w, const char *smem, const int (&a)[3][2], Hook hook)
 {
     f32x16 acc;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
     f16x8 x[18];
     auto ld = [&](int st) __attribute__((always_inline)) {
         const int tap = st >> 1, ks = st & 1, ky = tap / 3, kx = tap % 3;
-        x[st] = *reinterpret_cast<const f16x8 *>((ky == 0 ? r0 : (ky == 1 ? r1 : r2)) + xo[kx][ks]);
+        x[st] = *reinterpret_cast<const f16x8 *>(smem + a[kx][ks] + ky * Y_ROWB);
     };
-    ld(0); ld(1); ld(2);
+#pragma unroll
+    for (int st = 0; st < AHEAD; ++st) ld(st);
 #pragma unroll
     for (int st = 0; st < 18; ++st) {
-        if (st + 3 < 18) ld(st + 3);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.f[st], x[st], acc, 0, 0, 0);
+        if (st + AHEAD < 18) ld(st + AHEAD);
+        if (RB_ABL & 4) {
+            if (st == 0) for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+            acc[st & 15] += (float)x[st][0] * (float)w.f[st][0];
+        } else if (st == 0) {
+            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.f[0], x[0], z, 0, 0, 0);
+        } else {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.f[st], x[st], acc, 0, 0, 0);
+        }
+        hook(st);
     }
     return acc;
 }
 
-}  // namespace
+// One pixel's 16 channels of this lane into ring row m of the Y ring at `ring` (and into its second copy, rows 0 and 1)
+__device__ __forceinline__ void put_row(char *smem, int ring, int m, int q0, const f16x4 (&y)[4])
+{
+    char *d = smem + ring + m * Y_ROWB;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) *reinterpret_cast<f16x4 *>(d + (q0 ^ (qd << 4))) = y[qd];
+    if (m < 2) {
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) *reinterpret_cast<f16x4 *>(d + YN * Y_ROWB + (q0 ^ (qd << 4))) = y[qd];
+    }
+}
 
 // Fused ResBlock_with_SFT, rows.  Grid = nstrips x nseg workgroups of 512 threads.
+template <int DPF, bool PIPE>
 __global__ __launch_bounds__(512) void le_rb_rows_kernel(RowsRbParams p)
 {
+    using G = RbGeo<DPF, PIPE>;
+    constexpr int LAG = G::LAG, XR = G::XR, CR = G::CR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -151,194 +214,231 @@ __global__ __launch_bounds__(512) void le_rb_rows_kernel(RowsRbParams p)
     const int x0 = strip * WS;
     const int y0 = seg * p.rows_per_seg, y1 = min(y0 + p.rows_per_seg, p.H);
     const int ya = y0 - 2;                                             // image row of ring row 0
-    const int nsteps = (y1 - ya + 5) / 2 + 1;
+    const int nsteps = (y1 - ya + LAG - 1) / 2 + 1;
     const int H = p.H, W = p.W;
-    float *sB = reinterpret_cast<float *>(smem + OFF_B);
+    float *sB = reinterpret_cast<float *>(smem + G::OFF_B);
     if (tid < 32) { sB[tid] = p.b1[tid]; sB[32 + tid] = p.b2[tid]; }
+    sft_tiles_to_lds(sB + 64, p.sft1_bias, tid);
+    sft_tiles_to_lds(sB + 64 + SFT_TILE_F, p.sft2_bias, tid);
+    const float *t1 = sB + 64 + 16 * lh, *t2 = t1 + SFT_TILE_F;
 
     const int g = wave & 3, gr = g >> 1, gh = g & 1;                   // this wave's 32-pixel group: row gr of the step's pair, column half gh
-    const dma_rsrc_t rx = dma_rsrc(p.x), rc = dma_rsrc(p.cond);
+    const int cx = 32 * gh + l31;                                      // this lane's pixel slot in its group's ring rows
+    int xo[3][2];                                                      // conv fragment offsets: output slot cx reads input slots cx .. cx + 2
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) xo[kx][ks] = (cx + kx) * 64 + ((((ks << 1) | lh) ^ swz32(cx + kx)) << 4);
+    const bool colfull = x0 >= 2 && x0 + 62 <= W;                      // no column of the strip's halo lies outside the image
 
     if (wave < 4) {
-        // ------------------------------------------------------------------ role B: conv1 + sft2, issues the x rows
+        // ------------------------------------------------------------------ role B: sft1, conv1, sft2 -- LDS to LDS, no memory operation
         Bank w1;
         load_bank(w1, p.w1, l31, lh);
-        Sft s2;
-        load_sft(s2, p.sft2_wfrag, p.sft2_bias, lane, lh);
-        const int cx = 32 * gh + l31;                                  // Y2 slot = conv1 output column x0 - 1 + cx
-        int xo[3][2];
+        SftW s1, s2;
+        load_sft(s1, p.sft1_wfrag, lane);
+        load_sft(s2, p.sft2_wfrag, lane);
+        const int q0 = cx * 64 + (swz32(cx) << 4) + 8 * lh;            // x read, Y1 / Y2 write: channel quad qd at q0 ^ (qd << 4)
+        const int co1 = cx * 32 + ((lh ^ ((cx >> 3) & 1)) << 4);       // sft1: slot cx = image column x0 - 2 + cx
+        const int co2 = (cx + 1) * 32 + ((lh ^ (((cx + 1) >> 3) & 1)) << 4);    // sft2: Y2 slot cx = image column x0 - 1 + cx = condition slot cx + 1
+        const bool col1 = (unsigned)(x0 - 2 + cx) < (unsigned)W, col2 = (unsigned)(x0 - 1 + cx) < (unsigned)W;
+        f16x4 yp[4] = {zero4(), zero4(), zero4(), zero4()};            // PIPE: conv1's result of the previous step
+        __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));
+        __builtin_amdgcn_s_barrier();
+        STAMP_DECL;
+        for (int s = 0; s < nsteps; ++s) {
+            STAMP(7);
+            const int ra = 2 * s + gr, rb = 2 * s - 3 + gr, r2 = PIPE ? rb - 2 : rb;      // ring rows: sft1 on ra; conv1 on rb; sft2 on r2
+            const char *xb = smem + G::OFF_X + ((ra + BIG) % XR) * X_ROWB;
+            const f16x8 c1 = *reinterpret_cast<const f16x8 *>(smem + G::OFF_C + ((ra + BIG) % CR) * C_ROWB + co1);
+            f16x4 ya4[4];
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
+            for (int qd = 0; qd < 4; ++qd) ya4[qd] = *reinterpret_cast<const f16x4 *>(xb + (q0 ^ (qd << 4)));
+            const f16x8 c2 = *reinterpret_cast<const f16x8 *>(smem + G::OFF_C + ((r2 + BIG) % CR) * C_ROWB + co2);
+            f32x4 bq[4];                                               // conv1's bias: read here, not behind the conv (four dependent LDS round trips there)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) xo[kx][ks] = (cx + kx) * 64 + ((((ks << 1) | lh) ^ swz32(cx + kx)) << 4);
-        const int yw = cx * 64 + (swz32(cx) << 4) + 8 * lh;            // Y2 write: channel quad qd at yw ^ (qd << 4)
-        const int co = (cx + 1) * 32 + ((lh ^ (((cx + 1) >> 3) & 1)) << 4);     // condition pixel of the same column (ring slot cx + 1)
-        const bool col_in = (unsigned)(x0 - 1 + cx) < (unsigned)W;
-        // LDS-DMA of the x rows: pieces 2 gh, 2 gh + 1 of row gr (16 pixels x 64 B each)
-        unsigned xl[2];
-        bool xok[2];
+            for (int qd = 0; qd < 4; ++qd) bq[qd] = *reinterpret_cast<const f32x4 *>(sB + 8 * qd + 4 * lh);
+            const bool row1 = (unsigned)(ya + ra) < (unsigned)H, row2 = (unsigned)(ya + r2) < (unsigned)H;   // outside the image: zero padding
+            const int m1 = (ra + BIG) % YN, m2 = (r2 + BIG) % YN;
+            int a[3][2];
+            {
+                const int wb = G::OFF_Y1 + ((rb - 1 + BIG) % YN) * Y_ROWB;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) a[kx][ks] = wb + xo[kx][ks];
+            }
+            // conv1 on row rb with row ra's SFT pass (and, PIPE, the one on the previous step's conv result) between its MFMAs: a
+            // pass is a chain of dependent MFMA -> VALU -> MFMA steps, the conv an independent stream that covers its latencies
+            f32x16 h1, sc1, sh1, h2, sc2, sh2;
+            auto finish1 = [&]() __attribute__((always_inline)) {
+                sft_modulate(sc1, sh1, ya4);
+                if (!(colfull && row1)) {
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) if (!(col1 && row1)) ya4[qd] = zero4();
+                }
+                put_row(smem, G::OFF_Y1, m1, q0, ya4);
+            };
+            auto finish2 = [&](f16x4 (&y)[4]) __attribute__((always_inline)) {
+                sft_modulate(sc2, sh2, y);
+                if (!(colfull && row2)) {
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) if (!(col2 && row2)) y[qd] = zero4();
+                }
+                put_row(smem, G::OFF_Y2, m2, q0, y);
+            };
+            const f32x16 acc = conv18<4>(w1, smem, a, [&](int st) __attribute__((always_inline)) {
+                if (RB_ABL & 8) { if (st == 12) put_row(smem, G::OFF_Y1, m1, q0, ya4); return; }
+                if (st == 1) h1 = sft_hidden(s1, c1, t1);
+                if (st == 6) sft_heads(s1, h1, t1, sc1, sh1);
+                if (st == 12) finish1();
+                if (PIPE) {
+                    if (st == 3) h2 = sft_hidden(s2, c2, t2);
+                    if (st == 9) sft_heads(s2, h2, t2, sc2, sh2);
+                    if (st == 15) finish2(yp);
+                }
+            });
+            STAMP(1);
+            f16x4 y[4];
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) y[qd] = __builtin_elementwise_max(bias_cvt4(acc, qd, bq[qd]), zero4());
+            if (PIPE) {
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) yp[qd] = y[qd];
+            } else if (RB_ABL & 8) {
+                put_row(smem, G::OFF_Y2, m2, q0, y);
+            } else {
+                h2 = sft_hidden(s2, c2, t2);
+                sft_heads(s2, h2, t2, sc2, sh2);
+                finish2(y);
+            }
+            STAMP(2);
+            __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));
+            STAMP(4);
+            if (!(RB_ABL & 16)) __builtin_amdgcn_s_barrier();
+            STAMP(5);
+        }
+        STAMP_DUMP(p);
+    } else {
+        // ------------------------------------------------------------------ role C: LDS-DMA, conv2 + x, stores
+        Bank w2;
+        load_bank(w2, p.w2, l31, lh);
+        const dma_rsrc_t rx = dma_rsrc(p.x), rc = dma_rsrc(p.cond);
+        // per step: pieces 2 gh, 2 gh + 1 of x row gr (16 pixels x 64 B each) and piece gh of condition row gr (32 pixels x 32 B)
+        unsigned xl[2], cl;
+        bool xok[2], cok;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int px = 16 * (2 * gh + j) + (lane >> 2), slot = lane & 3;
             xl[j] = (unsigned)(px * 64 + ((slot ^ swz32(px)) << 4));
             xok[j] = (unsigned)(x0 - 2 + px) < (unsigned)W;
         }
-        auto issue_x = [&](int sq) __attribute__((always_inline)) {
-            const int rr = 2 * sq + gr, r = ya + rr;
-            const bool rok = (unsigned)r < (unsigned)H && r <= y1 + 1;
-            const unsigned base = (unsigned)((r * W + x0 - 2) * 64);
-            char *d = smem + OFF_X + ((rr + BIG) % XR) * X_ROWB + (2 * gh) * 1024;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) dma16(rx, d + j * 1024, (rok && xok[j]) ? base + xl[j] : DMA_OOB);
-        };
-#pragma unroll
-        for (int sq = 0; sq < DPF; ++sq) issue_x(sq);
-        __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));
-        __builtin_amdgcn_s_barrier();
-        STAMP_DECL;
-        for (int s = 0; s < nsteps; ++s) {
-            STAMP(7);
-            issue_x(s + DPF);
-            __builtin_amdgcn_sched_barrier(0);
-            STAMP(0);
-            const int rr = 2 * s - 3 + gr, r = ya + rr;                // the row this wave convolves
-            const f16x8 c0 = *reinterpret_cast<const f16x8 *>(smem + OFF_C + ((rr + BIG) % CR) * C_ROWB + co);
-            const char *y1b = smem + OFF_Y1;
-            const f32x16 acc = conv18(w1, y1b + ((rr - 1 + BIG) % YR) * Y_ROWB, y1b + ((rr + BIG) % YR) * Y_ROWB,
-                                      y1b + ((rr + 1 + BIG) % YR) * Y_ROWB, xo);
-            STAMP(1);
-            f16x4 y[4];
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(sB + 8 * qd + 4 * lh);
-                y[qd][0] = (f16)act_fast(acc[4 * qd + 0] + b4[0], 0.f); y[qd][1] = (f16)act_fast(acc[4 * qd + 1] + b4[1], 0.f);
-                y[qd][2] = (f16)act_fast(acc[4 * qd + 2] + b4[2], 0.f); y[qd][3] = (f16)act_fast(acc[4 * qd + 3] + b4[3], 0.f);
-            }
-            sft_apply(s2, c0, y);
-            const bool in = col_in && (unsigned)r < (unsigned)H;       // outside the image: conv2's zero padding
-            char *yd = smem + OFF_Y2 + ((rr + BIG) % YR) * Y_ROWB;
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                if (!in) y[qd] = f16x4{(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
-                *reinterpret_cast<f16x4 *>(yd + (yw ^ (qd << 4))) = y[qd];
-            }
-            STAMP(2);
-            // the rows of step s + 1 were issued DPF - 1 steps ago: all but the 2 (DPF - 1) youngest pieces have landed
-            __builtin_amdgcn_s_waitcnt(waitcnt_imm(2 * (DPF - 1), 0));
-            STAMP(4);
-            __builtin_amdgcn_s_barrier();
-            STAMP(5);
+        {
+            const int px = 32 * gh + (lane >> 1);
+            cl = (unsigned)(px * 32 + (((lane & 1) ^ ((px >> 3) & 1)) << 4));
+            cok = (unsigned)(x0 - 2 + px) < (unsigned)W;
         }
-        STAMP_DUMP(p);
-    } else {
-        // ------------------------------------------------------------------ role C: sft1, conv2 + x, stores; issues the cond rows
-        Bank w2;
-        load_bank(w2, p.w2, l31, lh);
-        Sft s1;
-        load_sft(s1, p.sft1_wfrag, p.sft1_bias, lane, lh);
-        const int cx = 32 * gh + l31;                                  // sft1: Y1 / x / cond ring slot = image column x0 - 2 + cx
-        const int xr0 = cx * 64 + (swz32(cx) << 4) + 8 * lh;           // x read and Y1 write: quad qd at xr0 ^ (qd << 4)
-        const int co = cx * 32 + ((lh ^ ((cx >> 3) & 1)) << 4);
-        const bool col_in = (unsigned)(x0 - 2 + cx) < (unsigned)W;
-        int xo[3][2];                                                  // conv2: output column x0 + cx reads Y2 slots cx .. cx + 2
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) xo[kx][ks] = (cx + kx) * 64 + ((((ks << 1) | lh) ^ swz32(cx + kx)) << 4);
-        // LDS-DMA of the condition rows: piece gh of row gr (32 pixels x 32 B)
-        const int cpx = 32 * gh + (lane >> 1);
-        const unsigned cl = (unsigned)(cpx * 32 + (((lane & 1) ^ ((cpx >> 3) & 1)) << 4));
-        const bool cok = (unsigned)(x0 - 2 + cpx) < (unsigned)W;
-        auto issue_c = [&](int sq) __attribute__((always_inline)) {
+        auto issue = [&](int sq) __attribute__((always_inline)) {
             const int rr = 2 * sq + gr, r = ya + rr;
             const bool rok = (unsigned)r < (unsigned)H && r <= y1 + 1;
-            dma16(rc, smem + OFF_C + ((rr + BIG) % CR) * C_ROWB + gh * 1024, (rok && cok) ? (unsigned)((r * W + x0 - 2) * 32) + cl : DMA_OOB);
+            const unsigned pix = (unsigned)(r * W + x0 - 2);
+            char *d = smem + G::OFF_X + ((rr + BIG) % XR) * X_ROWB + (2 * gh) * 1024;
+            if (RB_ABL & 1) return;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dma16(rx, d + j * 1024, (rok && xok[j]) ? pix * 64u + xl[j] : DMA_OOB);
+            dma16(rc, smem + G::OFF_C + ((rr + BIG) % CR) * C_ROWB + gh * 1024, (rok && cok) ? pix * 32u + cl : DMA_OOB);
         };
-        // epilogue: this lane's two 16-byte chunks = pixels (it * 16 + (lane >> 2)) of the group, channel chunk c8
-        char *strip_b = smem + OFF_ST + g * STRIP;
+        // epilogue: the result + x goes through a wave-private strip and leaves as 16-byte chunks: this lane stores pixels
+        // it * 16 + (lane >> 2) of the group, channel chunk c8 -- one step LATER, in front of the next conv (the strip's
+        // write -> read -> store chain then runs under that conv's MFMAs)
+        char *strip_b = smem + G::OFF_ST + g * STRIP;
         const int c8 = lane & 3, spx = lane >> 2;
         char *trash = p.trash + tid * 16;
+        const int xr0 = (cx + 2) * 64 + (swz32(cx + 2) << 4) + 8 * lh; // x of output column x0 + cx: ring slot cx + 2
+        const int sw0 = l31 * OUT_ROWB + 8 * lh;                       // strip write: quad qd at sw0 + 16 qd
+        f32x4 bq[4];                                                   // conv2's bias
 #pragma unroll
-        for (int sq = 0; sq < DPF; ++sq) issue_c(sq);
+        for (int qd = 0; qd < 4; ++qd) bq[qd] = *reinterpret_cast<const f32x4 *>(p.b2 + 8 * qd + 4 * lh);
+        auto store_row = [&](int rr) __attribute__((always_inline)) {   // the strip holds ring row rr (output row ya + rr)
+            const int r = ya + rr;
+            const bool row_ok = r >= y0 && r < y1;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int ox = 32 * gh + it * 16 + spx;
+                const f16x8 v = *reinterpret_cast<const f16x8 *>(strip_b + (it * 16 + spx) * OUT_ROWB + c8 * 16);
+                const bool ok = row_ok && ox < WS && x0 + ox < W;
+                f16 *d = ok ? p.dst + ((size_t)r * W + x0 + ox) * 32 + c8 * 8 : reinterpret_cast<f16 *>(trash);
+                if (RB_ABL & 2) { if (v[0] == (f16)123.25f) *reinterpret_cast<f16x8 *>(trash) = v; continue; }
+                *reinterpret_cast<f16x8 *>(d) = v;
+            }
+        };
+#pragma unroll
+        for (int sq = 0; sq < DPF; ++sq) issue(sq);
         __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));
         __builtin_amdgcn_s_barrier();
         STAMP_DECL;
         for (int s = 0; s < nsteps; ++s) {
             STAMP(7);
-            issue_c(s + DPF);
+            store_row(2 * (s - 1) - LAG + gr);                         // (step 0: a row above the segment, masked)
+            issue(s + DPF);
             __builtin_amdgcn_sched_barrier(0);
             STAMP(0);
-            {   // sft1 on row 2 s + gr
-                const int rr = 2 * s + gr, r = ya + rr;
-                const char *xb = smem + OFF_X + ((rr + BIG) % XR) * X_ROWB;
-                const f16x8 c0 = *reinterpret_cast<const f16x8 *>(smem + OFF_C + ((rr + BIG) % CR) * C_ROWB + co);
-                f16x4 y[4];
+            const int rr = 2 * s - LAG + gr;
+            const char *xb = smem + G::OFF_X + ((rr + BIG) % XR) * X_ROWB;
+            f16x4 res[4];
 #pragma unroll
-                for (int qd = 0; qd < 4; ++qd) y[qd] = *reinterpret_cast<const f16x4 *>(xb + (xr0 ^ (qd << 4)));
-                sft_apply(s1, c0, y);
-                const bool in = col_in && (unsigned)r < (unsigned)H;   // outside the image: conv1's zero padding
-                char *yd = smem + OFF_Y1 + ((rr + BIG) % YR) * Y_ROWB;
+            for (int qd = 0; qd < 4; ++qd) res[qd] = *reinterpret_cast<const f16x4 *>(xb + (xr0 ^ (qd << 4)));
+            int a[3][2];
+            {
+                const int wb = G::OFF_Y2 + ((rr - 1 + BIG) % YN) * Y_ROWB;
 #pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                    if (!in) y[qd] = f16x4{(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
-                    *reinterpret_cast<f16x4 *>(yd + (xr0 ^ (qd << 4))) = y[qd];
-                }
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) a[kx][ks] = wb + xo[kx][ks];
             }
-            STAMP(2);
-            {   // conv2 on row 2 s - 6 + gr, + x, store
-                const int rr = 2 * s - 6 + gr, r = ya + rr;
-                const char *y2b = smem + OFF_Y2;
-                const f32x16 acc = conv18(w2, y2b + ((rr - 1 + BIG) % YR) * Y_ROWB, y2b + ((rr + BIG) % YR) * Y_ROWB,
-                                          y2b + ((rr + 1 + BIG) % YR) * Y_ROWB, xo);
-                STAMP(1);
+            const f32x16 acc = conv18<6>(w2, smem, a, [](int) {});
+            STAMP(1);
 #pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(sB + 32 + 8 * qd + 4 * lh);
-                    f16x4 o;
-                    o[0] = (f16)(acc[4 * qd + 0] + b4[0]); o[1] = (f16)(acc[4 * qd + 1] + b4[1]);
-                    o[2] = (f16)(acc[4 * qd + 2] + b4[2]); o[3] = (f16)(acc[4 * qd + 3] + b4[3]);
-                    *reinterpret_cast<f16x4 *>(strip_b + l31 * OUT_ROWB + (8 * qd + 4 * lh) * 2) = o;
-                }
-                const char *xb = smem + OFF_X + ((rr + BIG) % XR) * X_ROWB;
-                const bool row_ok = r >= y0 && r < y1;
-#pragma unroll
-                for (int it = 0; it < 2; ++it) {
-                    const int ox = 32 * gh + it * 16 + spx, xs = ox + 2;          // output column x0 + ox; its x lives in ring slot ox + 2
-                    f16x8 v = *reinterpret_cast<const f16x8 *>(strip_b + (it * 16 + spx) * OUT_ROWB + c8 * 16);
-                    const f16x8 res = *reinterpret_cast<const f16x8 *>(xb + xs * 64 + ((c8 ^ swz32(xs)) << 4));
-                    v = v + res;
-                    const bool ok = row_ok && ox < WS && x0 + ox < W;
-                    f16 *d = ok ? p.dst + ((size_t)r * W + x0 + ox) * 32 + c8 * 8 : reinterpret_cast<f16 *>(trash);
-                    *reinterpret_cast<f16x8 *>(d) = v;
-                }
-            }
+            for (int qd = 0; qd < 4; ++qd) *reinterpret_cast<f16x4 *>(strip_b + sw0 + 16 * qd) = bias_cvt4(acc, qd, bq[qd]) + res[qd];
             STAMP(3);
-            // per step and wave: one DMA piece, then two stores (always issued): the piece of step s + 1 is older than
-            // 3 (DPF - 1) + 2 operations
-            __builtin_amdgcn_s_waitcnt(waitcnt_imm(3 * (DPF - 1) + 2, 0));
+            // per step and wave: two stores, then three DMA pieces (all always issued): the pieces of step s + 1 are older
+            // than the 5 (DPF - 1) operations of the steps since
+            __builtin_amdgcn_s_waitcnt(waitcnt_imm((RB_ABL & 3) ? 0 : 5 * (DPF - 1), 0));
             STAMP(4);
-            __builtin_amdgcn_s_barrier();
+            if (!(RB_ABL & 16)) __builtin_amdgcn_s_barrier();
             STAMP(5);
         }
+        store_row(2 * (nsteps - 1) - LAG + gr);
         STAMP_DUMP(p);
     }
 }
 
-hipError_t le_rb_rows_launch(RowsRbParams p, int n_cu, hipStream_t s)
+template <int DPF, bool PIPE>
+hipError_t launch_rb(RowsRbParams p, int nseg, hipStream_t s)
 {
-    if ((size_t)p.H * p.W * 64 >= 0x7f000000ull || !p.trash) return hipErrorInvalidValue;
+    using G = RbGeo<DPF, PIPE>;
     static DevOnce attr_once;
+    auto kern = le_rb_rows_kernel<DPF, PIPE>;
     if (attr_once.need()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(le_rb_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_RB);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
         if (e != hipSuccess) return e;
         attr_once.done();
     }
+    hipLaunchKernelGGL(kern, dim3(p.nstrips * nseg), dim3(512), G::SMEM, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// variant: 0 = sft2 inside its own step (DMA three steps ahead), 1 = sft2 one step behind, inside the next conv1 (DMA two steps ahead)
+hipError_t le_rb_rows_launch(RowsRbParams p, int n_cu, hipStream_t s, int variant)
+{
+    if ((size_t)p.H * p.W * 64 >= 0x7f000000ull || !p.trash) return hipErrorInvalidValue;
     p.nstrips = (p.W + WS - 1) / WS;
     int nseg = n_cu / p.nstrips;
     if (nseg < 1) nseg = 1;
     if (nseg > p.H) nseg = p.H;
     p.rows_per_seg = (p.H + nseg - 1) / nseg;
     nseg = (p.H + p.rows_per_seg - 1) / p.rows_per_seg;
-    hipLaunchKernelGGL(le_rb_rows_kernel, dim3(p.nstrips * nseg), dim3(512), SMEM_RB, s, p);
-    return hipGetLastError();
+    return variant == 1 ? launch_rb<2, true>(p, nseg, s) : launch_rb<3, false>(p, nseg, s);
 }
