@@ -226,6 +226,26 @@ struct RowsRbParams {
     int nstrips, rows_per_seg;              // set by the launcher
 };
 
+// Parameter block of the row-streaming fused tail of the LE net (le_rows.hip):
+// out = res + conv_last(relu(HR_conv2(sft(relu(shuffle(up_conv(u))) + skip, cond))))
+struct RowsTailParams {
+    const f16 *u;          // NHWC 32 [H/2][W/2]: the half-resolution trunk output
+    const f16 *fea0;       // NHWC 32 [H][W]: the skip
+    const f16 *cond;       // NHWC 16 [H][W]
+    const f16 *res_planar; // f16 [3][H][W]: the long skip (agcm output)
+    f16 *dst_planar;       // f16 [3][H][W]
+    const f16 *w_up;       // [9][128][32], rows in PixelShuffle order (pack_conv ps_cps = 32)
+    const float *b_up;     // [128]
+    const f16 *sft_wfrag;
+    const float *sft_bias;
+    const f16 *w_hr, *w_last;               // [9][32][32]
+    const float *b_hr, *b_last;             // [32]
+    char *trash;           // >= 8 KiB write-only scratch for masked-off lanes
+    void *dump;            // diagnostic builds (make STAMP=1)
+    int H, W;
+    int nstrips, rows_per_seg;              // set by the launcher
+};
+
 // Letterbox (letterbox.hip): u8 BGR [sh][sw][3] -> u8 BGR [dh][dw][3], resized region [y0, y0+new_h) x [x0, x0+new_w)
 enum { LB_COPY = 0, LB_AREA_INT = 1, LB_AREA_FRAC = 2, LB_CUBIC = 3 };
 struct LetterboxParams {

@@ -1889,6 +1889,26 @@ int run_le(hdrtv_ctx *c, Seq &q, const f16 *img, f16 *out_planar)
     f16 *up2 = wsp<f16>(c, "le.up2"), *t5 = wsp<f16>(c, "le.t5");
     q.conv32("LE.up_conv2.0", t4, nullptr, "", s.H2, s.W2, ACT_RELU, ST_PS, up2, 32, s.H1, s.W1, fea1);
     q.resblock("LE.recon_trunk5.0", up2, cond2, s.H1, s.W1, l1b, t5);
+    // the full-resolution tail: one row-streaming launch (le_rows.hip) when all of it is fp16 and the shapes are even, else per layer
+    const bool tail_fused = q.ok() && c->var.at("le_rows") && !(H & 1) && !(W & 1) && s.H1 * 2 == H && s.W1 * 2 == W && q.rows_fit(H, W) &&
+                            c->conv.count("LE.up_conv3.0") && c->conv.count("LE.HR_conv2") && c->conv.count("LE.conv_last") &&
+                            !c->sft.at("LE.SFT_layer2").q;
+    if (tail_fused) {
+        const ConvLayer &Lu = c->conv.at("LE.up_conv3.0"), &Lh = c->conv.at("LE.HR_conv2"), &Ll = c->conv.at("LE.conv_last");
+        const SftLayer &S2 = c->sft.at("LE.SFT_layer2");
+        RowsTailParams p;
+        memset(&p, 0, sizeof p);
+        p.u = t5; p.fea0 = fea0; p.cond = cond1; p.res_planar = img; p.dst_planar = out_planar; p.H = H; p.W = W;
+        p.w_up = wtp<f16>(c, Lu.wpk); p.b_up = wtp<float>(c, Lu.shift);
+        p.sft_wfrag = wtp<f16>(c, S2.wfrag); p.sft_bias = wtp<float>(c, S2.bias);
+        p.w_hr = wtp<f16>(c, Lh.wpk); p.b_hr = wtp<float>(c, Lh.shift); p.w_last = wtp<f16>(c, Ll.wpk); p.b_last = wtp<float>(c, Ll.shift);
+        p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
+        p.dump = q.stamp_buf();
+        const double npx = (double)H * W;
+        q.chk(le_tail_rows_launch(p, c->n_cu, q.s), "LE.tail", "le_tail_rows", npx * (32.0 * 9 * 128 / 4 + 2.0 * (16 * 16 + 16 * 32) + 32.0 * 9 * 32 + 32.0 * 9 * 3),
+              npx * (16 + 64 + 32 + 6 + 6) + 2.0 * 9 * 32 * (128 + 32 + 32));
+        return q.rc;
+    }
     q.conv32("LE.up_conv3.0", t5, nullptr, "", s.H1, s.W1, ACT_RELU, ST_PS, up3, 32, H, W, fea0);
     q.conv32("LE.HR_conv2", up3, cond1, "LE.SFT_layer2", H, W, ACT_RELU, ST_NHWC, f0b, 32, H, W);
     q.conv32("LE.conv_last", f0b, nullptr, "", H, W, ACT_NONE, ST_PLANAR3, nullptr, 0, H, W, nullptr, nullptr, out_planar, img);

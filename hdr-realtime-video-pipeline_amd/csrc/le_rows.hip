@@ -106,11 +106,11 @@ __device__ __forceinline__ f16x8 lrelu_pack16(const f32x16 &a, int s)
 // A 3x3 32 -> 32 filter bank as 18 A fragments of v_mfma_f32_32x32x16_f16 (wpk = [tap][32 out][32 in]; fragment (tap, ks):
 // lane = out channel l31, input channels 16 ks + 8 lh ..)
 struct Bank { f16x8 f[18]; };
-__device__ __forceinline__ void load_bank(Bank &b, const f16 *wpk, int l31, int lh)
+__device__ __forceinline__ void load_bank(Bank &b, const f16 *wpk, int l31, int lh, int coutp = 32, int n0 = 0)
 {
 #pragma unroll
     for (int st = 0; st < 18; ++st)
-        b.f[st] = *reinterpret_cast<const f16x8 *>(wpk + ((st >> 1) * 32 + l31) * 32 + 16 * (st & 1) + 8 * lh);
+        b.f[st] = *reinterpret_cast<const f16x8 *>(wpk + ((st >> 1) * coutp + n0 + l31) * 32 + 16 * (st & 1) + 8 * lh);
 }
 
 // The SFT layer's operands (pack_sft, hdrtv_api.hip): three A fragments (hidden stack, scale head, shift head) in registers;
@@ -160,14 +160,14 @@ __device__ __forceinline__ void sft_modulate(const f32x16 &sc, const f32x16 &sh,
 // 3x3 conv of one 32-pixel group out of a Y ring: a[kx][ks] = this lane's fragment address (kernel column kx, k-step ks) in
 // the window's FIRST row; the window's rows are Y_ROWB apart (it never wraps, see YPH).  K order (tap, k-step); reads run
 // AHEAD steps in front of the MFMAs; hook(st) runs behind MFMA st.
-template <int AHEAD, class Hook>
+template <int AHEAD, int ROWB = Y_ROWB, class Hook>
 __device__ __forceinline__ f32x16 conv18(const Bank &w, const char *smem, const int (&a)[3][2], Hook hook)
 {
     f32x16 acc;
     f16x8 x[18];
     auto ld = [&](int st) __attribute__((always_inline)) {
         const int tap = st >> 1, ks = st & 1, ky = tap / 3, kx = tap % 3;
-        x[st] = *reinterpret_cast<const f16x8 *>(smem + a[kx][ks] + ky * Y_ROWB);
+        x[st] = *reinterpret_cast<const f16x8 *>(smem + a[kx][ks] + ky * ROWB);
     };
 #pragma unroll
     for (int st = 0; st < AHEAD; ++st) ld(st);
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(512) void le_rb_rows_kernel(RowsRbParams p)
                 }
                 put_row(smem, G::OFF_Y2, m2, q0, y);
             };
-            const f32x16 acc = conv18<4>(w1, smem, a, [&](int st) __attribute__((always_inline)) {
+            const f32x16 acc = conv18<4, Y_ROWB>(w1, smem, a, [&](int st) __attribute__((always_inline)) {
                 if (RB_ABL & 8) { if (st == 12) put_row(smem, G::OFF_Y1, m1, q0, ya4); return; }
                 if (st == 1) h1 = sft_hidden(s1, c1, t1);
                 if (st == 6) sft_heads(s1, h1, t1, sc1, sh1);
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(512) void le_rb_rows_kernel(RowsRbParams p)
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) a[kx][ks] = wb + xo[kx][ks];
             }
-            const f32x16 acc = conv18<6>(w2, smem, a, [](int) {});
+            const f32x16 acc = conv18<6, Y_ROWB>(w2, smem, a, [](int) {});
             STAMP(1);
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) *reinterpret_cast<f16x4 *>(strip_b + sw0 + 16 * qd) = bias_cvt4(acc, qd, bq[qd]) + res[qd];
@@ -409,6 +409,256 @@ __global__ __launch_bounds__(512) void le_rb_rows_kernel(RowsRbParams p)
             STAMP(5);
         }
         store_row(2 * (nsteps - 1) - LAG + gr);
+        STAMP_DUMP(p);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The full-resolution tail of the LE net in one launch (HDRUNet3T1_arch.py:196-206):
+//     out = agcm + conv_last(relu(HR_conv2(SFT_layer2(relu(shuffle(up_conv3(u))) + fea0, cond1))))
+// u is the half-resolution trunk output; the per-layer form is conv32p<4> (up-conv + PixelShuffle + ReLU + skip, 0.53 GB
+// written), conv32s<sft> (read back, 0.53 GB written) and conv32s<plain, planar> (read back).  Here the two 32-channel
+// full-resolution tensors live in LDS rings (Y: the modulated up-conv output, Z: relu(HR_conv2)); HBM sees u, fea0, cond1, the
+// residual planes and the three output planes.  Strip / segment / step structure, rings and roles as the ResBlock kernel above:
+//     step s:  LDS-DMA of fea0 / cond rows 2s+6, 2s+7 and of u row s+4 (half resolution: 34 of 48 slots used)
+//              role T1 (waves 0-3, wave b = PixelShuffle position (b >> 1, b & 1)): up_conv3 bank b on u rows s-1 .. s+1 -> 32
+//                   half-resolution pixels = every other pixel of full-resolution row 2s + (b >> 1); ReLU, + fea0, SFT_layer2
+//                   (its two cond MLPs inside the conv's MFMA stream) -> Y rows 2s, 2s+1
+//              role T2 (waves 4-7, group (g >> 1, g & 1)): the DMA; HR_conv2 + ReLU -> Z rows 2s-3, 2s-2; conv_last + residual
+//                   -> output rows 2s-6, 2s-5 (planar)
+// Per element the arithmetic, K order and rounding points are those of the per-layer kernels: results are bit-identical.
+constexpr int U_SLOTS = 48, U_ROWB = U_SLOTS * 64, UN = 6, UPH = UN + 2;     // u ring: rows mirrored as the Y rings (a second DMA)
+template <int DPF> struct TailGeo {
+    static constexpr int FR = 2 * DPF + 2;                   // fea0 / cond rings: fetched 2 DPF rows ahead of their one use
+    static_assert(DPF + 3 <= UN, "u ring");
+    static constexpr int OFF_U = 0, OFF_F = OFF_U + UPH * U_ROWB, OFF_C = OFF_F + FR * X_ROWB, OFF_Y = OFF_C + FR * C_ROWB;
+    static constexpr int OFF_Z = OFF_Y + YPH * Y_ROWB, OFF_TR = OFF_Z + YPH * Y_ROWB;       // TR: 4 x 1 KiB the unused mirror DMAs land in
+    static constexpr int OFF_R = OFF_TR + 4096;              // residual planes: per T2 wave (DPF + 1) slots of [3 planes][32 px] f16
+    static constexpr int R_SLOTB = 256, R_WAVEB = (DPF + 1) * R_SLOTB;
+    static constexpr int OFF_B = OFF_R + 4 * R_WAVEB;        // SFT_layer2's bias tiles
+    static constexpr int SMEM = OFF_B + SFT_TILE_F * 4;
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+    static_assert(BIG % FR == 0, "BIG");
+};
+
+template <int DPF>
+__global__ __launch_bounds__(512) void le_tail_rows_kernel(RowsTailParams p)
+{
+    using G = TailGeo<DPF>;
+    constexpr int FR = G::FR, LAG = 6;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int strip = blockIdx.x % p.nstrips, seg = blockIdx.x / p.nstrips;
+    const int x0 = strip * WS, hx0 = x0 >> 1;
+    const int y0 = seg * p.rows_per_seg, y1 = min(y0 + p.rows_per_seg, p.H);      // rows_per_seg is even
+    const int ya = y0 - 2, hya = ya >> 1;                              // image row of ring row 0 (even); its half-resolution row
+    const int nsteps = (y1 - ya + LAG - 1) / 2 + 1;
+    const int H = p.H, W = p.W, H1 = H >> 1, W1 = W >> 1;
+    float *sB = reinterpret_cast<float *>(smem + G::OFF_B);
+    sft_tiles_to_lds(sB, p.sft_bias, tid);
+    const float *t2 = sB + 16 * lh;
+    const bool colfull = x0 >= 2 && x0 + 62 <= W;
+
+    if (wave < 4) {
+        // ------------------------------------------------------------------ role T1: up_conv3 bank b, + fea0, SFT_layer2 -> Y
+        const int b = wave, bi = b >> 1, bj = b & 1;
+        Bank wu;
+        load_bank(wu, p.w_up, l31, lh, 128, 32 * b);
+        SftW s2;
+        load_sft(s2, p.sft_wfrag, lane);
+        f32x4 bq[4];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) bq[qd] = *reinterpret_cast<const f32x4 *>(p.b_up + 32 * b + 8 * qd + 4 * lh);
+        int xo[3][2];                                                  // half-resolution pixel l31 reads u slots l31 .. l31 + 2
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) xo[kx][ks] = (l31 + kx) * 64 + ((((ks << 1) | lh) ^ swz32(l31 + kx)) << 4);
+        const int cx = 2 * l31 + bj;                                   // full-resolution slot (image column x0 - 2 + cx) of this lane's pixel
+        const int q0 = cx * 64 + (swz32(cx) << 4) + 8 * lh;            // fea0 read, Y write: channel quad qd at q0 ^ (qd << 4)
+        const int co = cx * 32 + ((lh ^ ((cx >> 3) & 1)) << 4);
+        const bool col = (unsigned)(x0 - 2 + cx) < (unsigned)W;
+        __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));
+        __builtin_amdgcn_s_barrier();
+        STAMP_DECL;
+        for (int s = 0; s < nsteps; ++s) {
+            STAMP(7);
+            const int ra = 2 * s + bi;                                 // the full-resolution ring row this wave produces
+            const char *fb = smem + G::OFF_F + ((ra + BIG) % FR) * X_ROWB;
+            const f16x8 c2 = *reinterpret_cast<const f16x8 *>(smem + G::OFF_C + ((ra + BIG) % FR) * C_ROWB + co);
+            f16x4 sk[4];
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) sk[qd] = *reinterpret_cast<const f16x4 *>(fb + (q0 ^ (qd << 4)));
+            const bool row = (unsigned)(ya + ra) < (unsigned)H;
+            const int m = (ra + BIG) % YN;
+            int a[3][2];
+            {
+                const int wb = G::OFF_U + ((s - 1 + BIG) % UN) * U_ROWB;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) a[kx][ks] = wb + xo[kx][ks];
+            }
+            f32x16 h2, sc2, sh2;
+            const f32x16 acc = conv18<4, U_ROWB>(wu, smem, a, [&](int st) __attribute__((always_inline)) {
+                if (st == 2) h2 = sft_hidden(s2, c2, t2);
+                if (st == 9) sft_heads(s2, h2, t2, sc2, sh2);
+            });
+            STAMP(1);
+            f16x4 y[4];
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) y[qd] = __builtin_elementwise_max(bias_cvt4(acc, qd, bq[qd]), zero4()) + sk[qd];
+            sft_modulate(sc2, sh2, y);
+            if (!(colfull && row)) {
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) if (!(col && row)) y[qd] = zero4();
+            }
+            put_row(smem, G::OFF_Y, m, q0, y);
+            STAMP(2);
+            __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));
+            STAMP(4);
+            __builtin_amdgcn_s_barrier();
+            STAMP(5);
+        }
+        STAMP_DUMP(p);
+    } else {
+        // ------------------------------------------------------------------ role T2: LDS-DMA, HR_conv2 -> Z, conv_last + residual -> out
+        const int g = wave & 3, gr = g >> 1, gh = g & 1;
+        Bank wh, wl;
+        load_bank(wh, p.w_hr, l31, lh);
+        load_bank(wl, p.w_last, l31, lh);
+        f32x4 bh[4];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) bh[qd] = *reinterpret_cast<const f32x4 *>(p.b_hr + 8 * qd + 4 * lh);
+        const float bl0 = p.b_last[0], bl1 = p.b_last[1], bl2 = p.b_last[2];
+        const int cx = 32 * gh + l31;
+        int xo[3][2];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) xo[kx][ks] = (cx + kx) * 64 + ((((ks << 1) | lh) ^ swz32(cx + kx)) << 4);
+        const int q0 = cx * 64 + (swz32(cx) << 4) + 8 * lh;            // Z write
+        const bool colz = (unsigned)(x0 - 1 + cx) < (unsigned)W;       // Z slot cx = image column x0 - 1 + cx
+        const dma_rsrc_t rf = dma_rsrc(p.fea0), rc = dma_rsrc(p.cond), ru = dma_rsrc(p.u), rr_ = dma_rsrc(p.res_planar);
+        // per step and wave: pieces 2 gh, 2 gh + 1 of fea0 row gr, piece gh of condition row gr, (waves 0-2) piece g of the u
+        // row and of its second copy, and the residual planes of an output row's 32 pixels (4-byte DMA: lane = plane * 16 +
+        // pixel pair) -- always six DMA instructions (the unused ones fetch nothing into a trash KiB).  No plain load: its
+        // first use would wait (vmcnt retires in order) for every DMA issued before it.
+        unsigned fl[2], cl, ul;
+        bool fok[2], cok, uok;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int px = 16 * (2 * gh + j) + (lane >> 2), slot = lane & 3;
+            fl[j] = (unsigned)(px * 64 + ((slot ^ swz32(px)) << 4));
+            fok[j] = (unsigned)(x0 - 2 + px) < (unsigned)W;
+        }
+        {
+            const int px = 32 * gh + (lane >> 1);
+            cl = (unsigned)(px * 32 + (((lane & 1) ^ ((px >> 3) & 1)) << 4));
+            cok = (unsigned)(x0 - 2 + px) < (unsigned)W;
+        }
+        {
+            const int px = 16 * g + (lane >> 2), slot = lane & 3;      // u slot px = half-resolution column hx0 - 2 + px
+            ul = (unsigned)(px * 64 + ((slot ^ swz32(px)) << 4));
+            uok = g < 3 && px < 34 && (unsigned)(hx0 - 2 + px) < (unsigned)W1;
+        }
+        char *tr = smem + G::OFF_TR + g * 1024;
+        char *rbuf = smem + G::OFF_R + g * G::R_WAVEB;
+        const size_t plane = (size_t)H * W;
+        const unsigned rl = (unsigned)((lane >> 4) * plane * 2 + (32 * gh + 2 * (lane & 15)) * 2);     // plane, pixel pair
+        const bool rlok = lane < 48 && x0 + 32 * gh + 2 * (lane & 15) < W;
+        auto issue_r = [&](int sq) __attribute__((always_inline)) {     // residual of the output row of step sq
+            const int r = ya + 2 * sq - LAG + gr;
+            const bool rok = r >= y0 && r < y1;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rr_, (__attribute__((address_space(3))) void *)(rbuf + ((sq + DPF + 1) % (DPF + 1)) * G::R_SLOTB), 4,
+                                                     (rok && rlok) ? (unsigned)((r * W + x0) * 2) + rl : DMA_OOB, 0, 0, 0);
+        };
+        auto issue_fc = [&](int sq) __attribute__((always_inline)) {
+            const int rr = 2 * sq + gr, r = ya + rr;
+            const bool rok = (unsigned)r < (unsigned)H && r <= y1 + 1;
+            const unsigned pix = (unsigned)(r * W + x0 - 2);
+            char *d = smem + G::OFF_F + ((rr + BIG) % FR) * X_ROWB + (2 * gh) * 1024;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dma16(rf, d + j * 1024, (rok && fok[j]) ? pix * 64u + fl[j] : DMA_OOB);
+            dma16(rc, smem + G::OFF_C + ((rr + BIG) % FR) * C_ROWB + gh * 1024, (rok && cok) ? pix * 32u + cl : DMA_OOB);
+        };
+        auto issue_u = [&](int ur) __attribute__((always_inline)) {     // u ring row ur = half-resolution image row hya + ur
+            const int hr = hya + ur, m = (ur + BIG) % UN;
+            const bool rok = (unsigned)hr < (unsigned)H1 && hr <= ((y1 + 1) >> 1) + 1;
+            const unsigned off = (rok && uok) ? (unsigned)((hr * W1 + hx0 - 2) * 64) + ul : DMA_OOB;
+            dma16(ru, g < 3 ? smem + G::OFF_U + m * U_ROWB + g * 1024 : tr, off);
+            dma16(ru, (g < 3 && m < 2) ? smem + G::OFF_U + (m + UN) * U_ROWB + g * 1024 : tr, (m < 2) ? off : DMA_OOB);
+        };
+        // output: channels 0..2 of pixel l31 sit in accumulator registers 0..2 of the lanes with lh == 0
+        char *trash = p.trash + tid * 16;
+        issue_u(-1);
+#pragma unroll
+        for (int sq = 0; sq < DPF; ++sq) { issue_fc(sq); issue_u(sq); issue_r(sq); }
+        issue_u(DPF);
+        __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));
+        __builtin_amdgcn_s_barrier();
+        STAMP_DECL;
+        for (int s = 0; s < nsteps; ++s) {
+            STAMP(7);
+            issue_fc(s + DPF);
+            issue_u(s + DPF + 1);
+            issue_r(s + DPF);
+            __builtin_amdgcn_sched_barrier(0);
+            // residual planes of this step's output row (fetched DPF steps ago)
+            const int ro = 2 * s - LAG + gr, r = ya + ro;
+            const bool ok = lh == 0 && r >= y0 && r < y1 && cx < WS && x0 + cx < W;
+            const size_t e = ok ? (size_t)r * W + x0 + cx : 0;
+            f16 res[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) res[ch] = *reinterpret_cast<const f16 *>(rbuf + (s % (DPF + 1)) * G::R_SLOTB + ch * 64 + l31 * 2);
+            STAMP(0);
+            {   // HR_conv2 + ReLU on ring row 2 s - 3 + gr -> Z
+                const int rb = 2 * s - 3 + gr;
+                int a[3][2];
+                const int wb = G::OFF_Y + ((rb - 1 + BIG) % YN) * Y_ROWB;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) a[kx][ks] = wb + xo[kx][ks];
+                const f32x16 acc = conv18<6, Y_ROWB>(wh, smem, a, [](int) {});
+                f16x4 z[4];
+                const bool in = colz && (unsigned)(ya + rb) < (unsigned)H;     // outside the image: conv_last's zero padding
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    z[qd] = __builtin_elementwise_max(bias_cvt4(acc, qd, bh[qd]), zero4());
+                    if (!in) z[qd] = zero4();
+                }
+                put_row(smem, G::OFF_Z, (rb + BIG) % YN, q0, z);
+            }
+            STAMP(1);
+            {   // conv_last on ring row 2 s - 6 + gr, + residual -> the three output planes
+                int a[3][2];
+                const int wb = G::OFF_Z + ((ro - 1 + BIG) % YN) * Y_ROWB;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) a[kx][ks] = wb + xo[kx][ks];
+                const f32x16 acc = conv18<6, Y_ROWB>(wl, smem, a, [](int) {});
+                const float o[3] = {acc[0] + bl0, acc[1] + bl1, acc[2] + bl2};
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    // the conv result is rounded to f16, the residual added in fp32 and the sum rounded again (conv32s PLANAR)
+                    const float v = (float)(f16)o[ch] + (float)res[ch];
+                    f16 *d = ok ? p.dst_planar + ch * plane + e : reinterpret_cast<f16 *>(trash);
+                    *d = (f16)v;
+                }
+            }
+            STAMP(3);
+            // per step and wave: 6 DMA instructions, then 3 stores (all always issued): the pieces of step s + 1 are older than
+            // the 9 (DPF - 1) operations of the steps since and the 3 stores of their own step
+            __builtin_amdgcn_s_waitcnt(waitcnt_imm(3 + 9 * (DPF - 1), 0));
+            STAMP(4);
+            __builtin_amdgcn_s_barrier();
+            STAMP(5);
+        }
         STAMP_DUMP(p);
     }
 }
@@ -429,6 +679,27 @@ hipError_t launch_rb(RowsRbParams p, int nseg, hipStream_t s)
 }
 
 }  // namespace
+
+// H, W even; u is [H/2][W/2][32]
+hipError_t le_tail_rows_launch(RowsTailParams p, int n_cu, hipStream_t s)
+{
+    if ((size_t)p.H * p.W * 64 >= 0x7f000000ull || !p.trash || (p.H & 1) || (p.W & 1)) return hipErrorInvalidValue;
+    using G = TailGeo<3>;
+    static DevOnce attr_once;
+    auto kern = le_tail_rows_kernel<3>;
+    if (attr_once.need()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
+        if (e != hipSuccess) return e;
+        attr_once.done();
+    }
+    p.nstrips = (p.W + WS - 1) / WS;
+    int nseg = n_cu / p.nstrips;
+    if (nseg < 1) nseg = 1;
+    p.rows_per_seg = ((p.H + nseg - 1) / nseg + 1) & ~1;
+    nseg = (p.H + p.rows_per_seg - 1) / p.rows_per_seg;
+    hipLaunchKernelGGL(kern, dim3(p.nstrips * nseg), dim3(512), G::SMEM, s, p);
+    return hipGetLastError();
+}
 
 // variant: 0 = sft2 inside its own step (DMA three steps ahead), 1 = sft2 one step behind, inside the next conv1 (DMA two steps ahead)
 hipError_t le_rb_rows_launch(RowsRbParams p, int n_cu, hipStream_t s, int variant)
