@@ -246,6 +246,24 @@ struct RowsTailParams {
     int nstrips, rows_per_seg;              // set by the launcher
 };
 
+// Parameter block of the row-streaming fused head of the LE net (le_rows.hip):
+// fea0 = relu(HR_conv1(sft(relu(conv_first(img)), cond))), fea1 = relu(down_conv1(fea0))
+struct RowsHeadParams {
+    const f16 *img;        // f16 [3][H][W]
+    const f16 *cond;       // NHWC 16 [H][W]
+    const f16 *c3_wfrag;   // conv_first: pack_c3 fragments [3 kernel rows][64 lanes][8], bias in the K axis
+    const f16 *sft_wfrag;
+    const float *sft_bias;
+    const f16 *w_hr, *w_down;               // [9][32][32]
+    const float *b_hr, *b_down;             // [32]
+    f16 *fea0;             // NHWC 32 [H][W]
+    f16 *fea1;             // NHWC 32 [H/2][W/2]
+    char *trash;
+    void *dump;
+    int H, W;
+    int nstrips, rows_per_seg;
+};
+
 // Letterbox (letterbox.hip): u8 BGR [sh][sw][3] -> u8 BGR [dh][dw][3], resized region [y0, y0+new_h) x [x0, x0+new_w)
 enum { LB_COPY = 0, LB_AREA_INT = 1, LB_AREA_FRAC = 2, LB_CUBIC = 3 };
 struct LetterboxParams {

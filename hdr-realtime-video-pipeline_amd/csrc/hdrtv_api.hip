@@ -1838,6 +1838,7 @@ int run_le(hdrtv_ctx *c, Seq &q, const f16 *img, f16 *out_planar)
     }
     // main branch: every SFT is fused into the 3x3 conv that follows it
     f16 *f0a = wsp<f16>(c, "le.f0a"), *f0b = wsp<f16>(c, "le.f0b"), *fea0 = wsp<f16>(c, "le.fea0"), *up3 = wsp<f16>(c, "le.up3");
+    bool head_fused = false;
     if (isq8("LE.conv_first")) {
         const char *g8 = getenv("HDRTV_NO_C3Q8");     // developer A/B switch (read per launch): the generic two-launch form
         if (g8 && atoi(g8)) {     // the 3 planes as NHWC int8 codes (3 of 32 bytes real), then the generic int8 conv
@@ -1858,7 +1859,24 @@ int run_le(hdrtv_ctx *c, Seq &q, const f16 *img, f16 *out_planar)
         // (developer A/B switches, read per launch); a W8A8 HR_conv1 behind an fp16 conv_first has no fused kernel.
         const char *nf = getenv("HDRTV_NO_C3FUSE"), *olds = getenv("HDRTV_CONV32_OLD");
         const bool fuse = !(nf && atoi(nf)) && !(olds && atoi(olds)) && c->q32.find("LE.HR_conv1") == c->q32.end();
-        if (fuse) {
+        // conv_first .. down_conv1 in one row-streaming launch (le_rows.hip) when all of it is fp16 and the shapes are even
+        head_fused = fuse && q.ok() && c->var.at("le_rows") && !(H & 1) && !(W & 1) && q.rows_fit(H, W) && c->conv.count("LE.HR_conv1") &&
+                     c->conv.count("LE.down_conv1") && !isq8("LE.down_conv1") && !c->sft.at("LE.SFT_layer1").q;
+        if (head_fused) {
+            const ConvLayer &Lh = c->conv.at("LE.HR_conv1"), &Ld = c->conv.at("LE.down_conv1");
+            const SftLayer &S1 = c->sft.at("LE.SFT_layer1");
+            RowsHeadParams p;
+            memset(&p, 0, sizeof p);
+            p.img = img; p.cond = cond1; p.H = H; p.W = W; p.fea0 = fea0; p.fea1 = wsp<f16>(c, "le.fea1a");
+            p.c3_wfrag = wtp<f16>(c, c->c3.at("le.conv_first").wfrag);
+            p.sft_wfrag = wtp<f16>(c, S1.wfrag); p.sft_bias = wtp<float>(c, S1.bias);
+            p.w_hr = wtp<f16>(c, Lh.wpk); p.b_hr = wtp<float>(c, Lh.shift); p.w_down = wtp<f16>(c, Ld.wpk); p.b_down = wtp<float>(c, Ld.shift);
+            p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
+            p.dump = q.stamp_buf();
+            const double npx = (double)H * W;
+            q.chk(le_head_rows_launch(p, c->n_cu, q.s), "LE.head", "le_head_rows", npx * (27.0 * 32 + 2.0 * (16 * 16 + 16 * 32) + 32.0 * 9 * 32 + 32.0 * 9 * 32 / 4),
+                  npx * (6 + 32 + 64 + 16) + 2.0 * 2 * 9 * 32 * 32);
+        } else if (fuse) {
             q.conv32("LE.HR_conv1", f0a, cond1, "LE.SFT_layer1", H, W, ACT_RELU, ST_NHWC, fea0, 32, H, W, nullptr, nullptr, nullptr, nullptr,
                      img, "le.conv_first");
         } else {
@@ -1871,7 +1889,7 @@ int run_le(hdrtv_ctx *c, Seq &q, const f16 *img, f16 *out_planar)
         if (isq8(key)) q.convq8(key, src, false, 32, Hi, Wi, ACT_RELU, dst, 32, nullptr);
         else q.conv(key, src, 32, nullptr, 0, Hi, Wi, ACT_RELU, ST_NHWC, dst, 32, Ho, Wo);
     };
-    down("LE.down_conv1", fea0, H, W, fea1a, s.H1, s.W1);
+    if (!head_fused) down("LE.down_conv1", fea0, H, W, fea1a, s.H1, s.W1);
     q.resblock("LE.recon_trunk1.0", fea1a, cond2, s.H1, s.W1, l1b, fea1);
     f16 *fea2a = wsp<f16>(c, "le.fea2a"), *fea2 = wsp<f16>(c, "le.fea2"), *l2b = wsp<f16>(c, "le.l2b");
     down("LE.down_conv2", fea1, s.H1, s.W1, fea2a, s.H2, s.W2);

@@ -663,6 +663,240 @@ __global__ __launch_bounds__(512) void le_tail_rows_kernel(RowsTailParams p)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The full-resolution head of the LE net in one launch (HDRUNet3T1_arch.py:168-172):
+//     fea0 = relu(HR_conv1(SFT_layer1(relu(conv_first(img)), cond1)));   fea1a = relu(down_conv1(fea0))
+// The per-layer form is conv32s<c3+sft> (conv_first recomputed per 16x16 tile on the prep waves: 2.4 TB/s) and conv_t16 (fea0
+// read back).  Here HBM sees the three image planes, cond1, and the two outputs.  Structure as above:
+//     step s:  role H1 (waves 0-3, group (g >> 1, g & 1)): global loads of image rows 2s+3, 2s+4 into registers, staged as
+//                   {R, G, B, 1} pixels into the patch ring at the end of the step; conv_first + ReLU + SFT_layer1 -> Y rows 2s, 2s+1;
+//                   wave (s & 3): down_conv1 on half-resolution row s-3 (fea0 rows 2s-7 .. 2s-5 of the F ring) -> fea1a
+//              role H2 (waves 4-7): LDS-DMA of cond rows 2s+6, 2s+7; HR_conv1 + ReLU -> F rows 2s-3, 2s-2 and (one step
+//                   later, through a strip) fea0
+// conv_first is conv32s's C3 form (K = (kernel column | pad, channel | bias slot) per kernel row, three MFMAs).
+constexpr int P_SLOTS = 72, P_ROWB = P_SLOTS * 8;            // patch ring: 68 of 72 pixel slots used (image columns x0 - 3 .. x0 + 64)
+template <int DPF> struct HeadGeo {
+    static constexpr int CR = 2 * DPF + 2;
+    static constexpr int OFF_P = 0, OFF_C = OFF_P + YPH * P_ROWB, OFF_Y = OFF_C + CR * C_ROWB, OFF_F = OFF_Y + YPH * Y_ROWB;
+    static constexpr int OFF_ST = OFF_F + YPH * Y_ROWB;      // H2's four output strips
+    static constexpr int OFF_B = OFF_ST + 4 * STRIP;         // SFT_layer1's bias tiles
+    static constexpr int SMEM = OFF_B + SFT_TILE_F * 4;
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+    static_assert(BIG % CR == 0, "BIG");
+};
+
+template <int DPF>
+__global__ __launch_bounds__(512) void le_head_rows_kernel(RowsHeadParams p)
+{
+    using G = HeadGeo<DPF>;
+    constexpr int CR = G::CR;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int strip = blockIdx.x % p.nstrips, seg = blockIdx.x / p.nstrips;
+    const int x0 = strip * WS, hx0 = x0 >> 1;
+    const int y0 = seg * p.rows_per_seg, y1 = min(y0 + p.rows_per_seg, p.H);      // rows_per_seg is even
+    const int ya = y0 - 2, hya = ya >> 1;
+    const int nsteps = (y1 - ya + 1) / 2 + 3;
+    const int H = p.H, W = p.W, W1 = (W + 1) >> 1;
+    float *sB = reinterpret_cast<float *>(smem + G::OFF_B);
+    sft_tiles_to_lds(sB, p.sft_bias, tid);
+    const float *t1 = sB + 16 * lh;
+    const bool colfull = x0 >= 2 && x0 + 62 <= W;
+    const int g = wave & 3, gr = g >> 1, gh = g & 1;
+    const int cx = 32 * gh + l31;
+    int xo[3][2];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) xo[kx][ks] = (cx + kx) * 64 + ((((ks << 1) | lh) ^ swz32(cx + kx)) << 4);
+    const int q0 = cx * 64 + (swz32(cx) << 4) + 8 * lh;                // Y / F write: channel quad qd at q0 ^ (qd << 4)
+
+    if (wave < 4) {
+        // ------------------------------------------------------------------ role H1: image patch, conv_first, SFT_layer1 -> Y; down_conv1
+        f16x8 c3w[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) c3w[ky] = reinterpret_cast<const f16x8 *>(p.c3_wfrag)[ky * 64 + lane];
+        SftW s1;
+        load_sft(s1, p.sft_wfrag, lane);
+        Bank wd;
+        load_bank(wd, p.w_down, l31, lh);
+        f32x4 bd[4];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) bd[qd] = *reinterpret_cast<const f32x4 *>(p.b_down + 8 * qd + 4 * lh);
+        const int co = cx * 32 + ((lh ^ ((cx >> 3) & 1)) << 4);
+        const bool col = (unsigned)(x0 - 2 + cx) < (unsigned)W;
+        const int po = (cx + 2 * lh) * 8;                              // patch pixels cx + 2 lh, + 1 of a kernel row = K slots 8 lh .. 8 lh + 7
+        // patch staging: thread t < 136 owns pixel (t / 68, t % 68) of the two new rows
+        const int pr = tid / 68, pc = tid - pr * 68;
+        const bool pth = tid < 136, pcol = pth && (unsigned)(x0 - 3 + pc) < (unsigned)W;
+        const size_t plane = (size_t)H * W;
+        f16 pv[3] = {(f16)0.f, (f16)0.f, (f16)0.f};
+        auto patch_fetch = [&](int rr0) __attribute__((always_inline)) {     // ring rows rr0, rr0 + 1
+            const int r = ya + rr0 + pr;
+            const bool ok = pcol && (unsigned)r < (unsigned)H && r <= y1 + 1;
+            const size_t o = ok ? (size_t)r * W + (x0 - 3 + pc) : 0;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                pv[ch] = p.img[ch * plane + o];
+                if (!ok) pv[ch] = (f16)0.f;
+            }
+        };
+        auto patch_stage = [&](int rr0) __attribute__((always_inline)) {
+            if (pth) {
+                const int m = (rr0 + pr + BIG) % YN;
+                char *d = smem + G::OFF_P + m * P_ROWB + pc * 8;
+                const f16x4 v = f16x4{pv[0], pv[1], pv[2], (f16)1.f};          // 1: the bias slot
+                *reinterpret_cast<f16x4 *>(d) = v;
+                if (m < 2) *reinterpret_cast<f16x4 *>(d + YN * P_ROWB) = v;
+            }
+        };
+        // down_conv1: half-resolution pixel l31 (column hx0 + l31, 30 used) reads F slots 2 l31 + kx (slot c = image column x0 - 1 + c)
+        int xd[3][2];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) xd[kx][ks] = (2 * l31 + kx) * 64 + ((((ks << 1) | lh) ^ swz32(2 * l31 + kx)) << 4);
+        const bool dcol = l31 < WS / 2 && hx0 + l31 < W1;
+        for (int e = tid; e < YPH * 4; e += 256)                        // the four pad slots of every patch row stay finite (zero weights read them)
+            *reinterpret_cast<f16x4 *>(smem + G::OFF_P + (e >> 2) * P_ROWB + (68 + (e & 3)) * 8) = zero4();
+        patch_fetch(-1); patch_stage(-1);
+        patch_fetch(1); patch_stage(1);
+        __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));
+        __builtin_amdgcn_s_barrier();
+        STAMP_DECL;
+        for (int s = 0; s < nsteps; ++s) {
+            STAMP(7);
+            patch_fetch(2 * s + 3);
+            const int ra = 2 * s + gr;
+            const f16x8 c1 = *reinterpret_cast<const f16x8 *>(smem + G::OFF_C + ((ra + BIG) % CR) * C_ROWB + co);
+            const char *pb = smem + G::OFF_P + ((ra - 1 + BIG) % YN) * P_ROWB + po;
+            f32x16 h;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const f16x4 u = *reinterpret_cast<const f16x4 *>(pb + ky * P_ROWB), v = *reinterpret_cast<const f16x4 *>(pb + ky * P_ROWB + 8);
+                const f16x8 xf = __builtin_shufflevector(u, v, 0, 1, 2, 3, 4, 5, 6, 7);
+                if (ky == 0) {
+                    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    h = __builtin_amdgcn_mfma_f32_32x32x16_f16(c3w[0], xf, z, 0, 0, 0);
+                } else {
+                    h = __builtin_amdgcn_mfma_f32_32x32x16_f16(c3w[ky], xf, h, 0, 0, 0);
+                }
+            }
+            f32x16 sc1, sh1;
+            sft_heads(s1, sft_hidden(s1, c1, t1), t1, sc1, sh1);
+            f16x4 y[4];
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) y[qd] = __builtin_elementwise_max(cvt4(h[4 * qd], h[4 * qd + 1], h[4 * qd + 2], h[4 * qd + 3]), zero4());
+            sft_modulate(sc1, sh1, y);
+            const bool row = (unsigned)(ya + ra) < (unsigned)H;
+            if (!(colfull && row)) {
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) if (!(col && row)) y[qd] = zero4();
+            }
+            put_row(smem, G::OFF_Y, (ra + BIG) % YN, q0, y);
+            STAMP(1);
+            if (wave == (s & 3)) {
+                // down_conv1 on ring half row s - 3: F rows 2 s - 7 .. 2 s - 5
+                const int j = s - 3, hr = hya + j;
+                int a[3][2];
+                const int wb = G::OFF_F + ((2 * j - 1 + BIG) % YN) * Y_ROWB;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) a[kx][ks] = wb + xd[kx][ks];
+                const f32x16 acc = conv18<4, Y_ROWB>(wd, smem, a, [](int) {});
+                if (dcol && hr >= (y0 >> 1) && hr < ((y1 + 1) >> 1)) {
+                    f16 *d = p.fea1 + ((size_t)hr * W1 + hx0 + l31) * 32 + 4 * lh;
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) *reinterpret_cast<f16x4 *>(d + 8 * qd) = __builtin_elementwise_max(bias_cvt4(acc, qd, bd[qd]), zero4());
+                }
+            }
+            STAMP(2);
+            patch_stage(2 * s + 3);
+            STAMP(3);
+            __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));
+            STAMP(4);
+            __builtin_amdgcn_s_barrier();
+            STAMP(5);
+        }
+        STAMP_DUMP(p);
+    } else {
+        // ------------------------------------------------------------------ role H2: LDS-DMA of cond, HR_conv1 -> F ring and fea0
+        Bank wh;
+        load_bank(wh, p.w_hr, l31, lh);
+        f32x4 bh[4];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) bh[qd] = *reinterpret_cast<const f32x4 *>(p.b_hr + 8 * qd + 4 * lh);
+        const bool colf = (unsigned)(x0 - 1 + cx) < (unsigned)W;       // F slot cx = image column x0 - 1 + cx
+        const dma_rsrc_t rc = dma_rsrc(p.cond);
+        const int cpx = 32 * gh + (lane >> 1);
+        const unsigned cl = (unsigned)(cpx * 32 + (((lane & 1) ^ ((cpx >> 3) & 1)) << 4));
+        const bool cok = (unsigned)(x0 - 2 + cpx) < (unsigned)W;
+        auto issue_c = [&](int sq) __attribute__((always_inline)) {
+            const int rr = 2 * sq + gr, r = ya + rr;
+            const bool rok = (unsigned)r < (unsigned)H && r <= y1;
+            dma16(rc, smem + G::OFF_C + ((rr + BIG) % CR) * C_ROWB + gh * 1024, (rok && cok) ? (unsigned)((r * W + x0 - 2) * 32) + cl : DMA_OOB);
+        };
+        char *strip_b = smem + G::OFF_ST + g * STRIP;
+        const int c8 = lane & 3, spx = lane >> 2;
+        char *trash = p.trash + tid * 16;
+        const int sw0 = l31 * OUT_ROWB + 8 * lh;
+        auto store_row = [&](int rr) __attribute__((always_inline)) {   // the strip holds F ring row rr: slots 32 gh .. (slot c = column x0 - 1 + c)
+            const int r = ya + rr;
+            const bool row_ok = r >= y0 && r < y1;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int c = 32 * gh + it * 16 + spx, ox = c - 1;
+                const f16x8 v = *reinterpret_cast<const f16x8 *>(strip_b + (it * 16 + spx) * OUT_ROWB + c8 * 16);
+                const bool ok = row_ok && ox >= 0 && ox < WS && x0 + ox < W;
+                f16 *d = ok ? p.fea0 + ((size_t)r * W + x0 + ox) * 32 + c8 * 8 : reinterpret_cast<f16 *>(trash);
+                *reinterpret_cast<f16x8 *>(d) = v;
+            }
+        };
+#pragma unroll
+        for (int sq = 0; sq < DPF; ++sq) issue_c(sq);
+        __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));
+        __builtin_amdgcn_s_barrier();
+        STAMP_DECL;
+        for (int s = 0; s < nsteps; ++s) {
+            STAMP(7);
+            store_row(2 * (s - 1) - 3 + gr);
+            issue_c(s + DPF);
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP(0);
+            const int rb = 2 * s - 3 + gr;
+            int a[3][2];
+            const int wb = G::OFF_Y + ((rb - 1 + BIG) % YN) * Y_ROWB;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) a[kx][ks] = wb + xo[kx][ks];
+            const f32x16 acc = conv18<6, Y_ROWB>(wh, smem, a, [](int) {});
+            STAMP(1);
+            f16x4 z[4];
+            const bool in = colf && (unsigned)(ya + rb) < (unsigned)H;     // outside the image: down_conv1's zero padding
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                z[qd] = __builtin_elementwise_max(bias_cvt4(acc, qd, bh[qd]), zero4());
+                *reinterpret_cast<f16x4 *>(strip_b + sw0 + 16 * qd) = z[qd];
+                if (!in) z[qd] = zero4();
+            }
+            put_row(smem, G::OFF_F, (rb + BIG) % YN, q0, z);
+            STAMP(3);
+            // per step and wave: two stores, then one DMA piece: the piece of step s + 1 is older than 3 (DPF - 1) operations
+            __builtin_amdgcn_s_waitcnt(waitcnt_imm(3 * (DPF - 1), 0));
+            STAMP(4);
+            __builtin_amdgcn_s_barrier();
+            STAMP(5);
+        }
+        store_row(2 * (nsteps - 1) - 3 + gr);
+        STAMP_DUMP(p);
+    }
+}
+
 template <int DPF, bool PIPE>
 hipError_t launch_rb(RowsRbParams p, int nseg, hipStream_t s)
 {
@@ -687,6 +921,27 @@ hipError_t le_tail_rows_launch(RowsTailParams p, int n_cu, hipStream_t s)
     using G = TailGeo<3>;
     static DevOnce attr_once;
     auto kern = le_tail_rows_kernel<3>;
+    if (attr_once.need()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
+        if (e != hipSuccess) return e;
+        attr_once.done();
+    }
+    p.nstrips = (p.W + WS - 1) / WS;
+    int nseg = n_cu / p.nstrips;
+    if (nseg < 1) nseg = 1;
+    p.rows_per_seg = ((p.H + nseg - 1) / nseg + 1) & ~1;
+    nseg = (p.H + p.rows_per_seg - 1) / p.rows_per_seg;
+    hipLaunchKernelGGL(kern, dim3(p.nstrips * nseg), dim3(512), G::SMEM, s, p);
+    return hipGetLastError();
+}
+
+// W even (strips start on even columns: the half-resolution map is cut at x0 / 2); fea1 is [(H + 1) / 2][(W + 1) / 2][32]
+hipError_t le_head_rows_launch(RowsHeadParams p, int n_cu, hipStream_t s)
+{
+    if ((size_t)p.H * p.W * 64 >= 0x7f000000ull || !p.trash || (p.W & 1) || (p.H & 1)) return hipErrorInvalidValue;
+    using G = HeadGeo<3>;
+    static DevOnce attr_once;
+    auto kern = le_head_rows_kernel<3>;
     if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
         if (e != hipSuccess) return e;
