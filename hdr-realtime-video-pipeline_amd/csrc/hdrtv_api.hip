@@ -264,7 +264,7 @@ int fail(hdrtv_ctx *c, int code, const char *fmt, ...)
 // ---- developer variants: name -> default.  hdrtv_set_variant changes one on a context; HDRTV_VARIANTS="a=1,b=0" seeds them at
 // hdrtv_create.  The launch path reads c->var only.
 const std::pair<const char *, int> k_variants[] = {
-    {"le_rows", 1},          // fused row-streaming LE kernels (le_rows.hip); 0 = the per-layer 16x16-tile kernels; 2 = sft2 pipelined
+    {"le_rows", 1},          // fused row-streaming LE kernels (le_rows.hip); 0 = the per-layer 16x16-tile kernels
 };
 void variants_init(hdrtv_ctx *c)
 {
@@ -1651,7 +1651,7 @@ struct Seq {
             p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
             p.dump = stamp_buf();
             const double npx = (double)H * W;
-            chk(le_rb_rows_launch(p, c->n_cu, s, c->var.at("le_rows") == 2), base.c_str(), c->var.at("le_rows") == 2 ? "le_rb_rows<pipe>" : "le_rb_rows", npx * (2.0 * 32 * 9 * 32 + 4.0 * (16 * 16 + 16 * 32)),
+            chk(le_rb_rows_launch(p, c->n_cu, s), base.c_str(), "le_rb_rows", npx * (2.0 * 32 * 9 * 32 + 4.0 * (16 * 16 + 16 * 32)),
                 npx * (64 + 32 + 64) + 2.0 * 2 * 9 * 32 * 32);
             return;
         }

@@ -20,7 +20,7 @@ hipError_t conv_prw_i8_launch(ConvI8Params p, int th, int n_cu, hipStream_t stre
 hipError_t conv1x1_i8_launch(ConvI8Params p, hipStream_t stream);
 hipError_t conv32p_launch(Conv32Params p, int n_cu, hipStream_t stream);
 hipError_t conv32s_launch(Conv32Params p, int n_cu, hipStream_t stream);   // the single-pass (CoutPad == 32) layers
-hipError_t le_rb_rows_launch(RowsRbParams p, int n_cu, hipStream_t stream, int variant = 0);   // fused ResBlock_with_SFT, row-streaming (le_rows.hip)
+hipError_t le_rb_rows_launch(RowsRbParams p, int n_cu, hipStream_t stream);   // fused ResBlock_with_SFT, row-streaming (le_rows.hip)
 hipError_t le_tail_rows_launch(RowsTailParams p, int n_cu, hipStream_t stream);   // up_conv3 .. conv_last in one launch (le_rows.hip)
 hipError_t le_head_rows_launch(RowsHeadParams p, int n_cu, hipStream_t stream);   // conv_first .. down_conv1 in one launch (le_rows.hip)
 hipError_t conv_t16_launch(ConvParams p, hipStream_t stream, int n_cu);

@@ -33,7 +33,7 @@ def test_fused_rows_are_bit_identical_to_the_per_layer_kernels(torch_cuda, golde
         for (h, w), seed in SIZES:
             f = W.synthetic_frame(h, w, seed=seed, kind="gradient" if seed % 2 else "noise")
             res, kernels = [], []
-            for v in (0, 1, 2):           # per-layer kernels | fused rows | fused rows with sft2 pipelined one step behind
+            for v in (0, 1):              # per-layer kernels | fused rows
                 p.set_variant("le_rows", v)
                 p.profile_enable(True)
                 out, _ = p.infer(p.preprocess(f))
@@ -42,7 +42,6 @@ def test_fused_rows_are_bit_identical_to_the_per_layer_kernels(torch_cuda, golde
                 res.append([out.clone()] + [p.tap(t).clone() for t in taps])
             if h * w >= 720 * 1280:
                 assert any(k.startswith("le_") and "rows" in k for k in kernels[1]), kernels[1]
-                assert any("rows<pipe>" in k for k in kernels[2]), kernels[2]
             assert not any("rows" in k for k in kernels[0]), kernels[0]
             for other in res[1:]:
                 for name, a, b in zip(("out",) + taps, res[0], other):
