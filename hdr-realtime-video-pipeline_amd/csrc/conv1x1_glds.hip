@@ -29,6 +29,7 @@ static_assert(NPIX * OUT_ROWB <= SMEM, "epilogue tile must fit");
 __device__ __forceinline__ int swz64(int row) { return (row >> 1) & 7; }
 
 
+#ifdef HDRTV_AB      // the one-tile-per-workgroup form: superseded by conv_glds1p below, kept in the A/B library as its yardstick
 __global__ __launch_bounds__(512) void conv_glds1_kernel(ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(512) void conv_glds1_kernel(ConvParams p)
                 *reinterpret_cast<const f16x8 *>(so + q * OUT_ROWB + c8 * 16);
     }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Persistent form (round 2): one workgroup per CU walks a run of tiles and the (tile, chunk) iterations form ONE stream
@@ -359,11 +361,12 @@ __global__ __launch_bounds__(512) void conv_glds1p_kernel(ConvParams p)
 }  // namespace
 
 // 1x1, stride 1, Cin (src0 [+ src1 concat]) multiple of 64, CoutPad multiple of 128, NHWC store, no residuals.
-hipError_t conv_glds1_launch(ConvParams p, hipStream_t stream, int n_cu)
+hipError_t conv_glds1_launch(ConvParams p, hipStream_t stream, int n_cu, bool old_form)
 {
     if ((p.c0 % CT) || (p.c1 % CT) || p.c0 + p.c1 < CT || (p.CoutPad % BN) || p.res1 || p.res2 || p.dst_full ||
         p.mode != ST_NHWC || !p.zeros)
         return hipErrorInvalidValue;
+#ifdef HDRTV_AB
     static DevOnce attr_once;   // hipFuncSetAttribute is per (function, device)
     if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_glds1_kernel),
@@ -371,14 +374,13 @@ hipError_t conv_glds1_launch(ConvParams p, hipStream_t stream, int n_cu)
         if (e != hipSuccess) return e;
         attr_once.done();
     }
+#endif
     p.tiles_x = (p.Wo + TW - 1) / TW;
     p.tiles_y = (p.Ho + TH - 1) / TH;
     const int grid = p.tiles_x * p.tiles_y * (p.CoutPad / BN);
-    // persistent form: needs two chunks for its pipeline, the trash line, ReLU or no activation; HDRTV_GLDS1_OLD=1 is the
-    // developer A/B switch (read per launch)
-    const char *olde = getenv("HDRTV_GLDS1_OLD");
+    // persistent form: needs two chunks for its pipeline, the trash line, ReLU or no activation (old_form: the caller's A/B switch)
     const int nchunk = (p.c0 + p.c1) / CT;
-    if (!(olde && atoi(olde)) && n_cu >= 8 && nchunk >= 2 && p.trash && p.CoutPad <= P_MAXC && (p.act == ACT_RELU || p.act == ACT_NONE)) {
+    if (!old_form && n_cu >= 8 && nchunk >= 2 && p.trash && p.CoutPad <= P_MAXC && (p.act == ACT_RELU || p.act == ACT_NONE)) {
         static DevOnce attr_p;
         if (attr_p.need()) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_glds1p_kernel),
@@ -389,6 +391,10 @@ hipError_t conv_glds1_launch(ConvParams p, hipStream_t stream, int n_cu)
         hipLaunchKernelGGL(conv_glds1p_kernel, dim3(grid < n_cu ? grid : n_cu), dim3(512), SMEM, stream, p);
         return hipGetLastError();
     }
+#ifdef HDRTV_AB
     hipLaunchKernelGGL(conv_glds1_kernel, dim3(grid), dim3(512), SMEM, stream, p);
     return hipGetLastError();
+#else
+    return hipErrorNotSupported;       // the one-tile-per-workgroup kernel exists in the A/B library only (make AB=1)
+#endif
 }

@@ -617,16 +617,20 @@ hipError_t launch_t(const Conv32Params &p, int n_cu, hipStream_t s)
 }  // namespace
 
 // src (and cond) must be followed by >= 64 zero bytes (the workspace guard): out-of-image halo lanes read them.
-hipError_t conv32p_launch(Conv32Params p, int n_cu, hipStream_t s)
+// nw: the caller's A/B switch -- 0 = per layer (below), 8 = 16x16 tiles, 4 = 8x16 tiles x 2 workgroups per CU
+hipError_t conv32p_launch(Conv32Params p, int n_cu, hipStream_t s, int nw)
 {
-    static int nw = 0;
-    if (!nw) {
-        const char *e = getenv("HDRTV_CONV32_NW");      // developer A/B switch: 8 = 16x16 tile, 4 = 8x16 tile x 2 workgroups/CU
-        nw = (e && atoi(e) == 4) ? 4 : 8;
-    }
     if ((size_t)p.H * p.W * 64 >= 0xf0000000ull) return hipErrorInvalidValue;     // 32-bit byte offsets
     const bool sft = p.cond != nullptr;
     p.tiles_x = (p.W + TW - 1) / TW;
+#ifndef HDRTV_AB
+    // the shipped library keeps the up-convs (32 -> 128 + PixelShuffle) here; the single-pass layers run on conv32s.hip and
+    // le_rows.hip, and their conv32p forms (the bit-identity yardstick of both) exist in the A/B library only (make AB=1)
+    (void)nw;
+    if (p.CoutPad != 128 || sft || p.sq_wfrag) return hipErrorNotSupported;
+    p.tiles_y = (p.H + 15) / 16;
+    return p.wpk8 ? launch_t<4, false, 8, true>(p, n_cu, s) : launch_t<4, false, 8>(p, n_cu, s);
+#else
     if (p.wpk8) {                                        // W8A8 layer: int8 MFMA on the quantised tile, 16x16 tiles only
         p.tiles_y = (p.H + 15) / 16;
         if (p.CoutPad == 32 && sft && p.sq_wfrag) return launch_t<1, true, 8, true, true>(p, n_cu, s);
@@ -637,7 +641,7 @@ hipError_t conv32p_launch(Conv32Params p, int n_cu, hipStream_t s)
     if (p.sq_wfrag) return hipErrorInvalidValue;         // W8A8 SFT convs in front of an fp16 conv: no kernel (no shipped recipe has it)
     // conv_last (32 -> 3, no SFT, planar store) is all per-tile latency: two 4-wave workgroups per CU hide it better
     // (0.286 -> 0.251 ms at 4K); every other layer is faster with the 16x16 tile
-    const bool small_tile = nw == 4 || (p.CoutPad == 32 && !sft && p.mode == ST_PLANAR3 && !getenv("HDRTV_CONV32_NW"));
+    const bool small_tile = nw == 4 || (p.CoutPad == 32 && !sft && p.mode == ST_PLANAR3 && nw == 0);
     if (!small_tile || p.CoutPad == 128) {               // the 72 KiB weight set of the up-convs leaves room for one workgroup only
         p.tiles_y = (p.H + 15) / 16;
         if (p.CoutPad == 32) return sft ? launch_t<1, true, 8>(p, n_cu, s) : launch_t<1, false, 8>(p, n_cu, s);
@@ -647,4 +651,5 @@ hipError_t conv32p_launch(Conv32Params p, int n_cu, hipStream_t s)
     p.tiles_y = (p.H + 7) / 8;
     if (p.CoutPad == 32) return sft ? launch_t<1, true, 4>(p, n_cu, s) : launch_t<1, false, 4>(p, n_cu, s);
     return hipErrorInvalidValue;
+#endif
 }

@@ -16,7 +16,7 @@
 //     that share every weight fragment -- and waves 4-7 prep waves -- X and P, three 32-slot halo groups each.  A SIMD holds
 //     one of each: the conv wave feeds the MFMA pipe while the prep wave is in the VALU / LDS-latency part, and neither
 //     waits for the other's memory operations (a conv wave issues no DMA, a prep wave no loads or stores).  Without the
-//     split (layers without a P pass; W8A8 SFT convs, whose P pass is too heavy for four waves; HDRTV_CONV32_NOSPLIT=1) every
+//     split (layers without a P pass; W8A8 SFT convs, whose P pass is too heavy for four waves; nosplit) every
 //     wave does both: waves 0-3 run R X M P E, waves 4-7 R P M E, one conv group each, two halo groups on waves 4-7 and one
 //     on waves 0-3;
 //   * ONE barrier per tile.  That takes (a) three halo buffers for fp16 layers: the conv reads A[t], P rewrites A[t+1]
@@ -715,23 +715,28 @@ hipError_t launch_k(const Conv32Params &p, int n_cu, hipStream_t s)
     return hipGetLastError();
 }
 
-// layers with a P pass run the role split (waves 0-3 convolve, waves 4-7 prepare the next tile) unless HDRTV_CONV32_NOSPLIT=1
-// (developer A/B switch, read per launch)
+// layers with a P pass run the role split (waves 0-3 convolve, waves 4-7 prepare the next tile) unless the caller's A/B switch
+// `nosplit` asks for the first form
 template <bool SFT, bool I8, bool SQ, bool PLANAR, bool C3 = false>
-hipError_t launch_t(const Conv32Params &p, int n_cu, hipStream_t s)
+hipError_t launch_t(const Conv32Params &p, int n_cu, hipStream_t s, bool nosplit)
 {
     if constexpr ((SFT || I8) && !SQ) {        // W8A8 SFT convs: their P pass is too heavy for four waves (1.52 -> 1.82 ms split)
-        const char *e = getenv("HDRTV_CONV32_NOSPLIT");
-        if (!(e && atoi(e))) return launch_k<SFT, I8, SQ, PLANAR, C3, true>(p, n_cu, s);
+#ifdef HDRTV_AB
+        if (nosplit) return launch_k<SFT, I8, SQ, PLANAR, C3, false>(p, n_cu, s);
+#else
+        if (nosplit) return hipErrorNotSupported;              // the first form exists in the A/B library only (make AB=1)
+#endif
+        return launch_k<SFT, I8, SQ, PLANAR, C3, true>(p, n_cu, s);
+    } else {
+        return launch_k<SFT, I8, SQ, PLANAR, C3, false>(p, n_cu, s);
     }
-    return launch_k<SFT, I8, SQ, PLANAR, C3, false>(p, n_cu, s);
 }
 
 }  // namespace
 
 // Single-pass (CoutPad == 32) layers only; src (and cond) must be followed by >= 64 zero bytes (the workspace guard),
 // p.zeros must hold >= 16 zero bytes and p.trash >= 8 KiB of write-only scratch.
-hipError_t conv32s_launch(Conv32Params p, int n_cu, hipStream_t s)
+hipError_t conv32s_launch(Conv32Params p, int n_cu, hipStream_t s, bool nosplit)
 {
     if ((size_t)p.H * p.W * 64 >= 0xf0000000ull || p.CoutPad != 32 || !p.zeros || !p.trash) return hipErrorInvalidValue;
     const bool sft = p.cond != nullptr, planar = p.mode == ST_PLANAR3;
@@ -740,12 +745,12 @@ hipError_t conv32s_launch(Conv32Params p, int n_cu, hipStream_t s)
     p.tiles_y = (p.H + TH - 1) / TH;
     if (p.wpk8) {
         if (p.c3_img) return hipErrorInvalidValue;
-        if (planar) return sft ? hipErrorInvalidValue : launch_t<false, true, false, true>(p, n_cu, s);
-        if (sft && p.sq_wfrag) return launch_t<true, true, true, false>(p, n_cu, s);
-        return sft ? launch_t<true, true, false, false>(p, n_cu, s) : launch_t<false, true, false, false>(p, n_cu, s);
+        if (planar) return sft ? hipErrorInvalidValue : launch_t<false, true, false, true>(p, n_cu, s, nosplit);
+        if (sft && p.sq_wfrag) return launch_t<true, true, true, false>(p, n_cu, s, nosplit);
+        return sft ? launch_t<true, true, false, false>(p, n_cu, s, nosplit) : launch_t<false, true, false, false>(p, n_cu, s, nosplit);
     }
     if (p.sq_wfrag) return hipErrorInvalidValue;         // W8A8 SFT convs in front of an fp16 conv: no kernel (no shipped recipe has it)
-    if (planar) return sft ? hipErrorInvalidValue : launch_t<false, false, false, true>(p, n_cu, s);
-    if (p.c3_img) return (sft && p.c3_wfrag) ? launch_t<true, false, false, false, true>(p, n_cu, s) : hipErrorInvalidValue;
-    return sft ? launch_t<true, false, false, false>(p, n_cu, s) : launch_t<false, false, false, false>(p, n_cu, s);
+    if (planar) return sft ? hipErrorInvalidValue : launch_t<false, false, false, true>(p, n_cu, s, nosplit);
+    if (p.c3_img) return (sft && p.c3_wfrag) ? launch_t<true, false, false, false, true>(p, n_cu, s, nosplit) : hipErrorInvalidValue;
+    return sft ? launch_t<true, false, false, false>(p, n_cu, s, nosplit) : launch_t<false, false, false, false>(p, n_cu, s, nosplit);
 }

@@ -225,7 +225,10 @@ __global__ __launch_bounds__(512) void conv_prw_kernel(ConvParams p)
                 if constexpr (MODE == ST_PS_DOT3) {
                     // this tap's DMA goes into the slot that was the last tile's strip: the partner must have read it
                     if (tap == 1 && cc == 0 && k > 0 && (wave & 1))
+                    {
                         while (s_flag[4 + (wave >> 1)] < k) __builtin_amdgcn_s_sleep(2);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     // nothing below (the DMA into the strip) moves above the poll
+                    }
                 }
                 // weights of the next tap into the slot whose fragments have been in registers since the end of the last tap
                 if (tap < 8) issue_W(cc, tap + 1, cur.n0, (ws + 1) & 1);
@@ -366,6 +369,7 @@ __global__ __launch_bounds__(512) void conv_prw_kernel(ConvParams p)
             } else {
                 const char *pst = stg + 2 * W_SLOT;                          // the partner's strip: same slot parity, next wave's ring
                 while (s_flag[pair] < k + 1) __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");        // the strip reads below stay behind the poll (compiler order, too)
 #pragma unroll
                 for (int pass = 0; pass < TH / 4; ++pass) {
                     const float4 v = *reinterpret_cast<const float4 *>(pst + pass * 1024 + eln * 16);

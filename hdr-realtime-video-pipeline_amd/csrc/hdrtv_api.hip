@@ -265,7 +265,34 @@ int fail(hdrtv_ctx *c, int code, const char *fmt, ...)
 // hdrtv_create.  The launch path reads c->var only.
 const std::pair<const char *, int> k_variants[] = {
     {"le_rows", 1},          // fused row-streaming LE kernels (le_rows.hip); 0 = the per-layer 16x16-tile kernels
+    {"prw", 1},              // HG 3x3 convs on conv_prw: 0 never (conv_pglds), 1 the cheapest shape per layer, 2 / 3 16-row / 8-row tiles wherever it applies
+    {"prw_i8", 1},           // int8 HG 3x3 convs on conv_prw_i8: 0 never, 1 only where the 8-row tiles win, 2 wherever "prw" selects it
+    {"pglds_nt_slow", 3},    // conv_pglds tile order: 0 / 1 Cout-tile fastest / slowest, 2 slowest for Cout >= 512, 3 slowest for the Up convs
+    {"no_t16", 0},           // 1: LE's stride-2 down-convs on the generic implicit-GEMM kernel
+    {"conv32_old", 0},       // 1: single-pass LE convs on conv32p's two-barrier schedule instead of conv32s
+    {"conv32_nosplit", 0},   // 1: conv32s without the conv / prep role split
+    {"conv32_nw", 0},        // conv32p tile shape: 0 per layer, 8 16x16 tiles, 4 8x16 tiles x 2 workgroups per CU
+    {"no_c3fuse", 0},        // 1: LE.conv_first as its own launch in front of HR_conv1
+    {"no_c3q8", 0},          // 1: the W8A8 LE.conv_first through planar3_to_q8 + conv_q8 instead of conv_c3_q8
+    {"glds1_old", 0},        // 1: HG 1x1 fuse convs on the non-persistent kernel
+    {"final_recompute", 0},  // 1: HG tail recomputes conv1 (hg_final_fused) instead of reading conv1's per-pixel sums
+    {"pre_split", 0},        // 1: preprocess as two kernels (unpack, condition resize)
+    {"force_ncu", 0},        // > 0: pretend the device has this many CUs (persistent grids)
 };
+// variants whose non-default settings select kernels that exist in the A/B library only (make AB=1 -> libhdrtv_mi355x_ab.so):
+// superseded schedules kept as bit-identity yardsticks of the shipped ones
+const char *const k_ab_only[] = {"conv32_old", "conv32_nosplit", "conv32_nw", "glds1_old", "final_recompute"};
+bool variant_allowed(const std::string &name, int value)
+{
+#ifdef HDRTV_AB
+    (void)name; (void)value;
+    return true;
+#else
+    if (value == 0) return true;
+    for (const char *n : k_ab_only) if (name == n) return false;
+    return true;
+#endif
+}
 void variants_init(hdrtv_ctx *c)
 {
     for (const auto &kv : k_variants) c->var[kv.first] = kv.second;
@@ -280,7 +307,7 @@ void variants_init(hdrtv_ctx *c)
         const size_t eq = one.find('=');
         if (eq != std::string::npos) {
             auto it = c->var.find(one.substr(0, eq));
-            if (it != c->var.end()) it->second = atoi(one.c_str() + eq + 1);
+            if (it != c->var.end() && variant_allowed(it->first, atoi(one.c_str() + eq + 1))) it->second = atoi(one.c_str() + eq + 1);
         }
         pos = nx + 1;
     }
@@ -1420,21 +1447,19 @@ struct Seq {
         p.zeros = wtp<f16>(c, c->zeros_off);
         const bool g64 = L.stride == 1 && L.cin_t == 64 && L.bn == 128 && !res1 && !res2 && !dst_full && mode != ST_PLANAR3;
         const bool pglds = g64 && L.ks == 3 && L.cout == L.coutPad;      // HG 3x3 convs: persistent LDS-DMA kernel
-        const bool glds1 = g64 && L.ks == 1 && mode == ST_NHWC;          // HG 1x1 fuse convs
+        const bool glds1 = g64 && L.ks == 1 && mode == ST_NHWC && (c0 + c1) >= 128 && L.coutPad <= 512 && (act == ACT_RELU || act == ACT_NONE);   // HG 1x1 fuse convs
         p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
-        static const int nt_slow = [] { const char *e = getenv("HDRTV_PGLDS_NT_SLOW"); return e ? atoi(e) : 3; }();
+        const int nt_slow = c->var.at("pglds_nt_slow");
         // default: the Up convs (Cout = 4 Cin: 4 .. 16 Cout-tiles per pixel tile) walk Cout-tile slowest -- an XCD then shares one
         // weight slab instead of re-fetching up to 16 (-17 % L2 misses, profiles/r02_pmc_traffic_tile_order.json); the other
         // layers walk it fastest so that the blocks of an XCD share halo tiles (+45 .. +75 % misses the other way round)
         p.nt_slow = nt_slow == 3 ? (mode == ST_PS) : (nt_slow == 2 ? (L.coutPad >= 512) : nt_slow);
         const bool s2g = L.ks == 3 && L.stride == 2 && L.cin_t == 64 && L.bn == L.coutPad && (L.coutPad == 64 || L.coutPad == 192);
-        static const bool no_t16 = getenv("HDRTV_NO_T16") != nullptr;       // developer A/B: the generic implicit-GEMM kernel
+        const bool no_t16 = c->var.at("no_t16") != 0;                         // developer A/B: the generic implicit-GEMM kernel
         const bool t16 = !no_t16 && L.ks == 3 && L.stride == 2 && L.cin == 32 && L.coutPad == 32 && !src1 && mode == ST_NHWC && !res1 && !res2;
-        // HG 3x3 convs with Cout a multiple of 256: the private-weight schedule (conv3x3_prw.hip); HDRTV_PRW=0: conv_pglds
-        // HDRTV_PRW: 0 = never, 1 (default) = the cheapest shape per layer, 2 / 3 = 16-row / 8-row tiles wherever it applies
-        // (read per launch: the A/B test flips it inside one process)
-        const char *prw_env = getenv("HDRTV_PRW");
-        const int use_prw_mode = prw_env ? atoi(prw_env) : 1;
+        // HG 3x3 convs with Cout a multiple of 256: the private-weight schedule (conv3x3_prw.hip); variant prw = 0: conv_pglds
+        // variant "prw": 0 = never, 1 (default) = the cheapest shape per layer, 2 / 3 = 16-row / 8-row tiles wherever it applies
+        const int use_prw_mode = c->var.at("prw");
         const bool use_prw = use_prw_mode != 0;
         const bool prw_dot3 = mode == ST_PS_DOT3 && L.coutPad == 256;                // Up_conv5: always the 16-row shape
         bool prw = pglds && use_prw && (L.coutPad % 256) == 0 && (mode != ST_PS_DOT3 || prw_dot3);
@@ -1468,7 +1493,7 @@ struct Seq {
         bytes += 2.0 * outel * (1 + (res1 ? 1 : 0) + (res2 ? 1 : 0) + (res_planar ? 1 : 0));
         chk(t16 ? conv_t16_launch(p, s, c->n_cu) : s2g ? conv3x3s2_preg_launch(p, c->n_cu, s)
                 : (pglds ? (prw ? conv_prw_launch(p, prw_th, c->n_cu, s) : conv_pglds_launch(p, c->n_cu, s))
-                         : (glds1 ? conv_glds1_launch(p, s, c->n_cu) : conv_igemm_launch(p, L.cin_t, L.bn, L.ks, L.stride, s))),
+                         : (glds1 ? conv_glds1_launch(p, s, c->n_cu, c->var.at("glds1_old") != 0) : conv_igemm_launch(p, L.cin_t, L.bn, L.ks, L.stride, s))),
             key.c_str(), tag, macs, bytes);
     }
     // W8A8 HG layer on int8 MFMA: 3x3 (conv3x3_pglds_i8.hip) or 1x1 (conv_i8_misc.hip)
@@ -1499,8 +1524,7 @@ struct Seq {
         const double bytes = (double)Hi * Wi * L.cin + (double)L.ks * L.ks * L.cin * L.cout +
                              (mode == ST_PS_DOT3 ? 16.0 * Hd * Wd : outel * (L.out_f16 ? 2.0 : 1.0));
         // the private-weight schedule (conv3x3_prw_i8.hip) and its tile shape, picked as for the fp16 layers (Seq::conv)
-        const char *prw_env = getenv("HDRTV_PRW");
-        const int prw_mode = prw_env ? atoi(prw_env) : 1;
+        const int prw_mode = c->var.at("prw");
         bool prw = prw_mode != 0 && L.ks == 3 && c0 != 64 && (L.cout % 256) == 0 && mode != ST_PS_DOT3 && !L.out_f16;
         int prw_th = 16;
         if (prw && prw_mode == 1) {
@@ -1513,9 +1537,8 @@ struct Seq {
         } else if (prw && prw_mode == 3) {
             prw_th = 8;
         }
-        // HDRTV_PRW_I8: 0 = never, 1 = only where the 8-row tiles win (the low-resolution layers), 2 = wherever HDRTV_PRW selects it
-        const char *i8_env = getenv("HDRTV_PRW_I8");
-        const int i8_mode = i8_env ? atoi(i8_env) : 1;
+        // variant "prw_i8": 0 = never, 1 = only where the 8-row tiles win (the low-resolution layers), 2 = wherever "prw" selects it
+        const int i8_mode = c->var.at("prw_i8");
         if (i8_mode == 0 || (i8_mode == 1 && prw_th != 8)) prw = false;
         if (prw) snprintf(tag, sizeof tag, "conv_prw%s_i8<%s>", prw_th == 8 ? "8" : "", mode == ST_POOL ? "pool" : (mode == ST_PS ? "ps" : "nhwc"));
         chk(L.ks == 3 ? (prw ? conv_prw_i8_launch(p, prw_th, c->n_cu, s) : conv_pglds_i8_launch(p, c->n_cu, s)) : conv1x1_i8_launch(p, s),
@@ -1593,9 +1616,7 @@ struct Seq {
         p.CoutPad = L.coutPad; p.Cout = L.cout; p.act = act; p.mode = mode;
         p.dst = dst; p.dstC = dstC; p.Hd = Hd; p.Wd = Wd; p.res1 = res1; p.res2 = res2;
         p.dst_planar = dst_planar; p.res_planar = res_planar; p.zeros = wtp<f16>(c, c->zeros_off);
-        // diagnostic builds (make STAMP=1) write per-phase cycle sums of launch #HDRTV_STAMP_LAUNCH here
-        static const int stamp_launch = [] { const char *e = getenv("HDRTV_STAMP_LAUNCH"); return e ? atoi(e) : -1; }();
-        p.dump = (stamp_launch >= 0 && c->launches == stamp_launch) ? wsp<f16>(c, "dbg.stamps") : nullptr;
+        p.dump = reinterpret_cast<f16 *>(stamp_buf());
         const double npx = (double)H * W;
         const double macs = npx * 32 * 9 * L.cout + (cond ? npx * 2 * (16 * 16 + 16 * 32) : 0.0) + (c3_img ? npx * 27 * 32 : 0.0);
         const double outb = mode == ST_PLANAR3 ? 6.0 * npx : 2.0 * npx * L.cout;
@@ -1606,14 +1627,13 @@ struct Seq {
             const C3Layer &L3 = c->c3.at(c3_key);
             p.c3_img = c3_img; p.c3_wfrag = wtp<f16>(c, L3.wfrag);      // bias inside the fragments (pack_c3), no BatchNorm
         }
-        // single-pass layers run the one-barrier schedule (conv32s.hip); HDRTV_CONV32_OLD=1 is the developer A/B switch
-        const char *olde = getenv("HDRTV_CONV32_OLD");      // read per launch: the bit-exactness test flips it within one process
-        const bool old_sched = olde && atoi(olde) != 0;
+        // single-pass layers run the one-barrier schedule (conv32s.hip); variant "conv32_old" is the developer A/B switch
+        const bool old_sched = c->var.at("conv32_old") != 0;
         const bool one_barrier = L.coutPad == 32 && !old_sched;
         char tag[48];
         snprintf(tag, sizeof tag, "conv32%c<%d,%s%s%s>", one_barrier ? 's' : 'p', L.coutPad / 32, c3_img ? "c3+" : "", cond ? (sq ? "sft-i8" : "sft") : "plain", i8 ? ",i8" : "");
         if (c3_img && !one_barrier) { rc = fail(c, HDRTV_ESTATE, "conv_first fusion needs the one-barrier schedule"); return; }
-        chk(one_barrier ? conv32s_launch(p, c->n_cu, s) : conv32p_launch(p, c->n_cu, s), key.c_str(), tag, macs, bytes);
+        chk(one_barrier ? conv32s_launch(p, c->n_cu, s, c->var.at("conv32_nosplit") != 0) : conv32p_launch(p, c->n_cu, s, c->var.at("conv32_nw")), key.c_str(), tag, macs, bytes);
     }
     // diagnostic builds (make STAMP=1) write per-phase cycle sums of launch number HDRTV_STAMP_LAUNCH (read once) here
     void *stamp_buf() const
@@ -1840,8 +1860,7 @@ int run_le(hdrtv_ctx *c, Seq &q, const f16 *img, f16 *out_planar)
     f16 *f0a = wsp<f16>(c, "le.f0a"), *f0b = wsp<f16>(c, "le.f0b"), *fea0 = wsp<f16>(c, "le.fea0"), *up3 = wsp<f16>(c, "le.up3");
     bool head_fused = false;
     if (isq8("LE.conv_first")) {
-        const char *g8 = getenv("HDRTV_NO_C3Q8");     // developer A/B switch (read per launch): the generic two-launch form
-        if (g8 && atoi(g8)) {     // the 3 planes as NHWC int8 codes (3 of 32 bytes real), then the generic int8 conv
+        if (c->var.at("no_c3q8")) {                  // developer A/B switch: the generic two-launch form     // the 3 planes as NHWC int8 codes (3 of 32 bytes real), then the generic int8 conv
             int8_t *img32 = wsp<int8_t>(c, "le8.img32");
             const QLayer &Lq = c->q8.at("LE.conv_first");
             if (q.ok()) q.chk(planar3_to_q8_launch(img, (size_t)H * W, Lq.q.inv(), Lq.q.zoff(), img32, q.s), "le.conv_first.pack", "planar3_to_q8", 0.0, 38.0 * H * W);
@@ -1855,10 +1874,9 @@ int run_le(hdrtv_ctx *c, Seq &q, const f16 *img, f16 *out_planar)
         q.conv32("LE.HR_conv1", f0a, cond1, "LE.SFT_layer1", H, W, ACT_RELU, ST_NHWC, fea0, 32, H, W);
     } else {
         // fp16 conv_first is computed inside HR_conv1's kernel from the three planes (conv32s.hip, C3): its 32-channel output
-        // (0.53 GB at 4K, written and read back) never exists.  HDRTV_NO_C3FUSE=1 / HDRTV_CONV32_OLD=1: the two-launch form
-        // (developer A/B switches, read per launch); a W8A8 HR_conv1 behind an fp16 conv_first has no fused kernel.
-        const char *nf = getenv("HDRTV_NO_C3FUSE"), *olds = getenv("HDRTV_CONV32_OLD");
-        const bool fuse = !(nf && atoi(nf)) && !(olds && atoi(olds)) && c->q32.find("LE.HR_conv1") == c->q32.end();
+        // (0.53 GB at 4K, written and read back) never exists.  Variants no_c3fuse / conv32_old: the two-launch form
+        // (developer A/B switches); a W8A8 HR_conv1 behind an fp16 conv_first has no fused kernel.
+        const bool fuse = !c->var.at("no_c3fuse") && !c->var.at("conv32_old") && c->q32.find("LE.HR_conv1") == c->q32.end();
         // conv_first .. down_conv1 in one row-streaming launch (le_rows.hip) when all of it is fp16 and the shapes are even
         head_fused = fuse && q.ok() && c->var.at("le_rows") && !(H & 1) && !(W & 1) && q.rows_fit(H, W) && c->conv.count("LE.HR_conv1") &&
                      c->conv.count("LE.down_conv1") && !isq8("LE.down_conv1") && !c->sft.at("LE.SFT_layer1").q;
@@ -1943,10 +1961,9 @@ int run_hg(hdrtv_ctx *c, Seq &q, const f16 *base, void *out, int out_f32)
     q.chk(hg_prep_launch(base, s.H, s.W, Hp, Wp, img, mask, c->mask_r, 0.1f, q.s), "hg_prep", "hg_prep", 0.0, 13.0 * Hp * Wp);
     float *part = wsp<float>(c, "hg.part");
     // conv1: only the pooled map is kept; its kernel also leaves conv10's second half (the 64 -> 3 sums over conv1's channels) per
-    // pixel, so the tail is a per-pixel kernel.  HDRTV_FINAL_RECOMPUTE=1 (developer A/B switch, read per launch): the tail
-    // recomputes conv1 instead (hg_final_fused) -- same arithmetic, same results.
-    const char *fr_env = getenv("HDRTV_FINAL_RECOMPUTE");
-    const bool light = !(fr_env && atoi(fr_env));
+    // pixel, so the tail is a per-pixel kernel.  Variant final_recompute (developer A/B switch): the tail recomputes conv1
+    // instead (hg_final_fused) -- same arithmetic, same results.
+    const bool light = !c->var.at("final_recompute");
     float *part2 = light ? wsp<float>(c, "hg.part2") : nullptr;
     const f16 *w2frag = light ? wtp<f16>(c, c->hgf_wfrag) + 6 * 64 * 8 : nullptr;      // fragments 6..9 of the tail's set
     if (c->hg_i8) {
@@ -2018,9 +2035,11 @@ int run_hg(hdrtv_ctx *c, Seq &q, const f16 *base, void *out, int out_f32)
     if (light)
         q.chk(hg_final_light_launch(fa, part2, q.s), "hg_final", "hg_final_light", (double)s.H * s.W * 6 * 3,
               (double)s.H * s.W * (6 + 1 + 32 + 3 * (out_f32 ? 4 : 2)));
+#ifdef HDRTV_AB
     else
         q.chk(hg_final_fused_launch(fa, c->n_cu, q.s), "hg_final", "hg_final_fused", (double)Hp * Wp * (128 * 3 + 6 * 3),
               (double)s.H * s.W * (6 + 1 + 16 + 3 * (out_f32 ? 4 : 2)));
+#endif
     return q.rc;
 }
 
@@ -2055,8 +2074,8 @@ int hdrtv_create(const void *hr_pack, size_t hr_bytes, const void *hg_pack, size
     c->n_cu = prop.multiProcessorCount;
     // test switch: a huge value gives every persistent kernel one tile per workgroup (tests/test_gpu_parity.py
     // compares that schedule bit for bit with the real one)
-    if (const char *e = getenv("HDRTV_FORCE_NCU")) { if (atoi(e) > 0) c->n_cu = atoi(e); }
     variants_init(c);
+    if (c->var.at("force_ncu") > 0) c->n_cu = c->var.at("force_ncu");
     if (hipMalloc((void **)&c->wts.dev, c->wts.size + 256) != hipSuccess) {
         c->wts.dev = nullptr;
         return fail(c, HDRTV_ENOMEM, "weight allocation failed");
@@ -2098,6 +2117,7 @@ int hdrtv_set_variant(hdrtv_ctx *c, const char *name, int value)
     if (!c || !name) return HDRTV_EINVAL;
     auto it = c->var.find(name);
     if (it == c->var.end()) return fail(c, HDRTV_EINVAL, "unknown variant %s", name);
+    if (!variant_allowed(name, value)) return fail(c, HDRTV_EINVAL, "variant %s = %d needs the A/B library (make AB=1)", name, value);
     it->second = value;
     return HDRTV_OK;
 }
@@ -2134,7 +2154,7 @@ int hdrtv_preprocess(hdrtv_ctx *c, void *stream, const uint8_t *bgr, int H, int 
     hipStream_t s = (hipStream_t)stream;
     Seq q{c, s};
     const Shapes sh = shapes_for(H, W);
-    static const bool split = getenv("HDRTV_PRE_SPLIT") != nullptr;      // developer A/B: the two-kernel form
+    const bool split = c->var.at("pre_split") != 0;                       // developer A/B: the two-kernel form
     if (H / 4 >= 1 && W / 4 >= 1 && !(split && c->cond_mode == 0)) {
         q.chk(pre_fused_launch(bgr, (f16 *)rgb, (f16 *)cond, H, W, sh.h4, sh.w4, wsp<float>(c, "aa.wx"), wsp<int>(c, "aa.xmn"),
                                wsp<int>(c, "aa.xns"), wsp<float>(c, "aa.wy"), wsp<int>(c, "aa.ymn"), wsp<int>(c, "aa.yns"), c->cond_mode, s),
@@ -2425,29 +2445,58 @@ int hdrtv_ring_acquire(hdrtv_ctx *c, int timeout_ms, uint16_t **host_ptr, uint16
     return i;
 }
 
+// Slot life cycle: 0 free -> (acquire) 1 acquired -> (commit) 2 committed -> (release) 0.  Every entry point looks its slot up
+// and checks its state under ring_mu (the consumer thread calls wait / release while the producer acquires and commits, and
+// hdrtv_ring_destroy may run between them): a call in the wrong state is HDRTV_ESTATE, not stale pixels.
 int hdrtv_ring_commit(hdrtv_ctx *c, int slot, void *stream)
 {
-    if (!c || slot < 0 || slot >= (int)c->ring.size()) return fail(c, HDRTV_EINVAL, "bad ring slot");
-    HIPCHK(c, hipMemcpyAsync(c->ring[slot].host, c->ring[slot].dev, (size_t)c->ring_H * c->ring_W * 6, hipMemcpyDeviceToHost,
-                             (hipStream_t)stream));
-    HIPCHK(c, hipEventRecord(c->ring[slot].ev, (hipStream_t)stream));
-    std::lock_guard<std::mutex> lk(c->ring_mu);
-    c->ring[slot].state = 2;
+    if (!c) return HDRTV_EINVAL;
+    uint16_t *host = nullptr, *dev = nullptr;
+    hipEvent_t ev = nullptr;
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> lk(c->ring_mu);
+        if (slot < 0 || slot >= (int)c->ring.size()) return fail(c, HDRTV_EINVAL, "bad ring slot");
+        if (c->ring[slot].state != 1) return fail(c, HDRTV_ESTATE, "ring slot %d is not acquired (state %d)", slot, c->ring[slot].state);
+        host = c->ring[slot].host; dev = c->ring[slot].dev; ev = c->ring[slot].ev;
+        bytes = (size_t)c->ring_H * c->ring_W * 6;
+        // enqueue under the lock: hdrtv_ring_destroy cannot free the buffers between the look-up and the copy (both calls
+        // only enqueue; neither blocks on the device)
+        hipError_t e = hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream);
+        if (e == hipSuccess) e = hipEventRecord(ev, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(c, HDRTV_EHIP, "ring commit failed: %s", hipGetErrorString(e));
+        c->ring[slot].state = 2;
+    }
     return HDRTV_OK;
 }
 
 int hdrtv_ring_wait(hdrtv_ctx *c, int slot)
 {
-    if (!c || slot < 0 || slot >= (int)c->ring.size()) return fail(c, HDRTV_EINVAL, "bad ring slot");
-    HIPCHK(c, hipEventSynchronize(c->ring[slot].ev));
+    if (!c) return HDRTV_EINVAL;
+    hipEvent_t ev = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(c->ring_mu);
+        if (slot < 0 || slot >= (int)c->ring.size()) return fail(c, HDRTV_EINVAL, "bad ring slot");
+        // an acquired-but-uncommitted slot has no copy in flight: its event was never recorded (or belongs to the slot's
+        // previous frame) and hipEventSynchronize would return at once on stale pixels
+        if (c->ring[slot].state != 2) return fail(c, HDRTV_ESTATE, "ring slot %d is not committed (state %d)", slot, c->ring[slot].state);
+        ev = c->ring[slot].ev;
+    }
+    const hipError_t e = hipEventSynchronize(ev);          // outside the lock: blocks until the copy has landed
+    if (e != hipSuccess) {
+        std::lock_guard<std::mutex> lk(c->ring_mu);
+        return fail(c, HDRTV_EHIP, "ring wait failed: %s", hipGetErrorString(e));
+    }
     return HDRTV_OK;
 }
 
 int hdrtv_ring_release(hdrtv_ctx *c, int slot)
 {
-    if (!c || slot < 0 || slot >= (int)c->ring.size()) return fail(c, HDRTV_EINVAL, "bad ring slot");
+    if (!c) return HDRTV_EINVAL;
     {
         std::lock_guard<std::mutex> lk(c->ring_mu);
+        if (slot < 0 || slot >= (int)c->ring.size()) return fail(c, HDRTV_EINVAL, "bad ring slot");
+        if (c->ring[slot].state == 0) return fail(c, HDRTV_ESTATE, "ring slot %d is already free", slot);
         c->ring[slot].state = 0;
     }
     c->ring_cv.notify_all();

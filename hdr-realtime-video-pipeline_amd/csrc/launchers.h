@@ -12,14 +12,14 @@ struct DevOnce {
 };
 
 hipError_t conv_igemm_launch(ConvParams p, int cin_t, int bn, int ks, int stride, hipStream_t stream);
-hipError_t conv_glds1_launch(ConvParams p, hipStream_t stream, int n_cu = 0);   // n_cu >= 8: the persistent form
+hipError_t conv_glds1_launch(ConvParams p, hipStream_t stream, int n_cu = 0, bool old_form = false);   // n_cu >= 8: the persistent form
 hipError_t conv_pglds_launch(ConvParams p, int n_cu, hipStream_t stream);
 hipError_t conv_prw_launch(ConvParams p, int th, int n_cu, hipStream_t stream);   // Cout % 256 == 0, modes NHWC / PS / POOL; th = 16 | 8
 hipError_t conv_pglds_i8_launch(ConvI8Params p, int n_cu, hipStream_t stream);
 hipError_t conv_prw_i8_launch(ConvI8Params p, int th, int n_cu, hipStream_t stream);   // Cin % 128 == 0, Cout % 256 == 0, int8 out
 hipError_t conv1x1_i8_launch(ConvI8Params p, hipStream_t stream);
-hipError_t conv32p_launch(Conv32Params p, int n_cu, hipStream_t stream);
-hipError_t conv32s_launch(Conv32Params p, int n_cu, hipStream_t stream);   // the single-pass (CoutPad == 32) layers
+hipError_t conv32p_launch(Conv32Params p, int n_cu, hipStream_t stream, int nw = 0);
+hipError_t conv32s_launch(Conv32Params p, int n_cu, hipStream_t stream, bool nosplit = false);   // the single-pass (CoutPad == 32) layers
 hipError_t le_rb_rows_launch(RowsRbParams p, int n_cu, hipStream_t stream);   // fused ResBlock_with_SFT, row-streaming (le_rows.hip)
 hipError_t le_tail_rows_launch(RowsTailParams p, int n_cu, hipStream_t stream);   // up_conv3 .. conv_last in one launch (le_rows.hip)
 hipError_t le_head_rows_launch(RowsHeadParams p, int n_cu, hipStream_t stream);   // conv_first .. down_conv1 in one launch (le_rows.hip)

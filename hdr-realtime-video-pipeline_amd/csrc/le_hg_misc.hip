@@ -395,6 +395,7 @@ struct HgFinalFusedParams {
     int out_f32, H, W, Hp, Wp;
 };
 
+#ifdef HDRTV_AB      // superseded by conv_c3<64,dot3> + hg_final_light; kept in the A/B library as their bit-identity yardstick
 __global__ __launch_bounds__(256) void hg_final_fused_kernel(HgFinalFusedParams p)
 {
     __shared__ __attribute__((aligned(16))) f16x4 s_px[C3_HH * C3_PW];
@@ -495,6 +496,7 @@ __global__ __launch_bounds__(256) void hg_final_fused_kernel(HgFinalFusedParams 
     }
     }   // tile loop
 }
+#endif
 
 // ============================================================================ hg_final_light
 // The HG tail when conv1's kernel has already left conv10's second half per pixel (conv_c3<64, DOT>): per pixel
@@ -635,6 +637,7 @@ hipError_t hg_final_light_launch(const HgFinalFusedArgs &a, const float *part2, 
     return hipGetLastError();
 }
 
+#ifdef HDRTV_AB
 hipError_t hg_final_fused_launch(const HgFinalFusedArgs &a, int n_cu, hipStream_t s)
 {
     HgFinalFusedParams p;
@@ -653,3 +656,4 @@ hipError_t hg_final_fused_launch(const HgFinalFusedArgs &a, int n_cu, hipStream_
     hipLaunchKernelGGL(hg_final_fused_kernel, dim3(grid), dim3(256), 0, s, p);
     return hipGetLastError();
 }
+#endif

@@ -11,6 +11,8 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_PKG), "lib", "libhdrtv_mi355x.so")
+# the A/B build (make AB=1): the same sources plus superseded kernels, for the GPU bit-identity tests only
+LIB_PATH_AB = os.path.join(os.path.dirname(_PKG), "lib", "libhdrtv_mi355x_ab.so")
 
 OK, EINVAL, EWEIGHTS, EHIP, ENOMEM, ESTATE = 0, -1, -2, -3, -4, -5
 F16, F32 = 0, 1
@@ -48,27 +50,27 @@ SYMBOLS = [
     ("hdrtv_last_error", C.c_char_p, [_VP]),
 ]
 
-_lib = None
+_libs = {}
 
 
-def load():
-    """Load the shared library (once).  Raises RuntimeError when it has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(ab=False):
+    """Load the shared library (once).  Raises RuntimeError when it has not been built.  ``ab=True``: the A/B library."""
+    path = LIB_PATH_AB if ab else LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} not found: the MI355X HIP extension is not built and there is no "
+            f"{path} not found: the MI355X HIP extension is not built and there is no "
             "fallback path (run __graft_entry__.build())")
     # PyTorch ships its own HIP runtime (libamdhip64 with the system library's SONAME).  Whichever copy a process loads
     # first serves both users, and torch on the system copy finds no device: make torch's the first.
     import torch  # noqa: F401
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)      # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    _libs[path] = lib
     return lib
 
 

@@ -80,7 +80,7 @@ class HDRTVNetMI355X:
                  compile_model=True, force_compile=False, compile_mode="auto",
                  use_cuda_graphs=False, force_channels_last=False,
                  predequantize="auto", hg_weights=None, use_hg=True,
-                 warmup_passes=3, fast_condition_resize=False):
+                 warmup_passes=3, fast_condition_resize=False, _ab_library=False):
         self.model_path = model_path
         self._warmup_passes = int(warmup_passes)
         env_true = lambda n: str(os.environ.get(n, "")).strip().lower() in ("1", "true", "yes", "on")   # noqa: E731
@@ -100,7 +100,7 @@ class HDRTVNetMI355X:
         self._memory_format_name = "nhwc-internal"
         self.engine_path = _L.LIB_PATH
         self.model = None               # no nn.Module exists; callers treat None as "0 MB"
-        self._lib = _L.load()
+        self._lib = _L.load(ab=bool(_ab_library))     # _ab_library: tests only (superseded kernels as bit-identity yardsticks)
         self._ctx = C.c_void_p()
 
         hr_state, hg_from_ckpt = _split_composite(_load_state(model_path, "model weights"))

@@ -264,9 +264,9 @@ def test_w8a8_checkpoint_file_and_loader_errors(golden_dir, tmp_path, qstate, ze
 
 def test_private_weight_int8_schedule_is_bit_identical(golden_dir, monkeypatch):
     """conv_prw_i8 (csrc/conv3x3_prw_i8.hip: the private-weight schedule of conv3x3_prw.hip on int8 MFMA) against
-    conv_pglds_i8 (HDRTV_PRW=0): exact integer sums and the same epilogue arithmetic, so every int8 tensor of the head, the
+    conv_pglds_i8 (variant prw = 0): exact integer sums and the same epilogue arithmetic, so every int8 tensor of the head, the
     dot-product partial sums and the final output agree bit for bit -- at 4K, 1080p and sizes with ragged tiles, with both
-    calibrations (integer and float zero points: the border-class constants), 16-row and 8-row tiles (HDRTV_PRW=2 / 3)."""
+    calibrations (integer and float zero points: the border-class constants), 16-row and 8-row tiles (prw = 2 / 3)."""
     import torch
     from hdrtv_mi355x import weights as W
     from hdrtv_mi355x.processor import HDRTVNetMI355X
@@ -280,9 +280,9 @@ def test_private_weight_int8_schedule_is_bit_identical(golden_dir, monkeypatch):
                     continue
                 f = W.synthetic_frame(h, w, seed=seed, kind="gradient")
                 res = []
-                monkeypatch.setenv("HDRTV_PRW_I8", "2")      # the default (1) keeps the 16-row shape off: slower in sustained runs
+                p.set_variant("prw_i8", 2)                   # the default (1) keeps the 16-row shape off: slower in sustained runs
                 for mode in ("0", "1", "2", "3"):
-                    monkeypatch.setenv("HDRTV_PRW", mode)
+                    p.set_variant("prw", int(mode))
                     out, _ = p.infer(p.preprocess(f))
                     res.append([out.clone()] + [p._tap_device(t).clone() for t in taps])
                     if mode != "0":
@@ -295,6 +295,4 @@ def test_private_weight_int8_schedule_is_bit_identical(golden_dir, monkeypatch):
                     for name, a, b in zip(("out",) + taps, res[0], other):
                         assert torch.equal(a, b), (hgw, h, w, name)
         finally:
-            monkeypatch.delenv("HDRTV_PRW", raising=False)
-            monkeypatch.delenv("HDRTV_PRW_I8", raising=False)
             p.close()

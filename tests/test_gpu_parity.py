@@ -300,7 +300,7 @@ def test_int8_checkpoint_storage(golden_dir, torch_cuda, tag, prec):
 def test_persistent_schedules_do_not_change_results(torch_cuda, golden_dir, monkeypatch):
     """Every conv kernel is persistent (a workgroup walks a run of tiles with cross-tile DMA prefetch and
     hand-counted vmcnt waits), but the small goldens give each workgroup a single tile.  At 3840x2160 with HG,
-    the real schedule must reproduce, bit for bit, the one-tile-per-workgroup schedule (HDRTV_FORCE_NCU) that
+    the real schedule must reproduce, bit for bit, the one-tile-per-workgroup schedule (variant force_ncu) that
     the goldens validate: per-tile arithmetic does not depend on which workgroup runs the tile or in what order."""
     from hdrtv_mi355x import weights as W
     from hdrtv_mi355x.processor import HDRTVNetMI355X
@@ -310,9 +310,9 @@ def test_persistent_schedules_do_not_change_results(torch_cuda, golden_dir, monk
     outs = []
     for force in (None, "4000000"):
         if force:
-            monkeypatch.setenv("HDRTV_FORCE_NCU", force)
+            monkeypatch.setenv("HDRTV_VARIANTS", "force_ncu=" + force)      # read once, by hdrtv_create
         else:
-            monkeypatch.delenv("HDRTV_FORCE_NCU", raising=False)
+            monkeypatch.delenv("HDRTV_VARIANTS", raising=False)
         p = HDRTVNetMI355X(path, use_hg=True, hg_weights="seeded:1234", warmup_passes=0)
         out, agcm = p.infer(p.preprocess(f))
         outs.append((out.clone(), agcm.clone(), p.tap("le.out").clone(), p.tap("hg.conv9").clone()))
@@ -413,33 +413,33 @@ def test_uhd_le_vs_oracle(proc_hr, hr_state):
 @pytest.mark.parametrize("variant", ["fp16", "int8-full", "int8-mixed"])
 def test_one_barrier_conv32_schedule_is_bit_identical(torch_cuda, golden_dir, monkeypatch, variant):
     """conv32s.hip (one barrier per tile, wave-private epilogue, counted vmcnt waits) against conv32p.hip's single-pass
-    kernels it replaces (HDRTV_CONV32_OLD=1): same tiles, same per-element arithmetic, so the LE output and every
+    kernels it replaces (variant conv32_old = 1): same tiles, same per-element arithmetic, so the LE output and every
     intermediate must agree bit for bit -- at 4K (126 tiles per workgroup: the steady state of the three-buffer
     pipeline), at 1080p and at sizes with ragged right / bottom tiles (masked lanes store to the trash line)."""
     from hdrtv_mi355x import weights as W
     from hdrtv_mi355x.processor import HDRTVNetMI355X
     torch = torch_cuda
     if variant == "fp16":
-        p = HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), use_hg=False, warmup_passes=0)
+        p = HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), use_hg=False, warmup_passes=0, _ab_library=True)
     else:
         tag = variant.split("-")[1]
         p = HDRTVNetMI355X(os.path.join(golden_dir, f"hr_int8_{tag}_qat.hdrw"), precision=variant, predequantize="off",
-                           use_hg=False, warmup_passes=0)
+                           use_hg=False, warmup_passes=0, _ab_library=True)
     taps = ("le.fea0", "le.fea1", "le.fea3", "le.up1", "le.up3", "le.out")
     try:
         for (h, w), seed in (((2160, 3840), 41), ((1080, 1920), 42), ((270, 486), 43), ((61, 103), 44)):
             f = W.synthetic_frame(h, w, seed=seed, kind="gradient" if seed % 2 else "noise")
             res = []
             # old schedule (conv_first as its own launch) | new schedule, conv_first unfused | new schedule with conv_first
-            # computed inside HR_conv1's kernel (the default for fp16 HR_conv1)
-            # (int8-full: HDRTV_NO_C3Q8 = the generic planar3_to_q8 + conv_q8 form of the W8A8 conv_first against conv_c3_q8)
-            # HDRTV_CONV32_NOSPLIT: every wave convolves and prepares (conv32s's first form) against the role split
-            for env in ({"HDRTV_CONV32_OLD": "1", "HDRTV_NO_C3Q8": "1"}, {"HDRTV_NO_C3FUSE": "1", "HDRTV_CONV32_NOSPLIT": "1"},
-                        {"HDRTV_CONV32_NOSPLIT": "1"}, {"HDRTV_NO_C3FUSE": "1"}, {}):
-                for k in ("HDRTV_CONV32_OLD", "HDRTV_NO_C3FUSE", "HDRTV_NO_C3Q8", "HDRTV_CONV32_NOSPLIT"):
-                    monkeypatch.delenv(k, raising=False)
-                for k, v in env.items():
-                    monkeypatch.setenv(k, v)
+            # computed inside HR_conv1's kernel (the default for fp16 HR_conv1 among the per-layer kernels)
+            # (int8-full: no_c3q8 = the generic planar3_to_q8 + conv_q8 form of the W8A8 conv_first against conv_c3_q8)
+            # conv32_nosplit: every wave convolves and prepares (conv32s's first form) against the role split
+            # le_rows = 0 throughout: the fused row-streaming kernels (tests/test_gpu_le_rows.py) would bypass these layers
+            switches = ("conv32_old", "no_c3fuse", "no_c3q8", "conv32_nosplit")
+            p.set_variant("le_rows", 0)
+            for env in ({"conv32_old": 1, "no_c3q8": 1}, {"no_c3fuse": 1, "conv32_nosplit": 1}, {"conv32_nosplit": 1}, {"no_c3fuse": 1}, {}):
+                for k in switches:
+                    p.set_variant(k, env.get(k, 0))
                 out, _ = p.infer(p.preprocess(f))
                 res.append([out.clone()] + [p.tap(t).clone() for t in taps])
             for other in res[1:]:
@@ -447,8 +447,6 @@ def test_one_barrier_conv32_schedule_is_bit_identical(torch_cuda, golden_dir, mo
                     assert torch.isfinite(a).all(), (h, w, name)
                     assert torch.equal(a, b), (h, w, name)
     finally:
-        for k in ("HDRTV_CONV32_OLD", "HDRTV_NO_C3FUSE", "HDRTV_NO_C3Q8", "HDRTV_CONV32_NOSPLIT"):
-            monkeypatch.delenv(k, raising=False)
         p.close()
 
 
@@ -491,37 +489,33 @@ def test_smallest_frames_and_rejections(torch_cuda, golden_dir, hr_state):
 def test_persistent_1x1_matches_tile_kernel(torch_cuda, golden_dir, monkeypatch):
     """conv_glds1p (the HG fuse convs conv6..conv9 as one persistent stream of (tile, chunk) iterations, wave-private
     epilogue strips, counted vmcnt waits across tile boundaries) against the one-tile-per-workgroup kernel it replaces
-    (HDRTV_GLDS1_OLD=1): same accumulation order, so every tap must agree bit for bit -- at 1080p (32 tiles per workgroup
+    (variant glds1_old = 1): same accumulation order, so every tap must agree bit for bit -- at 1080p (32 tiles per workgroup
     on conv9) and at a size with ragged tiles."""
     from hdrtv_mi355x import weights as W
     from hdrtv_mi355x.processor import HDRTVNetMI355X
     torch = torch_cuda
-    p = HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), use_hg=True, hg_weights="seeded:1234", warmup_passes=0)
+    p = HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), use_hg=True, hg_weights="seeded:1234", warmup_passes=0, _ab_library=True)
     try:
         for (h, w), seed in (((1080, 1920), 51), ((270, 486), 52)):
             f = W.synthetic_frame(h, w, seed=seed, kind="gradient")
             res = []
-            for old in ("1", None):
-                if old:
-                    monkeypatch.setenv("HDRTV_GLDS1_OLD", old)
-                else:
-                    monkeypatch.delenv("HDRTV_GLDS1_OLD", raising=False)
+            for old in (1, 0):
+                p.set_variant("glds1_old", old)
                 out, _ = p.infer(p.preprocess(f))
                 res.append([out.clone()] + [p.tap(t).clone() for t in ("hg.conv6", "hg.conv7", "hg.conv8", "hg.conv9")])
             for name, a, b in zip(("out", "conv6", "conv7", "conv8", "conv9"), res[0], res[1]):
                 assert torch.isfinite(a).all(), (h, w, name)
                 assert torch.equal(a, b), (h, w, name)
     finally:
-        monkeypatch.delenv("HDRTV_GLDS1_OLD", raising=False)
         p.close()
 
 
 def test_private_weight_conv_schedule_is_bit_identical(torch_cuda, golden_dir, monkeypatch):
     """conv_prw (csrc/conv3x3_prw.hip: 256 output channels per workgroup, a wave owns 32 of them for the whole 16x16 tile
-    and keeps its weight rows in a private LDS ring; one barrier per 64-channel chunk) against conv_pglds (HDRTV_PRW=0):
+    and keeps its weight rows in a private LDS ring; one barrier per 64-channel chunk) against conv_pglds (variant prw = 0):
     same accumulation order per output element, so every HG tensor and the final output agree bit for bit -- at 4K (the
     steady state of the cross-tile software pipeline), at 1080p, and at sizes with ragged right / bottom tiles and with
-    fewer tiles than workgroups.  HDRTV_PRW=2 forces the new schedule onto every layer it can run (the default, 1, leaves
+    fewer tiles than workgroups.  prw = 2 forces the new schedule onto every layer it can run (the default, 1, leaves
     the low-resolution layers on conv_pglds)."""
     from hdrtv_mi355x import weights as W
     from hdrtv_mi355x.processor import HDRTVNetMI355X
@@ -533,7 +527,7 @@ def test_private_weight_conv_schedule_is_bit_identical(torch_cuda, golden_dir, m
             f = W.synthetic_frame(h, w, seed=seed, kind="gradient")
             res = []
             for mode in ("0", "1", "2"):
-                monkeypatch.setenv("HDRTV_PRW", mode)
+                p.set_variant("prw", int(mode))
                 out, _ = p.infer(p.preprocess(f))
                 res.append([out.clone()] + [p._tap_device(t).clone() for t in taps] + [p._tap_device("hg.part").clone()])
                 if mode != "0":
@@ -556,7 +550,6 @@ def test_private_weight_conv_schedule_is_bit_identical(torch_cuda, golden_dir, m
                         assert torch.equal(a, b), (h, w, name)
             assert torch.equal(res[1][0], res[2][0]) and torch.equal(res[1][-1], res[2][-1])      # both conv_prw runs agree exactly
     finally:
-        monkeypatch.delenv("HDRTV_PRW", raising=False)
         p.close()
 
 
@@ -564,20 +557,20 @@ def test_private_weight_conv_schedule_is_bit_identical(torch_cuda, golden_dir, m
 def test_hg_tail_variants_are_bit_identical(torch_cuda, golden_dir, monkeypatch):
     """The HG tail (conv10's second half over conv1, conv_last, mask blend; Hallucination_arch.py:130-137): by default conv1's
     kernel leaves the 64 -> 3 sums per pixel (conv_c3<64,dot3>) and a per-pixel kernel finishes (hg_final_light);
-    HDRTV_FINAL_RECOMPUTE=1 recomputes conv1 inside the tail (hg_final_fused).  Same fragments, same expressions in the same order:
+    variant final_recompute = 1 recomputes conv1 inside the tail (hg_final_fused).  Same fragments, same expressions in the same order:
     the outputs agree bit for bit -- at 4K, at 1080p, at a width that is not a multiple of 4 (scalar stores) and at a size with
     fewer tiles than workgroups; fp16 and W8A8 HG heads."""
     from hdrtv_mi355x import weights as W
     from hdrtv_mi355x.processor import HDRTVNetMI355X
     torch = torch_cuda
     for hgw in ("seeded:1234", "seeded-w8a8:1234"):
-        p = HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), use_hg=True, hg_weights=hgw, warmup_passes=0)
+        p = HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), use_hg=True, hg_weights=hgw, warmup_passes=0, _ab_library=True)
         try:
             for (h, w), seed in (((2160, 3840), 81), ((1080, 1920), 82), ((97, 131), 83), ((64, 96), 84)):
                 f = W.synthetic_frame(h, w, seed=seed, kind="gradient")
                 res = {}
                 for mode in ("1", "0"):
-                    monkeypatch.setenv("HDRTV_FINAL_RECOMPUTE", mode)
+                    p.set_variant("final_recompute", int(mode))
                     out, _ = p.infer(p.preprocess(f))
                     p.profile_enable(True)
                     p.infer(p.preprocess(f))
@@ -590,5 +583,4 @@ def test_hg_tail_variants_are_bit_identical(torch_cuda, golden_dir, monkeypatch)
                 assert torch.equal(res["0"][0], res["1"][0]), (hgw, h, w, (res["0"][0] - res["1"][0]).abs().max().item())
                 assert torch.equal(res["0"][1], res["1"][1]), (hgw, h, w)
         finally:
-            monkeypatch.delenv("HDRTV_FINAL_RECOMPUTE", raising=False)
             p.close()

@@ -21,7 +21,8 @@ pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not ins
 
 def _asm(src, tmp_path):
     out = tmp_path / (src + ".s")
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-S", "--cuda-device-only",
+    # -DHDRTV_AB: the A/B library's superset (the shipped kernels + the superseded ones the GPU bit-identity tests run)
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-DHDRTV_AB", "-S", "--cuda-device-only",
                     os.path.join(CSRC, src), "-o", str(out)], check=True, capture_output=True)
     text = out.read_text()
     kernels = {}
@@ -195,17 +196,77 @@ def test_prw_has_no_scratch_and_the_waits_it_counts_on(tmp_path):
 
 
 @pytest.mark.parametrize("src", ["conv3x3_prw.hip", "conv3x3_pglds.hip", "conv3x3_pglds_i8.hip", "conv1x1_glds.hip", "conv_i8_misc.hip",
-                                 "conv3x3s2_preg.hip", "conv32s.hip", "conv32p.hip", "conv_tile_f16.hip"])
+                                 "conv3x3s2_preg.hip", "conv32s.hip", "conv32p.hip", "conv_tile_f16.hip", "le_rows.hip"])
 def test_lds_dma_kernels_spill_nothing_and_use_the_buffer_form(src, tmp_path):
     """Every kernel that stages through LDS-DMA: (1) no scratch -- a scratch load with a DMA in flight is guarded by
     vmcnt(0), i.e. it drains the DMA queue in the middle of the pipeline (round 2's conv3x3s2_preg<12> spilled 3 VGPRs);
     (2) the DMA is `buffer_load_dwordx4 ... lds`, never the FLAT-encoded global_load_lds, after which hipcc's waitcnt pass
     stops counting."""
     out = tmp_path / (src + ".s")
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", str(out)],
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-DHDRTV_AB", "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", str(out)],
                    check=True, capture_output=True)
     text = out.read_text()
     spills = [int(v) for v in re.findall(r"\.vgpr_spill_count:\s*(\d+)", text)]
     assert spills and max(spills) == 0, (src, spills)
     assert "global_load_lds" not in text and re.search(r"buffer_load_dwordx4 .* lds", text), src
     assert not re.search(r"^\s*scratch_", text, re.M), src
+
+
+def test_le_rows_step_loops_never_drain_the_dma_queue(tmp_path):
+    """le_rows.hip keeps LDS-DMA two to three steps (4-6 rows) ahead of its consumers and counts its waits by hand.  (1) Every
+    s_waitcnt vmcnt inside a step loop must be one of the counted ones: hipcc guards an LDS load that carries no alias metadata
+    (HIP's struct vector types) and a plain global load's first use with vmcnt(0) while a DMA is in flight, which would drain
+    the prefetch queue every step -- the kernels read LDS through clang ext_vector types only and fetch the tail's residual
+    planes by DMA for that reason.  (2) The DMA-issuing role issues exactly the piece count its closing wait assumes, on every
+    control-flow path (hipcc turns the wave-uniform row tests into branches).  (3) MFMA counts, no scratch."""
+    kernels = _asm("le_rows.hip", tmp_path)
+    # kernel -> (MFMAs in the text, counted closing waits of its DMA role(s))
+    want = {"le_rb_rows_kernel": (2 * 18 + 2 * 3, {10}), "le_tail_rows_kernel": (3 * 18 + 3, {12}), "le_head_rows_kernel": (2 * 18 + 3 + 3, {6})}
+    seen = 0
+    for name, body in kernels.items():
+        key = next((k for k in want if k in name), None)
+        if key is None:
+            continue
+        n_mfma, counted = want[key]
+        assert "scratch_" not in body and "global_load_lds" not in body, name
+        assert len(re.findall(r"v_mfma_f32_32x32x16_f16", body)) == n_mfma, (name, len(re.findall(r"v_mfma_f32_32x32x16_f16", body)))
+        lines = [ln for ln in body.split("\n") if ln.strip() and not ln.strip().startswith(";")]
+        # step loops = the loops that hold an s_barrier
+        groups, cur = {}, None
+        for ln in lines:
+            lm = re.match(r"\.L(BB\d+_\d+):", ln)
+            if lm:
+                hm = re.search(r"Header=(BB\d+_\d+)", ln)
+                cur = hm.group(1) if hm else (lm.group(1) if "Loop Header" in ln else None)
+            if cur:
+                groups.setdefault(cur, []).append(ln)
+        loops = [g for g in groups.values() if any(re.match(r"\s*s_barrier", ln) for ln in g)]
+        assert len(loops) == 2, (name, len(loops))               # one per role
+        waits = set()
+        for loop in loops:
+            w = [int(v) for ln in loop for v in re.findall(r"s_waitcnt vmcnt\((\d+)\)", ln)]
+            if key != "le_head_rows_kernel" or any("buffer_load" in ln for ln in loop):
+                # (the head's first role stages the image patch with plain loads and issues no DMA: hipcc's own waits are right there)
+                waits |= set(w)
+        assert waits == counted, (name, sorted(waits), sorted(counted))
+        seen += 1
+    assert seen == 3
+
+
+def test_prw_dot3_strip_reads_stay_behind_the_flag_poll(tmp_path):
+    """conv_prw<ST_PS_DOT3>: the even wave polls an LDS flag and then reads its partner's partial sums from the partner's
+    strip with plain loads.  An acquire fence behind both polls keeps hipcc from hoisting those reads (or the odd wave's DMA
+    into the strip) above the loop; here: no LDS read between a poll and the loop's closing branch, and the strip reads
+    (TH / 4 ds_read_b96: three of a float4) behind it."""
+    kernels = _asm("conv3x3_prw.hip", tmp_path)
+    body = [b for n, b in kernels.items() if re.search(r"conv_prw_kernelILi4ELi16E", n)]
+    assert len(body) == 1
+    lines = [ln.strip() for ln in body[0].split("\n") if ln.strip() and not ln.strip().startswith(";")]
+    polls = [i for i, ln in enumerate(lines) if ln.startswith("s_sleep")]
+    assert len(polls) == 2, polls
+    for i in polls:
+        j = next(k for k in range(i, len(lines)) if lines[k].startswith("s_cbranch_execnz"))
+        assert not any(ln.startswith("ds_read") for ln in lines[i:j]), lines[i:j]
+    j = next(k for k in range(polls[1], len(lines)) if lines[k].startswith("s_cbranch_execnz"))
+    nxt = lines[j + 1:j + 40]
+    assert sum(ln.startswith("ds_read_b96") or ln.startswith("ds_read_b128") for ln in nxt) >= 4, nxt      # (x, y, z of a float4: b96)

@@ -283,3 +283,37 @@ def test_cond_modes_oracle_vs_reference(golden_dir, hr_state):
     assert np.abs(out - d["out_bilinear"]).max() <= 2e-5 and np.abs(agcm - d["agcm_bilinear"]).max() <= 2e-5
     out, agcm = O.hr_forward(hr_state, t, np.zeros_like(cb))
     assert np.abs(out - d["out_zero"]).max() <= 2e-5 and np.abs(agcm - d["agcm_zero"]).max() <= 2e-5
+
+
+def test_oracle_vs_reference_at_1920x1080_aligned_fast_graph(golden_dir, hr_state, hg_state):
+    """The oracle against the reference's own run at 1920x1080 -- configs[1], the size at which ``HDRTVNetTorch`` switches
+    HDRUNet3T1 to ``_forward_assume_aligned`` (HDRUNet3T1_arch.py:106-150; tests/golden/gen_golden_fullsize.py asserts the
+    flag) -- with the seeded HG head on the 1088-row padded frame: every Conv2d on multi-tile shapes, all border classes.
+    ATen's CPU kernels under the oracle's graphs (the plain-C operators take minutes at this size and are held to ATen in
+    test_c_operators_agree_with_aten); strided samples, dense patches, whole-tensor summaries, every RGB48 integer's sum."""
+    from hdrtv_mi355x import weights as W
+    d = np.load(os.path.join(golden_dir, "full_1080x1920_hg_s11.npz"))
+    assert bool(d["aligned"])
+    h, w = (int(v) for v in d["shape"])
+    rs, cs = (int(v) for v in d["stride"])
+    frame = W.synthetic_frame(h, w, seed=int(d["seed"]), kind=str(d["kind"]))
+    O.use_backend("aten")
+    try:
+        t, c = O.preprocess(frame)
+        taps = {}
+        out, agcm = O.hg_composite(hr_state, hg_state, t, c, taps)
+    finally:
+        O.use_backend("c")
+    base = taps["base"]
+    e = {k: float(np.abs(v[:, ::rs, ::cs] - d[k]).max()) for k, v in (("agcm_out", agcm), ("base", base), ("out", out))}
+    print(f"  oracle vs reference at {w}x{h}: max |delta| {e}")
+    assert e["agcm_out"] <= 2e-5 and e["base"] <= 2e-5 and e["out"] <= 1e-4
+    assert np.array_equal((O.hg_mask(base) > 0)[:, ::rs, ::cs], d["mask"]) and int((O.hg_mask(base) > 0).sum()) == int(d["mask_count"])
+    assert np.abs(out[:, :32, :48] - d["out_corner"]).max() <= 1e-4
+    assert np.abs(out[:, h // 2 - 16:h // 2 + 16, w // 2 - 24:w // 2 + 24] - d["out_centre"]).max() <= 1e-4
+    rgb = O.post_rgb48(out)
+    dl = np.abs(rgb[::rs, ::cs].astype(np.int64) - d["rgb48"].astype(np.int64))
+    sums = np.array([int(rgb[..., ch].astype(np.int64).sum()) for ch in range(3)], np.float64)
+    print(f"  RGB48: sampled |LSB error| max {int(dl.max())} exact {float((dl == 0).mean()):.4f}; relative delta of the sums {np.abs(sums - d['rgb48_sum']) / d['rgb48_sum']}")
+    assert dl.max() <= 7 and (dl == 0).mean() >= 0.9 and (np.abs(sums - d["rgb48_sum"]) / d["rgb48_sum"]).max() <= 1e-6
+    assert np.abs(O.postprocess_u8(out)[::rs, ::cs].astype(int) - d["u8_bgr"].astype(int)).max() <= 1

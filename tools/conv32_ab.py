@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: LE taps with conv32s.hip (default) against conv32p.hip (HDRTV_CONV32_OLD=1), first differing tap and where.
+"""Diagnostic: LE taps with conv32s.hip (default) against conv32p.hip (HDRTV_VARIANTS=conv32_old=1,le_rows=0), first differing tap and where.
 usage: python tools/conv32_ab.py [H W] [fp16|int8-full|int8-mixed]"""
 import os
 import sys
@@ -24,9 +24,9 @@ f = W.synthetic_frame(h, w, seed=41, kind="gradient")
 res = []
 for old in ("1", None):
     if old:
-        os.environ["HDRTV_CONV32_OLD"] = old
+        os.environ["HDRTV_VARIANTS"] = "le_rows=0,conv32_old=" + old
     else:
-        os.environ.pop("HDRTV_CONV32_OLD", None)
+        os.environ["HDRTV_VARIANTS"] = "le_rows=0"
     out, _ = p.infer(p.preprocess(f))
     r = {"out": out.float().cpu().numpy()}
     for t in taps:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Probe: do two frame pipelines on disjoint CU subsets (HDRTV_FORCE_NCU) out-run one pipeline on the whole chip?
+"""Probe: do two frame pipelines on disjoint CU subsets (HDRTV_VARIANTS=force_ncu=N) out-run one pipeline on the whole chip?
 LE is HBM / latency bound, the HG convs are MFMA / power bound, so a second frame's LE might hide under the first frame's HG.
 usage: python tools/overlap_probe.py K NCU [frames]   (K contexts, each launched with NCU persistent workgroups)"""
 import ctypes as C
@@ -12,7 +12,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "hdr-realtime-video-pipeline_amd"))
 K, NCU = int(sys.argv[1]), int(sys.argv[2])
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 150
-os.environ["HDRTV_FORCE_NCU"] = str(NCU)
+os.environ["HDRTV_VARIANTS"] = "force_ncu=" + str(NCU)
 import contextlib
 
 import torch

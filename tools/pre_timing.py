@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer aid (GPU box): HIP-event timing of hdrtv_preprocess / hdrtv_post_rgb48 alone at 3840x2160 (un-profiled),
-with the HBM bytes each moves.  HDRTV_PRE_SPLIT=1 selects the two-kernel preprocess."""
+with the HBM bytes each moves.  HDRTV_VARIANTS=pre_split=1 selects the two-kernel preprocess."""
 import ctypes as C
 import os
 import sys
@@ -37,7 +37,7 @@ def timeit(fn, n=50):
 
 t = timeit(lambda: p._lib.hdrtv_preprocess(p._ctx, st, fr.data_ptr(), H, Wd, p._gpu_input.data_ptr(), p._gpu_cond.data_ptr()))
 mb = (H * Wd * 3 + H * Wd * 6 + (H // 4) * (Wd // 4) * 6) / 1e6
-print(f"preprocess ({'split' if os.environ.get('HDRTV_PRE_SPLIT') else 'fused'}): {t:.1f} us, {mb:.1f} MB algorithmic -> {mb / t * 1e3:.0f} GB/s")
+print(f"preprocess ({'split' if 'pre_split=1' in os.environ.get('HDRTV_VARIANTS', '') else 'fused'}): {t:.1f} us, {mb:.1f} MB algorithmic -> {mb / t * 1e3:.0f} GB/s")
 t = timeit(lambda: p._lib.hdrtv_post_rgb48(p._ctx, st, out32.data_ptr(), L.F32, H, Wd, u16.data_ptr()))
 mb = H * Wd * 18 / 1e6
 print(f"post_rgb48 (f32 in): {t:.1f} us, {mb:.1f} MB -> {mb / t * 1e3:.0f} GB/s")

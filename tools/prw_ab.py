@@ -1,4 +1,4 @@
-"""A/B of the HG 3x3 conv schedules on one box: HDRTV_PRW=0 (conv_pglds) against HDRTV_PRW=1 (conv_prw), taps compared bit for bit,
+"""A/B of the HG 3x3 conv schedules on one box: HDRTV_VARIANTS=prw=0 (conv_pglds) against prw=1 (conv_prw), taps compared bit for bit,
 per-layer HIP-event times printed side by side.  python tools/prw_ab.py [H W]"""
 import os
 import subprocess
@@ -45,7 +45,7 @@ if __name__ == "__main__":
     outs = []
     for v in modes:
         path = f"/tmp/prw_ab_{v}.pt"
-        env = dict(os.environ, HDRTV_PRW=v)
+        env = dict(os.environ, HDRTV_VARIANTS='prw=' + v)
         subprocess.run([sys.executable, __file__, "--child", str(h), str(w), path], env=env, check=True, stdout=subprocess.DEVNULL)
         outs.append(torch.load(path, weights_only=False))
     a = outs[0]
@@ -53,7 +53,7 @@ if __name__ == "__main__":
         bad = [n for n in ("out",) + TAPS if not torch.equal(a[n], b[n])]
         for n in bad:
             print(f"   {n}: max|d| = {float((a[n].float() - b[n].float()).abs().max()):.3e}")
-        print(f"HDRTV_PRW={v} vs {modes[0]}: {'all taps bit-identical' if not bad else 'DIFFERENT: ' + ' '.join(bad)}")
+        print(f"prw={v} vs {modes[0]}: {'all taps bit-identical' if not bad else 'DIFFERENT: ' + ' '.join(bad)}")
     tot = [0.0] * len(modes)
     print(f"{'layer':14s} " + " | ".join(f"PRW={v:1s} kernel              ms     TF" for v in modes))
     for layer, (kern, ms, macs) in a["prof"].items():

@@ -6,10 +6,10 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r02_kt -o p -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/r02_kt.json 2> $R/gpurun_out/r02_kt.err
 echo "kt exit $?"
 for nt in 0 1; do
-  export HDRTV_PGLDS_NT_SLOW=$nt
+  export HDRTV_VARIANTS=pglds_nt_slow=$nt
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $R/gpurun_out/r02_pmc_${ctr}_nt$nt -o p -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-int8-extra > $R/gpurun_out/r02_pmc_${ctr}_nt$nt.log 2>&1
     echo "pmc $ctr nt=$nt exit $?"
   done
 done
-unset HDRTV_PGLDS_NT_SLOW
+unset HDRTV_VARIANTS

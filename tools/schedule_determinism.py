@@ -1,5 +1,5 @@
 """Run-to-run and schedule-to-schedule determinism of one tensor at 3840x2160 (default: hg.part), on the GPU box.
-The one-tile-per-workgroup schedule (HDRTV_FORCE_NCU) is the reference; prints where the real schedule deviates.
+The one-tile-per-workgroup schedule (HDRTV_VARIANTS=force_ncu=N) is the reference; prints where the real schedule deviates.
 usage: python tools/schedule_determinism.py"""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,8 +10,8 @@ from hdrtv_mi355x.processor import HDRTVNetMI355X
 f = W.synthetic_frame(2160, 3840, seed=21, kind="gradient")
 res = {}
 for force in (None, "4000000"):
-    if force: os.environ["HDRTV_FORCE_NCU"] = force
-    else: os.environ.pop("HDRTV_FORCE_NCU", None)
+    if force: os.environ["HDRTV_VARIANTS"] = "force_ncu=" + str(force)
+    else: os.environ.pop("HDRTV_VARIANTS", None)
     p = HDRTVNetMI355X(os.path.join(REPO, "tests/golden/hr_weights.hdrw"), use_hg=True, hg_weights="seeded:1234", warmup_passes=0)
     tc = p.preprocess(f)
     parts = []

@@ -34,7 +34,7 @@ buf = torch.empty(cc.value, dtype=torch.float32, device="cuda")
 from hdrtv_mi355x.processor import _hip_memcpy_d2d
 _hip_memcpy_d2d(buf.data_ptr(), ptr.value, cc.value * 4); torch.cuda.synchronize()
 st = buf.cpu().numpy().view(np.uint64).reshape(-1, 8).astype(np.float64)
-if os.environ.get("HDRTV_CONV32_OLD"):
+if "conv32_old=1" in os.environ.get("HDRTV_VARIANTS", ""):
     names = ["0 offsets+resid", "1 conv MFMA", "2 staging write", "3 wait vmcnt", "4 barrier1", "5 DMA issue+stores", "6 SFT(t+1)", "7 barrier2+loop"]
 else:       # conv32s.hip
     names = ["0 addr+resid+DMA issue", "1 conv MFMA", "2 SFT(t+1)", "3 epilogue+vmcnt(0)", "4 closing wait", "5 barrier", "6 -", "7 loop"]
