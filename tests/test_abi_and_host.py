@@ -36,9 +36,31 @@ def test_library_exports_every_symbol():
     assert loaded.hdrtv_last_error(None) == b"null context"
 
 
+def test_null_context_calls_are_refused_not_dereferenced():
+    """Argument checks that need no device: every ring / variant entry point on a NULL context is an error code."""
+    from hdrtv_mi355x import lib
+    so = lib.load()
+    v = ctypes.c_int(0)
+    assert so.hdrtv_ring_commit(None, 0, None) == lib.EINVAL and so.hdrtv_ring_wait(None, 0) == lib.EINVAL
+    assert so.hdrtv_ring_release(None, 0) == lib.EINVAL and so.hdrtv_ring_destroy(None) == lib.OK
+    assert so.hdrtv_set_variant(None, b"le_rows", 0) == lib.EINVAL and so.hdrtv_get_variant(None, b"le_rows", ctypes.byref(v)) == lib.EINVAL
+
+
+def test_ab_library_is_a_superset(monkeypatch):
+    """The A/B build (make AB=1: the shipped sources + superseded kernels for the GPU bit-identity tests) exports the same C ABI."""
+    from hdrtv_mi355x import lib
+    if not os.path.exists(lib.LIB_PATH_AB):
+        import __graft_entry__ as g
+        g.build()
+    so = ctypes.CDLL(lib.LIB_PATH_AB)
+    for name in _header_symbols():
+        assert hasattr(so, name), name
+    assert os.path.getsize(lib.LIB_PATH_AB) > os.path.getsize(lib.LIB_PATH)
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from hdrtv_mi355x import lib
-    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "_libs", {})
     monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libhdrtv_mi355x.so")
     with pytest.raises(RuntimeError, match="no fallback"):
         lib.load()

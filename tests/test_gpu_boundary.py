@@ -315,3 +315,42 @@ def test_bench_prints_exactly_one_line_on_stdout():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["dispatcher_host_fed"]["value"] > 0
+
+
+def test_ring_slot_state_machine(golden_dir):
+    """hdrtv_ring_*: a slot cycles free -> acquired -> committed -> free; every call in the wrong state is HDRTV_ESTATE instead of
+    stale pixels (waiting on an acquired-but-uncommitted slot used to return at once on a never-recorded event)."""
+    import ctypes as C
+    import torch
+    from hdrtv_mi355x import lib as L
+    from hdrtv_mi355x.processor import HDRTVNetMI355X
+    p = HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), use_hg=False, warmup_passes=0)
+    lib, ctx = p._lib, p._ctx
+    try:
+        assert lib.hdrtv_ring_wait(ctx, 0) == L.EINVAL                      # no ring yet
+        assert lib.hdrtv_ring_create(ctx, 2, 64, 96) == 0
+        hp, dp = C.c_void_p(), C.c_void_p()
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        assert lib.hdrtv_ring_commit(ctx, 0, st) == L.ESTATE                # free slot: nothing to commit
+        assert lib.hdrtv_ring_release(ctx, 0) == L.ESTATE                   # double release
+        s0 = lib.hdrtv_ring_acquire(ctx, 10, C.byref(hp), C.byref(dp))
+        assert s0 == 0 and hp.value and dp.value
+        assert lib.hdrtv_ring_wait(ctx, s0) == L.ESTATE                     # acquired, not committed: no copy in flight
+        assert b"not committed" in lib.hdrtv_last_error(ctx)
+        out = torch.rand((3, 64, 96), dtype=torch.float16, device="cuda")
+        assert lib.hdrtv_post_rgb48(ctx, st, out.data_ptr(), L.F16, 64, 96, dp) == 0
+        assert lib.hdrtv_ring_commit(ctx, s0, st) == 0
+        assert lib.hdrtv_ring_commit(ctx, s0, st) == L.ESTATE               # committed twice
+        assert lib.hdrtv_ring_wait(ctx, s0) == 0
+        host = np.ctypeslib.as_array(C.cast(hp.value, C.POINTER(C.c_uint16)), shape=(64, 96, 3)).copy()
+        from oracle import hdrtvnet_oracle as O
+        assert np.array_equal(host, O.post_rgb48(out.float().cpu().numpy()))
+        s1 = lib.hdrtv_ring_acquire(ctx, 10, C.byref(hp), C.byref(dp))
+        assert s1 == 1
+        assert lib.hdrtv_ring_acquire(ctx, 10, C.byref(hp), C.byref(dp)) == L.ESTATE      # exhausted
+        assert lib.hdrtv_ring_release(ctx, s0) == 0 and lib.hdrtv_ring_release(ctx, s1) == 0     # an acquired slot may be given back
+        assert lib.hdrtv_ring_wait(ctx, 5) == L.EINVAL
+        assert lib.hdrtv_ring_destroy(ctx) == 0
+        assert lib.hdrtv_ring_wait(ctx, 0) == L.EINVAL and lib.hdrtv_ring_commit(ctx, 0, st) == L.EINVAL
+    finally:
+        p.close()

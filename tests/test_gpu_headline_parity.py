@@ -19,7 +19,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 OUT_MAX, OUT_MEAN = 6e-3, 5e-4              # test_gpu_parity.py's float bars for the final output
-LSB_MAX, LSB_MEAN = int(OUT_MAX * 65535) + 1, OUT_MEAN * 65535
+# RGB48 against the reference's own integers: 1.5 x the worst case measured on the r04 build over every golden below and the
+# full-size fixtures of test_gpu_fullsize_reference.py (max 151 LSB, mean 9.5 LSB of 65535), not the float bars converted to LSB
+LSB_MAX, LSB_MEAN = 230, 14.5
 
 
 @pytest.fixture(scope="module")
@@ -98,7 +100,7 @@ def test_rgb48_end_to_end_vs_reference_hg(torch_cuda, golden_dir, name):
     assert (~same).mean() <= 0.002
     _lsb_histogram(name + " (all pixels)", got, d["rgb48"])
     mx, mean = _lsb_histogram(name + " (mask bit equal)", got, d["rgb48"], keep=same)
-    assert mx <= int(8e-3 * 65535) + 1 and mean <= 6e-4 * 65535          # test_hg_golden's float bars in LSB
+    assert mx <= LSB_MAX and mean <= LSB_MEAN
 
 
 @pytest.mark.parametrize("tag,prec", [("full_qat", "int8-full"), ("mixed_qat", "int8-mixed")])
@@ -114,6 +116,39 @@ def test_rgb48_end_to_end_vs_reference_int8_storage(torch_cuda, golden_dir, tag,
         p.close()
     mx, mean = _lsb_histogram(f"int8 {tag} (pre-dequantised)", got, d["rgb48"])
     assert mx <= LSB_MAX and mean <= LSB_MEAN
+
+
+@pytest.mark.parametrize("name", ["hr_64x96_noise_s0", "hr_60x100_noise_s2", "hr_52x76_gradient_s5"])
+def test_rgb48_vs_the_oracle_with_f16_layer_io(torch_cuda, golden_dir, hr_state, name):
+    """A second yardstick that separates "f16 storage" from "our kernels": the oracle re-run with every convolution's input,
+    weights and output rounded to f16 (what an ideal f16-storage / fp32-accumulate execution of the reference's graph does by
+    construction; tests/test_oracle_golden.py::test_w8a8_fp16_storage_sensitivity uses the same device).  Measured: that ideal
+    execution is as far from the fp32 reference (mean 6-9 LSB) as the device is (7-9.5 LSB), and the two f16 executions are as
+    far from EACH OTHER (9-12 LSB: independent rounding noise adds in quadrature) -- so an f16-I/O oracle is not a tighter
+    reference for the integers, but it bounds what the kernels may add: the device must be no further from the reference than
+    1.25 x the ideal f16 execution is."""
+    from hdrtv_mi355x.processor import HDRTVNetMI355X
+    from oracle import hdrtvnet_oracle as O
+    d = np.load(os.path.join(golden_dir, name + ".npz"))
+    p = HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), use_hg=False, warmup_passes=0)
+    try:
+        out, _ = p.infer(p.preprocess(d["frame"]))
+        got = _rgb48(p, out)
+    finally:
+        p.close()
+    r16 = lambda a: np.asarray(a, np.float32).astype(np.float16).astype(np.float32)      # noqa: E731
+    orig = O.conv2d
+    O.conv2d = lambda x, w, b=None, stride=1, pad=0: r16(orig(r16(x), r16(w), b, stride, pad))
+    try:
+        rt, rc = O.preprocess(d["frame"])
+        out16, _ = O.hr_forward(hr_state, r16(rt), r16(rc))
+    finally:
+        O.conv2d = orig
+    want16 = O.post_rgb48(out16)
+    mx, mean = _lsb_histogram(name + " vs the f16-I/O oracle", got, want16)
+    mxr, meanr = _lsb_histogram(name + ": f16-I/O oracle vs the reference", want16, d["rgb48"])
+    mxd, meand = _lsb_histogram(name + " vs the reference (fp32), again", got, d["rgb48"])
+    assert meand <= 1.25 * meanr and mxd <= 1.5 * mxr + 16 and mean <= 1.6 * meanr
 
 
 # ------------------------------------------------------------------------------------------ configs[0]: 960x540 on the device

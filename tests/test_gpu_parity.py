@@ -4,8 +4,8 @@ vectors.  All tests here need a real MI355X: ``pytest -m gpu``.
 Tolerances (stated once, used below):
   * pre/post quantisers, given identical float inputs: EXACT integers.
   * network floats: the product computes in fp16 storage / fp32 accumulate, the oracle and
-    the goldens are the reference's CPU fp32 path.  Bars: AGCM out max_abs <= 4e-3;
-    LE/HG final out max_abs <= 1.5e-2 and mean_abs <= 2e-3 on O(1) values; u8 within 3 LSB,
+    the goldens are the reference's CPU fp32 path.  Bars (the constants below): AGCM out max_abs <= 2e-3;
+    LE/HG final out max_abs <= 6e-3 and mean_abs <= 5e-4 on O(1) values; u8 within 3 LSB,
     mean u8 error <= 0.6 LSB.  (The reference's own bar for a re-quantised graph is
     float MAE <= 0.02 and u8 MAE <= 5, scripts/validate_tensorrt_sources.py:598-609.)
 """
