@@ -245,17 +245,19 @@ def test_uhd_hg_vs_oracle(torch_cuda, golden_dir, hg_state):
 
 
 # ------------------------------------------------------------------------------------------ configs[4]: int8 HR + int8 HG
+@pytest.mark.parametrize("size", [(272, 480), (1080, 1920)])
 @pytest.mark.parametrize("tag", ["full", "mixed"])
-def test_native_int8_hr_with_int8_hg_vs_fake_quant_oracle(torch_cuda, golden_dir, tag):
+def test_native_int8_hr_with_int8_hg_vs_fake_quant_oracle(torch_cuda, golden_dir, tag, size):
     """The configuration ``bench.py --int8`` / ``config4_int8`` times: the shipped QAT checkpoint with its W8A8 layers on
-    int8 MFMA (``predequantize="off"``) feeding the W8A8 HG head (reference-style min/max calibration), at 272x480, against
+    int8 MFMA (``predequantize="off"``) feeding the W8A8 HG head (reference-style min/max calibration), at 272x480 and at
+    1920x1080 (thousands of tiles per int8 kernel, all 16 border classes of the zero-point constants; ~25 s of ATen), against
     the oracle's fake-quant composite (fp32, ATen convolutions: the arithmetic of the reference's CPU run).  Bars: the
     reference's own for a re-quantised graph (float MAE <= 0.02, u8 MAE <= 5, scripts/validate_tensorrt_sources.py:598-609)
     end to end; the HG head alone, on the device's own LE output, the bars of test_gpu_int8_hg.py."""
     from hdrtv_mi355x import weights as W
     from hdrtv_mi355x.processor import HDRTVNetMI355X
     from oracle import hdrtvnet_oracle as O
-    h, w = 272, 480
+    h, w = size
     f = W.synthetic_frame(h, w, seed=11, kind="gradient")
     qstate = W.seeded_hg_w8a8_state(1234, integer_zero=False)
     p = HDRTVNetMI355X(os.path.join(golden_dir, f"hr_int8_{tag}_qat.hdrw"), precision=f"int8-{tag}", predequantize="off",
