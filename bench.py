@@ -107,7 +107,8 @@ def cpu_baseline(args, use_hg):
     torch.set_num_threads(physical cores used) -- timed per stage (pre / run / post as process_timed does,
     hdrtvnet_torch.py:2380-2395) at 960x540 and 1920x1080.  `--cpu-protocol full` is the protocol to the letter
     (5 warm-up + 20 timed frames at both sizes and 2 timed frames at the workload size, minutes of CPU time); the default
-    is the same measurement on a bounded sample so that a bench run stays within a few minutes.  The plain-C oracle is
+    keeps the 960x540 part, 1 + 5 frames at 1920x1080 and 1 warm-up + 2 timed frames at the workload size (~2.5 min of CPU
+    time for 3840x2160 with HG on 16 cores).  The plain-C oracle is
     timed beside it as an extra."""
     import torch
     from hdrtv_mi355x import weights as W
@@ -119,7 +120,7 @@ def cpu_baseline(args, use_hg):
     hr = W.load_pack(os.path.join(REPO, "tests", "golden", "hr_weights.hdrw"))
     hg = W.seeded_hg_state(1234) if use_hg else None
     plan = {"full": [(540, 960, 5, 20), (1080, 1920, 5, 20), (args.height, args.width, 0, 2)],
-            "bounded": [(540, 960, 5, 20), (1080, 1920, 1, 5), (args.height, args.width, 0, 1)],
+            "bounded": [(540, 960, 5, 20), (1080, 1920, 1, 5), (args.height, args.width, 1, 2)],
             "quick": [(540, 960, 1, 3), (1080, 1920, 0, 1)]}[args.cpu_protocol]
     seen = set()
     plan = [p for p in plan if not (p[:2] in seen or seen.add(p[:2]))]         # --height/--width equal to a fixed size: once
@@ -251,8 +252,8 @@ def rank_stub():
         dist.destroy_process_group()
 
 
-def dispatcher_host_fed(args, frames, device_index, use_hg, steps, warmup=5):
-    """The in-product N = 1 form of the host-fed path (hdrtv_mi355x/dispatch.py): this process only fills shared-memory slots
+def dispatcher_host_fed(args, frames, device_index, use_hg, steps, warmup=5, n_workers=1):
+    """The in-product form of the host-fed path, N = n_workers GPUs (`python bench.py --dispatcher --gpus N`) (hdrtv_mi355x/dispatch.py): this process only fills shared-memory slots
     (a 24.9 MB memcpy per 4K frame) and consumes RGB48 views in order; ONE worker process owns the GPU context, DMAs straight
     from / into the page-locked slots and keeps two frames in flight.  Comparable with value_pcie_inclusive; never `value`."""
     from hdrtv_mi355x.dispatch import FrameDispatcher
@@ -267,17 +268,25 @@ def dispatcher_host_fed(args, frames, device_index, use_hg, steps, warmup=5):
             "hg_weights": "seeded:1234" if use_hg else None}
     try:
         # (bounded waits: an extra must never push a default run past the driver's limit)
-        with FrameDispatcher(1, H, Wd, sink, init_args=init, devices=[device_index], slots=3, start_timeout=150.0) as d:
-            for i in range(warmup):
-                d.submit(frames[i % len(frames)])
+        devices = [device_index] if n_workers == 1 else list(range(n_workers))
+        if os.environ.get("HDRTV_BENCH_ONE_DEVICE"):
+            devices = [0] * n_workers                    # rehearsal on a box with fewer GPUs than workers
+        with FrameDispatcher(n_workers, H, Wd, sink, init_args=init, devices=devices, slots=3, start_timeout=150.0) as d:
+            # one producer thread per worker copies the frames in (submit_async); with one worker the caller's thread does
+            put = d.submit if n_workers == 1 else d.submit_async
+            for i in range(warmup * n_workers):
+                put(frames[i % len(frames)])
             d.flush(timeout=100)
+            steps *= n_workers
             t0 = time.perf_counter()
             for i in range(steps):
-                d.submit(frames[i % len(frames)])
+                put(frames[i % len(frames)])
             d.flush(timeout=100)
             el = time.perf_counter() - t0
-        return {"value": round(steps / el, 3), "unit": "frames/s", "frames": steps, "workers": 1, "slots": 3, "frames_in_flight": 2,
+            placement = d.placement
+        return {"value": round(steps / el, 3), "unit": "frames/s", "frames": steps, "workers": n_workers, "slots": 3, "frames_in_flight": 2,
                 "ms_per_frame": round(el / steps * 1e3, 3), "worker_exit_codes": d.exit_codes,
+                "placement": [{k: (p[k] if k != "cpus" else len(p[k])) for k in ("device", "numa_node", "cpus", "pinned")} for p in placement],
                 "what": "FrameDispatcher: parent memcpy into a pinned shared slot -> worker hipMemcpyAsync H2D -> pre + infer + post_rgb48 "
                         "-> hipMemcpyAsync D2H into a pinned shared slot -> hipEvent -> in-order sink"}
     except Exception as exc:  # noqa: BLE001  (an extra: never take the headline line down with it)
@@ -286,20 +295,28 @@ def dispatcher_host_fed(args, frames, device_index, use_hg, steps, warmup=5):
 
 def main():
     args = parse()
+    if args.dispatcher:
+        # one parent, N worker processes (no torch.distributed): the in-product multi-GPU form
+        from hdrtv_mi355x import weights as W
+        frames = [W.synthetic_frame(args.height, args.width, seed=1234 + i, kind="noise" if i % 2 == 0 else "gradient") for i in range(4)]
+        print(json.dumps({"dispatcher_host_fed": dispatcher_host_fed(args, frames, 0, not args.no_hg, max(40, args.steps), n_workers=max(1, args.gpus))}), flush=True)
+        return None
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         sys.exit(self_launch(args))
     if os.environ.get("HDRTV_BENCH_RANK_STUB"):
         return rank_stub()
-    if args.dispatcher:
-        from hdrtv_mi355x import weights as W
-        frames = [W.synthetic_frame(args.height, args.width, seed=1234 + i, kind="noise" if i % 2 == 0 else "gradient") for i in range(4)]
-        print(json.dumps({"dispatcher_host_fed": dispatcher_host_fed(args, frames, 0, not args.no_hg, max(40, args.steps))}), flush=True)
-        return None
-    import torch
-    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # placement before anything touches the GPU: this rank's threads (and the pinned buffers it allocates below) on its GPU's
+    # NUMA node (hdrtv_mi355x/numa.py reads sysfs, makes no HIP call); N = 1 leaves the affinity alone (the CPU baseline
+    # wants the box's 16-core share)
+    from hdrtv_mi355x import numa
+    place = numa.pin_to_gpu_node(0 if os.environ.get("HDRTV_BENCH_ONE_DEVICE") else local_rank, apply=world > 1)
+    if world > 1:
+        print(f"[bench] rank {rank}: {numa.describe(place)}", file=sys.stderr, flush=True)
+    import torch
+    import torch.distributed as dist
     # rehearsal switches for a box with fewer GPUs than ranks (never set by the driver): HDRTV_BENCH_BACKEND=gloo and
     # HDRTV_BENCH_ONE_DEVICE=1 put every rank on cuda:0, so the N > 1 code path can be exercised on one GPU
     backend = os.environ.get("HDRTV_BENCH_BACKEND", "nccl")
@@ -398,6 +415,7 @@ def main():
         evs[i][1].record()
     ring_drain()
     torch.cuda.synchronize(dev)
+    elapsed_own = time.perf_counter() - t0          # this rank's own K frames (per_rank_frames_per_s)
     barrier()
     elapsed = time.perf_counter() - t0
     per_frame_ms = sorted(a.elapsed_time(b) for a, b in evs)
@@ -406,8 +424,13 @@ def main():
     # 1 % low as main.py:599-604: mean of the lowest 1 % of the per-frame fps samples (at least one sample)
     fps_samples = sorted(1000.0 / max(ms, 1e-6) for ms in per_frame_ms)
     one_pct_low = float(np.mean(fps_samples[:max(1, len(fps_samples) // 100)]))
+    per_rank_fps, per_rank_node = [round(args.steps / elapsed_own, 3)], [place["numa_node"]]
     if world > 1:
         red_dev = dev if backend == "nccl" else "cpu"
+        mine = torch.tensor([args.steps / elapsed_own, float(place["numa_node"])], device=red_dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_fps, per_rank_node = [round(float(t[0].item()), 3) for t in every], [int(t[1].item()) for t in every]
         tt = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -556,6 +579,8 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "p50_ms": round(p50, 3), "p99_ms": round(p99, 3),
             "one_percent_low_fps": round(one_pct_low, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i8+f16" if args.int8 else "f16",
+            "world_size": dist.get_world_size() if world > 1 else 1, "backend": (backend if backend != "nccl" else "nccl (RCCL)") if world > 1 else None,
+            "per_rank_frames_per_s": per_rank_fps, "per_rank_numa_node": per_rank_node,
             "data": "synthetic (seeded u8 noise + gradient/highlight frames; HR.pt weights, seeded HG weights)",
             "config": {"workload": ((f"configs[4]: INT8-QAT HDRTVNet++ {Wd}x{H}: HR = the reference's HR_original_int8_{args.int8_recipe}_qat checkpoint, "
                                      + ("int8 weights dequantised to fp16 (the reference's ROCm behaviour)" if args.int8_predequantize else

@@ -21,6 +21,13 @@ between frames.  Slots are the hand-off unit in both directions (``slots`` per w
 ``HDRTVNET_FEEDER_GPU_RGB48_RING_FRAMES``): ``submit`` blocks while worker *i mod N* has no free input slot, a worker
 holds back while all its output slots are still with the sink.
 
+NUMA (a two-socket node has four GPUs per socket): a worker first restricts itself to the cores of its GPU's NUMA node
+(``numa.pin_to_gpu_node``, before anything touches the GPU), then CREATES and first-touches its own slot segment -- its pages
+land on that node -- and only then builds its processor and page-locks the slots; the parent attaches to the segment by
+name.  ``placement`` reports what every worker did.  On the parent, ``submit`` copies in the caller's thread;
+``submit_async`` hands the frame to a producer thread per worker, so that the input copies of N workers run on N threads
+(one Python thread copies ~10 GB/s: four 4K workers' worth).
+
 The worker body comes from ``make_worker(rank, device_index, init_args)``.  It is either a plain function
 ``process(frame_u8[H,W,3], out_u16[H,W,3])`` (synchronous: tests substitute CPU stand-ins of this form) or an object with
 ``begin(frame, out) -> token`` / ``finish(token)`` (+ optional ``depth``, ``pin(buffer)``, ``close()``): the product's
@@ -32,6 +39,7 @@ import collections
 import contextlib
 import gc
 import multiprocessing as mp
+import os
 import queue as _queue
 import sys
 import threading
@@ -163,13 +171,24 @@ class _SyncBody:
         return None
 
 
-def _worker_main(rank, device_index, make_worker, init_args, shm_name, geom, task_q, done_q):
+def _worker_main(rank, device_index, make_worker, init_args, geom, task_q, done_q, use_numa):
     shm, ins, outs, body = None, None, None, None
     code = 0
     try:
         h, w, slots = geom
         in_b, out_b = h * w * 3, h * w * 6
-        shm = shared_memory.SharedMemory(name=shm_name)
+        # placement first: affinity, then the slots (created and first-touched HERE, on the GPU's node), then the GPU
+        from . import numa
+        info = numa.pin_to_gpu_node(device_index, apply=bool(use_numa)) if use_numa is not None else {"device": device_index, "numa_node": -1, "cpus": [], "pinned": False}
+        shm = shared_memory.SharedMemory(create=True, size=slots * (in_b + out_b))
+        try:        # the parent unlinks the segment (it outlives this process's views); keep this process's tracker out of it
+            from multiprocessing import resource_tracker
+            resource_tracker.unregister(shm._name, "shared_memory")
+        except Exception:  # noqa: BLE001
+            pass
+        numa.first_touch(shm.buf)
+        info = dict(info, pid=os.getpid(), slot_bytes=slots * (in_b + out_b))
+        done_q.put(("shm", rank, shm.name, info))
         body = make_worker(rank, device_index, init_args)
         if not hasattr(body, "begin"):
             body = _SyncBody(body)
@@ -234,29 +253,29 @@ def _worker_main(rank, device_index, make_worker, init_args, shm_name, geom, tas
 
 class FrameDispatcher:
     def __init__(self, n_workers, height, width, sink, make_worker=mi355x_worker, init_args=None, devices=None, slots=3,
-                 start_timeout=600.0):
+                 start_timeout=600.0, numa=True):
         """``sink(index, rgb48_view)`` is called in index order from the reorder thread; the view is only valid during the
-        call (the slot goes back to its worker afterwards)."""
+        call (the slot goes back to its worker afterwards).  ``numa``: workers pin themselves to their GPU's NUMA node
+        (False: report only)."""
         if n_workers < 1 or slots < 2:
             raise ValueError("n_workers >= 1 and slots >= 2")
         self.n, self.h, self.w, self.slots = int(n_workers), int(height), int(width), int(slots)
         self._sink = sink
         ctx = mp.get_context("spawn")           # fresh interpreters: nothing GPU-related is inherited
         self._in_b, self._out_b = self.h * self.w * 3, self.h * self.w * 6
-        self._shm = [shared_memory.SharedMemory(create=True, size=self.slots * (self._in_b + self._out_b)) for _ in range(self.n)]
+        self._shm = [None] * self.n             # created by the workers (first touch on their GPU's node), attached below
+        self.placement = [None] * self.n
         self._task = [ctx.Queue() for _ in range(self.n)]
         self._done = ctx.Queue()
         devices = list(devices) if devices is not None else list(range(self.n))
         self._stop = False
         self._procs = [ctx.Process(target=_worker_main, daemon=True,
-                                   args=(r, devices[r], make_worker, dict(init_args or {}), self._shm[r].name,
-                                         (self.h, self.w, self.slots), self._task[r], self._done)) for r in range(self.n)]
+                                   args=(r, devices[r], make_worker, dict(init_args or {}),
+                                         (self.h, self.w, self.slots), self._task[r], self._done, bool(numa))) for r in range(self.n)]
         for p in self._procs:
             p.start()
-        self._ins = [[np.ndarray((self.h, self.w, 3), np.uint8, self._shm[r].buf, offset=s * self._in_b) for s in range(self.slots)]
-                     for r in range(self.n)]
-        self._outs = [[np.ndarray((self.h, self.w, 3), np.uint16, self._shm[r].buf, offset=self.slots * self._in_b + s * self._out_b)
-                       for s in range(self.slots)] for r in range(self.n)]
+        self._ins, self._outs = [None] * self.n, [None] * self.n
+        self._producers, self._prod_q = None, None
         self._free_in = [_queue.Queue() for _ in range(self.n)]
         for r in range(self.n):
             for s in range(self.slots):
@@ -271,7 +290,7 @@ class FrameDispatcher:
         ready, t_end = 0, time.monotonic() + start_timeout
         while ready < self.n:
             try:
-                kind, rank, _, payload = self._done.get(timeout=0.5)
+                kind, rank, name, payload = self._done.get(timeout=0.5)
             except _queue.Empty:
                 dead = self._dead_worker()
                 if dead or time.monotonic() > t_end:
@@ -281,6 +300,14 @@ class FrameDispatcher:
             if kind == "error":
                 self.close()
                 raise RuntimeError(f"dispatcher worker {rank} failed to start:\n{payload}")
+            if kind == "shm":                   # the worker's slot segment: attach, build the views
+                self._shm[rank] = shared_memory.SharedMemory(name=name)
+                self.placement[rank] = payload
+                buf = self._shm[rank].buf
+                self._ins[rank] = [np.ndarray((self.h, self.w, 3), np.uint8, buf, offset=s * self._in_b) for s in range(self.slots)]
+                self._outs[rank] = [np.ndarray((self.h, self.w, 3), np.uint16, buf, offset=self.slots * self._in_b + s * self._out_b)
+                                    for s in range(self.slots)]
+                continue
             ready += 1
         self._thread = threading.Thread(target=self._reorder, name="dispatch-reorder", daemon=True)
         self._thread.start()
@@ -325,6 +352,38 @@ class FrameDispatcher:
             self._free_in[r].put(s)
             raise
         return self.commit()
+
+    def submit_async(self, frame):
+        """As ``submit``, but the copy into the slot runs on worker ``i mod N``'s producer thread: the call returns at once
+        and ``frame`` must stay unchanged until the frame has been emitted (or ``flush`` has returned).  Do not mix with
+        ``reserve`` / ``submit`` on one dispatcher."""
+        if self._producers is None:
+            self._prod_q = [_queue.Queue() for _ in range(self.n)]
+            self._producers = [threading.Thread(target=self._produce, args=(r,), name=f"dispatch-producer-{r}", daemon=True) for r in range(self.n)]
+            for t in self._producers:
+                t.start()
+        self._raise_if_failed()
+        i = self._next_submit
+        self._next_submit = i + 1
+        self._prod_q[i % self.n].put((i, frame))
+        return i
+
+    def _produce(self, r):
+        while not self._stop:
+            try:
+                i, frame = self._prod_q[r].get(timeout=0.1)
+            except _queue.Empty:
+                continue
+            while not self._stop and self._error is None:
+                try:
+                    s = self._free_in[r].get(timeout=0.1)
+                    break
+                except _queue.Empty:
+                    continue
+            else:
+                return
+            np.copyto(self._ins[r][s], frame)
+            self._task[r].put(("frame", i, s))
 
     def flush(self, timeout=600.0):
         """Wait until every submitted frame has been handed to the sink."""
@@ -407,6 +466,8 @@ class FrameDispatcher:
         self._ins = self._outs = None
         gc.collect()
         for s in getattr(self, "_shm", []):
+            if s is None:
+                continue
             try:
                 s.close()
             except Exception:  # noqa: BLE001

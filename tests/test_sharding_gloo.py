@@ -192,3 +192,79 @@ def test_dispatcher_keeps_two_frames_in_flight_and_zero_copy_submit():
         assert seen[i][1, 1, 0] == (i + 1) * 257
     overlapped = sum(int(seen[i][0, 0, 2]) >= 1 for i in range(n))
     assert overlapped >= n - 4, overlapped          # the parent submits ahead: all but the first / last frames had a successor begun
+
+
+# ------------------------------------------------------------------------------------------ NUMA placement (hdrtv_mi355x/numa.py)
+def _fake_sysfs(root, gpus, nodes):
+    """A sysfs tree with a two-socket topology: ``gpus`` = [(location_id, domain, numa_node)], ``nodes`` = {node: cpulist}."""
+    top = os.path.join(root, "class/kfd/kfd/topology/nodes")
+    os.makedirs(os.path.join(top, "0"))
+    open(os.path.join(top, "0", "properties"), "w").write("cpu_cores_count 64\nsimd_count 0\nlocation_id 0\ndomain 0\n")
+    for i, (loc, dom, node) in enumerate(gpus):
+        os.makedirs(os.path.join(top, str(i + 1)))
+        open(os.path.join(top, str(i + 1), "properties"), "w").write(f"cpu_cores_count 0\nsimd_count 1024\nlocation_id {loc}\ndomain {dom}\n")
+        bdf = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7:x}"
+        os.makedirs(os.path.join(root, "bus/pci/devices", bdf))
+        open(os.path.join(root, "bus/pci/devices", bdf, "numa_node"), "w").write(f"{node}\n")
+    for n, cl in nodes.items():
+        os.makedirs(os.path.join(root, "devices/system/node", f"node{n}"))
+        open(os.path.join(root, "devices/system/node", f"node{n}", "cpulist"), "w").write(cl + "\n")
+
+
+def test_numa_placement_from_sysfs(tmp_path):
+    """Eight GPUs on two sockets, as the KFD topology lists them: device i -> its PCI address -> its NUMA node -> that node's
+    cores (intersected with the process's affinity).  No HIP call: the worker runs this before it touches the GPU."""
+    from hdrtv_mi355x import numa
+    root = str(tmp_path)
+    have = sorted(os.sched_getaffinity(0))
+    half = max(1, len(have) // 2)
+    lo, hi = have[:half], have[half:] or have[:half]
+    gpus = [((0x05 + 0x10 * i) << 8, 0, 0 if i < 4 else 1) for i in range(8)]
+    _fake_sysfs(root, gpus, {0: ",".join(map(str, lo)), 1: ",".join(map(str, hi))})
+    assert numa.parse_cpulist("0-3,8,10-11") == {0, 1, 2, 3, 8, 10, 11}
+    assert numa.gpu_pci_addresses(root)[:2] == ["0000:05:00.0", "0000:15:00.0"] and len(numa.gpu_pci_addresses(root)) == 8
+    assert [numa.gpu_numa_node(i, root, env={}) for i in range(8)] == [0, 0, 0, 0, 1, 1, 1, 1]
+    assert numa.gpu_numa_node(1, root, env={"HIP_VISIBLE_DEVICES": "6,2"}) == 0 and numa.gpu_numa_node(0, root, env={"HIP_VISIBLE_DEVICES": "6,2"}) == 1
+    assert numa.gpu_numa_node(9, root, env={}) == -1
+    i0 = numa.pin_to_gpu_node(1, root, env={}, apply=False)
+    i1 = numa.pin_to_gpu_node(5, root, env={}, apply=False)
+    assert i0["numa_node"] == 0 and i0["cpus"] == lo and i1["numa_node"] == 1 and i1["cpus"] == hi
+    # a machine without the topology (this container, a single-node box): nothing is changed, nothing fails
+    none = numa.pin_to_gpu_node(0, os.path.join(root, "nowhere"), env={})
+    assert none["numa_node"] == -1 and not none["pinned"] and none["cpus"] == have
+    assert "numa_node=1" in numa.describe(i1)
+
+
+def _placement_worker(rank, device_index, init_args):
+    """Stand-in that reports where it runs: by the time the body is built the worker has pinned itself and created its slots."""
+    aff = sorted(os.sched_getaffinity(0))
+
+    def process(frame, out):
+        out[...] = 0
+        out[0, 0, 0] = len(aff)
+        out[0, 0, 1] = os.getpid() % 60000
+
+    return process
+
+
+def test_dispatcher_workers_own_their_slots_and_producers_scale():
+    """The slot segments are created (and first-touched) by the WORKER processes, after they have pinned themselves -- not by
+    the parent -- and ``submit_async`` copies on one producer thread per worker; order and contents as with ``submit``."""
+    from hdrtv_mi355x.dispatch import FrameDispatcher
+    h, w, n = 16, 24, 31
+    seen = {}
+    with FrameDispatcher(3, h, w, lambda i, v: seen.__setitem__(i, v.copy()), make_worker=_placement_worker, init_args={}, slots=2) as d:
+        assert len(d.placement) == 3 and all(p is not None for p in d.placement)
+        pids = [p["pid"] for p in d.placement]
+        assert os.getpid() not in pids and len(set(pids)) == 3                  # three worker processes created three segments
+        assert all(p["slot_bytes"] == 2 * (h * w * 3 + h * w * 6) for p in d.placement)
+        assert all(p["numa_node"] == -1 and not p["pinned"] for p in d.placement)        # this container has no GPU topology
+        frames = [np.full((h, w, 3), i % 200, np.uint8) for i in range(n)]
+        for f in frames:
+            d.submit_async(f)
+        d.flush(timeout=60)
+        assert sorted(t.name for t in d._producers) == ["dispatch-producer-0", "dispatch-producer-1", "dispatch-producer-2"]
+    assert sorted(seen) == list(range(n))
+    for i in range(n):
+        assert int(seen[i][0, 0, 1]) == pids[i % 3] % 60000                     # frame i ran in worker i mod N's process
+    assert d.exit_codes == [0, 0, 0]
