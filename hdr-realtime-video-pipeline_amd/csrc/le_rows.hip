@@ -52,6 +52,20 @@ namespace {
 #ifndef RB_ABL
 #define RB_ABL 0
 #endif
+// Schedule knobs (tools/ab_rows.sh builds variants with EXTRA="-DROWS_...=n" on one box): fragment-read lead and PIN mode
+// (see conv18) of the convs that carry an SFT pass in their MFMA stream (H) and of the plain ones (F)
+#ifndef ROWS_PIN_H
+#define ROWS_PIN_H 0
+#endif
+#ifndef ROWS_PIN_F
+#define ROWS_PIN_F 1
+#endif
+#ifndef ROWS_AHEAD_H
+#define ROWS_AHEAD_H 4
+#endif
+#ifndef ROWS_AHEAD_F
+#define ROWS_AHEAD_F 10
+#endif
 
 constexpr int WS = 60;                  // output columns of a strip
 constexpr int WI = 64;                  // input columns: 2 halo columns each side
@@ -182,7 +196,11 @@ __device__ __forceinline__ void sft_modulate(const f32x16 &sc, const f32x16 &sh,
 // 3x3 conv of one 32-pixel group out of a mirrored ring: va[kx][ks] = this lane's fragment address (kernel column kx, k-step
 // ks; buffer base included) in ring row 0, `win` the byte offset of the window's first row; the window's rows are ROWB apart.
 // K order (tap, k-step); reads run AHEAD steps in front of the MFMAs; hook(st) runs behind MFMA st.
-template <int AHEAD, int ROWB, class Hook>
+// PIN: left alone, hipcc sinks the fragment reads down to their MFMAs to save registers (the last six became read -> lgkmcnt(0)
+// -> MFMA pairs, a full LDS round trip each).  1: source order is the schedule (sched_barrier per step; for convs without hooks:
+// a hook's VALU would sit between two MFMAs as one block).  2: reads and MFMAs alternate as written, everything else floats
+// (sched_group_barrier; for convs with hooks).  0: hipcc's order.
+template <int AHEAD, int ROWB, int PIN, class Hook>
 __device__ __forceinline__ f32x16 conv18(const Bank &w, const unsigned (&va)[3][2], int win, Hook hook)
 {
     unsigned a[3][2];
@@ -196,10 +214,12 @@ __device__ __forceinline__ f32x16 conv18(const Bank &w, const unsigned (&va)[3][
         const int tap = st >> 1, ks = st & 1, ky = tap / 3, kx = tap % 3;
         x[st] = lds_rd<f16x8>(a[kx][ks] + ky * ROWB);
     };
+    if (PIN == 2) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int st = 0; st < AHEAD; ++st) ld(st);
 #pragma unroll
     for (int st = 0; st < 18; ++st) {
+        if (PIN == 1) __builtin_amdgcn_sched_barrier(0);
         if (st + AHEAD < 18) ld(st + AHEAD);
         if (RB_ABL & 4) {
             if (st == 0) acc = zero16();
@@ -210,6 +230,18 @@ __device__ __forceinline__ f32x16 conv18(const Bank &w, const unsigned (&va)[3][
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.f[st], x[st], acc, 0, 0, 0);
         }
         hook(st);
+    }
+    if (PIN == 2) {
+        // AHEAD reads, then {MFMA, read} pairs, then the remaining MFMAs; a hook's MFMAs and LDS reads take slots of the same
+        // sequence (the pattern is longer than the conv alone needs)
+        __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
+#pragma unroll
+        for (int st = 0; st < 18 - AHEAD + 12; ++st) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, AHEAD, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
     return acc;
 }
@@ -312,7 +344,7 @@ __global__ __launch_bounds__(512) void le_rb_rows_kernel(RowsRbParams p)
             // the SFT pass is a chain of dependent MFMA -> VALU -> MFMA steps, the conv an independent stream that covers its
             // latencies: the pass's two cond MLPs run between the conv's MFMAs, only the modulation waits for the conv
             f32x16 h2, sc2, sh2;
-            const f32x16 acc = conv18<4, Y_ROWB>(w1, va, wn.o, [&](int st) __attribute__((always_inline)) {
+            const f32x16 acc = conv18<ROWS_AHEAD_H, Y_ROWB, ROWS_PIN_H>(w1, va, wn.o, [&](int st) __attribute__((always_inline)) {
                 if (RB_ABL & 8) return;
                 if (st == 2) h2 = sft_hidden(s2, c2);
                 if (st == 10) sft_heads(s2, h2, t2, sc2, sh2);
@@ -417,7 +449,7 @@ __global__ __launch_bounds__(512) void le_rb_rows_kernel(RowsRbParams p)
             const bool row1 = (unsigned)(ro_img + LAG) < (unsigned)H;  // outside the image: conv1's zero padding
             // conv2 on row ro with row ra's whole SFT pass (independent of it) between its MFMAs
             f32x16 h1, sc1, sh1;
-            const f32x16 acc = conv18<6, Y_ROWB>(w2, va, wn.o, [&](int st) __attribute__((always_inline)) {
+            const f32x16 acc = conv18<ROWS_AHEAD_H + 2, Y_ROWB, ROWS_PIN_H>(w2, va, wn.o, [&](int st) __attribute__((always_inline)) {
                 if (RB_ABL & 8) { if (st == 13) put_row(vq, ya1.o, ya1.mirrored(), y1); return; }
                 if (st == 1) h1 = sft_hidden(s1, c1);
                 if (st == 7) sft_heads(s1, h1, t1, sc1, sh1);
@@ -583,7 +615,7 @@ __global__ __launch_bounds__(512) void le_tail_rows_kernel(RowsTailParams p)
             for (int qd = 0; qd < 4; ++qd) sk[qd] = lds_rd<f16x4>(vq[qd] + fa.o);
             const bool row = (unsigned)ra_img < (unsigned)H;
             f32x16 h2, sc2, sh2;
-            const f32x16 acc = conv18<4, U_ROWB>(wu, va, uw, [&](int st) __attribute__((always_inline)) {
+            const f32x16 acc = conv18<ROWS_AHEAD_H, U_ROWB, ROWS_PIN_H>(wu, va, uw, [&](int st) __attribute__((always_inline)) {
                 if (st == 2) h2 = sft_hidden(s2, c2);
                 if (st == 9) sft_heads(s2, h2, t2, sc2, sh2);
             });
@@ -644,7 +676,7 @@ __global__ __launch_bounds__(512) void le_tail_rows_kernel(RowsTailParams p)
             for (int ch = 0; ch < 3; ++ch) res[ch] = lds_rd<f16>(rbuf + rs * G::R_SLOTB + ch * 64);
             STAMP(0);
             {   // conv_last + residual -> the three output planes
-                const f32x16 acc = conv18<6, Y_ROWB>(wl, va, wz.o, [](int) {});
+                const f32x16 acc = conv18<ROWS_AHEAD_F, Y_ROWB, ROWS_PIN_F>(wl, va, wz.o, [](int) {});
                 const float o[3] = {acc[0] + bl0, acc[1] + bl1, acc[2] + bl2};
                 const bool ok = cok && r >= y0 && r < y1;
                 f16 *d = p.dst_planar + (size_t)r * W + x0 + cx;
@@ -657,7 +689,7 @@ __global__ __launch_bounds__(512) void le_tail_rows_kernel(RowsTailParams p)
             }
             STAMP(1);
             {   // HR_conv2 + ReLU -> Z
-                const f32x16 acc = conv18<6, Y_ROWB>(wh, va, wy.o, [](int) {});
+                const f32x16 acc = conv18<ROWS_AHEAD_F, Y_ROWB, ROWS_PIN_F>(wh, va, wy.o, [](int) {});
                 f16x4 z[4];
                 const bool in = colz && (unsigned)rb_img < (unsigned)H;     // outside the image: conv_last's zero padding
 #pragma unroll
@@ -815,7 +847,7 @@ __global__ __launch_bounds__(512) void le_head_rows_kernel(RowsHeadParams p)
             STAMP(1);
             if (wave == (s & 3)) {
                 const int hr = hya + s - 3;                            // down_conv1 on half-resolution row s - 3
-                const f32x16 acc = conv18<4, Y_ROWB>(wd, vd, wf.o, [](int) {});
+                const f32x16 acc = conv18<6, Y_ROWB, ROWS_PIN_F>(wd, vd, wf.o, [](int) {});
                 if (dcol && hr >= (y0 >> 1) && hr < ((y1 + 1) >> 1)) {
                     f16 *d = d1 + (size_t)hr * W1 * 32;
 #pragma unroll
@@ -879,7 +911,7 @@ __global__ __launch_bounds__(512) void le_head_rows_kernel(RowsHeadParams p)
             __builtin_amdgcn_sched_barrier(0);
             STAMP(0);
             if (RB_ABL & 64) { __builtin_amdgcn_s_waitcnt(waitcnt_imm(3 * (DPF - 1), 0)); __builtin_amdgcn_s_barrier(); cd.step(); rb_img += 2; continue; }
-            const f32x16 acc = conv18<6, Y_ROWB>(wh, va, wy.o, [](int) {});
+            const f32x16 acc = conv18<ROWS_AHEAD_F, Y_ROWB, ROWS_PIN_F>(wh, va, wy.o, [](int) {});
             STAMP(1);
             f16x4 z[4];
             const bool in = colf && (unsigned)rb_img < (unsigned)H;        // outside the image: down_conv1's zero padding
