@@ -211,6 +211,10 @@ struct ConvQ8MultiParams {
     ConvQ8Group g[3];
 };
 
+// Activation fake-quantiser of a W8A8 layer as the reference's W8A8Conv2d.forward applies it to its input (hdrtvnet_torch.py:
+// 351-358): q = clamp(rint(x * inv + zoff), 0, 255), x' = f16(q * scale + zero)  (le_rows.hip applies it in registers)
+struct FqParam { float inv, zoff, scale, zero; };
+
 // Parameter block of the row-streaming fused ResBlock_with_SFT (le_rows.hip): y = x + conv2(sft2(relu(conv1(sft1(x, c))), c))
 struct RowsRbParams {
     const f16 *x;          // NHWC 32 [H][W]
@@ -224,6 +228,10 @@ struct RowsRbParams {
     void *dump;            // diagnostic builds (make STAMP=1): per-phase cycle sums
     int H, W;
     int nstrips, rows_per_seg;              // set by the launcher
+    // W8A8 layers as fake-quant on the fp16 kernel (weights = the dequantised int8 weights): bit 0 conv1's input, 1 conv2's,
+    // 2 sft1's four convs, 3 sft2's.  fq_s*: cond -> scale branch, cond -> shift branch, scale hidden, shift hidden
+    int fq;
+    FqParam fq_c1, fq_c2, fq_s1[4], fq_s2[4];
 };
 
 // Parameter block of the row-streaming fused tail of the LE net (le_rows.hip):
@@ -244,6 +252,9 @@ struct RowsTailParams {
     void *dump;            // diagnostic builds (make STAMP=1)
     int H, W;
     int nstrips, rows_per_seg;              // set by the launcher
+    // fake-quant (see RowsRbParams): bit 0 up_conv's input (u), 1 HR_conv2's (the modulated sum), 2 conv_last's, 3 the SFT layer's convs
+    int fq;
+    FqParam fq_u, fq_y, fq_z, fq_s[4];
 };
 
 // Parameter block of the row-streaming fused head of the LE net (le_rows.hip):
@@ -262,6 +273,9 @@ struct RowsHeadParams {
     void *dump;
     int H, W;
     int nstrips, rows_per_seg;
+    // fake-quant (see RowsRbParams): bit 0 conv_first's input (the image), 1 HR_conv1's, 2 down_conv1's, 3 the SFT layer's convs
+    int fq;
+    FqParam fq_img, fq_y, fq_f, fq_s[4];
 };
 
 // Letterbox (letterbox.hip): u8 BGR [sh][sw][3] -> u8 BGR [dh][dw][3], resized region [y0, y0+new_h) x [x0, x0+new_w)

@@ -168,6 +168,7 @@ struct SftLayer {
     bool q = false;                         // all four 1x1 convs are W8A8: int8 fragments + dequantisation constants
     size_t qfrag = 0, qconst = 0;
     float inv[2] = {0, 0}, zoff[2] = {0, 0}, hzoff[2] = {0, 0};
+    ActQf fq[4];                            // the input quantisers of scale_conv0, shift_conv0, scale_conv1, shift_conv1 (le_rows.hip's fake-quant form)
 };
 
 struct Tensor {
@@ -265,6 +266,7 @@ int fail(hdrtv_ctx *c, int code, const char *fmt, ...)
 // hdrtv_create.  The launch path reads c->var only.
 const std::pair<const char *, int> k_variants[] = {
     {"le_rows", 1},          // fused row-streaming LE kernels (le_rows.hip); 0 = the per-layer 16x16-tile kernels
+    {"le_rows_fq", 1},       // ... also for W8A8 layers (fake-quant in registers, fp16 MFMA); 0 = those layers on the int8-MFMA per-layer kernels
     {"prw", 1},              // HG 3x3 convs on conv_prw: 0 never (conv_pglds), 1 the cheapest shape per layer, 2 / 3 16-row / 8-row tiles wherever it applies
     {"prw_i8", 1},           // int8 HG 3x3 convs on conv_prw_i8: 0 never, 1 only where the 8-row tiles win, 2 wherever "prw" selects it
     {"pglds_nt_slow", 3},    // conv_pglds tile order: 0 / 1 Cout-tile fastest / slowest, 2 slowest for Cout >= 512, 3 slowest for the Up convs
@@ -895,6 +897,7 @@ bool pack_sft(hdrtv_ctx *c, const Pack &pk, const std::string &key, const std::s
                 }
             }
         L.q = true;
+        for (int i = 0; i < 4; ++i) L.fq[i] = r[i].q;
         L.qfrag = c->wts.put(qf.data(), qf.size());
         L.qconst = c->wts.put(K.data(), K.size() * 4);
         for (int b = 0; b < 2; ++b) { L.inv[b] = r[b].q.inv(); L.zoff[b] = r[b].q.zoff(); L.hzoff[b] = r[2 + b].q.zoff(); }
@@ -1073,7 +1076,8 @@ bool build_weights(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
         if (isq("LE.CondNet2.2") && !pack_tail_q8(c, hr)) return false;
     }
     if (!pack_cond_trunk(c, hr) || !pack_cond_tail(c, hr, "LE.CondNet2.2", "LE.CondNet2.4")) return false;
-    if (isq("LE.conv_first") ? !(pack_conv_q8(c, hr, "LE.conv_first", 32, 32, 3, 1, 3) && pack_c3_q8(c, hr, "LE.conv_first"))
+    if (isq("LE.conv_first") ? !(pack_conv_q8(c, hr, "LE.conv_first", 32, 32, 3, 1, 3) && pack_c3_q8(c, hr, "LE.conv_first") &&
+                                 pack_c3(c, hr, "le.conv_first#fq", "LE.conv_first", 32, ""))
                              : !pack_c3(c, hr, "le.conv_first", "LE.conv_first", 32, ""))
         return false;
     if (!c->trunk_q8 && isq("LE.CondNet1.4") && !pack_q_last(c, hr, "LE.CondNet1.4", c->q_trunk6)) return false;
@@ -1089,6 +1093,9 @@ bool build_weights(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
         if (isq(s.name)) {
             if (s.ks == 3 && s.stride == 1 ? !pack_conv32_i8(c, hr, s.name, s.co, s.ps) : !pack_conv_q8(c, hr, s.name, s.co, s.ci, s.ks, s.stride))
                 return false;
+            // ... and, for the fused row kernels (le_rows.hip), its dequantised weights as an fp16 layer "<name>#fq": they apply the
+            // layer's activation quantiser in registers and convolve in fp16 -- W8A8Conv2d.forward's own arithmetic
+            if (s.ci == 32 && s.ks == 3 && !pack_conv(c, hr, std::string(s.name) + "#fq", s.name, s.co, s.ci, s.ks, s.stride, "", s.ps)) return false;
         } else if (!pack_conv(c, hr, s.name, s.name, s.co, s.ci, s.ks, s.stride, "", s.ps)) {
             return false;
         }
@@ -1109,9 +1116,11 @@ bool build_weights(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
         for (int b = 0; b < trunk_n[t]; ++b) {
             snprintf(nm, sizeof nm, "LE.%s.%d", trunks[t], b);
             const std::string base = nm;
-            for (const char *cv : {".conv1", ".conv2"})
+            for (const char *cv : {".conv1", ".conv2"}) {
                 if (isq(base + cv) ? !pack_conv32_i8(c, hr, base + cv, 32, 0) : !pack_conv(c, hr, base + cv, base + cv, 32, 32, 3, 1, "", 0))
                     return false;
+                if (isq(base + cv) && !pack_conv(c, hr, base + cv + "#fq", base + cv, 32, 32, 3, 1, "", 0)) return false;
+            }
             if (!pack_sft(c, hr, base + ".sft1", base + ".sft1") || !pack_sft(c, hr, base + ".sft2", base + ".sft2")) return false;
         }
     if (!pack_sft(c, hr, "LE.SFT_layer1", "LE.SFT_layer1") || !pack_sft(c, hr, "LE.SFT_layer2", "LE.SFT_layer2")) return false;
@@ -1645,6 +1654,32 @@ struct Seq {
         return nullptr;
 #endif
     }
+    // a conv inside a fused row kernel: its fp16 pack, or (W8A8 layer, variant le_rows_fq) the dequantised pack + its activation quantiser
+    static FqParam fqp(const ActQf &q) { return FqParam{q.inv(), q.zoff(), q.scale, q.asym ? q.zero : -128.f * q.scale}; }
+    const ConvLayer *rows_conv(const std::string &key, FqParam &fq, bool &on) const
+    {
+        on = false;
+        auto it = c->conv.find(key);
+        if (it != c->conv.end()) return &it->second;
+        if (!c->var.at("le_rows_fq")) return nullptr;
+        it = c->conv.find(key + "#fq");
+        if (it == c->conv.end()) return nullptr;
+        auto iq = c->q32.find(key);
+        const ActQf *q = iq != c->q32.end() ? &iq->second.q : nullptr;
+        if (!q) { auto i8 = c->q8.find(key); if (i8 != c->q8.end()) q = &i8->second.q; }
+        if (!q) return nullptr;
+        fq = fqp(*q);
+        on = true;
+        return &it->second;
+    }
+    // its SFT layer: fp16 convs, or all four W8A8 (fake-quant)
+    bool rows_sft(const SftLayer &S, FqParam (&fq)[4], bool &on) const
+    {
+        on = S.q;
+        if (S.q && !c->var.at("le_rows_fq")) return false;
+        for (int i = 0; i < 4; ++i) fq[i] = fqp(S.fq[i]);
+        return true;
+    }
     // the row-streaming kernels (le_rows.hip) cut a map into 60-column strips x row segments, one workgroup each: worth it
     // when a segment is long against its 4 .. 6 warm-up rows
     bool rows_fit(int H, int W) const
@@ -1658,22 +1693,25 @@ struct Seq {
     {
         // fp16 block without a second residual, enough rows per segment to amortise the 4-row warm-up: ONE row-streaming
         // launch (le_rows.hip), the intermediate never leaves LDS; bit-identical to the two launches below
-        if (ok() && c->var.at("le_rows") && !extra && rows_fit(H, W) && c->conv.count(base + ".conv1") && c->conv.count(base + ".conv2") &&
-            !c->sft.at(base + ".sft1").q && !c->sft.at(base + ".sft2").q) {
-            const ConvLayer &L1 = c->conv.at(base + ".conv1"), &L2 = c->conv.at(base + ".conv2");
-            const SftLayer &S1 = c->sft.at(base + ".sft1"), &S2 = c->sft.at(base + ".sft2");
+        if (ok() && c->var.at("le_rows") && !extra && rows_fit(H, W)) {
             RowsRbParams p;
             memset(&p, 0, sizeof p);
-            p.x = x; p.cond = cond; p.H = H; p.W = W; p.dst = y;
-            p.w1 = wtp<f16>(c, L1.wpk); p.w2 = wtp<f16>(c, L2.wpk); p.b1 = wtp<float>(c, L1.shift); p.b2 = wtp<float>(c, L2.shift);
-            p.sft1_wfrag = wtp<f16>(c, S1.wfrag); p.sft1_bias = wtp<float>(c, S1.bias);
-            p.sft2_wfrag = wtp<f16>(c, S2.wfrag); p.sft2_bias = wtp<float>(c, S2.bias);
-            p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
-            p.dump = stamp_buf();
-            const double npx = (double)H * W;
-            chk(le_rb_rows_launch(p, c->n_cu, s), base.c_str(), "le_rb_rows", npx * (2.0 * 32 * 9 * 32 + 4.0 * (16 * 16 + 16 * 32)),
-                npx * (64 + 32 + 64) + 2.0 * 2 * 9 * 32 * 32);
-            return;
+            bool q1, q2, qs1, qs2;
+            const ConvLayer *L1 = rows_conv(base + ".conv1", p.fq_c1, q1), *L2 = rows_conv(base + ".conv2", p.fq_c2, q2);
+            const SftLayer &S1 = c->sft.at(base + ".sft1"), &S2 = c->sft.at(base + ".sft2");
+            if (L1 && L2 && rows_sft(S1, p.fq_s1, qs1) && rows_sft(S2, p.fq_s2, qs2)) {
+                p.fq = (q1 ? 1 : 0) | (q2 ? 2 : 0) | (qs1 ? 4 : 0) | (qs2 ? 8 : 0);
+                p.x = x; p.cond = cond; p.H = H; p.W = W; p.dst = y;
+                p.w1 = wtp<f16>(c, L1->wpk); p.w2 = wtp<f16>(c, L2->wpk); p.b1 = wtp<float>(c, L1->shift); p.b2 = wtp<float>(c, L2->shift);
+                p.sft1_wfrag = wtp<f16>(c, S1.wfrag); p.sft1_bias = wtp<float>(c, S1.bias);
+                p.sft2_wfrag = wtp<f16>(c, S2.wfrag); p.sft2_bias = wtp<float>(c, S2.bias);
+                p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
+                p.dump = stamp_buf();
+                const double npx = (double)H * W;
+                chk(le_rb_rows_launch(p, c->n_cu, s), base.c_str(), p.fq ? "le_rb_rows<fq>" : "le_rb_rows",
+                    npx * (2.0 * 32 * 9 * 32 + 4.0 * (16 * 16 + 16 * 32)), npx * (64 + 32 + 64) + 2.0 * 2 * 9 * 32 * 32);
+                return;
+            }
         }
         conv32(base + ".conv1", x, cond, base + ".sft1", H, W, ACT_RELU, ST_NHWC, tb, 32, H, W);
         conv32(base + ".conv2", tb, cond, base + ".sft2", H, W, ACT_NONE, ST_NHWC, y, 32, H, W, x, extra);
@@ -1859,47 +1897,56 @@ int run_le(hdrtv_ctx *c, Seq &q, const f16 *img, f16 *out_planar)
     // main branch: every SFT is fused into the 3x3 conv that follows it
     f16 *f0a = wsp<f16>(c, "le.f0a"), *f0b = wsp<f16>(c, "le.f0b"), *fea0 = wsp<f16>(c, "le.fea0"), *up3 = wsp<f16>(c, "le.up3");
     bool head_fused = false;
-    if (isq8("LE.conv_first")) {
-        if (c->var.at("no_c3q8")) {                  // developer A/B switch: the generic two-launch form     // the 3 planes as NHWC int8 codes (3 of 32 bytes real), then the generic int8 conv
-            int8_t *img32 = wsp<int8_t>(c, "le8.img32");
-            const QLayer &Lq = c->q8.at("LE.conv_first");
-            if (q.ok()) q.chk(planar3_to_q8_launch(img, (size_t)H * W, Lq.q.inv(), Lq.q.zoff(), img32, q.s), "le.conv_first.pack", "planar3_to_q8", 0.0, 38.0 * H * W);
-            q.convq8("LE.conv_first", img32, true, 32, H, W, ACT_RELU, f0a, 32, nullptr);
-        } else if (q.ok()) {      // quantised while the patch is staged, K = (ky | kx4, c4): two int8 MFMAs per 32 pixels (conv_c3_q8)
-            const QLayer &Lq = c->q8.at("LE.conv_first#c3");
-            q.chk(conv_c3_q8_launch(img, H, W, wtp<int8_t>(c, Lq.wpk8), wtp<float>(c, Lq.scale), wtp<float>(c, Lq.shift), Lq.q.inv(),
-                                    Lq.q.zoff(), ACT_RELU, f0a, c->n_cu, q.s),
-                  "LE.conv_first", "conv_c3_q8", (double)H * W * 27 * 32, (double)H * W * (6.0 + 64.0));
-        }
-        q.conv32("LE.HR_conv1", f0a, cond1, "LE.SFT_layer1", H, W, ACT_RELU, ST_NHWC, fea0, 32, H, W);
-    } else {
-        // fp16 conv_first is computed inside HR_conv1's kernel from the three planes (conv32s.hip, C3): its 32-channel output
-        // (0.53 GB at 4K, written and read back) never exists.  Variants no_c3fuse / conv32_old: the two-launch form
-        // (developer A/B switches); a W8A8 HR_conv1 behind an fp16 conv_first has no fused kernel.
-        const bool fuse = !c->var.at("no_c3fuse") && !c->var.at("conv32_old") && c->q32.find("LE.HR_conv1") == c->q32.end();
-        // conv_first .. down_conv1 in one row-streaming launch (le_rows.hip) when all of it is fp16 and the shapes are even
-        head_fused = fuse && q.ok() && c->var.at("le_rows") && !(H & 1) && !(W & 1) && q.rows_fit(H, W) && c->conv.count("LE.HR_conv1") &&
-                     c->conv.count("LE.down_conv1") && !isq8("LE.down_conv1") && !c->sft.at("LE.SFT_layer1").q;
-        if (head_fused) {
-            const ConvLayer &Lh = c->conv.at("LE.HR_conv1"), &Ld = c->conv.at("LE.down_conv1");
-            const SftLayer &S1 = c->sft.at("LE.SFT_layer1");
-            RowsHeadParams p;
-            memset(&p, 0, sizeof p);
+    // conv_first .. down_conv1 in one row-streaming launch (le_rows.hip) when the shapes are even and every layer is fp16 or a W8A8
+    // layer the kernel runs as fake-quant (variant le_rows_fq)
+    if (q.ok() && c->var.at("le_rows") && !c->var.at("no_c3fuse") && !c->var.at("conv32_old") && !(H & 1) && !(W & 1) && q.rows_fit(H, W)) {
+        RowsHeadParams p;
+        memset(&p, 0, sizeof p);
+        bool qh, qd, qs, qi = isq8("LE.conv_first");
+        const ConvLayer *Lh = q.rows_conv("LE.HR_conv1", p.fq_y, qh), *Ld = q.rows_conv("LE.down_conv1", p.fq_f, qd);
+        const SftLayer &S1 = c->sft.at("LE.SFT_layer1");
+        auto i3 = c->c3.find(qi ? "le.conv_first#fq" : "le.conv_first");
+        if (Lh && Ld && q.rows_sft(S1, p.fq_s, qs) && i3 != c->c3.end() && (!qi || c->var.at("le_rows_fq"))) {
+            if (qi) p.fq_img = Seq::fqp(c->q8.at("LE.conv_first").q);
+            p.fq = (qi ? 1 : 0) | (qh ? 2 : 0) | (qd ? 4 : 0) | (qs ? 8 : 0);
             p.img = img; p.cond = cond1; p.H = H; p.W = W; p.fea0 = fea0; p.fea1 = wsp<f16>(c, "le.fea1a");
-            p.c3_wfrag = wtp<f16>(c, c->c3.at("le.conv_first").wfrag);
+            p.c3_wfrag = wtp<f16>(c, i3->second.wfrag);
             p.sft_wfrag = wtp<f16>(c, S1.wfrag); p.sft_bias = wtp<float>(c, S1.bias);
-            p.w_hr = wtp<f16>(c, Lh.wpk); p.b_hr = wtp<float>(c, Lh.shift); p.w_down = wtp<f16>(c, Ld.wpk); p.b_down = wtp<float>(c, Ld.shift);
+            p.w_hr = wtp<f16>(c, Lh->wpk); p.b_hr = wtp<float>(c, Lh->shift); p.w_down = wtp<f16>(c, Ld->wpk); p.b_down = wtp<float>(c, Ld->shift);
             p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
             p.dump = q.stamp_buf();
             const double npx = (double)H * W;
-            q.chk(le_head_rows_launch(p, c->n_cu, q.s), "LE.head", "le_head_rows", npx * (27.0 * 32 + 2.0 * (16 * 16 + 16 * 32) + 32.0 * 9 * 32 + 32.0 * 9 * 32 / 4),
-                  npx * (6 + 32 + 64 + 16) + 2.0 * 2 * 9 * 32 * 32);
-        } else if (fuse) {
-            q.conv32("LE.HR_conv1", f0a, cond1, "LE.SFT_layer1", H, W, ACT_RELU, ST_NHWC, fea0, 32, H, W, nullptr, nullptr, nullptr, nullptr,
-                     img, "le.conv_first");
-        } else {
-            q.c3("le.conv_first", img, H, W, ACT_RELU, f0a, nullptr);
+            q.chk(le_head_rows_launch(p, c->n_cu, q.s), "LE.head", p.fq ? "le_head_rows<fq>" : "le_head_rows",
+                  npx * (27.0 * 32 + 2.0 * (16 * 16 + 16 * 32) + 32.0 * 9 * 32 + 32.0 * 9 * 32 / 4), npx * (6 + 32 + 64 + 16) + 2.0 * 2 * 9 * 32 * 32);
+            head_fused = true;
+        }
+    }
+    if (!head_fused) {
+        if (isq8("LE.conv_first")) {
+            if (c->var.at("no_c3q8")) {                  // developer A/B switch: the generic two-launch form     // the 3 planes as NHWC int8 codes (3 of 32 bytes real), then the generic int8 conv
+                int8_t *img32 = wsp<int8_t>(c, "le8.img32");
+                const QLayer &Lq = c->q8.at("LE.conv_first");
+                if (q.ok()) q.chk(planar3_to_q8_launch(img, (size_t)H * W, Lq.q.inv(), Lq.q.zoff(), img32, q.s), "le.conv_first.pack", "planar3_to_q8", 0.0, 38.0 * H * W);
+                q.convq8("LE.conv_first", img32, true, 32, H, W, ACT_RELU, f0a, 32, nullptr);
+            } else if (q.ok()) {      // quantised while the patch is staged, K = (ky | kx4, c4): two int8 MFMAs per 32 pixels (conv_c3_q8)
+                const QLayer &Lq = c->q8.at("LE.conv_first#c3");
+                q.chk(conv_c3_q8_launch(img, H, W, wtp<int8_t>(c, Lq.wpk8), wtp<float>(c, Lq.scale), wtp<float>(c, Lq.shift), Lq.q.inv(),
+                                        Lq.q.zoff(), ACT_RELU, f0a, c->n_cu, q.s),
+                      "LE.conv_first", "conv_c3_q8", (double)H * W * 27 * 32, (double)H * W * (6.0 + 64.0));
+            }
             q.conv32("LE.HR_conv1", f0a, cond1, "LE.SFT_layer1", H, W, ACT_RELU, ST_NHWC, fea0, 32, H, W);
+        } else {
+            // fp16 conv_first is computed inside HR_conv1's kernel from the three planes (conv32s.hip, C3): its 32-channel output
+            // (0.53 GB at 4K, written and read back) never exists.  Variants no_c3fuse / conv32_old: the two-launch form
+            // (developer A/B switches); a W8A8 HR_conv1 behind an fp16 conv_first has no fused kernel.
+            const bool fuse = !c->var.at("no_c3fuse") && !c->var.at("conv32_old") && c->q32.find("LE.HR_conv1") == c->q32.end();
+            if (fuse) {
+                q.conv32("LE.HR_conv1", f0a, cond1, "LE.SFT_layer1", H, W, ACT_RELU, ST_NHWC, fea0, 32, H, W, nullptr, nullptr, nullptr, nullptr,
+                         img, "le.conv_first");
+            } else {
+                q.c3("le.conv_first", img, H, W, ACT_RELU, f0a, nullptr);
+                q.conv32("LE.HR_conv1", f0a, cond1, "LE.SFT_layer1", H, W, ACT_RELU, ST_NHWC, fea0, 32, H, W);
+            }
         }
     }
     f16 *fea1a = wsp<f16>(c, "le.fea1a"), *fea1 = wsp<f16>(c, "le.fea1"), *l1b = wsp<f16>(c, "le.l1b");
@@ -1925,25 +1972,28 @@ int run_le(hdrtv_ctx *c, Seq &q, const f16 *img, f16 *out_planar)
     f16 *up2 = wsp<f16>(c, "le.up2"), *t5 = wsp<f16>(c, "le.t5");
     q.conv32("LE.up_conv2.0", t4, nullptr, "", s.H2, s.W2, ACT_RELU, ST_PS, up2, 32, s.H1, s.W1, fea1);
     q.resblock("LE.recon_trunk5.0", up2, cond2, s.H1, s.W1, l1b, t5);
-    // the full-resolution tail: one row-streaming launch (le_rows.hip) when all of it is fp16 and the shapes are even, else per layer
-    const bool tail_fused = q.ok() && c->var.at("le_rows") && !(H & 1) && !(W & 1) && s.H1 * 2 == H && s.W1 * 2 == W && q.rows_fit(H, W) &&
-                            c->conv.count("LE.up_conv3.0") && c->conv.count("LE.HR_conv2") && c->conv.count("LE.conv_last") &&
-                            !c->sft.at("LE.SFT_layer2").q;
-    if (tail_fused) {
-        const ConvLayer &Lu = c->conv.at("LE.up_conv3.0"), &Lh = c->conv.at("LE.HR_conv2"), &Ll = c->conv.at("LE.conv_last");
-        const SftLayer &S2 = c->sft.at("LE.SFT_layer2");
+    // the full-resolution tail: one row-streaming launch (le_rows.hip) when the shapes are even and every layer is fp16 or a W8A8
+    // layer the kernel runs as fake-quant, else per layer
+    if (q.ok() && c->var.at("le_rows") && !(H & 1) && !(W & 1) && s.H1 * 2 == H && s.W1 * 2 == W && q.rows_fit(H, W)) {
         RowsTailParams p;
         memset(&p, 0, sizeof p);
-        p.u = t5; p.fea0 = fea0; p.cond = cond1; p.res_planar = img; p.dst_planar = out_planar; p.H = H; p.W = W;
-        p.w_up = wtp<f16>(c, Lu.wpk); p.b_up = wtp<float>(c, Lu.shift);
-        p.sft_wfrag = wtp<f16>(c, S2.wfrag); p.sft_bias = wtp<float>(c, S2.bias);
-        p.w_hr = wtp<f16>(c, Lh.wpk); p.b_hr = wtp<float>(c, Lh.shift); p.w_last = wtp<f16>(c, Ll.wpk); p.b_last = wtp<float>(c, Ll.shift);
-        p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
-        p.dump = q.stamp_buf();
-        const double npx = (double)H * W;
-        q.chk(le_tail_rows_launch(p, c->n_cu, q.s), "LE.tail", "le_tail_rows", npx * (32.0 * 9 * 128 / 4 + 2.0 * (16 * 16 + 16 * 32) + 32.0 * 9 * 32 + 32.0 * 9 * 3),
-              npx * (16 + 64 + 32 + 6 + 6) + 2.0 * 9 * 32 * (128 + 32 + 32));
-        return q.rc;
+        bool qu, qh, ql, qs;
+        const ConvLayer *Lu = q.rows_conv("LE.up_conv3.0", p.fq_u, qu), *Lh = q.rows_conv("LE.HR_conv2", p.fq_y, qh),
+                        *Ll = q.rows_conv("LE.conv_last", p.fq_z, ql);
+        const SftLayer &S2 = c->sft.at("LE.SFT_layer2");
+        if (Lu && Lh && Ll && q.rows_sft(S2, p.fq_s, qs)) {
+            p.fq = (qu ? 1 : 0) | (qh ? 2 : 0) | (ql ? 4 : 0) | (qs ? 8 : 0);
+            p.u = t5; p.fea0 = fea0; p.cond = cond1; p.res_planar = img; p.dst_planar = out_planar; p.H = H; p.W = W;
+            p.w_up = wtp<f16>(c, Lu->wpk); p.b_up = wtp<float>(c, Lu->shift);
+            p.sft_wfrag = wtp<f16>(c, S2.wfrag); p.sft_bias = wtp<float>(c, S2.bias);
+            p.w_hr = wtp<f16>(c, Lh->wpk); p.b_hr = wtp<float>(c, Lh->shift); p.w_last = wtp<f16>(c, Ll->wpk); p.b_last = wtp<float>(c, Ll->shift);
+            p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
+            p.dump = q.stamp_buf();
+            const double npx = (double)H * W;
+            q.chk(le_tail_rows_launch(p, c->n_cu, q.s), "LE.tail", p.fq ? "le_tail_rows<fq>" : "le_tail_rows",
+                  npx * (32.0 * 9 * 128 / 4 + 2.0 * (16 * 16 + 16 * 32) + 32.0 * 9 * 32 + 32.0 * 9 * 3), npx * (16 + 64 + 32 + 6 + 6) + 2.0 * 9 * 32 * (128 + 32 + 32));
+            return q.rc;
+        }
     }
     q.conv32("LE.up_conv3.0", t5, nullptr, "", s.H1, s.W1, ACT_RELU, ST_PS, up3, 32, H, W, fea0);
     q.conv32("LE.HR_conv2", up3, cond1, "LE.SFT_layer2", H, W, ACT_RELU, ST_NHWC, f0b, 32, H, W);

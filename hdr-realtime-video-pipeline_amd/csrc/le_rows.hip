@@ -173,16 +173,48 @@ __device__ __forceinline__ f32x16 ld_tile(unsigned a)
     }
     return t;
 }
+// The reference's activation fake-quantiser (W8A8Conv2d.forward, hdrtvnet_torch.py:351-358) on four / eight f16 values in registers:
+// u8 code by one FMA + v_cvt_pk_u8_f32 (rint, saturating; common.h quant4), back by v_cvt_f32_ubyteN + one FMA, rounded to f16
+__device__ __forceinline__ f16x4 fq4(const f16x4 &x, const FqParam &q)
+{
+    unsigned w = 0;
+    w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)x[0], q.inv, q.zoff), 0, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)x[1], q.inv, q.zoff), 1, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)x[2], q.inv, q.zoff), 2, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)x[3], q.inv, q.zoff), 3, w);
+    return cvt4(__builtin_fmaf((float)(w & 255u), q.scale, q.zero), __builtin_fmaf((float)((w >> 8) & 255u), q.scale, q.zero),
+                __builtin_fmaf((float)((w >> 16) & 255u), q.scale, q.zero), __builtin_fmaf((float)(w >> 24), q.scale, q.zero));
+}
+__device__ __forceinline__ f16x8 fq8(const f16x8 &x, const FqParam &q)
+{
+    const f16x4 lo = fq4(__builtin_shufflevector(x, x, 0, 1, 2, 3), q), hi = fq4(__builtin_shufflevector(x, x, 4, 5, 6, 7), q);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ void fq_row(f16x4 (&y)[4], const FqParam &q)
+{
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) y[qd] = fq4(y[qd], q);
+}
+
 // y = x * (scale + 1) + shift on one pixel's 16 channels of this lane (channel quads qd: channels 8 qd + 4 lh ..), in three
 // stages so that a caller can put independent work between the dependent MFMAs (conv32s's arithmetic, bit for bit).
 // tiles = LDS address of this lane half's head tiles (sft_tiles_to_lds + 64 lh)
-__device__ __forceinline__ f32x16 sft_hidden(const SftW &s, const f16x8 &c0)
+// fq (W8A8 SFT convs): its four quantisers {cond -> scale branch, cond -> shift branch, scale hidden, shift hidden}, or null.  The
+// two first layers then see differently quantised copies of the condition pixel: two MFMAs, each with the other branch's
+// rows of the stacked A fragment zeroed (l31 < 16: scale branch).
+__device__ __forceinline__ f32x16 sft_hidden(const SftW &s, const f16x8 &c0, const FqParam *fq = nullptr, int l31 = 0)
 {
+    if (fq) {
+        const f16x8 z = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+        const f32x16 h = __builtin_amdgcn_mfma_f32_32x32x16_f16(l31 < 16 ? s.a0 : z, fq8(c0, fq[0]), s.bh, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(l31 < 16 ? z : s.a0, fq8(c0, fq[1]), h, 0, 0, 0);
+    }
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(s.a0, c0, s.bh, 0, 0, 0);
 }
-__device__ __forceinline__ void sft_heads(const SftW &s, const f32x16 &h, unsigned tiles, f32x16 &sc, f32x16 &sh)
+__device__ __forceinline__ void sft_heads(const SftW &s, const f32x16 &h, unsigned tiles, f32x16 &sc, f32x16 &sh, const FqParam *fq = nullptr)
 {
-    const f16x8 hs = lrelu_pack16(h, 0), ht = lrelu_pack16(h, 1);
+    f16x8 hs = lrelu_pack16(h, 0), ht = lrelu_pack16(h, 1);
+    if (fq) { hs = fq8(hs, fq[2]); ht = fq8(ht, fq[3]); }
     sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(s.a1s, hs, ld_tile(tiles), 0, 0, 0);
     sh = __builtin_amdgcn_mfma_f32_32x32x16_f16(s.a1t, ht, ld_tile(tiles + 128), 0, 0, 0);
 }
@@ -284,16 +316,17 @@ template <int DPF> struct RbGeo {
     static constexpr int CR = 2 * DPF + LAG;                 // condition ring: last read by sft2, 3 rows behind sft1
     static constexpr int OFF_X = 0, OFF_C = OFF_X + XR * X_ROWB, OFF_Y1 = OFF_C + CR * C_ROWB, OFF_Y2 = OFF_Y1 + YPH * Y_ROWB;
     static constexpr int OFF_ST = OFF_Y2 + YPH * Y_ROWB;
-    static constexpr int OFF_B = OFF_ST + 4 * STRIP;         // the head tiles of sft2, then of sft1
-    static constexpr int SMEM = OFF_B + 2 * SFT_TILE_B;
+    static constexpr int OFF_B = OFF_ST + 4 * STRIP;         // the head tiles of sft2, then of sft1, then conv2's bias
+    static constexpr int SMEM = OFF_B + 2 * SFT_TILE_B + 128;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
     static_assert(BIG % XR == 0 && BIG % CR == 0 && BIG % YN == 0, "BIG");
 };
 
-template <int DPF>
+template <int DPF, bool FQ>
 __global__ __launch_bounds__(512) void le_rb_rows_kernel(RowsRbParams p)
 {
     using G = RbGeo<DPF>;
+    const FqParam *const fqs1 = (FQ && (p.fq & 4)) ? p.fq_s1 : nullptr, *const fqs2 = (FQ && (p.fq & 8)) ? p.fq_s2 : nullptr;
     constexpr int LAG = G::LAG, XR = G::XR, CR = G::CR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned sm = lds_off(smem);
@@ -308,6 +341,7 @@ __global__ __launch_bounds__(512) void le_rb_rows_kernel(RowsRbParams p)
     const int H = p.H, W = p.W;
     sft_tiles_to_lds(smem + G::OFF_B, p.sft2_bias, tid);
     sft_tiles_to_lds(smem + G::OFF_B + SFT_TILE_B, p.sft1_bias, tid);
+    if (tid < 32) reinterpret_cast<float *>(smem + G::OFF_B + 2 * SFT_TILE_B)[tid] = p.b2[tid];
 
     const int g = wave & 3, gr = g >> 1, gh = g & 1;                   // this wave's 32-pixel group: row gr of the step's pair, column half gh
     const int cx = 32 * gh + l31;                                      // this lane's pixel slot in its group's ring rows
@@ -344,10 +378,10 @@ __global__ __launch_bounds__(512) void le_rb_rows_kernel(RowsRbParams p)
             // the SFT pass is a chain of dependent MFMA -> VALU -> MFMA steps, the conv an independent stream that covers its
             // latencies: the pass's two cond MLPs run between the conv's MFMAs, only the modulation waits for the conv
             f32x16 h2, sc2, sh2;
-            const f32x16 acc = conv18<ROWS_AHEAD_H, Y_ROWB, ROWS_PIN_H>(w1, va, wn.o, [&](int st) __attribute__((always_inline)) {
+            const f32x16 acc = conv18<ROWS_AHEAD_H - (FQ ? 1 : 0), Y_ROWB, ROWS_PIN_H>(w1, va, wn.o, [&](int st) __attribute__((always_inline)) {
                 if (RB_ABL & 8) return;
-                if (st == 2) h2 = sft_hidden(s2, c2);
-                if (st == 10) sft_heads(s2, h2, t2, sc2, sh2);
+                if (st == 2) h2 = sft_hidden(s2, c2, fqs2, l31);
+                if (st == 10) sft_heads(s2, h2, t2, sc2, sh2, fqs2);
             });
             STAMP(1);
             f16x4 y[4];
@@ -355,6 +389,7 @@ __global__ __launch_bounds__(512) void le_rb_rows_kernel(RowsRbParams p)
             for (int qd = 0; qd < 4; ++qd) y[qd] = __builtin_elementwise_max(bias_cvt4(acc, qd, bq[qd]), zero4());
             if (!(RB_ABL & 8)) {
                 sft_modulate(sc2, sh2, y);
+                if (FQ && (p.fq & 2)) fq_row(y, p.fq_c2);                 // conv2 is W8A8: its input quantiser
                 if (!(colfull && row2)) {
 #pragma unroll
                     for (int qd = 0; qd < 4; ++qd) if (!(col2 && row2)) y[qd] = zero4();
@@ -449,12 +484,13 @@ __global__ __launch_bounds__(512) void le_rb_rows_kernel(RowsRbParams p)
             const bool row1 = (unsigned)(ro_img + LAG) < (unsigned)H;  // outside the image: conv1's zero padding
             // conv2 on row ro with row ra's whole SFT pass (independent of it) between its MFMAs
             f32x16 h1, sc1, sh1;
-            const f32x16 acc = conv18<ROWS_AHEAD_H + 2, Y_ROWB, ROWS_PIN_H>(w2, va, wn.o, [&](int st) __attribute__((always_inline)) {
+            const f32x16 acc = conv18<ROWS_AHEAD_H + (FQ ? 0 : 2), Y_ROWB, ROWS_PIN_H>(w2, va, wn.o, [&](int st) __attribute__((always_inline)) {
                 if (RB_ABL & 8) { if (st == 13) put_row(vq, ya1.o, ya1.mirrored(), y1); return; }
-                if (st == 1) h1 = sft_hidden(s1, c1);
-                if (st == 7) sft_heads(s1, h1, t1, sc1, sh1);
+                if (st == 1) h1 = sft_hidden(s1, c1, fqs1, l31);
+                if (st == 7) sft_heads(s1, h1, t1, sc1, sh1, fqs1);
                 if (st == 13) {
                     sft_modulate(sc1, sh1, y1);
+                    if (FQ && (p.fq & 1)) fq_row(y1, p.fq_c1);            // conv1 is W8A8: its input quantiser
                     if (!(colfull && row1)) {
 #pragma unroll
                         for (int qd = 0; qd < 4; ++qd) if (!(col1 && row1)) y1[qd] = zero4();
@@ -463,6 +499,10 @@ __global__ __launch_bounds__(512) void le_rb_rows_kernel(RowsRbParams p)
                 }
             });
             STAMP(1);
+            if (FQ) {       // (the fake-quant variant has no registers to spare for the bias: from LDS, behind the conv)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) bq[qd] = lds_rd<f32x4>(sm + G::OFF_B + 2 * SFT_TILE_B + 32 * qd + 16 * lh);
+            }
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) lds_wr(sw0 + 16 * qd, bias_cvt4(acc, qd, bq[qd]) + res[qd]);
             xd.step(); xa.step(); xres.step(); cd.step(); ca.step(); ya1.step(); wn.step();
@@ -507,10 +547,11 @@ template <int DPF> struct TailGeo {
     static_assert(BIG % FR == 0 && BIG % UN == 0, "BIG");
 };
 
-template <int DPF>
+template <int DPF, bool FQ>
 __global__ __launch_bounds__(512) void le_tail_rows_kernel(RowsTailParams p)
 {
     using G = TailGeo<DPF>;
+    const FqParam *const fqs = (FQ && (p.fq & 8)) ? p.fq_s : nullptr;
     constexpr int FR = G::FR, LAG = G::LAG, RN = G::RN;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned sm = lds_off(smem);
@@ -593,7 +634,25 @@ __global__ __launch_bounds__(512) void le_tail_rows_kernel(RowsTailParams p)
         Cur<G::OFF_Y, YN, Y_ROWB> yw(gr);
         int uw = G::OFF_U + ((-1 + BIG) % UN) * U_ROWB, ud = G::OFF_U + ((DPF + 1 + BIG) % UN) * U_ROWB, rs = DPF % RN;
         int ra_img = ya + gr;
+        // W8A8 up_conv: its input quantiser runs ONCE per element over a landed u row, in place (a quarter of the row per wave: 34 of
+        // the row's 136 16-byte chunks), two steps before the row's first window; rows 0 / 1 of a lap also into their second copy
+        auto fq_u_row = [&](int uo, int hr) __attribute__((always_inline)) {       // hr: the row's half-resolution image row
+            const int upx = (34 * g + lane) >> 2;
+            if (lane < 34 && (unsigned)hr < (unsigned)H1 && (unsigned)(hx0 - 2 + upx) < (unsigned)W1) {
+                const unsigned a = sm + uo + (34 * g + lane) * 16;
+                const f16x8 v = fq8(lds_rd<f16x8>(a), p.fq_u);
+                lds_wr(a, v);
+                if (uo < G::OFF_U + 2 * U_ROWB) lds_wr(a + UN * U_ROWB, v);
+            }
+        };
+        int uq = G::OFF_U + ((2 + BIG) % UN) * U_ROWB;                 // the row the pass of step 0 takes: u row 2
         __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));
+        if (FQ && (p.fq & 1)) {
+            __builtin_amdgcn_s_barrier();                              // (every wave's prologue pieces have landed)
+#pragma unroll
+            for (int ur = -1; ur <= 1; ++ur) fq_u_row(G::OFF_U + ((ur + BIG) % UN) * U_ROWB, hya + ur);
+            __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));
+        }
         __builtin_amdgcn_s_barrier();
         STAMP_DECL;
         for (int s = 0; s < nsteps; ++s) {
@@ -609,6 +668,7 @@ __global__ __launch_bounds__(512) void le_tail_rows_kernel(RowsTailParams p)
                 fd.step(); cd.step(); ud += U_ROWB; if (ud >= G::OFF_U + UN * U_ROWB) ud -= UN * U_ROWB; rs = rs + 1 == RN ? 0 : rs + 1; ra_img += 2;
                 continue;
             }
+            if (FQ && (p.fq & 1)) fq_u_row(uq, hya + s + 2);
             const f16x8 c2 = lds_rd<f16x8>(vc + ca.o);
             f16x4 sk[4];
 #pragma unroll
@@ -616,14 +676,15 @@ __global__ __launch_bounds__(512) void le_tail_rows_kernel(RowsTailParams p)
             const bool row = (unsigned)ra_img < (unsigned)H;
             f32x16 h2, sc2, sh2;
             const f32x16 acc = conv18<ROWS_AHEAD_H, U_ROWB, ROWS_PIN_H>(wu, va, uw, [&](int st) __attribute__((always_inline)) {
-                if (st == 2) h2 = sft_hidden(s2, c2);
-                if (st == 9) sft_heads(s2, h2, t2, sc2, sh2);
+                if (st == 2) h2 = sft_hidden(s2, c2, fqs, l31);
+                if (st == 9) sft_heads(s2, h2, t2, sc2, sh2, fqs);
             });
             STAMP(1);
             f16x4 y[4];
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) y[qd] = __builtin_elementwise_max(bias_cvt4(acc, qd, bq[qd]), zero4()) + sk[qd];
             sft_modulate(sc2, sh2, y);
+            if (FQ && (p.fq & 2)) fq_row(y, p.fq_y);                      // HR_conv2 is W8A8: its input quantiser
             if (!(colfull && row)) {
 #pragma unroll
                 for (int qd = 0; qd < 4; ++qd) if (!(col && row)) y[qd] = zero4();
@@ -632,6 +693,7 @@ __global__ __launch_bounds__(512) void le_tail_rows_kernel(RowsTailParams p)
             fa.step(); fd.step(); ca.step(); cd.step(); yw.step();
             uw += U_ROWB; if (uw >= G::OFF_U + UN * U_ROWB) uw -= UN * U_ROWB;
             ud += U_ROWB; if (ud >= G::OFF_U + UN * U_ROWB) ud -= UN * U_ROWB;
+            uq += U_ROWB; if (uq >= G::OFF_U + UN * U_ROWB) uq -= UN * U_ROWB;
             rs = rs + 1 == RN ? 0 : rs + 1;
             ra_img += 2;
             STAMP(2);
@@ -665,6 +727,7 @@ __global__ __launch_bounds__(512) void le_tail_rows_kernel(RowsTailParams p)
         Cur<G::OFF_Z, YN, Y_ROWB> zw(gr - 3), wz(gr - LAG - 1);
         int rb_img = ya + gr - 3, rs = 0;
         __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));
+        if (FQ && (p.fq & 1)) __builtin_amdgcn_s_barrier();            // (role T1's in-place pass over the first u rows)
         __builtin_amdgcn_s_barrier();
         STAMP_DECL;
         for (int s = 0; s < nsteps; ++s) {
@@ -695,6 +758,7 @@ __global__ __launch_bounds__(512) void le_tail_rows_kernel(RowsTailParams p)
 #pragma unroll
                 for (int qd = 0; qd < 4; ++qd) {
                     z[qd] = __builtin_elementwise_max(bias_cvt4(acc, qd, bh[qd]), zero4());
+                    if (FQ && (p.fq & 4)) z[qd] = fq4(z[qd], p.fq_z);     // conv_last is W8A8: its input quantiser
                     if (!in) z[qd] = zero4();
                 }
                 put_row(vq, zw.o, zw.mirrored(), z);
@@ -732,10 +796,11 @@ template <int DPF> struct HeadGeo {
     static_assert(BIG % CR == 0, "BIG");
 };
 
-template <int DPF>
+template <int DPF, bool FQ>
 __global__ __launch_bounds__(512) void le_head_rows_kernel(RowsHeadParams p)
 {
     using G = HeadGeo<DPF>;
+    const FqParam *const fqs = (FQ && (p.fq & 8)) ? p.fq_s : nullptr;
     constexpr int CR = G::CR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned sm = lds_off(smem);
@@ -777,9 +842,11 @@ __global__ __launch_bounds__(512) void le_head_rows_kernel(RowsHeadParams p)
         const size_t plane = (size_t)H * W;
         const f16 *pimg = p.img + (x0 - 3 + pc);
         f16 pv[3] = {(f16)0.f, (f16)0.f, (f16)0.f};
+        bool pin_img = false;
         auto patch_fetch = [&](int r0) __attribute__((always_inline)) {      // image rows r0, r0 + 1
             const int r = r0 + pr;
             const bool ok = pcol && (unsigned)r < (unsigned)H && r <= y1 + 1;
+            pin_img = ok;
             const f16 *src = ok ? pimg + (size_t)r * W : p.img;
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
@@ -792,7 +859,9 @@ __global__ __launch_bounds__(512) void le_head_rows_kernel(RowsHeadParams p)
                 int ms = m0 + pr;
                 if (ms >= YN) ms -= YN;
                 const unsigned a = sm + G::OFF_P + ms * P_ROWB + pc * 8;
-                const f16x4 v = f16x4{pv[0], pv[1], pv[2], (f16)1.f};          // 1: the bias slot
+                f16x4 v = f16x4{pv[0], pv[1], pv[2], (f16)0.f};
+                if (FQ && (p.fq & 1) && pin_img) v = fq4(v, p.fq_img);          // conv_first is W8A8: its input quantiser (zero padding stays zero)
+                v[3] = (f16)1.f;                                                // 1: the bias slot
                 lds_wr(a, v);
                 if (ms < 2) lds_wr(a + YN * P_ROWB, v);                         // the second copy of a lap's rows 0 and 1
             }
@@ -833,11 +902,12 @@ __global__ __launch_bounds__(512) void le_head_rows_kernel(RowsHeadParams p)
                 h = __builtin_amdgcn_mfma_f32_32x32x16_f16(c3w[ky], xf, ky == 0 ? zero16() : h, 0, 0, 0);
             }
             f32x16 sc1, sh1;
-            sft_heads(s1, sft_hidden(s1, c1), t1, sc1, sh1);
+            sft_heads(s1, sft_hidden(s1, c1, fqs, l31), t1, sc1, sh1, fqs);
             f16x4 y[4];
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) y[qd] = __builtin_elementwise_max(cvt4(h[4 * qd], h[4 * qd + 1], h[4 * qd + 2], h[4 * qd + 3]), zero4());
             sft_modulate(sc1, sh1, y);
+            if (FQ && (p.fq & 2)) fq_row(y, p.fq_y);                      // HR_conv1 is W8A8: its input quantiser
             const bool row = (unsigned)ra_img < (unsigned)H;
             if (!(colfull && row)) {
 #pragma unroll
@@ -918,7 +988,8 @@ __global__ __launch_bounds__(512) void le_head_rows_kernel(RowsHeadParams p)
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
                 z[qd] = __builtin_elementwise_max(bias_cvt4(acc, qd, bh[qd]), zero4());
-                lds_wr(sw0 + 16 * qd, z[qd]);
+                lds_wr(sw0 + 16 * qd, z[qd]);                             // fea0 as the tail's skip wants it: not quantised
+                if (FQ && (p.fq & 4)) z[qd] = fq4(z[qd], p.fq_f);         // down_conv1 is W8A8: its input quantiser
                 if (!in) z[qd] = zero4();
             }
             put_row(vq, fw.o, fw.mirrored(), z);
@@ -962,10 +1033,16 @@ hipError_t le_rb_rows_launch(RowsRbParams p, int n_cu, hipStream_t s)
 {
     if ((size_t)p.H * p.W * 64 >= 0x7f000000ull || !p.trash) return hipErrorInvalidValue;
     static DevOnce once;
-    if (hipError_t e = set_lds(le_rb_rows_kernel<3>, RbGeo<3>::SMEM, once)) return e;
+    static DevOnce once_q;
     int nseg;
     strips(p, n_cu, false, nseg);
-    hipLaunchKernelGGL(le_rb_rows_kernel<3>, dim3(p.nstrips * nseg), dim3(512), RbGeo<3>::SMEM, s, p);
+    if (p.fq) {
+        if (hipError_t e = set_lds(le_rb_rows_kernel<3, true>, RbGeo<3>::SMEM, once_q)) return e;
+        hipLaunchKernelGGL((le_rb_rows_kernel<3, true>), dim3(p.nstrips * nseg), dim3(512), RbGeo<3>::SMEM, s, p);
+    } else {
+        if (hipError_t e = set_lds(le_rb_rows_kernel<3, false>, RbGeo<3>::SMEM, once)) return e;
+        hipLaunchKernelGGL((le_rb_rows_kernel<3, false>), dim3(p.nstrips * nseg), dim3(512), RbGeo<3>::SMEM, s, p);
+    }
     return hipGetLastError();
 }
 
@@ -974,10 +1051,16 @@ hipError_t le_tail_rows_launch(RowsTailParams p, int n_cu, hipStream_t s)
 {
     if ((size_t)p.H * p.W * 64 >= 0x7f000000ull || !p.trash || (p.H & 1) || (p.W & 1)) return hipErrorInvalidValue;
     static DevOnce once;
-    if (hipError_t e = set_lds(le_tail_rows_kernel<3>, TailGeo<3>::SMEM, once)) return e;
+    static DevOnce once_q;
     int nseg;
     strips(p, n_cu, true, nseg);
-    hipLaunchKernelGGL(le_tail_rows_kernel<3>, dim3(p.nstrips * nseg), dim3(512), TailGeo<3>::SMEM, s, p);
+    if (p.fq) {
+        if (hipError_t e = set_lds(le_tail_rows_kernel<3, true>, TailGeo<3>::SMEM, once_q)) return e;
+        hipLaunchKernelGGL((le_tail_rows_kernel<3, true>), dim3(p.nstrips * nseg), dim3(512), TailGeo<3>::SMEM, s, p);
+    } else {
+        if (hipError_t e = set_lds(le_tail_rows_kernel<3, false>, TailGeo<3>::SMEM, once)) return e;
+        hipLaunchKernelGGL((le_tail_rows_kernel<3, false>), dim3(p.nstrips * nseg), dim3(512), TailGeo<3>::SMEM, s, p);
+    }
     return hipGetLastError();
 }
 
@@ -986,9 +1069,15 @@ hipError_t le_head_rows_launch(RowsHeadParams p, int n_cu, hipStream_t s)
 {
     if ((size_t)p.H * p.W * 64 >= 0x7f000000ull || !p.trash || (p.W & 1) || (p.H & 1)) return hipErrorInvalidValue;
     static DevOnce once;
-    if (hipError_t e = set_lds(le_head_rows_kernel<3>, HeadGeo<3>::SMEM, once)) return e;
+    static DevOnce once_q;
     int nseg;
     strips(p, n_cu, true, nseg);
-    hipLaunchKernelGGL(le_head_rows_kernel<3>, dim3(p.nstrips * nseg), dim3(512), HeadGeo<3>::SMEM, s, p);
+    if (p.fq) {
+        if (hipError_t e = set_lds(le_head_rows_kernel<3, true>, HeadGeo<3>::SMEM, once_q)) return e;
+        hipLaunchKernelGGL((le_head_rows_kernel<3, true>), dim3(p.nstrips * nseg), dim3(512), HeadGeo<3>::SMEM, s, p);
+    } else {
+        if (hipError_t e = set_lds(le_head_rows_kernel<3, false>, HeadGeo<3>::SMEM, once)) return e;
+        hipLaunchKernelGGL((le_head_rows_kernel<3, false>), dim3(p.nstrips * nseg), dim3(512), HeadGeo<3>::SMEM, s, p);
+    }
     return hipGetLastError();
 }

@@ -51,3 +51,46 @@ def test_fused_rows_are_bit_identical_to_the_per_layer_kernels(torch_cuda, golde
             p.set_variant("no_such_variant", 1)
     finally:
         p.close()
+
+
+@pytest.mark.parametrize("tag", ["full", "mixed"])
+def test_w8a8_layers_as_fake_quant_in_the_fused_kernels(torch_cuda, golden_dir, tag):
+    """W8A8 layers inside the fused kernels (variant le_rows_fq, the default): the layer's activation quantiser is applied in
+    registers (u8 code and back, common.h FqParam) and the convolution runs in fp16 on the dequantised weights -- the
+    arithmetic of the reference's ``W8A8Conv2d.forward`` itself (hdrtvnet_torch.py:351-364: fake-quant, then F.conv2d in the
+    compute dtype).  Against the fake-quant oracle (fp32, ATen) at 1920x1080 it must be no further away than the int8-MFMA
+    per-layer kernels it replaces (le_rows_fq = 0), within the reference's own bar for a re-quantised graph (u8 MAE <= 5)."""
+    import numpy as np
+    from hdrtv_mi355x import weights as W
+    from hdrtv_mi355x.processor import HDRTVNetMI355X
+    from oracle import hdrtvnet_oracle as O
+    h, w = 1080, 1920
+    f = W.synthetic_frame(h, w, seed=91, kind="gradient")
+    p = HDRTVNetMI355X(os.path.join(golden_dir, f"hr_int8_{tag}_qat.hdrw"), precision=f"int8-{tag}", predequantize="off", use_hg=False, warmup_passes=0)
+    got = {}
+    try:
+        for v in (1, 0):
+            p.set_variant("le_rows_fq", v)
+            p.profile_enable(True)
+            out, _ = p.infer(p.preprocess(f))
+            kern = {k for _, k, *_ in p.profile_read()}
+            p.profile_enable(False)
+            assert any("rows<fq>" in k for k in kern) == (v == 1), kern
+            got[v] = (out.float().cpu().numpy()[0], p.postprocess(out).copy())
+    finally:
+        p.close()
+    sd = O.w8a8_state(W.load_pack(os.path.join(golden_dir, f"hr_int8_{tag}_qat.hdrw")))
+    O.use_backend("aten")
+    try:
+        ref, _ = O.hr_forward(sd, *O.preprocess(f))
+    finally:
+        O.use_backend("c")
+    ru8 = O.postprocess_u8(ref)
+    err = {}
+    for v in (1, 0):
+        d = np.abs(got[v][0] - ref)
+        du8 = np.abs(got[v][1].astype(int) - ru8.astype(int))
+        err[v] = (float(d.mean()), float(du8.mean()))
+        print(f"  int8-{tag} le_rows_fq={v}: out max {d.max():.3e} mean {d.mean():.3e}; u8 max {du8.max()} MAE {du8.mean():.4f}")
+    assert err[1][1] <= 5.0 and err[1][0] <= 0.02                       # the reference's bar
+    assert err[1][0] <= 1.15 * err[0][0] + 1e-5 and err[1][1] <= 1.15 * err[0][1] + 0.01
