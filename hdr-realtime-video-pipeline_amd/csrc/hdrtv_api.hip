@@ -266,6 +266,7 @@ int fail(hdrtv_ctx *c, int code, const char *fmt, ...)
 // hdrtv_create.  The launch path reads c->var only.
 const std::pair<const char *, int> k_variants[] = {
     {"le_rows", 1},          // fused row-streaming LE kernels (le_rows.hip); 0 = the per-layer 16x16-tile kernels
+    {"le_rows_min", 12},     // ... when a strip segment has at least this many rows (it pays 4 .. 6 warm-up rows)
     {"le_rows_fq", 1},       // ... also for W8A8 layers (fake-quant in registers, fp16 MFMA); 0 = those layers on the int8-MFMA per-layer kernels
     {"prw", 1},              // HG 3x3 convs on conv_prw: 0 never (conv_pglds), 1 the cheapest shape per layer, 2 / 3 16-row / 8-row tiles wherever it applies
     {"prw_i8", 1},           // int8 HG 3x3 convs on conv_prw_i8: 0 never, 1 only where the 8-row tiles win, 2 wherever "prw" selects it
@@ -1685,7 +1686,7 @@ struct Seq {
     bool rows_fit(int H, int W) const
     {
         const int nstrips = (W + 59) / 60, nseg = std::max(1, c->n_cu / nstrips);
-        return W >= 60 && (H + nseg - 1) / nseg >= 12;
+        return W >= 60 && (H + nseg - 1) / nseg >= c->var.at("le_rows_min");
     }
     // ResBlock_with_SFT (arch_util.py:89-95): y = x + conv2(sft2(relu(conv1(sft1(x,c))),c))  [+ extra]; 2 launches
     void resblock(const std::string &base, const f16 *x, const f16 *cond, int H, int W, f16 *tb, f16 *y,
