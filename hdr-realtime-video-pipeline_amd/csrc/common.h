@@ -278,6 +278,28 @@ struct RowsHeadParams {
     FqParam fq_img, fq_y, fq_f, fq_s[4];
 };
 
+// precision="fp32" (fp32_ops.hip): one generic convolution over planar CHW fp32 tensors
+struct F32ConvParams {
+    const float *x0, *x1;            // input planes; x1 = the second half of a channel concat (torch.cat((a, b), 1)) or null
+    int c0, c1;
+    int Hi, Wi, Ho, Wo;
+    const float *w;                  // [cout group][cin][tap][cot]
+    const float *bias;               // padded to the group size, like every per-channel vector below
+    const float *bn_s, *bn_t;        // BatchNorm2d(eval) as scale / shift, or null
+    const float *gfm_s, *gfm_t;      // GFM modulation v*s + t + v, or null
+    const float *res;                // residual [cout][Ho][Wo] added after the activation, or null
+    float *y;
+    int cout, cot, pad, act;         // act: 0 none, 1 ReLU, 2 LeakyReLU(slope)
+    float slope;
+    int ps;                          // store through PixelShuffle(2): y is [cout/4][2Ho][2Wo]
+};
+struct F32GfmParams {
+    const float *w[6], *b[6];        // cond_scale_{first,HR,last}, cond_shift_{first,HR,last}: Linear(6 -> n)
+    int n[6];
+    const float *fea;                // the classifier's 6-vector
+    float *out;                      // [6][64]
+};
+
 // Letterbox (letterbox.hip): u8 BGR [sh][sw][3] -> u8 BGR [dh][dw][3], resized region [y0, y0+new_h) x [x0, x0+new_w)
 enum { LB_COPY = 0, LB_AREA_INT = 1, LB_AREA_FRAC = 2, LB_CUBIC = 3 };
 struct LetterboxParams {

@@ -181,6 +181,12 @@ struct Tensor {
     }
 };
 
+struct F32Layer {                            // precision="fp32": one conv layer of fp32_graph.inc
+    size_t w = 0, b = 0, bn_s = 0, bn_t = 0;
+    int cin = 0, cout = 0, cot = 32, ks = 1;
+    bool bn = false;
+};
+
 struct RingSlot {
     uint16_t *host = nullptr, *dev = nullptr;
     // host: page-locked slot the consumer reads; dev: device staging buffer the post kernel writes (commit copies)
@@ -194,6 +200,8 @@ struct hdrtv_ctx {
     int device = 0;
     int n_cu = 256;
     bool has_hg = false;
+    bool fp32 = false;                    // hdrtv_create_ex(..., HDRTV_PREC_F32): the fp32 graph (fp32_graph.inc) on planar fp32 tensors
+    std::map<std::string, F32Layer> conv32f;
     std::string err;
     Arena wts;
     std::map<std::string, ConvLayer> conv;
@@ -1284,6 +1292,8 @@ Shapes shapes_for(int H, int W)
     return s;
 }
 
+int f32_plan(hdrtv_ctx *c, int H, int W);   // fp32_graph.inc: registers the fp32 graph's tensors
+
 int do_reserve(hdrtv_ctx *c, int H, int W)
 {
     if (c->H == H && c->W == W && c->ws.dev) return HDRTV_OK;
@@ -1313,6 +1323,9 @@ int do_reserve(hdrtv_ctx *c, int H, int W)
     ws_add(c, "aa.wx", (int)wx.size(), 1, 1, 3); ws_add(c, "aa.wy", (int)wy.size(), 1, 1, 3);
     ws_add(c, "aa.xmn", s.w4, 1, 1, 3); ws_add(c, "aa.xns", s.w4, 1, 1, 3);
     ws_add(c, "aa.ymn", s.h4, 1, 1, 3); ws_add(c, "aa.yns", s.h4, 1, 1, 3);
+    if (c->fp32) {
+        f32_plan(c, H, W);
+    } else {
     // AGCM
     const int cls_co[5] = {16, 32, 64, 128, 128};
     char nm[64];
@@ -1380,6 +1393,7 @@ int do_reserve(hdrtv_ctx *c, int H, int W)
             ws_add(c, "hg8.up3", 256, Hp / 4, Wp / 4, 5); ws_add(c, "hg8.conv8", 128, Hp / 4, Wp / 4, 5);
         }
         if (!c->hg_i8) ws_add(c, "hg.conv9", 64, Hp / 2, Wp / 2, 0);
+    }
     }
     if (hipMalloc((void **)&c->ws.dev, c->ws.size + 4096) != hipSuccess) {
         c->ws.dev = nullptr;
@@ -1718,6 +1732,14 @@ struct Seq {
         conv32(base + ".conv2", tb, cond, base + ".sft2", H, W, ACT_NONE, ST_NHWC, y, 32, H, W, x, extra);
     }
 };
+
+#include "fp32_graph.inc"
+
+int f32_plan(hdrtv_ctx *c, int H, int W)
+{
+    Seq q{c, nullptr};
+    return run_f32(c, q, true, H, W, nullptr, nullptr, nullptr, nullptr);
+}
 
 int run_agcm(hdrtv_ctx *c, Seq &q, const f16 *rgb, const f16 *cond, f16 *agcm_out)
 {
@@ -2103,17 +2125,26 @@ const char *hdrtv_version(void) { return "hdrtv_mi355x 0.1 gfx950 (MFMA f16 impl
 
 int hdrtv_create(const void *hr_pack, size_t hr_bytes, const void *hg_pack, size_t hg_bytes, int device_id, hdrtv_ctx **out)
 {
+    return hdrtv_create_ex(hr_pack, hr_bytes, hg_pack, hg_bytes, device_id, HDRTV_PREC_F16, out);
+}
+
+int hdrtv_create_ex(const void *hr_pack, size_t hr_bytes, const void *hg_pack, size_t hg_bytes, int device_id, int precision,
+                    hdrtv_ctx **out)
+{
     if (!out) return HDRTV_EINVAL;
     *out = nullptr;
     hdrtv_ctx *c = new hdrtv_ctx();
     *out = c;   // returned even on failure so hdrtv_last_error() can be read; caller still destroys it
     c->device = device_id;
+    if (precision != HDRTV_PREC_F16 && precision != HDRTV_PREC_F32) return fail(c, HDRTV_EINVAL, "bad precision %d", precision);
+    c->fp32 = precision == HDRTV_PREC_F32;
     if (!hr_pack || hr_bytes == 0) return fail(c, HDRTV_EINVAL, "hr_pack is required");
     Pack hr, hg;
     if (!hr.parse(hr_pack, hr_bytes, c->err)) return HDRTV_EWEIGHTS;
     c->has_hg = hg_pack != nullptr && hg_bytes > 0;
     if (c->has_hg && !hg.parse(hg_pack, hg_bytes, c->err)) return HDRTV_EWEIGHTS;
-    if (!build_weights(c, hr, c->has_hg ? &hg : nullptr)) return HDRTV_EWEIGHTS;
+    if (c->fp32 ? !build_weights_f32(c, hr, c->has_hg ? &hg : nullptr) : !build_weights(c, hr, c->has_hg ? &hg : nullptr))
+        return HDRTV_EWEIGHTS;
     int ndev = 0;
     HIPCHK(c, hipGetDeviceCount(&ndev));
     if (device_id < 0 || device_id >= ndev) return fail(c, HDRTV_EINVAL, "device %d not available (%d devices)", device_id, ndev);
@@ -2205,6 +2236,12 @@ int hdrtv_preprocess(hdrtv_ctx *c, void *stream, const uint8_t *bgr, int H, int 
     hipStream_t s = (hipStream_t)stream;
     Seq q{c, s};
     const Shapes sh = shapes_for(H, W);
+    if (c->fp32) {                       // precision="fp32": rgb / cond are fp32 tensors
+        q.chk(pre_f32_launch(bgr, (float *)rgb, (float *)cond, H, W, sh.h4, sh.w4, wsp<float>(c, "aa.wx"), wsp<int>(c, "aa.xmn"),
+                             wsp<int>(c, "aa.xns"), wsp<float>(c, "aa.wy"), wsp<int>(c, "aa.ymn"), wsp<int>(c, "aa.yns"),
+                             c->cond_mode, s), "pre_f32");
+        return q.rc;
+    }
     const bool split = c->var.at("pre_split") != 0;                       // developer A/B: the two-kernel form
     if (H / 4 >= 1 && W / 4 >= 1 && !(split && c->cond_mode == 0)) {
         q.chk(pre_fused_launch(bgr, (f16 *)rgb, (f16 *)cond, H, W, sh.h4, sh.w4, wsp<float>(c, "aa.wx"), wsp<int>(c, "aa.xmn"),
@@ -2225,13 +2262,15 @@ int hdrtv_infer(hdrtv_ctx *c, void *stream, const void *rgb, const void *cond, i
     if (!c || !rgb || !cond || !out) return fail(c, HDRTV_EINVAL, "null argument");
     if (c->H != H || c->W != W || !c->ws.dev) return fail(c, HDRTV_ESTATE, "call hdrtv_reserve(%d,%d) first", H, W);
     if (out_dtype != HDRTV_F16 && out_dtype != HDRTV_F32) return fail(c, HDRTV_EINVAL, "bad out_dtype");
-    if (!c->has_hg && out_dtype != HDRTV_F16) return fail(c, HDRTV_EINVAL, "the no-HG model returns f16");
+    if (c->fp32 && out_dtype != HDRTV_F32) return fail(c, HDRTV_EINVAL, "an fp32 context takes and returns f32 tensors");
+    if (!c->fp32 && !c->has_hg && out_dtype != HDRTV_F16) return fail(c, HDRTV_EINVAL, "the no-HG model returns f16");
     HIPCHK(c, hipSetDevice(c->device));
     Seq q{c, (hipStream_t)stream};
     c->launches = 0;
     c->macs = 0.0;
     c->prof.clear();
     q.mark();
+    if (c->fp32) return run_f32(c, q, false, H, W, (const float *)rgb, (const float *)cond, (float *)out, (float *)agcm_out);
     f16 *agcm = agcm_out ? (f16 *)agcm_out : wsp<f16>(c, "agcm.out");
     if (run_agcm(c, q, (const f16 *)rgb, (const f16 *)cond, agcm) != HDRTV_OK) return q.rc;
     f16 *le_out = c->has_hg ? wsp<f16>(c, "le.out") : (f16 *)out;

@@ -107,3 +107,18 @@ hipError_t hg_final_light_launch(const HgFinalFusedArgs &a, const float *part2, 
 hipError_t letterbox_launch(const LetterboxParams &p, hipStream_t s);
 hipError_t metrics_launch(const MetricsParams &p, hipStream_t s);
 int metrics_blocks(int H, int W);
+
+// precision="fp32" (fp32_ops.hip)
+hipError_t conv_f32_launch(const F32ConvParams &p, int ks, int stride, hipStream_t s);
+hipError_t ew_f32_launch(int op, const float *a, const float *b, const float *c, float *y, size_t n, hipStream_t s);
+hipError_t avgpool3s2_leaky_f32_launch(const float *x, float *y, int C, int H, int W, float slope, hipStream_t s);
+hipError_t instnorm_f32_launch(float *x, const float *gamma, const float *beta, int C, int n, float eps, hipStream_t s);
+hipError_t plane_mean_f32_launch(const float *x, float *y, int C, int n, hipStream_t s);
+hipError_t gfm_heads_f32_launch(const F32GfmParams &p, hipStream_t s);
+hipError_t maxpool2_f32_launch(const float *x, float *y, int C, int H, int W, hipStream_t s);
+hipError_t window_f32_launch(const float *x, float *y, int C, int H, int W, int Ho, int Wo, int mode, hipStream_t s);
+hipError_t hg_mask_f32_launch(const float *base, float *mask, size_t npix, float r, hipStream_t s);
+hipError_t hg_blend_f32_launch(const float *t, const float *img, const float *mask, float *out, int H, int W, int Hp, int Wp,
+                               hipStream_t s);
+hipError_t pre_f32_launch(const uint8_t *bgr, float *rgb, float *cond, int H, int W, int Ho, int Wo, const float *wx,
+                          const int *xmn, const int *xns, const float *wy, const int *ymn, const int *yns, int mode, hipStream_t s);

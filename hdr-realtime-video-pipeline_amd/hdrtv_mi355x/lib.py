@@ -16,12 +16,14 @@ LIB_PATH_AB = os.path.join(os.path.dirname(_PKG), "lib", "libhdrtv_mi355x_ab.so"
 
 OK, EINVAL, EWEIGHTS, EHIP, ENOMEM, ESTATE = 0, -1, -2, -3, -4, -5
 F16, F32 = 0, 1
+PREC_F16, PREC_F32 = 0, 1
 
 # every symbol include/hdrtv_mi355x.h declares: (name, restype, argtypes)
 _VP, _I, _SZ = C.c_void_p, C.c_int, C.c_size_t
 SYMBOLS = [
     ("hdrtv_version", C.c_char_p, []),
     ("hdrtv_create", _I, [_VP, _SZ, _VP, _SZ, _I, C.POINTER(_VP)]),
+    ("hdrtv_create_ex", _I, [_VP, _SZ, _VP, _SZ, _I, _I, C.POINTER(_VP)]),
     ("hdrtv_destroy", _I, [_VP]),
     ("hdrtv_has_hg", _I, [_VP]),
     ("hdrtv_set_hg_mask_r", _I, [_VP, C.c_float]),

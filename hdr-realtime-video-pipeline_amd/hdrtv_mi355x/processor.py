@@ -92,7 +92,9 @@ class HDRTVNetMI355X:
         self.device = self._resolve_device(device)
         self.precision = self._resolve_precision(precision)
         self._use_cuda = True
-        self._dtype = torch.float16
+        # fp32: the reference's maximum-precision preset -- the same graph on fp32 tensors (csrc/fp32_ops.hip, fp32_graph.inc)
+        self._fp32 = self.precision == "fp32"
+        self._dtype = torch.float32 if self._fp32 else torch.float16
         self._compiled = False          # nothing is JIT-compiled; warmup_compile() is a no-op
         self._compile_mode = None
         self._trt_engine = None
@@ -164,8 +166,8 @@ class HDRTVNetMI355X:
         hr_blob = _W.pack_state(hr_state if self._is_w8_model else {k: hr_state[k] for k, _ in _arch_hr()})
         hg_blob = _W.pack_state({k: v for k, v in hg_state.items()
                                  if not k.endswith("num_batches_tracked")}) if hg_state is not None else b""
-        rc = self._lib.hdrtv_create(hr_blob, len(hr_blob), hg_blob if hg_blob else None, len(hg_blob),
-                                    self.device.index or 0, C.byref(self._ctx))
+        rc = self._lib.hdrtv_create_ex(hr_blob, len(hr_blob), hg_blob if hg_blob else None, len(hg_blob),
+                                       self.device.index or 0, _L.PREC_F32 if self._fp32 else _L.PREC_F16, C.byref(self._ctx))
         if rc < 0:
             msg = self._lib.hdrtv_last_error(self._ctx).decode() if self._ctx else "allocation failed"
             self._lib.hdrtv_destroy(self._ctx)
@@ -205,9 +207,7 @@ class HDRTVNetMI355X:
             raise ValueError("precision must be one of: auto, fp16, fp32, int8-full, int8-mixed")
         if p in ("auto", "fp16"):
             return "fp16"
-        if p in ("int8-full", "int8-mixed"):
-            return p          # INT8 storage, fp16 compute (the reference's own ROCm behaviour)
-        raise ValueError("precision 'fp32' is not implemented by the MI355X backend (fp16 compute only)")
+        return p              # int8-*: INT8 storage, fp16 compute (the reference's own ROCm behaviour); fp32: the fp32 graph
 
     def _resolve_hg_weights(self, model_path):
         """hdrtvnet_torch.py:2016-2042 (the user override is handled by the caller): HG.pt next to the checkpoint, then
@@ -245,12 +245,12 @@ class HDRTVNetMI355X:
             self._chk(self._lib.hdrtv_reserve(self._ctx, h, w), "hdrtv_reserve")
             ch, cw = max(1, h // 4), max(1, w // 4)
             dev = self.device
-            self._gpu_input = torch.empty((1, 3, h, w), dtype=torch.float16, device=dev)
-            self._gpu_cond = torch.empty((1, 3, ch, cw), dtype=torch.float16, device=dev)
+            self._gpu_input = torch.empty((1, 3, h, w), dtype=self._dtype, device=dev)
+            self._gpu_cond = torch.empty((1, 3, ch, cw), dtype=self._dtype, device=dev)
             self._gpu_raw = torch.empty((h, w, 3), dtype=torch.uint8, device=dev)
             self._gpu_u8 = torch.empty((h, w, 3), dtype=torch.uint8, device=dev)
-            self._gpu_out = torch.empty((1, 3, h, w), dtype=torch.float32 if self._use_hg else torch.float16, device=dev)
-            self._gpu_agcm = torch.empty((1, 3, h, w), dtype=torch.float16, device=dev)
+            self._gpu_out = torch.empty((1, 3, h, w), dtype=torch.float32 if (self._use_hg or self._fp32) else torch.float16, device=dev)
+            self._gpu_agcm = torch.empty((1, 3, h, w), dtype=self._dtype, device=dev)
             self._pin_input = torch.empty((h, w, 3), dtype=torch.uint8, pin_memory=True)
             self._pin_output = torch.empty((h, w, 3), dtype=torch.uint8, pin_memory=True)
         self._buf_hw = (h, w)
@@ -318,8 +318,8 @@ class HDRTVNetMI355X:
         """hdrtvnet_torch.py:2301-2346.  Returns ``(out, agcm_out)`` like the eager model; both are
         processor-owned and overwritten by the next call (as HDRTVNetTensorRT's output is)."""
         tensor, cond = input_cond
-        if tensor.dtype != torch.float16 or cond.dtype != torch.float16 or not tensor.is_cuda:
-            raise ValueError("infer expects the fp16 CUDA tensors returned by preprocess()")
+        if tensor.dtype != self._dtype or cond.dtype != self._dtype or not tensor.is_cuda:
+            raise ValueError(f"infer expects the {self.precision if self._fp32 else 'fp16'} CUDA tensors returned by preprocess()")
         h, w = int(tensor.shape[2]), int(tensor.shape[3])
         self._ensure_buffers(h, w)
         tensor = tensor.contiguous()
@@ -329,7 +329,7 @@ class HDRTVNetMI355X:
         if self._use_cuda_graphs and not self._profiling:
             return self._infer_graph(tensor, cond, h, w)
         self._chk(self._lib.hdrtv_infer(self._ctx, self._stream(), tensor.data_ptr(), cond.data_ptr(), h, w,
-                                        self._gpu_out.data_ptr(), _L.F32 if self._use_hg else _L.F16,
+                                        self._gpu_out.data_ptr(), _L.F32 if (self._use_hg or self._fp32) else _L.F16,
                                         self._gpu_agcm.data_ptr()), "hdrtv_infer")
         return self._gpu_out, self._gpu_agcm
 
@@ -344,7 +344,7 @@ class HDRTVNetMI355X:
 
         def launch():
             self._chk(self._lib.hdrtv_infer(self._ctx, self._stream(), self._gpu_input.data_ptr(), self._gpu_cond.data_ptr(), h, w,
-                                            self._gpu_out.data_ptr(), _L.F32 if self._use_hg else _L.F16,
+                                            self._gpu_out.data_ptr(), _L.F32 if (self._use_hg or self._fp32) else _L.F16,
                                             self._gpu_agcm.data_ptr()), "hdrtv_infer")
 
         g = self._graphs.get((h, w))

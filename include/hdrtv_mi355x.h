@@ -48,6 +48,17 @@ const char *hdrtv_version(void);
  * into MFMA operand layouts and uploaded to `device_id`. */
 int hdrtv_create(const void *hr_pack, size_t hr_bytes, const void *hg_pack, size_t hg_bytes,
                  int device_id, hdrtv_ctx **out);
+
+/* The same with the compute precision of HDRTVNetTorch(precision=...) (hdrtvnet_torch.py:1694-1712).
+ * HDRTV_PREC_F16 (= hdrtv_create): f16 storage / fp32 accumulate on the MFMA kernels; tensors at the boundary are f16
+ * (the HG head's output f32).  HDRTV_PREC_F32: the reference's fp32 preset -- the same graph on planar fp32 tensors with
+ * vector-FMA kernels (csrc/fp32_ops.hip; no matrix path exists for fp32 on gfx950, so roughly 1/30 of the f16 frame rate):
+ * hdrtv_preprocess writes f32 `rgb` / `cond`, hdrtv_infer takes them and writes f32 `out` / `agcm_out` (out_dtype must
+ * be HDRTV_F32), the post kernels take dtype HDRTV_F32.  An INT8 checkpoint is refused (HDRTV_EWEIGHTS). */
+#define HDRTV_PREC_F16 0
+#define HDRTV_PREC_F32 1
+int hdrtv_create_ex(const void *hr_pack, size_t hr_bytes, const void *hg_pack, size_t hg_bytes,
+                    int device_id, int precision, hdrtv_ctx **out);
 int hdrtv_destroy(hdrtv_ctx *ctx);
 
 /* 1 if the context was created with HG weights. */
