@@ -212,6 +212,49 @@ def int8_extra(args, dev, dev_frames, steps=20, warmup=3, recipe="full"):
         return {"error": f"{type(exc).__name__}: {exc}"}
 
 
+def fp32_extra(args, dev, steps=10, warmup=2, H=1080, Wd=1920):
+    """The reference's fp32 preset (precision="fp32", csrc/fp32_ops.hip) beside the headline, at 1920x1080 (never `value`):
+    pre + infer + post_rgb48 on fp32 tensors, frames resident in HBM."""
+    import contextlib
+    import torch
+    from hdrtv_mi355x import lib as L
+    from hdrtv_mi355x import weights as W
+    from hdrtv_mi355x.processor import HDRTVNetMI355X
+    try:
+        with contextlib.redirect_stdout(sys.stderr):
+            proc = HDRTVNetMI355X(os.path.join(REPO, "tests", "golden", "hr_weights.hdrw"), device=str(dev), precision="fp32",
+                                  use_hg=True, hg_weights="seeded:1234", warmup_passes=0)
+        proc._ensure_buffers(H, Wd)
+        lib, ctx = proc._lib, proc._ctx
+        frames = [torch.from_numpy(W.synthetic_frame(H, Wd, seed=40 + i, kind="gradient" if i else "noise")).to(dev) for i in range(2)]
+        rgb48 = torch.empty((H, Wd, 3), dtype=torch.uint16, device=dev)
+
+        def step(i):
+            st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            proc._chk(lib.hdrtv_preprocess(ctx, st, frames[i % 2].data_ptr(), H, Wd, proc._gpu_input.data_ptr(), proc._gpu_cond.data_ptr()), "preprocess")
+            proc._chk(lib.hdrtv_infer(ctx, st, proc._gpu_input.data_ptr(), proc._gpu_cond.data_ptr(), H, Wd,
+                                      proc._gpu_out.data_ptr(), L.F32, proc._gpu_agcm.data_ptr()), "infer")
+            proc._chk(lib.hdrtv_post_rgb48(ctx, st, proc._gpu_out.data_ptr(), L.F32, H, Wd, rgb48.data_ptr()), "post_rgb48")
+
+        for i in range(warmup):
+            step(i)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        launches, macs = C.c_int(), C.c_double()
+        lib.hdrtv_infer_stats(ctx, C.byref(launches), C.byref(macs))
+        proc.close()
+        return {"metric": f"frames/sec, HDRTVNet++ precision=fp32 (planar fp32 tensors, vector-FMA kernels) {Wd}x{H}, frames resident in HBM",
+                "value": round(steps / el, 3), "unit": "frames/s", "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
+                "dtype": "f32", "launches_per_frame": launches.value,
+                "tflops_end_to_end": round(2 * macs.value * steps / el / 1e12, 1), "fp32_vector_peak_tflops": 157.3}
+    except Exception as exc:  # noqa: BLE001  (an extra: never take the headline line down with it)
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the N ranks as fresh child processes -- this
     process has not imported torch or touched a GPU, and it never replaces itself with another program -- wait for them and
@@ -603,6 +646,7 @@ def main():
             line["config4_int8"] = int8_extra(args, dev, dev_frames)
             # the reference's default preset is the mixed recipe (gui_config.py: DEFAULT_PRECISION_KEY = "INT8 Mixed (QAT)")
             line["config4_int8_mixed"] = int8_extra(args, dev, dev_frames, recipe="mixed")
+            line["preset_fp32_1080p"] = fp32_extra(args, dev)
         if world == 1 and not args.int8 and not args.no_dispatcher:
             line["dispatcher_host_fed"] = dispatcher_host_fed(args, frames, local_rank, use_hg, max(40, args.steps))
         if world == 1 and not args.no_cpu_baseline:

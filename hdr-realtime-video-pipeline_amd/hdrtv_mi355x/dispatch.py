@@ -122,7 +122,7 @@ class _Mi355xWorker:
         st = C.c_void_p(main.cuda_stream)
         p._chk(p._lib.hdrtv_preprocess(p._ctx, st, self._raw[k].data_ptr(), h, w, p._gpu_input.data_ptr(),
                                        p._gpu_cond.data_ptr()), "hdrtv_preprocess")
-        dt = L.F32 if p._use_hg else L.F16
+        dt = L.F32 if (p._use_hg or getattr(p, "_fp32", False)) else L.F16
         p._chk(p._lib.hdrtv_infer(p._ctx, st, p._gpu_input.data_ptr(), p._gpu_cond.data_ptr(), h, w, p._gpu_out.data_ptr(), dt,
                                   p._gpu_agcm.data_ptr()), "hdrtv_infer")
         p._chk(p._lib.hdrtv_post_rgb48(p._ctx, st, p._gpu_out.data_ptr(), dt, h, w, self._u16[k].data_ptr()), "hdrtv_post_rgb48")

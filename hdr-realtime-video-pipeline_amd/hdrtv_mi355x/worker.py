@@ -37,7 +37,9 @@ def _int8_preset(recipe, suffix):
 PRECISIONS = {
     "FP16": {"precision": "fp16", "model": "original/HR.pt", "model_nohg": "original/HR.pt",
              "hg_weights": "original/HG.pt"},
-    # the six INT8 presets (all of gui_config.py's); "FP32" and the TensorRT-only FP8 presets are not served by this backend
+    "FP32": {"precision": "fp32", "model": "original/HR.pt", "model_nohg": "original/HR.pt",
+             "hg_weights": "original/HG.pt"},
+    # the six INT8 presets (all of gui_config.py's); the TensorRT-only FP8 presets are not served by this backend
     "INT8 Mixed (PTQ)": _int8_preset("mixed", ""),
     "INT8 Mixed (QAT)": _int8_preset("mixed", "_qat"),
     "INT8 Mixed (QAT) (Film)": _int8_preset("mixed", "_qat_film"),
