@@ -14,59 +14,75 @@ namespace {
 // w: [cout group][cin][tap][COT]; bias / bn / gfm vectors padded to the group size.
 // epilogue, in the reference's op order: v = conv + bias; BatchNorm2d(eval) v*bn_s + bn_t (Hallucination_arch.py:24-29);
 // GFM v*s + t + v (Condition_arch.py:573-583); ReLU / LeakyReLU; + residual; store (optionally through PixelShuffle(2)).
-template <int KS, int STRIDE, int COT>
+template <int KS, int STRIDE, int COT, int NPY>
 __global__ __launch_bounds__(256) void conv_f32_kernel(F32ConvParams p)
 {
+    // a lane: NPY vertically adjacent output pixels x COT output channels; a workgroup: 64 columns x 4 NPY rows
     constexpr int KK = KS * KS;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int ox = blockIdx.x * 64 + lane, oy = blockIdx.y * 4 + wv;
+    const int ox = blockIdx.x * 64 + lane, oy0 = (blockIdx.y * 4 + wv) * NPY;
     const int cog = blockIdx.z;
-    const bool live = ox < p.Wo && oy < p.Ho;
-    int off[KK];
-    bool ok[KK];
+    int off[NPY][KK];
+    bool ok[NPY][KK];
 #pragma unroll
-    for (int t = 0; t < KK; ++t) {
-        const int iy = oy * STRIDE + t / KS - p.pad, ix = ox * STRIDE + t % KS - p.pad;
-        ok[t] = live && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
-        off[t] = ok[t] ? iy * p.Wi + ix : 0;
-    }
-    float acc[COT];
+    for (int r = 0; r < NPY; ++r)
 #pragma unroll
-    for (int j = 0; j < COT; ++j) acc[j] = 0.f;
+        for (int t = 0; t < KK; ++t) {
+            const int iy = (oy0 + r) * STRIDE + t / KS - p.pad, ix = ox * STRIDE + t % KS - p.pad;
+            ok[r][t] = ox < p.Wo && oy0 + r < p.Ho && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+            off[r][t] = ok[r][t] ? iy * p.Wi + ix : 0;
+        }
+    float acc[NPY][COT];
+#pragma unroll
+    for (int r = 0; r < NPY; ++r)
+#pragma unroll
+        for (int j = 0; j < COT; ++j) acc[r][j] = 0.f;
     const size_t plane = (size_t)p.Hi * p.Wi;
     const int cin = p.c0 + p.c1;
     const float *__restrict__ w = p.w + (size_t)cog * cin * KK * COT;
     for (int ci = 0; ci < cin; ++ci) {
         const float *__restrict__ xp = ci < p.c0 ? p.x0 + (size_t)ci * plane : p.x1 + (size_t)(ci - p.c0) * plane;
-        float xv[KK];
+        float xv[NPY][KK];
 #pragma unroll
-        for (int t = 0; t < KK; ++t) xv[t] = xp[off[t]];          // off = 0 where the tap is outside: always a valid address
+        for (int r = 0; r < NPY; ++r)
 #pragma unroll
-        for (int t = 0; t < KK; ++t) xv[t] = ok[t] ? xv[t] : 0.f;
+            for (int t = 0; t < KK; ++t) xv[r][t] = xp[off[r][t]];   // off = 0 where the tap is outside: always a valid address
+#pragma unroll
+        for (int r = 0; r < NPY; ++r)
+#pragma unroll
+            for (int t = 0; t < KK; ++t) xv[r][t] = ok[r][t] ? xv[r][t] : 0.f;
         const float *__restrict__ wc = w + (size_t)ci * KK * COT;
 #pragma unroll
         for (int t = 0; t < KK; ++t) {
 #pragma unroll
-            for (int j = 0; j < COT; ++j) acc[j] = fmaf(xv[t], wc[t * COT + j], acc[j]);
+            for (int j = 0; j < COT; ++j) {
+                const float wt = wc[t * COT + j];                     // wave-uniform: one scalar load serves every row
+#pragma unroll
+                for (int r = 0; r < NPY; ++r) acc[r][j] = fmaf(xv[r][t], wt, acc[r][j]);
+            }
         }
     }
-    if (!live) return;
     const size_t oplane = (size_t)p.Ho * p.Wo;
 #pragma unroll
-    for (int j = 0; j < COT; ++j) {
-        const int co = cog * COT + j;
-        if (co >= p.cout) break;
-        float v = __fadd_rn(acc[j], p.bias[co]);
-        if (p.bn_s) v = __fadd_rn(__fmul_rn(v, p.bn_s[co]), p.bn_t[co]);
-        if (p.gfm_s) v = __fadd_rn(__fadd_rn(__fmul_rn(v, p.gfm_s[co]), p.gfm_t[co]), v);
-        if (p.act == 1) v = v > 0.f ? v : 0.f;
-        else if (p.act == 2) v = v >= 0.f ? v : __fmul_rn(v, p.slope);
-        if (p.res) v = __fadd_rn(p.res[(size_t)co * oplane + (size_t)oy * p.Wo + ox], v);
-        if (p.ps) {
-            const int c = co >> 2, dy = (co >> 1) & 1, dx = co & 1;
-            p.y[((size_t)c * (2 * p.Ho) + 2 * oy + dy) * (size_t)(2 * p.Wo) + 2 * ox + dx] = v;
-        } else {
-            p.y[(size_t)co * oplane + (size_t)oy * p.Wo + ox] = v;
+    for (int r = 0; r < NPY; ++r) {
+        const int oy = oy0 + r;
+        if (ox >= p.Wo || oy >= p.Ho) continue;
+#pragma unroll
+        for (int j = 0; j < COT; ++j) {
+            const int co = cog * COT + j;
+            if (co >= p.cout) break;
+            float v = __fadd_rn(acc[r][j], p.bias[co]);
+            if (p.bn_s) v = __fadd_rn(__fmul_rn(v, p.bn_s[co]), p.bn_t[co]);
+            if (p.gfm_s) v = __fadd_rn(__fadd_rn(__fmul_rn(v, p.gfm_s[co]), p.gfm_t[co]), v);
+            if (p.act == 1) v = v > 0.f ? v : 0.f;
+            else if (p.act == 2) v = v >= 0.f ? v : __fmul_rn(v, p.slope);
+            if (p.res) v = __fadd_rn(p.res[(size_t)co * oplane + (size_t)oy * p.Wo + ox], v);
+            if (p.ps) {
+                const int c = co >> 2, dy = (co >> 1) & 1, dx = co & 1;
+                p.y[((size_t)c * (2 * p.Ho) + 2 * oy + dy) * (size_t)(2 * p.Wo) + 2 * ox + dx] = v;
+            } else {
+                p.y[(size_t)co * oplane + (size_t)oy * p.Wo + ox] = v;
+            }
         }
     }
 }
@@ -75,9 +91,12 @@ template <int KS, int STRIDE>
 hipError_t conv_f32_pick(const F32ConvParams &p, hipStream_t s)
 {
     const int cot = p.cot;
-    dim3 grid((p.Wo + 63) / 64, (p.Ho + 3) / 4, (p.cout + cot - 1) / cot);
-    if (cot == 32) hipLaunchKernelGGL((conv_f32_kernel<KS, STRIDE, 32>), grid, dim3(256), 0, s, p);
-    else if (cot == 8) hipLaunchKernelGGL((conv_f32_kernel<KS, STRIDE, 8>), grid, dim3(256), 0, s, p);
+    const int npy = p.Ho >= 16 ? 2 : 1;
+    dim3 grid((p.Wo + 63) / 64, (p.Ho + 4 * npy - 1) / (4 * npy), (p.cout + cot - 1) / cot);
+    if (cot == 32 && npy == 2) hipLaunchKernelGGL((conv_f32_kernel<KS, STRIDE, 32, 2>), grid, dim3(256), 0, s, p);
+    else if (cot == 32) hipLaunchKernelGGL((conv_f32_kernel<KS, STRIDE, 32, 1>), grid, dim3(256), 0, s, p);
+    else if (cot == 8 && npy == 2) hipLaunchKernelGGL((conv_f32_kernel<KS, STRIDE, 8, 2>), grid, dim3(256), 0, s, p);
+    else if (cot == 8) hipLaunchKernelGGL((conv_f32_kernel<KS, STRIDE, 8, 1>), grid, dim3(256), 0, s, p);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

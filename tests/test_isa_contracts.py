@@ -221,13 +221,17 @@ def test_le_rows_step_loops_never_drain_the_dma_queue(tmp_path):
     control-flow path (hipcc turns the wave-uniform row tests into branches).  (3) MFMA counts, no scratch."""
     kernels = _asm("le_rows.hip", tmp_path)
     # kernel -> (MFMAs in the text, counted closing waits of its DMA role(s))
-    want = {"le_rb_rows_kernel": (2 * 18 + 2 * 3, {10}), "le_tail_rows_kernel": (3 * 18 + 3, {12}), "le_head_rows_kernel": (2 * 18 + 3 + 3, {6})}
+    # (the <.., true> instances -- W8A8 layers as fake-quant -- carry the SFT hidden-layer MFMA twice where a layer's input may
+    # or may not be quantised, the mixed recipe: a wave-uniform branch)
+    want = {"le_rb_rows_kernel": ((2 * 18 + 2 * 3, 2 * 18 + 2 * 3 + 4), {10}), "le_tail_rows_kernel": ((3 * 18 + 3, 3 * 18 + 3 + 2), {12}),
+            "le_head_rows_kernel": ((2 * 18 + 3 + 3, 2 * 18 + 3 + 3 + 2), {6})}
     seen = 0
     for name, body in kernels.items():
         key = next((k for k in want if k in name), None)
         if key is None:
             continue
         n_mfma, counted = want[key]
+        n_mfma = n_mfma[1 if "Lb1E" in name else 0]
         assert "scratch_" not in body and "global_load_lds" not in body, name
         assert len(re.findall(r"v_mfma_f32_32x32x16_f16", body)) == n_mfma, (name, len(re.findall(r"v_mfma_f32_32x32x16_f16", body)))
         lines = [ln for ln in body.split("\n") if ln.strip() and not ln.strip().startswith(";")]
@@ -250,7 +254,7 @@ def test_le_rows_step_loops_never_drain_the_dma_queue(tmp_path):
                 waits |= set(w)
         assert waits == counted, (name, sorted(waits), sorted(counted))
         seen += 1
-    assert seen == 3
+    assert seen == 6          # three kernels x {fp16, fake-quant} instances
 
 
 def test_prw_dot3_strip_reads_stay_behind_the_flag_poll(tmp_path):
