@@ -14,90 +14,79 @@ namespace {
 // w: [cout group][cin][tap][COT]; bias / bn / gfm vectors padded to the group size.
 // epilogue, in the reference's op order: v = conv + bias; BatchNorm2d(eval) v*bn_s + bn_t (Hallucination_arch.py:24-29);
 // GFM v*s + t + v (Condition_arch.py:573-583); ReLU / LeakyReLU; + residual; store (optionally through PixelShuffle(2)).
-template <int KS, int STRIDE, int COT, int NPY>
+template <int KS, int STRIDE, int COT>
 __global__ __launch_bounds__(256) void conv_f32_kernel(F32ConvParams p)
 {
-    // a lane: NPY vertically adjacent output pixels x COT output channels; a workgroup: 64 columns x 4 NPY rows
+    // a lane: one output pixel x COT output channels; a workgroup: 64 columns x 4 rows; blockIdx.z: the channel group.
+    // The filter is packed in groups of p.cot (>= COT) channels: a COT-wide kernel reads its slice of a group.
     constexpr int KK = KS * KS;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int ox = blockIdx.x * 64 + lane, oy0 = (blockIdx.y * 4 + wv) * NPY;
-    const int cog = blockIdx.z;
-    int off[NPY][KK];
-    bool ok[NPY][KK];
+    const int ox = blockIdx.x * 64 + lane, oy = blockIdx.y * 4 + wv;
+    const int co0 = blockIdx.z * COT;
+    const bool live = ox < p.Wo && oy < p.Ho;
+    int off[KK];
+    bool ok[KK];
 #pragma unroll
-    for (int r = 0; r < NPY; ++r)
+    for (int t = 0; t < KK; ++t) {
+        const int iy = oy * STRIDE + t / KS - p.pad, ix = ox * STRIDE + t % KS - p.pad;
+        ok[t] = live && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+        off[t] = ok[t] ? iy * p.Wi + ix : 0;
+    }
+    float acc[COT];
 #pragma unroll
-        for (int t = 0; t < KK; ++t) {
-            const int iy = (oy0 + r) * STRIDE + t / KS - p.pad, ix = ox * STRIDE + t % KS - p.pad;
-            ok[r][t] = ox < p.Wo && oy0 + r < p.Ho && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
-            off[r][t] = ok[r][t] ? iy * p.Wi + ix : 0;
-        }
-    float acc[NPY][COT];
-#pragma unroll
-    for (int r = 0; r < NPY; ++r)
-#pragma unroll
-        for (int j = 0; j < COT; ++j) acc[r][j] = 0.f;
+    for (int j = 0; j < COT; ++j) acc[j] = 0.f;
     const size_t plane = (size_t)p.Hi * p.Wi;
-    const int cin = p.c0 + p.c1;
-    const float *__restrict__ w = p.w + (size_t)cog * cin * KK * COT;
+    const int cin = p.c0 + p.c1, PW = p.cot;
+    const float *__restrict__ w = p.w + (size_t)(co0 / PW) * cin * KK * PW + co0 % PW;
+    auto plane_of = [&](int ci) { return ci < p.c0 ? p.x0 + (size_t)ci * plane : p.x1 + (size_t)(ci - p.c0) * plane; };
     for (int ci = 0; ci < cin; ++ci) {
-        const float *__restrict__ xp = ci < p.c0 ? p.x0 + (size_t)ci * plane : p.x1 + (size_t)(ci - p.c0) * plane;
-        float xv[NPY][KK];
+        const float *__restrict__ xp = plane_of(ci);
+        float xv[KK];
 #pragma unroll
-        for (int r = 0; r < NPY; ++r)
+        for (int t = 0; t < KK; ++t) xv[t] = xp[off[t]];              // off = 0 where the tap is outside: always a valid address
 #pragma unroll
-            for (int t = 0; t < KK; ++t) xv[r][t] = xp[off[r][t]];   // off = 0 where the tap is outside: always a valid address
-#pragma unroll
-        for (int r = 0; r < NPY; ++r)
-#pragma unroll
-            for (int t = 0; t < KK; ++t) xv[r][t] = ok[r][t] ? xv[r][t] : 0.f;
-        const float *__restrict__ wc = w + (size_t)ci * KK * COT;
+        for (int t = 0; t < KK; ++t) xv[t] = ok[t] ? xv[t] : 0.f;
+        // (loading channel ci + 1's taps under these FMAs by hand was 5 % slower: the compiler's own schedule and six waves
+        // per SIMD already cover the latency)
+        const float *__restrict__ wc = w + (size_t)ci * KK * PW;
 #pragma unroll
         for (int t = 0; t < KK; ++t) {
 #pragma unroll
-            for (int j = 0; j < COT; ++j) {
-                const float wt = wc[t * COT + j];                     // wave-uniform: one scalar load serves every row
-#pragma unroll
-                for (int r = 0; r < NPY; ++r) acc[r][j] = fmaf(xv[r][t], wt, acc[r][j]);
-            }
+            for (int j = 0; j < COT; ++j) acc[j] = fmaf(xv[t], wc[t * PW + j], acc[j]);   // wave-uniform address: scalar loads
         }
     }
+    if (!live) return;
     const size_t oplane = (size_t)p.Ho * p.Wo;
 #pragma unroll
-    for (int r = 0; r < NPY; ++r) {
-        const int oy = oy0 + r;
-        if (ox >= p.Wo || oy >= p.Ho) continue;
-#pragma unroll
-        for (int j = 0; j < COT; ++j) {
-            const int co = cog * COT + j;
-            if (co >= p.cout) break;
-            float v = __fadd_rn(acc[r][j], p.bias[co]);
-            if (p.bn_s) v = __fadd_rn(__fmul_rn(v, p.bn_s[co]), p.bn_t[co]);
-            if (p.gfm_s) v = __fadd_rn(__fadd_rn(__fmul_rn(v, p.gfm_s[co]), p.gfm_t[co]), v);
-            if (p.act == 1) v = v > 0.f ? v : 0.f;
-            else if (p.act == 2) v = v >= 0.f ? v : __fmul_rn(v, p.slope);
-            if (p.res) v = __fadd_rn(p.res[(size_t)co * oplane + (size_t)oy * p.Wo + ox], v);
-            if (p.ps) {
-                const int c = co >> 2, dy = (co >> 1) & 1, dx = co & 1;
-                p.y[((size_t)c * (2 * p.Ho) + 2 * oy + dy) * (size_t)(2 * p.Wo) + 2 * ox + dx] = v;
-            } else {
-                p.y[(size_t)co * oplane + (size_t)oy * p.Wo + ox] = v;
-            }
+    for (int j = 0; j < COT; ++j) {
+        const int co = co0 + j;
+        if (co >= p.cout) break;
+        float v = __fadd_rn(acc[j], p.bias[co]);
+        if (p.bn_s) v = __fadd_rn(__fmul_rn(v, p.bn_s[co]), p.bn_t[co]);
+        if (p.gfm_s) v = __fadd_rn(__fadd_rn(__fmul_rn(v, p.gfm_s[co]), p.gfm_t[co]), v);
+        if (p.act == 1) v = v > 0.f ? v : 0.f;
+        else if (p.act == 2) v = v >= 0.f ? v : __fmul_rn(v, p.slope);
+        if (p.res) v = __fadd_rn(p.res[(size_t)co * oplane + (size_t)oy * p.Wo + ox], v);
+        if (p.ps) {
+            const int c = co >> 2, dy = (co >> 1) & 1, dx = co & 1;
+            p.y[((size_t)c * (2 * p.Ho) + 2 * oy + dy) * (size_t)(2 * p.Wo) + 2 * ox + dx] = v;
+        } else {
+            p.y[(size_t)co * oplane + (size_t)oy * p.Wo + ox] = v;
         }
     }
 }
 
 template <int KS, int STRIDE>
-hipError_t conv_f32_pick(const F32ConvParams &p, hipStream_t s)
+hipError_t conv_f32_pick(const F32ConvParams &p, int n_cu, hipStream_t s)
 {
-    const int cot = p.cot;
-    const int npy = p.Ho >= 16 ? 2 : 1;
-    dim3 grid((p.Wo + 63) / 64, (p.Ho + 4 * npy - 1) / (4 * npy), (p.cout + cot - 1) / cot);
-    if (cot == 32 && npy == 2) hipLaunchKernelGGL((conv_f32_kernel<KS, STRIDE, 32, 2>), grid, dim3(256), 0, s, p);
-    else if (cot == 32) hipLaunchKernelGGL((conv_f32_kernel<KS, STRIDE, 32, 1>), grid, dim3(256), 0, s, p);
-    else if (cot == 8 && npy == 2) hipLaunchKernelGGL((conv_f32_kernel<KS, STRIDE, 8, 2>), grid, dim3(256), 0, s, p);
-    else if (cot == 8) hipLaunchKernelGGL((conv_f32_kernel<KS, STRIDE, 8, 1>), grid, dim3(256), 0, s, p);
-    else return hipErrorInvalidValue;
+    // 32 channels per lane (one pixel load feeds 32 FMAs) unless that leaves fewer than `few` workgroups per CU (the
+    // low-resolution layers of the HG head): then 8 per lane, four times the workgroups
+    const int sp = ((p.Wo + 63) / 64) * ((p.Ho + 3) / 4);
+    const int few = p.narrow_below > 0 ? p.narrow_below : 3;
+    const int cot = p.cot == 32 && sp * ((p.cout + 31) / 32) >= few * n_cu ? 32 : 8;
+    dim3 grid((p.Wo + 63) / 64, (p.Ho + 3) / 4, (p.cout + cot - 1) / cot);
+    if (cot == 32) hipLaunchKernelGGL((conv_f32_kernel<KS, STRIDE, 32>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv_f32_kernel<KS, STRIDE, 8>), grid, dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
@@ -306,13 +295,13 @@ inline dim3 ew_grid_f32(size_t n)
 
 }  // namespace
 
-hipError_t conv_f32_launch(const F32ConvParams &p, int ks, int stride, hipStream_t s)
+hipError_t conv_f32_launch(const F32ConvParams &p, int ks, int stride, int n_cu, hipStream_t s)
 {
-    if (p.Ho <= 0 || p.Wo <= 0 || p.cout <= 0 || p.c0 <= 0) return hipErrorInvalidValue;
-    if (ks == 1 && stride == 1) return conv_f32_pick<1, 1>(p, s);
-    if (ks == 3 && stride == 1) return conv_f32_pick<3, 1>(p, s);
-    if (ks == 3 && stride == 2) return conv_f32_pick<3, 2>(p, s);
-    if (ks == 1 && stride == 2) return conv_f32_pick<1, 2>(p, s);
+    if (p.Ho <= 0 || p.Wo <= 0 || p.cout <= 0 || p.c0 <= 0 || (p.cot != 8 && p.cot != 32)) return hipErrorInvalidValue;
+    if (ks == 1 && stride == 1) return conv_f32_pick<1, 1>(p, n_cu, s);
+    if (ks == 3 && stride == 1) return conv_f32_pick<3, 1>(p, n_cu, s);
+    if (ks == 3 && stride == 2) return conv_f32_pick<3, 2>(p, n_cu, s);
+    if (ks == 1 && stride == 2) return conv_f32_pick<1, 2>(p, n_cu, s);
     return hipErrorInvalidValue;
 }
 

@@ -289,6 +289,7 @@ const std::pair<const char *, int> k_variants[] = {
     {"final_recompute", 0},  // 1: HG tail recomputes conv1 (hg_final_fused) instead of reading conv1's per-pixel sums
     {"pre_split", 0},        // 1: preprocess as two kernels (unpack, condition resize)
     {"force_ncu", 0},        // > 0: pretend the device has this many CUs (persistent grids)
+    {"f32_narrow_below", 0}, // precision="fp32": workgroups per CU below which conv_f32 runs 8 channels per lane (0 = 3)
 };
 // variants whose non-default settings select kernels that exist in the A/B library only (make AB=1 -> libhdrtv_mi355x_ab.so):
 // superseded schedules kept as bit-identity yardsticks of the shipped ones

@@ -109,7 +109,7 @@ hipError_t metrics_launch(const MetricsParams &p, hipStream_t s);
 int metrics_blocks(int H, int W);
 
 // precision="fp32" (fp32_ops.hip)
-hipError_t conv_f32_launch(const F32ConvParams &p, int ks, int stride, hipStream_t s);
+hipError_t conv_f32_launch(const F32ConvParams &p, int ks, int stride, int n_cu, hipStream_t s);
 hipError_t ew_f32_launch(int op, const float *a, const float *b, const float *c, float *y, size_t n, hipStream_t s);
 hipError_t avgpool3s2_leaky_f32_launch(const float *x, float *y, int C, int H, int W, float slope, hipStream_t s);
 hipError_t instnorm_f32_launch(float *x, const float *gamma, const float *beta, int C, int n, float eps, hipStream_t s);
