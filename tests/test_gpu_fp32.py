@@ -133,12 +133,13 @@ def test_fp32_condition_map_shortcuts(torch_cuda, golden_dir):
         p.close()
 
 
-def test_fp32_at_1920x1080_vs_the_reference(p32_hg, golden_dir, torch_cuda):
-    """BASELINE configs[1]'s size: the fixture tests/golden/gen_golden_fullsize.py took from HDRTVNetTorch (fp32, the aligned fast
-    graph) -- strided samples, dense patches, whole-tensor summaries and the sums of all RGB48 integers."""
+@pytest.mark.parametrize("fixture", ["full_1080x1920_hg_s11.npz", "full_2160x3840_hg_s12.npz"])
+def test_fp32_at_the_baseline_sizes_vs_the_reference(p32_hg, golden_dir, torch_cuda, fixture):
+    """BASELINE configs[1]'s and configs[2]'s sizes: the fixtures tests/golden/gen_golden_fullsize.py took from HDRTVNetTorch
+    (fp32; at 1920x1080 the aligned fast graph) -- strided samples, dense patches and the sums of all RGB48 integers."""
     import time
     from hdrtv_mi355x import weights as W
-    d = np.load(os.path.join(golden_dir, "full_1080x1920_hg_s11.npz"))
+    d = np.load(os.path.join(golden_dir, fixture))
     h, w = (int(v) for v in d["shape"])
     frame = W.synthetic_frame(h, w, seed=int(d["seed"]), kind=str(d["kind"]))
     t, c = p32_hg.preprocess(frame)
