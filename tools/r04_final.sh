@@ -11,6 +11,8 @@ python3 $R/bench.py --int8 --int8-recipe mixed $B --no-cpu-baseline --no-dispatc
 python3 $R/bench.py --int8 --int8-predequantize $B --no-cpu-baseline --no-dispatcher > $O/r04_int8_predeq_bench.json 2> /dev/null; echo "bench int8 predeq $?"
 HDRTV_VARIANTS=le_rows_fq=0 python3 $R/bench.py --int8 $B --no-cpu-baseline --no-dispatcher > $O/r04_int8_fq_off_bench.json 2> /dev/null; echo "bench int8 fq off $?"
 python3 $R/bench.py --height 1080 --width 1920 $B --no-cpu-baseline --no-dispatcher --no-int8-extra > $O/r04_bench_1080p.json 2> /dev/null; echo "bench 1080p $?"
+python3 $R/bench.py --steps 1500 --warmup 5 --no-cpu-baseline --no-dispatcher --no-int8-extra > $O/r04_soak_1500.json 2> /dev/null; echo "soak $?"
+python3 $R/tools/fp32_layers.py --variant f32_narrow_below=3 --top 40 > $O/r04_fp32_layers.txt 2>&1; echo "fp32 layers $?"
 cd /tmp && export TMPDIR=/tmp
 Q="--no-cpu-baseline --no-int8-extra --no-dispatcher"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r04f_kt -o p -- python3 $R/bench.py $B $Q > $O/r04f_kt.json 2> $O/r04f_kt.err; echo "kt $?"
