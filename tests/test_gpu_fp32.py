@@ -176,3 +176,70 @@ def test_fp32_refuses_an_int8_checkpoint(torch_cuda, golden_dir):
     from hdrtv_mi355x.processor import HDRTVNetMI355X
     with pytest.raises(ValueError):
         HDRTVNetMI355X(os.path.join(golden_dir, "hr_int8_full_qat.hdrw"), precision="fp32", use_hg=False, warmup_passes=0)
+
+
+def test_fp32_through_hip_graph_replay_and_the_dispatcher(torch_cuda, golden_dir):
+    """The fp32 graph (186 launches + one D2D copy) captured into a hipGraph replays bit for bit, and a dispatcher worker built
+    with precision="fp32" hands back the RGB48 frames an in-process fp32 processor produces."""
+    import ctypes as C
+    from hdrtv_mi355x import lib as L, weights as W
+    from hdrtv_mi355x.dispatch import FrameDispatcher
+    from hdrtv_mi355x.processor import HDRTVNetMI355X
+    h, w = 272, 480
+    frames = [W.synthetic_frame(h, w, seed=70 + i, kind="gradient" if i % 2 else "noise") for i in range(4)]
+    path = os.path.join(golden_dir, "hr_weights.hdrw")
+    outs, want = [], []
+    for graphs in (False, True):
+        p = HDRTVNetMI355X(path, precision="fp32", use_hg=True, hg_weights="seeded:1234", warmup_passes=0, use_cuda_graphs=graphs)
+        try:
+            t, c = p.preprocess(frames[1])
+            for _ in range(3):
+                out, agcm = p.infer((t, c))
+            torch_cuda.cuda.synchronize()
+            outs.append((out.clone(), agcm.clone()))
+            if not graphs:
+                for f in frames:
+                    o, _ = p.infer(p.preprocess(f))
+                    want.append(_rgb48(p, o, torch_cuda).copy())
+        finally:
+            p.close()
+    assert torch_cuda.equal(outs[0][0], outs[1][0]) and torch_cuda.equal(outs[0][1], outs[1][1])
+    got = {}
+    args = {"model_path": path, "precision": "fp32", "use_hg": True, "hg_weights": "seeded:1234"}
+    with FrameDispatcher(1, h, w, lambda i, v: got.__setitem__(i, v.copy()), init_args=args, devices=[0], slots=2) as d:
+        for f in frames:
+            d.submit(f)
+        d.flush(timeout=120)
+    assert d.exit_codes == [0] and sorted(got) == list(range(len(frames)))
+    for i in range(len(frames)):
+        assert np.array_equal(got[i], want[i]), i
+
+
+def test_create_ex_argument_checks(torch_cuda, golden_dir):
+    """hdrtv_create_ex: a precision it does not know is EINVAL, an INT8 pack with HDRTV_PREC_F32 is EWEIGHTS, and an fp32 context
+    refuses f16 outputs -- each with a message behind hdrtv_last_error."""
+    import ctypes as C
+    from hdrtv_mi355x import lib as L
+    lib = L.load()
+    blob = open(os.path.join(golden_dir, "hr_weights.hdrw"), "rb").read()
+    ctx = C.c_void_p()
+    assert lib.hdrtv_create_ex(blob, len(blob), None, 0, 0, 7, C.byref(ctx)) == L.EINVAL
+    assert b"precision" in lib.hdrtv_last_error(ctx)
+    lib.hdrtv_destroy(ctx)
+    q = open(os.path.join(golden_dir, "hr_int8_full_qat.hdrw"), "rb").read()
+    ctx = C.c_void_p()
+    assert lib.hdrtv_create_ex(q, len(q), None, 0, 0, L.PREC_F32, C.byref(ctx)) == L.EWEIGHTS
+    assert b"INT8" in lib.hdrtv_last_error(ctx)
+    lib.hdrtv_destroy(ctx)
+    ctx = C.c_void_p()
+    assert lib.hdrtv_create_ex(blob, len(blob), None, 0, 0, L.PREC_F32, C.byref(ctx)) == 0
+    assert lib.hdrtv_reserve(ctx, 64, 96) == 0
+    x = torch_cuda.zeros((3, 64, 96), dtype=torch_cuda.float32, device="cuda")
+    cnd = torch_cuda.zeros((3, 16, 24), dtype=torch_cuda.float32, device="cuda")
+    out = torch_cuda.zeros((3, 64, 96), dtype=torch_cuda.float32, device="cuda")
+    st = C.c_void_p(torch_cuda.cuda.current_stream().cuda_stream)
+    assert lib.hdrtv_infer(ctx, st, x.data_ptr(), cnd.data_ptr(), 64, 96, out.data_ptr(), L.F16, None) == L.EINVAL
+    assert lib.hdrtv_infer(ctx, st, x.data_ptr(), cnd.data_ptr(), 64, 96, out.data_ptr(), L.F32, None) == 0
+    torch_cuda.cuda.synchronize()
+    assert bool(torch_cuda.isfinite(out).all())
+    lib.hdrtv_destroy(ctx)
