@@ -545,7 +545,7 @@ def main():
         lib.hdrtv_ring_destroy(ctx)
 
     # ---- roofline of the dominant kernel: HIP events around every launch of hdrtv_infer
-    roof, layers = None, None
+    roof, roof_next, layers = None, None, None
     if rank == 0:
         proc.profile_enable(True)
         agg = {}
@@ -559,16 +559,14 @@ def main():
                 a[0] += ms; a[1] += macs; a[2] += nbytes; a[3] += 1
         proc.profile_enable(False)
         infer_ms = sum(v[0] for v in agg.values()) / nprof
-        kern, (ms, macs, nbytes, n) = max(agg.items(), key=lambda kv: kv[1][0])
-        avg_ms = ms / n
-        tflops = 2.0 * macs / n / (avg_ms * 1e-3) / 1e12
-        # HBM bytes per launch of that kernel from the PMC counters: collected by rocprofv3 in separate
-        # --pmc passes of this same command (tools/pmc_pass.sh, tools/pmc_to_json.py) and committed
-        traffic = None
+        # HBM bytes per launch from the PMC counters: collected by rocprofv3 in separate --pmc passes of this same
+        # command (tools/r04_final.sh, tools/pmc_to_json.py) and committed
         try:
             pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic_int8.json" if args.int8 else "pmc_traffic.json")))["kernels"]
-            # profile tag -> kernel name in the rocprofv3 counter CSV (template argument = store mode, common.h)
-            key = {"conv_prw<nhwc>": "conv_prw_kernel<0, 16>", "conv_prw<ps>": "conv_prw_kernel<1, 16>", "conv_prw<pool>": "conv_prw_kernel<2, 16>",
+        except (OSError, KeyError, ValueError):
+            pmc = {}
+        # profile tag -> kernel name in the rocprofv3 counter CSV (template argument = store mode, common.h)
+        pmc_key = {"conv_prw<nhwc>": "conv_prw_kernel<0, 16>", "conv_prw<ps>": "conv_prw_kernel<1, 16>", "conv_prw<pool>": "conv_prw_kernel<2, 16>",
                    "conv_prw<ps_dot3>": "conv_prw_kernel<4, 16>", "conv_prw8<nhwc>": "conv_prw_kernel<0, 8>", "conv_prw8<ps>": "conv_prw_kernel<1, 8>",
                    "conv_prw8<pool>": "conv_prw_kernel<2, 8>",
                    "conv_prw_i8<nhwc>": "conv_prw_i8_kernel<0, 16>", "conv_prw_i8<ps>": "conv_prw_i8_kernel<1, 16>",
@@ -576,7 +574,10 @@ def main():
                    "conv_prw8_i8<ps>": "conv_prw_i8_kernel<1, 8>", "conv_prw8_i8<pool>": "conv_prw_i8_kernel<2, 8>",
                    "conv_pglds<nhwc>": "conv_pglds_kernel<0>", "conv_pglds<ps>": "conv_pglds_kernel<1>",
                    "conv_pglds<pool>": "conv_pglds_kernel<2>", "conv_pglds<ps_dot3>": "conv_pglds_kernel<4>",
-                   "conv_glds1": "conv_glds1_kernel",
+                   "conv_glds1": "conv_glds1p_kernel",
+                   "le_rb_rows": "le_rb_rows_kernel<3, false>", "le_tail_rows": "le_tail_rows_kernel<3, false>",
+                   "le_head_rows": "le_head_rows_kernel<3, false>", "le_rb_rows<fq>": "le_rb_rows_kernel<3, true>",
+                   "le_tail_rows<fq>": "le_tail_rows_kernel<3, true>", "le_head_rows<fq>": "le_head_rows_kernel<3, true>",
                    "conv_pglds_i8<nhwc>": "conv_pglds_i8_kernel<0, false>", "conv_pglds_i8<ps>": "conv_pglds_i8_kernel<1, false>",
                    "conv_pglds_i8<pool>": "conv_pglds_i8_kernel<2, false>", "conv_pglds_i8<nhwc,c64>": "conv_pglds_i8_kernel<0, true>",
                    "conv_pglds_i8<ps_dot3,c64>": "conv_pglds_i8_kernel<4, true>", "conv1x1_i8": "conv1x1_i8_kernel<false>",
@@ -584,27 +585,40 @@ def main():
                    "conv32s<1,c3+sft>": "conv32s_kernel<true, false, false, false, true, true>",
                    "conv32s<1,sft-i8,i8>": "conv32s_kernel<true, true, true, false, false, false>",
                    "conv32s<1,sft,i8>": "conv32s_kernel<true, true, false, false, false, true>",
-                   "conv32p<4,plain>": "conv32p_kernel<4, false, 8>", "conv32s<1,plain>": "conv32s_kernel<false, false, false, true, false, false>",
-                   "conv3x3s2_preg<192>": "conv3x3s2_preg_kernel<12>", "conv3x3s2_preg<64>": "conv3x3s2_preg_kernel<4>"}.get(kern, kern)
-            if (H, Wd) == (2160, 3840) and use_hg and key in pmc:
-                traffic = pmc[key]["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
+                   "conv32p<4,plain>": "conv32p_kernel<4, false, 8, false, false>", "conv32s<1,plain>": "conv32s_kernel<false, false, false, true, false, false>",
+                   "conv3x3s2_preg<192>": "conv3x3s2_preg_kernel<12>", "conv3x3s2_preg<64>": "conv3x3s2_preg_kernel<4>"}
+
+        def roof_of(kern, ms, macs, nbytes, n):
+            """achieved = ALGORITHMIC flops (or bytes) per launch / average launch time, against the roof that bounds the kernel:
+            its algorithmic intensity vs the machine balance (peak FLOP/s / 8 TB/s)."""
+            avg_ms = ms / n
+            tflops = 2.0 * macs / n / (avg_ms * 1e-3) / 1e12
             traffic = None
-        peak = MFMA_F16_DENSE_PEAK_TFLOPS * (2.0 if "_i8" in kern else 1.0)       # int8 MFMA: twice the K per instruction
-        # which roof bounds this kernel: its algorithmic intensity against the machine balance (peak FLOP/s / 8 TB/s)
-        if 2.0 * macs / max(nbytes, 1.0) >= peak * 1e12 / (HBM_PEAK_GBS * 1e9):
-            roof = {"kernel": kern, "bound": "mfma", "achieved": round(tflops, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(tflops / peak, 4), "traffic": traffic}
-        else:
-            gbs = nbytes / n / (avg_ms * 1e-3) / 1e9
-            roof = {"kernel": kern, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic}
+            key = pmc_key.get(kern, kern)
+            if (H, Wd) == (2160, 3840) and use_hg:
+                hit = [v for k, v in pmc.items() if k == key or k.endswith(key) or (len(key) > 12 and key in k)]
+                if hit:
+                    traffic = hit[0]["hbm_bytes_per_launch"]
+            peak = MFMA_F16_DENSE_PEAK_TFLOPS * (2.0 if "_i8" in kern else 1.0)       # int8 MFMA: twice the K per instruction
+            if 2.0 * macs / max(nbytes, 1.0) >= peak * 1e12 / (HBM_PEAK_GBS * 1e9):
+                r = {"kernel": kern, "bound": "mfma", "achieved": round(tflops, 2), "peak": peak,
+                     "unit": "TFLOP/s", "frac": round(tflops / peak, 4), "traffic": traffic}
+            else:
+                gbs = nbytes / n / (avg_ms * 1e-3) / 1e9
+                r = {"kernel": kern, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic}
+            r.update({"algorithmic_bytes_per_launch": round(nbytes / n), "launches_per_frame": n // nprof,
+                      "avg_launch_ms": round(avg_ms, 4), "share_of_infer_time": round(ms / nprof / infer_ms, 3)})
+            return r
+
+        ranked = sorted(agg.items(), key=lambda kv: -kv[1][0])
+        kern, (ms, macs, nbytes, n) = ranked[0]
+        roof = roof_of(kern, ms, macs, nbytes, n)
         roof.update({
-                "traffic_source": ("profiles/pmc_traffic_int8.json" if args.int8 else "profiles/pmc_traffic.json") + " (rocprofv3 --pmc passes of this command, corrected as MI355X_MICROARCH.md prescribes; not re-measured in this run)" if traffic is not None else None,
-                "algorithmic_bytes_per_launch": round(nbytes / n),
-                "launches_per_frame": n // nprof, "avg_launch_ms": round(avg_ms, 4),
-                "flop_per_launch": 2.0 * macs / n, "share_of_infer_time": round(ms / nprof / infer_ms, 3),
-                "infer_ms_profiled": round(infer_ms, 3)})
+                "traffic_source": ("profiles/pmc_traffic_int8.json" if args.int8 else "profiles/pmc_traffic.json") + " (rocprofv3 --pmc passes of this command, corrected as MI355X_MICROARCH.md prescribes; not re-measured in this run)" if roof["traffic"] is not None else None,
+                "flop_per_launch": 2.0 * macs / n, "infer_ms_profiled": round(infer_ms, 3)})
+        # the same figures for the next kernels by time (never `roofline`: the dominant kernel is the one above)
+        roof_next = [roof_of(k, *v) for k, v in ranked[1:7] if v[1] > 0 or v[2] > 0]
         if args.layers:
             for kname, (kms, kmacs, kb, kn) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
                 print(f"[kernel] {kname:28s} n/frame={kn // nprof:3d} ms/frame={kms / nprof:8.3f} "
@@ -641,6 +655,7 @@ def main():
             "value_is": "u8 frames resident in HBM -> pre_fused + infer + post_rgb48 -> pinned host RGB48 ring (hipMemcpyAsync + hipEvent); "
                         "value_device_only leaves the RGB48 frame in HBM; value_pcie_inclusive also uploads each frame from pinned host memory",
             "roofline": roof,
+            "roofline_next": roof_next,
         }
         if world == 1 and use_hg and not args.int8 and not args.no_int8_extra:
             line["config4_int8"] = int8_extra(args, dev, dev_frames)
