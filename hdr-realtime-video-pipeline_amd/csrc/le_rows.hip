@@ -232,7 +232,10 @@ __device__ __forceinline__ void sft_modulate(const f32x16 &sc, const f32x16 &sh,
 // -> MFMA pairs, a full LDS round trip each).  1: source order is the schedule (sched_barrier per step; for convs without hooks:
 // a hook's VALU would sit between two MFMAs as one block).  2: reads and MFMAs alternate as written, everything else floats
 // (sched_group_barrier; for convs with hooks).  0: hipcc's order.
-template <int AHEAD, int ROWB, int PIN, class Hook>
+#ifndef ROWS_PRIO_MASK
+#define ROWS_PRIO_MASK 4   // which convs raise their wave's priority (s_setprio 1) for the length of their MFMA stream: bit 0 / 1 ResBlock conv1 / conv2,
+#endif                     // 2 / 3 tail up_conv / HR_conv2 + conv_last, 4 / 5 head down_conv1 duty / HR_conv1
+template <int AHEAD, int ROWB, int PIN, int PRIO = 0, class Hook>
 __device__ __forceinline__ f32x16 conv18(const Bank &w, const unsigned (&va)[3][2], int win, Hook hook)
 {
     unsigned a[3][2];
@@ -246,6 +249,7 @@ __device__ __forceinline__ f32x16 conv18(const Bank &w, const unsigned (&va)[3][
         const int tap = st >> 1, ks = st & 1, ky = tap / 3, kx = tap % 3;
         x[st] = lds_rd<f16x8>(a[kx][ks] + ky * ROWB);
     };
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
     if (PIN == 2) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int st = 0; st < AHEAD; ++st) ld(st);
@@ -275,6 +279,7 @@ __device__ __forceinline__ f32x16 conv18(const Bank &w, const unsigned (&va)[3][
         __builtin_amdgcn_sched_group_barrier(0x008, AHEAD, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
     return acc;
 }
 // this lane's fragment addresses for output slot c of a 64-byte-pixel ring row: input slots c .. c + 2 (row 0, base `b`)
@@ -378,7 +383,7 @@ __global__ __launch_bounds__(512) void le_rb_rows_kernel(RowsRbParams p)
             // the SFT pass is a chain of dependent MFMA -> VALU -> MFMA steps, the conv an independent stream that covers its
             // latencies: the pass's two cond MLPs run between the conv's MFMAs, only the modulation waits for the conv
             f32x16 h2, sc2, sh2;
-            const f32x16 acc = conv18<ROWS_AHEAD_H - (FQ ? 1 : 0), Y_ROWB, ROWS_PIN_H>(w1, va, wn.o, [&](int st) __attribute__((always_inline)) {
+            const f32x16 acc = conv18<ROWS_AHEAD_H - (FQ ? 1 : 0), Y_ROWB, ROWS_PIN_H, ROWS_PRIO_MASK & 1>(w1, va, wn.o, [&](int st) __attribute__((always_inline)) {
                 if (RB_ABL & 8) return;
                 if (st == 2) h2 = sft_hidden(s2, c2, fqs2, l31);
                 if (st == 10) sft_heads(s2, h2, t2, sc2, sh2, fqs2);
@@ -484,7 +489,7 @@ __global__ __launch_bounds__(512) void le_rb_rows_kernel(RowsRbParams p)
             const bool row1 = (unsigned)(ro_img + LAG) < (unsigned)H;  // outside the image: conv1's zero padding
             // conv2 on row ro with row ra's whole SFT pass (independent of it) between its MFMAs
             f32x16 h1, sc1, sh1;
-            const f32x16 acc = conv18<ROWS_AHEAD_H + (FQ ? 0 : 2), Y_ROWB, ROWS_PIN_H>(w2, va, wn.o, [&](int st) __attribute__((always_inline)) {
+            const f32x16 acc = conv18<ROWS_AHEAD_H + (FQ ? 0 : 2), Y_ROWB, ROWS_PIN_H, (ROWS_PRIO_MASK >> 1) & 1>(w2, va, wn.o, [&](int st) __attribute__((always_inline)) {
                 if (RB_ABL & 8) { if (st == 13) put_row(vq, ya1.o, ya1.mirrored(), y1); return; }
                 if (st == 1) h1 = sft_hidden(s1, c1, fqs1, l31);
                 if (st == 7) sft_heads(s1, h1, t1, sc1, sh1, fqs1);
@@ -675,7 +680,7 @@ __global__ __launch_bounds__(512) void le_tail_rows_kernel(RowsTailParams p)
             for (int qd = 0; qd < 4; ++qd) sk[qd] = lds_rd<f16x4>(vq[qd] + fa.o);
             const bool row = (unsigned)ra_img < (unsigned)H;
             f32x16 h2, sc2, sh2;
-            const f32x16 acc = conv18<ROWS_AHEAD_H, U_ROWB, ROWS_PIN_H>(wu, va, uw, [&](int st) __attribute__((always_inline)) {
+            const f32x16 acc = conv18<ROWS_AHEAD_H, U_ROWB, ROWS_PIN_H, (ROWS_PRIO_MASK >> 2) & 1>(wu, va, uw, [&](int st) __attribute__((always_inline)) {
                 if (st == 2) h2 = sft_hidden(s2, c2, fqs, l31);
                 if (st == 9) sft_heads(s2, h2, t2, sc2, sh2, fqs);
             });
@@ -739,7 +744,7 @@ __global__ __launch_bounds__(512) void le_tail_rows_kernel(RowsTailParams p)
             for (int ch = 0; ch < 3; ++ch) res[ch] = lds_rd<f16>(rbuf + rs * G::R_SLOTB + ch * 64);
             STAMP(0);
             {   // conv_last + residual -> the three output planes
-                const f32x16 acc = conv18<ROWS_AHEAD_F, Y_ROWB, ROWS_PIN_F>(wl, va, wz.o, [](int) {});
+                const f32x16 acc = conv18<ROWS_AHEAD_F, Y_ROWB, ROWS_PIN_F, (ROWS_PRIO_MASK >> 3) & 1>(wl, va, wz.o, [](int) {});
                 const float o[3] = {acc[0] + bl0, acc[1] + bl1, acc[2] + bl2};
                 const bool ok = cok && r >= y0 && r < y1;
                 f16 *d = p.dst_planar + (size_t)r * W + x0 + cx;
@@ -752,7 +757,7 @@ __global__ __launch_bounds__(512) void le_tail_rows_kernel(RowsTailParams p)
             }
             STAMP(1);
             {   // HR_conv2 + ReLU -> Z
-                const f32x16 acc = conv18<ROWS_AHEAD_F, Y_ROWB, ROWS_PIN_F>(wh, va, wy.o, [](int) {});
+                const f32x16 acc = conv18<ROWS_AHEAD_F, Y_ROWB, ROWS_PIN_F, (ROWS_PRIO_MASK >> 3) & 1>(wh, va, wy.o, [](int) {});
                 f16x4 z[4];
                 const bool in = colz && (unsigned)rb_img < (unsigned)H;     // outside the image: conv_last's zero padding
 #pragma unroll
@@ -917,7 +922,7 @@ __global__ __launch_bounds__(512) void le_head_rows_kernel(RowsHeadParams p)
             STAMP(1);
             if (wave == (s & 3)) {
                 const int hr = hya + s - 3;                            // down_conv1 on half-resolution row s - 3
-                const f32x16 acc = conv18<6, Y_ROWB, ROWS_PIN_F>(wd, vd, wf.o, [](int) {});
+                const f32x16 acc = conv18<6, Y_ROWB, ROWS_PIN_F, (ROWS_PRIO_MASK >> 4) & 1>(wd, vd, wf.o, [](int) {});
                 if (dcol && hr >= (y0 >> 1) && hr < ((y1 + 1) >> 1)) {
                     f16 *d = d1 + (size_t)hr * W1 * 32;
 #pragma unroll
@@ -981,7 +986,7 @@ __global__ __launch_bounds__(512) void le_head_rows_kernel(RowsHeadParams p)
             __builtin_amdgcn_sched_barrier(0);
             STAMP(0);
             if (RB_ABL & 64) { __builtin_amdgcn_s_waitcnt(waitcnt_imm(3 * (DPF - 1), 0)); __builtin_amdgcn_s_barrier(); cd.step(); rb_img += 2; continue; }
-            const f32x16 acc = conv18<ROWS_AHEAD_F, Y_ROWB, ROWS_PIN_F>(wh, va, wy.o, [](int) {});
+            const f32x16 acc = conv18<ROWS_AHEAD_F, Y_ROWB, ROWS_PIN_F, (ROWS_PRIO_MASK >> 5) & 1>(wh, va, wy.o, [](int) {});
             STAMP(1);
             f16x4 z[4];
             const bool in = colf && (unsigned)rb_img < (unsigned)H;        // outside the image: down_conv1's zero padding
