@@ -16,6 +16,11 @@ constexpr int T_HH = T_TH + 2, T_HW = T_TW + 2;
 constexpr int NFRAG = 40;                          // 4 (L1) + 4x8 (L2..L5) + 4 (L6)
 constexpr int NBIAS = 64 * 5 + 32;
 constexpr int STG_ROWB = 128 + 16;                 // per-wave output staging row (64 ch f16 + pad)
+#ifndef TRUNK_SUBS
+#define TRUNK_SUBS 3                               // 4-wave groups per workgroup sharing one copy of the weight fragments (1: two workgroups per CU)
+#endif
+constexpr int SUBS = TRUNK_SUBS, TRUNK_NT = 256 * SUBS;
+constexpr int SIN_B = ((3 * T_HH * (T_HW + 2) * 2 + 15) / 16) * 16, SUB_B = SIN_B + 4 * 32 * STG_ROWB;
 
 __device__ __forceinline__ f32x16 bias_tile_l(const float *b, int lh)
 {
@@ -76,22 +81,24 @@ __device__ __forceinline__ f32x16 qlast_apply(const QLast &q, const f16x8 *bf, i
 }
 
 template <bool Q6>
-__global__ __launch_bounds__(256, 2) void le_cond_trunk_kernel(const f16 *__restrict__ img, int H, int W,
+__global__ __launch_bounds__(TRUNK_NT, SUBS == 1 ? 2 : 1) void le_cond_trunk_kernel(const f16 *__restrict__ img, int H, int W,
                                                                const f16 *__restrict__ wfrag, const float *__restrict__ bias,
                                                                f16 *__restrict__ cond, f16 *__restrict__ cond1, QLast ql)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f16x8 *s_w = reinterpret_cast<f16x8 *>(smem);                               // [NFRAG][64]
     float *s_b = reinterpret_cast<float *>(smem + NFRAG * 64 * 16);              // [NBIAS]
-    f16 *s_in = reinterpret_cast<f16 *>(smem + NFRAG * 64 * 16 + ((NBIAS * 4 + 15) / 16) * 16);   // [3][T_HH][T_HW+2]
-    char *s_stg = reinterpret_cast<char *>(s_in) + ((3 * T_HH * (T_HW + 2) * 2 + 15) / 16) * 16;  // [4 waves][32][STG_ROWB]
+    const int sub = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);      // this thread's 4-wave group: its own tile, patch and staging
+    char *s_sub = smem + NFRAG * 64 * 16 + ((NBIAS * 4 + 15) / 16) * 16 + sub * SUB_B;
+    f16 *s_in = reinterpret_cast<f16 *>(s_sub);                                  // [3][T_HH][T_HW+2]
+    char *s_stg = s_sub + SIN_B;                                                 // [4 waves][32][STG_ROWB]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int tiles_x = (W + T_TW - 1) / T_TW, ntiles = tiles_x * ((H + T_TH - 1) / T_TH);
 
     // persistent: the 40 KiB of weight fragments are staged once per workgroup, not once per 256 pixels
-    for (int e = tid; e < NFRAG * 64; e += 256) s_w[e] = reinterpret_cast<const f16x8 *>(wfrag)[e];
-    for (int e = tid; e < NBIAS; e += 256) s_b[e] = bias[e];
+    for (int e = threadIdx.x; e < NFRAG * 64; e += TRUNK_NT) s_w[e] = reinterpret_cast<const f16x8 *>(wfrag)[e];
+    for (int e = threadIdx.x; e < NBIAS; e += TRUNK_NT) s_b[e] = bias[e];
 
     // this thread's share of a tile's 3 x 10 x 34 input patch, fetched one tile ahead
     constexpr int NE = (3 * T_HH * T_HW + 255) / 256;
@@ -103,14 +110,18 @@ __global__ __launch_bounds__(256, 2) void le_cond_trunk_kernel(const f16 *__rest
             const int e = tid + 256 * i;
             const int c = e / (T_HH * T_HW), r = (e / T_HW) % T_HH, q = e % T_HW;
             const int iy = oy0 - 1 + r, ix = ox0 - 1 + q;
-            const bool ok = e < 3 * T_HH * T_HW && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const bool ok = t < ntiles && e < 3 * T_HH * T_HW && iy >= 0 && iy < H && ix >= 0 && ix < W;
             pre[i] = img[ok ? ((size_t)c * H + iy) * W + ix : 0];
             if (!ok) pre[i] = (f16)0.f;
         }
     };
-    int t = blockIdx.x;
-    if (t < ntiles) fetch(t);
-    for (; t < ntiles; t += gridDim.x) {
+    // the groups of a workgroup walk tiles tb + sub in lockstep (shared barriers); a group past the last tile idles through them
+    const int tstep = (int)gridDim.x * SUBS;
+    int tb = blockIdx.x * SUBS;
+    if (tb < ntiles) fetch(tb + sub);
+    for (; tb < ntiles; tb += tstep) {
+    const int t = tb + sub;
+    const bool active = t < ntiles;
     const int ox0 = (t % tiles_x) * T_TW, oy0 = (t / tiles_x) * T_TH;
     __syncthreads();                                   // layer 1 of the previous tile is done with s_in
 #pragma unroll
@@ -120,7 +131,8 @@ __global__ __launch_bounds__(256, 2) void le_cond_trunk_kernel(const f16 *__rest
         if (e < 3 * T_HH * T_HW) s_in[(c * T_HH + r) * (T_HW + 2) + q] = pre[i];
     }
     __syncthreads();
-    if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
+    if (tb + tstep < ntiles) fetch(tb + tstep + sub);
+    if (!active) continue;
 
     // ---- layer 1: 3x3 conv as a K = 27 (padded 32) GEMM, im2col fragments gathered from LDS
     f16x8 bf[2][4];   // activations of the two 32-pixel groups (rows 2*wave, 2*wave+1) as B fragments
@@ -301,8 +313,7 @@ __global__ __launch_bounds__(256) void cond_tail_kernel(const f16 *__restrict__ 
     }
 }
 
-constexpr int TRUNK_SMEM = NFRAG * 64 * 16 + ((NBIAS * 4 + 15) / 16) * 16 + ((3 * T_HH * (T_HW + 2) * 2 + 15) / 16) * 16 +
-                           4 * 32 * STG_ROWB;
+constexpr int TRUNK_SMEM = NFRAG * 64 * 16 + ((NBIAS * 4 + 15) / 16) * 16 + SUBS * SUB_B;
 
 }  // namespace
 
@@ -320,13 +331,15 @@ hipError_t le_cond_trunk_launch(const f16 *img, int H, int W, const f16 *wfrag, 
         attr_once.done();
     }
     const int ntiles = ((W + T_TW - 1) / T_TW) * ((H + T_TH - 1) / T_TH);
-    const int grid = ntiles < 2 * n_cu ? ntiles : 2 * n_cu;          // two workgroups per CU (LDS: ~60 KiB each)
+    const int per_cu = SUBS == 1 ? 2 : 1;                            // SUBS = 1: two workgroups per CU (LDS: ~60 KiB each)
+    const int want = (ntiles + SUBS - 1) / SUBS;
+    const int grid = want < per_cu * n_cu ? want : per_cu * n_cu;
     QLast ql{nullptr, nullptr, 0.f, 0.f};
     if (q6) {
         ql = QLast{reinterpret_cast<const i32x4 *>(q6->wq), q6->ss, q6->q_inv, q6->q_zoff};
-        hipLaunchKernelGGL(le_cond_trunk_kernel<true>, dim3(grid), dim3(256), TRUNK_SMEM, s, img, H, W, wfrag, bias, cond, cond1, ql);
+        hipLaunchKernelGGL(le_cond_trunk_kernel<true>, dim3(grid), dim3(TRUNK_NT), TRUNK_SMEM, s, img, H, W, wfrag, bias, cond, cond1, ql);
     } else {
-        hipLaunchKernelGGL(le_cond_trunk_kernel<false>, dim3(grid), dim3(256), TRUNK_SMEM, s, img, H, W, wfrag, bias, cond, cond1, ql);
+        hipLaunchKernelGGL(le_cond_trunk_kernel<false>, dim3(grid), dim3(TRUNK_NT), TRUNK_SMEM, s, img, H, W, wfrag, bias, cond, cond1, ql);
     }
     return hipGetLastError();
 }
