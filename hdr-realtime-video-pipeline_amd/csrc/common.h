@@ -112,7 +112,11 @@ struct ConvParams {
     const float *dotw;     // ST_PS_DOT3: [3][dstC] weights of the 1x1 conv fused behind the pixel shuffle
     float *dst_dot;        // ST_PS_DOT3: f32 [Hd][Wd][4] partial sums (x,y,z used)
     void *trash;           // conv_pglds: >= 2 KiB scratch that out-of-image lanes store to (never read)
-    int nt_slow;           // conv_pglds tile order: 0 = Cout-tile fastest (an XCD shares halos), 1 = Cout-tile slowest (shares a weight slab)
+    int nt_slow;           // conv_pglds tile order: 0 = Cout-tile fastest (an XCD shares halos), 1 = Cout-tile slowest (shares a weight slab)    // conv3x3s2_preg<192> only: CondNet2.{2,4} (cond_tail_kernel's chain, le_fused.hip) computed from output channels 0..63 while the
+    // tile is in LDS -- those channels are then not stored.  tail_w: its 12 fragments, tail_b: [64] + [32] bias, tail_out: NHWC 16
+    const f16 *tail_w;
+    const float *tail_b;
+    f16 *tail_out;
 };
 
 // Parameter block of the int8 HG convolutions (conv3x3_pglds_i8.hip, conv_i8_misc.hip).  Activations are int8 codes

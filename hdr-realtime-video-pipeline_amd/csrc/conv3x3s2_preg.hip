@@ -27,6 +27,26 @@ constexpr int PIXB = 128;
 constexpr int A_PIECES = (NPIX + 7) / 8;                            // 71 one-KiB pieces (8 pixels each)
 constexpr int A_BYTES = 72 * 1024;
 constexpr int SMEM = 2 * A_BYTES;
+constexpr int TAIL_OFF = 2 * A_BYTES, TAIL_WB = 12 * 1024, TAIL_SMEM = TAIL_WB + 96 * 4;   // the fused CondNet2 tail's fragments + bias
+
+// (cond_tail_kernel's helpers, le_fused.hip: the fused tail must reproduce its arithmetic bit for bit)
+__device__ __forceinline__ f32x16 tail_bias_tile(const float *b, int lh)
+{
+    f32x16 a;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 v = *reinterpret_cast<const float4 *>(b + 8 * g + 4 * lh);
+        a[4 * g + 0] = v.x; a[4 * g + 1] = v.y; a[4 * g + 2] = v.z; a[4 * g + 3] = v.w;
+    }
+    return a;
+}
+__device__ __forceinline__ f16x8 tail_lrelu_pack(const f32x16 &a, int s)
+{
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (f16)a[8 * s + j];
+    return __builtin_elementwise_max(o, o * (f16)0.1f);
+}
 
 
 template <int NW>   // waves = 16-channel tiles: Cout = 16 * NW
@@ -74,6 +94,13 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3s2_preg_kernel(ConvParams p
 #pragma unroll
     for (int c7 = 0; c7 < 8; ++c7) xo[c7] = l15 * PIXB + ((kg ^ ((c7 + l15) & 7)) << 4);
 
+    // ---- the fused CondNet2 tail (NW = 12 only): its weights ride in LDS behind the two halo buffers
+    const bool tail = NW == 12 && p.tail_w != nullptr;
+    if (NW == 12 && tail) {
+        for (int e = tid; e < 12 * 64; e += NT) reinterpret_cast<f16x8 *>(smem + TAIL_OFF)[e] = reinterpret_cast<const f16x8 *>(p.tail_w)[e];
+        if (tid < 96) reinterpret_cast<float *>(smem + TAIL_OFF + TAIL_WB)[tid] = p.tail_b[tid];
+    }
+
     // ---- prologue: tile 0 landed, tile 1 in flight ---------------------------------------------
     int t = blockIdx.x;
     const int step = gridDim.x;
@@ -115,6 +142,9 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3s2_preg_kernel(ConvParams p
         // ---- epilogue: everyone is done reading this halo buffer -> it becomes the output tile
         __syncthreads();
         char *so = smem + buf * A_BYTES;
+        int eln = lane, etid = tid;                            // (opaque copies: nothing of the epilogue's addressing is hoisted over the MFMA stream)
+        asm volatile("" : "+v"(eln), "+v"(etid));
+        const int el15 = eln & 15, ekg = eln >> 4;
 #pragma unroll
         for (int pt = 0; pt < TH; ++pt) {
             f16x4 o;
@@ -122,19 +152,71 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3s2_preg_kernel(ConvParams p
             o[1] = (f16)act_fast(acc[pt][1] * sc.y + sh.y, aslope);
             o[2] = (f16)act_fast(acc[pt][2] * sc.z + sh.z, aslope);
             o[3] = (f16)act_fast(acc[pt][3] * sc.w + sh.w, aslope);
-            *reinterpret_cast<f16x4 *>(so + (pt * TW + l15) * OUT_ROWB + (wave * 16 + 4 * kg) * 2) = o;
+            *reinterpret_cast<f16x4 *>(so + (pt * TW + el15) * OUT_ROWB + (wave * 16 + 4 * ekg) * 2) = o;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // next tile's halo landed (and older stores retired)
         __syncthreads();
         const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
         const int oy0 = ty * TH, ox0 = tx * TW;
         constexpr int CPP = COUT / 8;
-        for (int e = tid; e < TH * TW * CPP; e += NT) {
-            const int qq = e / CPP, c8 = e % CPP;
-            const int oy = oy0 + qq / TW, ox = ox0 + qq % TW;
-            if (oy < p.Ho && ox < p.Wo)
-                *reinterpret_cast<f16x8 *>(p.dst + ((size_t)oy * p.Wo + ox) * p.dstC + c8 * 8) =
-                    *reinterpret_cast<const f16x8 *>(so + qq * OUT_ROWB + c8 * 16);
+        if (NW == 12 && tail) {
+            if (wave < 4) {
+                // waves 0..3: CondNet2.2 (1x1 64 -> 64, LeakyReLU) + CondNet2.4 (1x1 64 -> 16) on the 32 pixels 32 wave .. of the tile,
+                // B fragments straight from the staged f16 tile (the values cond_tail_kernel would read back from HBM), its MFMA order
+                // (per-lane addresses rebuilt from an opaque copy of the lane id: hoisted out of the tile loop they would be spilled --
+                // the MFMA stream has no register to spare -- and a scratch reload drains the DMA queue)
+                const int oln = eln;
+                const int l31 = oln & 31, lh = oln >> 5;
+                const int qq = 32 * wave + l31;
+                const char *px = so + qq * OUT_ROWB + 16 * lh;
+                f16x8 cur[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) cur[s] = *reinterpret_cast<const f16x8 *>(px + 32 * s);
+                const f16x8 *tw = reinterpret_cast<const f16x8 *>(smem + TAIL_OFF);
+                const float *tb = reinterpret_cast<const float *>(smem + TAIL_OFF + TAIL_WB);
+                // (the two halves of the hidden layer one after the other: with the 72-VGPR filter bank live there is no room for both
+                // accumulator tiles at once; each tile's own accumulation order is cond_tail_kernel's)
+                f16x8 bf[4];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    f32x16 h = tail_bias_tile(tb + 32 * mt, lh);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) h = __builtin_amdgcn_mfma_f32_32x32x16_f16(tw[(4 * mt + s) * 64 + oln], cur[s], h, 0, 0, 0);
+                    bf[2 * mt] = tail_lrelu_pack(h, 0);
+                    bf[2 * mt + 1] = tail_lrelu_pack(h, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                f32x16 o = tail_bias_tile(tb + 64, lh);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) o = __builtin_amdgcn_mfma_f32_32x32x16_f16(tw[(8 + s) * 64 + oln], bf[s], o, 0, 0, 0);
+                const int oy = oy0 + qq / TW, ox = ox0 + qq % TW;
+                if (oy < p.Ho && ox < p.Wo) {
+                    f16x4 lo, hi;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { lo[k] = (f16)o[k]; hi[k] = (f16)o[4 + k]; }
+                    f16 *d = p.tail_out + ((size_t)oy * p.Wo + ox) * 16;
+                    *reinterpret_cast<f16x4 *>(d + 4 * lh) = lo;
+                    *reinterpret_cast<f16x4 *>(d + 8 + 4 * lh) = hi;
+                }
+            } else {
+                // waves 4..11: channels 64..191 of the tile (the first 64 have no other reader)
+                constexpr int CP2 = CPP - 8;
+                for (int e = etid - 256; e < TH * TW * CP2; e += NT - 256) {
+                    const int qq = e / CP2, c8 = 8 + e % CP2;
+                    const int oy = oy0 + qq / TW, ox = ox0 + qq % TW;
+                    if (oy < p.Ho && ox < p.Wo)
+                        *reinterpret_cast<f16x8 *>(p.dst + ((size_t)oy * p.Wo + ox) * p.dstC + c8 * 8) =
+                            *reinterpret_cast<const f16x8 *>(so + qq * OUT_ROWB + c8 * 16);
+                }
+            }
+        } else {
+            for (int e = etid; e < TH * TW * CPP; e += NT) {
+                const int qq = e / CPP, c8 = e % CPP;
+                const int oy = oy0 + qq / TW, ox = ox0 + qq % TW;
+                if (oy < p.Ho && ox < p.Wo)
+                    *reinterpret_cast<f16x8 *>(p.dst + ((size_t)oy * p.Wo + ox) * p.dstC + c8 * 8) =
+                        *reinterpret_cast<const f16x8 *>(so + qq * OUT_ROWB + c8 * 16);
+            }
         }
         __syncthreads();                                       // output tile read out: the buffer is free again
         if (t + 2 * step < ntiles) issue_tile(t + 2 * step, buf);
@@ -147,12 +229,12 @@ hipError_t launch_s2(ConvParams p, int n_cu, hipStream_t s)
     static DevOnce attr_once;   // hipFuncSetAttribute is per (function, device)
     auto kern = conv3x3s2_preg_kernel<NW>;
     if (attr_once.need()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM + (NW == 12 ? TAIL_SMEM : 0));
         if (e != hipSuccess) return e;
         attr_once.done();
     }
     const int ntiles = p.tiles_x * p.tiles_y;
-    hipLaunchKernelGGL(kern, dim3(ntiles < n_cu ? ntiles : n_cu), dim3(64 * NW), SMEM, s, p);
+    hipLaunchKernelGGL(kern, dim3(ntiles < n_cu ? ntiles : n_cu), dim3(64 * NW), SMEM + (NW == 12 ? TAIL_SMEM : 0), s, p);
     return hipGetLastError();
 }
 
@@ -162,7 +244,7 @@ hipError_t launch_s2(ConvParams p, int n_cu, hipStream_t s)
 hipError_t conv3x3s2_preg_launch(ConvParams p, int n_cu, hipStream_t s)
 {
     if (p.c0 != 64 || p.c1 != 0 || p.mode != ST_NHWC || p.res1 || p.res2 || !p.zeros || p.s0_stride < 64 ||
-        p.Cout != p.CoutPad || p.dstC < p.Cout || n_cu < 1)
+        p.Cout != p.CoutPad || p.dstC < p.Cout || n_cu < 1 || (p.tail_w && (p.CoutPad != 192 || !p.tail_b || !p.tail_out)))
         return hipErrorInvalidValue;
     p.tiles_x = (p.Wo + TW - 1) / TW;
     p.tiles_y = (p.Ho + TH - 1) / TH;

@@ -94,3 +94,33 @@ def test_w8a8_layers_as_fake_quant_in_the_fused_kernels(torch_cuda, golden_dir, 
         print(f"  int8-{tag} le_rows_fq={v}: out max {d.max():.3e} mean {d.mean():.3e}; u8 max {du8.max()} MAE {du8.mean():.4f}")
     assert err[1][1] <= 5.0 and err[1][0] <= 0.02                       # the reference's bar
     assert err[1][0] <= 1.15 * err[0][0] + 1e-5 and err[1][1] <= 1.15 * err[0][1] + 0.01
+
+
+def test_cond2_tail_in_the_stride2_heads_epilogue_is_bit_identical(torch_cuda, golden_dir):
+    """CondNet2.2 + .4 computed from conv3x3s2_preg<192>'s staged output tile (variant cond2_fused, the default) against the
+    separate cond_tail launch: the same f16 inputs, fragments, MFMA order and rounding points -> `le.cond2`, CondNet3 / 4's
+    maps (which read the channels that are still stored) and the LE output bit for bit, also where tiles are ragged."""
+    from hdrtv_mi355x import weights as W
+    from hdrtv_mi355x.processor import HDRTVNetMI355X
+    torch = torch_cuda
+    p = HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), use_hg=False, warmup_passes=0)
+    taps = ("le.cond2", "le.cond3", "le.cond4", "le.fea1", "le.out")
+    try:
+        assert p.get_variant("cond2_fused") == 1
+        for (h, w), seed in SIZES + (((60, 100), 48), ((52, 76), 49)):
+            f = W.synthetic_frame(h, w, seed=seed, kind="gradient" if seed % 2 else "noise")
+            res, kernels = [], []
+            for v in (0, 1):
+                p.set_variant("cond2_fused", v)
+                p.profile_enable(True)
+                out, _ = p.infer(p.preprocess(f))
+                kernels.append({k for _, k, *_ in p.profile_read()})
+                p.profile_enable(False)
+                res.append([out.clone()] + [p.tap(t).clone() for t in taps])
+            assert "cond_tail" in kernels[0] and "cond_tail" not in kernels[1], kernels
+            assert any(k.endswith("+tail") for k in kernels[1]), kernels[1]
+            for name, a, b in zip(("out",) + taps, res[0], res[1]):
+                assert torch.isfinite(a).all(), (h, w, name)
+                assert torch.equal(a, b), (h, w, name, int((a != b).sum()))
+    finally:
+        p.close()
