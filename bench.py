@@ -586,7 +586,7 @@ def main():
                    "conv32s<1,sft-i8,i8>": "conv32s_kernel<true, true, true, false, false, false>",
                    "conv32s<1,sft,i8>": "conv32s_kernel<true, true, false, false, false, true>",
                    "conv32p<4,plain>": "conv32p_kernel<4, false, 8, false, false>", "conv32s<1,plain>": "conv32s_kernel<false, false, false, true, false, false>",
-                   "conv3x3s2_preg<192>": "conv3x3s2_preg_kernel<12>", "conv3x3s2_preg<192>+tail": "conv3x3s2_preg_kernel<12>", "conv3x3s2_preg<64>": "conv3x3s2_preg_kernel<4>"}
+                   "conv3x3s2_preg<192>": "conv3x3s2_preg_kernel<12>", "conv3x3s2_preg<192>+tail": "conv3x3s2_preg_kernel<12>", "conv3x3s2_preg<64>": "conv3x3s2_preg_kernel<4>", "conv3x3s2_preg<64>+tail": "conv3x3s2_preg_kernel<4>"}
 
         def roof_of(kern, ms, macs, nbytes, n):
             """achieved = ALGORITHMIC flops (or bytes) per launch / average launch time, against the roof that bounds the kernel:

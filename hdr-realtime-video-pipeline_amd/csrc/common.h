@@ -114,8 +114,12 @@ struct ConvParams {
     void *trash;           // conv_pglds: >= 2 KiB scratch that out-of-image lanes store to (never read)
     int nt_slow;           // conv_pglds tile order: 0 = Cout-tile fastest (an XCD shares halos), 1 = Cout-tile slowest (shares a weight slab)    // conv3x3s2_preg<192> only: CondNet2.{2,4} (cond_tail_kernel's chain, le_fused.hip) computed from output channels 0..63 while the
     // tile is in LDS -- those channels are then not stored.  tail_w: its 12 fragments, tail_b: [64] + [32] bias, tail_out: NHWC 16
+    // conv3x3s2_preg<64>: tail_s != null selects the other fused tail -- ONE 1x1 layer without activation (CondNet3.4, conv_igemm's
+    // arithmetic: K order 16-channel steps from a zero accumulator, then acc * tail_s + tail_b) on ALL 64 output channels, which
+    // are then not stored at all.  tail_w: that layer's packed weights [32][64]
     const f16 *tail_w;
     const float *tail_b;
+    const float *tail_s;
     f16 *tail_out;
 };
 

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3s2_preg_kernel(ConvParams p
     for (int c7 = 0; c7 < 8; ++c7) xo[c7] = l15 * PIXB + ((kg ^ ((c7 + l15) & 7)) << 4);
 
     // ---- the fused CondNet2 tail (NW = 12 only): its weights ride in LDS behind the two halo buffers
-    const bool tail = NW == 12 && p.tail_w != nullptr;
+    const bool tail = NW == 12 && p.tail_w != nullptr && !p.tail_s;
     if (NW == 12 && tail) {
         for (int e = tid; e < 12 * 64; e += NT) reinterpret_cast<f16x8 *>(smem + TAIL_OFF)[e] = reinterpret_cast<const f16x8 *>(p.tail_w)[e];
         if (tid < 96) reinterpret_cast<float *>(smem + TAIL_OFF + TAIL_WB)[tid] = p.tail_b[tid];
@@ -159,7 +159,32 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3s2_preg_kernel(ConvParams p
         const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
         const int oy0 = ty * TH, ox0 = tx * TW;
         constexpr int CPP = COUT / 8;
-        if (NW == 12 && tail) {
+        if (NW == 4 && p.tail_s) {
+            // CondNet3.4 (1x1 64 -> 16, no activation) on the staged tile: each of the four waves takes 32 pixels; the 64-channel map has
+            // no other reader and is not stored.  conv_igemm's arithmetic: four 16-channel k-steps from zero, then acc * scale + shift
+            const int l31 = eln & 31, lh = eln >> 5;
+            const int qq = 32 * wave + l31;
+            const char *px = so + qq * OUT_ROWB + 16 * lh;
+            f32x16 o;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) o[k] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const f16x8 w = *reinterpret_cast<const f16x8 *>(p.tail_w + l31 * 64 + 16 * s + 8 * lh);
+                o = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, *reinterpret_cast<const f16x8 *>(px + 32 * s), o, 0, 0, 0);
+            }
+            const int oy = oy0 + qq / TW, ox = ox0 + qq % TW;
+            if (oy < p.Ho && ox < p.Wo) {
+                f16x4 lo, hi;
+                const float4 s0 = *reinterpret_cast<const float4 *>(p.tail_s + 4 * lh), s1 = *reinterpret_cast<const float4 *>(p.tail_s + 8 + 4 * lh);
+                const float4 b0 = *reinterpret_cast<const float4 *>(p.tail_b + 4 * lh), b1 = *reinterpret_cast<const float4 *>(p.tail_b + 8 + 4 * lh);
+                lo[0] = (f16)(o[0] * s0.x + b0.x); lo[1] = (f16)(o[1] * s0.y + b0.y); lo[2] = (f16)(o[2] * s0.z + b0.z); lo[3] = (f16)(o[3] * s0.w + b0.w);
+                hi[0] = (f16)(o[4] * s1.x + b1.x); hi[1] = (f16)(o[5] * s1.y + b1.y); hi[2] = (f16)(o[6] * s1.z + b1.z); hi[3] = (f16)(o[7] * s1.w + b1.w);
+                f16 *d = p.tail_out + ((size_t)oy * p.Wo + ox) * 16;
+                *reinterpret_cast<f16x4 *>(d + 4 * lh) = lo;
+                *reinterpret_cast<f16x4 *>(d + 8 + 4 * lh) = hi;
+            }
+        } else if (NW == 12 && tail) {
             if (wave < 4) {
                 // waves 0..3: CondNet2.2 (1x1 64 -> 64, LeakyReLU) + CondNet2.4 (1x1 64 -> 16) on the 32 pixels 32 wave .. of the tile,
                 // B fragments straight from the staged f16 tile (the values cond_tail_kernel would read back from HBM), its MFMA order
@@ -244,7 +269,7 @@ hipError_t launch_s2(ConvParams p, int n_cu, hipStream_t s)
 hipError_t conv3x3s2_preg_launch(ConvParams p, int n_cu, hipStream_t s)
 {
     if (p.c0 != 64 || p.c1 != 0 || p.mode != ST_NHWC || p.res1 || p.res2 || !p.zeros || p.s0_stride < 64 ||
-        p.Cout != p.CoutPad || p.dstC < p.Cout || n_cu < 1 || (p.tail_w && (p.CoutPad != 192 || !p.tail_b || !p.tail_out)))
+        p.Cout != p.CoutPad || p.dstC < p.Cout || n_cu < 1 || (p.tail_w && (!p.tail_b || !p.tail_out || (p.tail_s ? p.CoutPad != 64 : p.CoutPad != 192))))
         return hipErrorInvalidValue;
     p.tiles_x = (p.Wo + TW - 1) / TW;
     p.tiles_y = (p.Ho + TH - 1) / TH;

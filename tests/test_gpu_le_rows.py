@@ -106,19 +106,21 @@ def test_cond2_tail_in_the_stride2_heads_epilogue_is_bit_identical(torch_cuda, g
     p = HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), use_hg=False, warmup_passes=0)
     taps = ("le.cond2", "le.cond3", "le.cond4", "le.fea1", "le.out")
     try:
-        assert p.get_variant("cond2_fused") == 1
+        assert p.get_variant("cond2_fused") == 1 and p.get_variant("cond3_fused") == 1
         for (h, w), seed in SIZES + (((60, 100), 48), ((52, 76), 49)):
             f = W.synthetic_frame(h, w, seed=seed, kind="gradient" if seed % 2 else "noise")
             res, kernels = [], []
             for v in (0, 1):
                 p.set_variant("cond2_fused", v)
+                p.set_variant("cond3_fused", v)          # likewise CondNet3.4 (conv_igemm's arithmetic) behind CondNet3.2
                 p.profile_enable(True)
                 out, _ = p.infer(p.preprocess(f))
                 kernels.append({k for _, k, *_ in p.profile_read()})
                 p.profile_enable(False)
                 res.append([out.clone()] + [p.tap(t).clone() for t in taps])
             assert "cond_tail" in kernels[0] and "cond_tail" not in kernels[1], kernels
-            assert any(k.endswith("+tail") for k in kernels[1]), kernels[1]
+            assert {"conv3x3s2_preg<192>+tail", "conv3x3s2_preg<64>+tail"} <= kernels[1], kernels[1]
+            assert "conv_igemm<64,32,1,1>" in kernels[0] and "conv_igemm<64,32,1,1>" not in kernels[1], kernels
             for name, a, b in zip(("out",) + taps, res[0], res[1]):
                 assert torch.isfinite(a).all(), (h, w, name)
                 assert torch.equal(a, b), (h, w, name, int((a != b).sum()))
