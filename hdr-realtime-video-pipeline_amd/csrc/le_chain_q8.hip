@@ -73,19 +73,28 @@ struct TrunkQ8Params {
     f16 *cond, *cond1;
 };
 
-__global__ __launch_bounds__(256, 2) void le_cond_trunk_q8_kernel(TrunkQ8Params p)
+#ifndef TRUNKQ_SUBS
+#define TRUNKQ_SUBS 4          // 4-wave groups per workgroup sharing one copy of the fragments and constants (1: TRUNKQ_PER_CU workgroups per CU)
+#endif
+#ifndef TRUNKQ_PER_CU
+#define TRUNKQ_PER_CU 3        // SUBS = 1: resident workgroups per CU (46 KiB of LDS and 120 VGPRs each)
+#endif
+constexpr int TQ_SUBS = TRUNKQ_SUBS, TQ_NT = 256 * TQ_SUBS;
+constexpr int TQ_SIN_B = ((3 * T_HH * T_PITCH + 15) / 16) * 16, TQ_SUB_B = TQ_SIN_B + 4 * 32 * STG_ROWB;
+__global__ __launch_bounds__(TQ_NT, TQ_SUBS == 1 ? TRUNKQ_PER_CU : 1) void le_cond_trunk_q8_kernel(TrunkQ8Params p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     i32x4 *s_w = reinterpret_cast<i32x4 *>(smem);                                        // [TQ_NFRAG][64]
     float *s_c = reinterpret_cast<float *>(smem + TQ_NFRAG * 1024);                       // [TQ_NCONST]
-    unsigned char *s_in = reinterpret_cast<unsigned char *>(s_c + TQ_NCONST);             // [3][T_HH][T_PITCH] codes
-    char *s_stg = reinterpret_cast<char *>(s_in) + ((3 * T_HH * T_PITCH + 15) / 16) * 16;  // [4 waves][32][STG_ROWB]
+    const int sub = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);               // this thread's 4-wave group: own tile, patch, staging
+    unsigned char *s_in = reinterpret_cast<unsigned char *>(s_c + TQ_NCONST) + sub * TQ_SUB_B;   // [3][T_HH][T_PITCH] codes
+    char *s_stg = reinterpret_cast<char *>(s_in) + TQ_SIN_B;                              // [4 waves][32][STG_ROWB]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int H = p.H, W = p.W;
     const int tiles_x = (W + T_TW - 1) / T_TW, ntiles = tiles_x * ((H + T_TH - 1) / T_TH);
-    for (int e = tid; e < TQ_NFRAG * 64; e += 256) s_w[e] = p.wfrag[e];
-    for (int e = tid; e < TQ_NCONST; e += 256) s_c[e] = p.consts[e];
+    for (int e = threadIdx.x; e < TQ_NFRAG * 64; e += TQ_NT) s_w[e] = p.wfrag[e];
+    for (int e = threadIdx.x; e < TQ_NCONST; e += TQ_NT) s_c[e] = p.consts[e];
 
     constexpr int NE = (3 * T_HH * T_HW + 255) / 256;
     f16 pre[NE];
@@ -97,13 +106,16 @@ __global__ __launch_bounds__(256, 2) void le_cond_trunk_q8_kernel(TrunkQ8Params 
             const int e = tid + 256 * i;
             const int c = e / (T_HH * T_HW), r = (e / T_HW) % T_HH, q = e % T_HW;
             const int iy = oy0 - 1 + r, ix = ox0 - 1 + q;
-            pre_ok[i] = e < 3 * T_HH * T_HW && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            pre_ok[i] = t < ntiles && e < 3 * T_HH * T_HW && iy >= 0 && iy < H && ix >= 0 && ix < W;
             pre[i] = p.img[pre_ok[i] ? ((size_t)c * H + iy) * W + ix : 0];
         }
     };
-    int t = blockIdx.x;
-    if (t < ntiles) fetch(t);
-    for (; t < ntiles; t += gridDim.x) {
+    // the groups of a workgroup walk tiles tb + sub in lockstep (shared barriers); a group past the last tile idles through them
+    const int tstep = (int)gridDim.x * TQ_SUBS;
+    int tb = blockIdx.x * TQ_SUBS;
+    if (tb < ntiles) fetch(tb + sub);
+    for (; tb < ntiles; tb += tstep) {
+        const int t = tb + sub;
         const int ox0 = (t % tiles_x) * T_TW, oy0 = (t / tiles_x) * T_TH;
         __syncthreads();
 #pragma unroll
@@ -116,7 +128,8 @@ __global__ __launch_bounds__(256, 2) void le_cond_trunk_q8_kernel(TrunkQ8Params 
             }
         }
         __syncthreads();
-        if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
+        if (tb + tstep < ntiles) fetch(tb + tstep + sub);
+        if (t >= ntiles) continue;
         char *stg = s_stg + wave * 32 * STG_ROWB;
 #pragma unroll 1
         for (int j = 0; j < 2; ++j) {
@@ -209,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void le_cond_trunk_q8_kernel(TrunkQ8Params 
     }
 }
 
-constexpr int TRUNK_Q8_SMEM = TQ_NFRAG * 1024 + TQ_NCONST * 4 + ((3 * T_HH * T_PITCH + 15) / 16) * 16 + 4 * 32 * STG_ROWB;
+constexpr int TRUNK_Q8_SMEM = TQ_NFRAG * 1024 + TQ_NCONST * 4 + TQ_SUBS * TQ_SUB_B;
 
 // ================================================================================== CondNet2 tail
 // x: int8 codes of CondNet2.2's quantiser, NHWC 64.  Fragments: layer 1 mt*2+kb (4, natural byte order), layer 2 kb (2).
@@ -357,8 +370,9 @@ hipError_t le_cond_trunk_q8_launch(const f16 *img, int H, int W, const TrunkQ8Ar
     for (int i = 0; i < 5; ++i) p.zoff[i] = a.zoff[i];
     p.cond = cond; p.cond1 = cond1;
     const int ntiles = ((W + T_TW - 1) / T_TW) * ((H + T_TH - 1) / T_TH);
-    const int grid = ntiles < 2 * n_cu ? ntiles : 2 * n_cu;
-    hipLaunchKernelGGL(le_cond_trunk_q8_kernel, dim3(grid), dim3(256), TRUNK_Q8_SMEM, s, p);
+    const int per_cu = TQ_SUBS == 1 ? TRUNKQ_PER_CU : 1, want = (ntiles + TQ_SUBS - 1) / TQ_SUBS;
+    const int grid = want < per_cu * n_cu ? want : per_cu * n_cu;
+    hipLaunchKernelGGL(le_cond_trunk_q8_kernel, dim3(grid), dim3(TQ_NT), TRUNK_Q8_SMEM, s, p);
     return hipGetLastError();
 }
 
