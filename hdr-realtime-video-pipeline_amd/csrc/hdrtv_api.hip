@@ -63,7 +63,7 @@ int hdrtv_create_ex(const void *hr_pack, size_t hr_bytes, const void *hg_pack, s
     HIPCHK(c, hipGetDeviceProperties(&prop, device_id));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(c, HDRTV_EINVAL, "device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
-    c->n_cu = prop.multiProcessorCount;
+    c->dev_ncu = c->n_cu = prop.multiProcessorCount;
     // test switch: a huge value gives every persistent kernel one tile per workgroup (tests/test_gpu_parity.py
     // compares that schedule bit for bit with the real one)
     variants_init(c);
@@ -110,6 +110,13 @@ int hdrtv_set_variant(hdrtv_ctx *c, const char *name, int value)
     auto it = c->var.find(name);
     if (it == c->var.end()) return fail(c, HDRTV_EINVAL, "unknown variant %s", name);
     if (!variant_allowed(name, value)) return fail(c, HDRTV_EINVAL, "variant %s = %d needs the A/B library (make AB=1)", name, value);
+    const std::string n(name);
+    // the row kernels take any segment height >= 1 (tests/test_gpu_le_rows.py: test_short_segments_*); 0 or less is a typo
+    if (n == "le_rows_min" && (value < 1 || value > 4096)) return fail(c, HDRTV_EINVAL, "variant le_rows_min must be 1 .. 4096");
+    if (n == "force_ncu") {                 // sizes grids at launch time only (no workspace depends on it): takes effect at once
+        if (value < 0) return fail(c, HDRTV_EINVAL, "variant force_ncu must be >= 0");
+        c->n_cu = value > 0 ? value : c->dev_ncu;
+    }
     it->second = value;
     return HDRTV_OK;
 }
@@ -422,8 +429,9 @@ int hdrtv_ring_create(hdrtv_ctx *c, int slots, int H, int W)
 
 int hdrtv_ring_acquire(hdrtv_ctx *c, int timeout_ms, uint16_t **host_ptr, uint16_t **dev_ptr)
 {
-    if (!c || c->ring.empty()) return fail(c, HDRTV_ESTATE, "ring not created");
+    if (!c) return HDRTV_EINVAL;
     std::unique_lock<std::mutex> lk(c->ring_mu);
+    if (c->ring.empty()) return fail(c, HDRTV_ESTATE, "ring not created");
     const int n = (int)c->ring.size();
     auto pick = [&]() -> int {
         for (int o = 0; o < n; ++o) {
@@ -434,8 +442,10 @@ int hdrtv_ring_acquire(hdrtv_ctx *c, int timeout_ms, uint16_t **host_ptr, uint16
     };
     int i = pick();
     if (i < 0) {
+        // (hdrtv_ring_destroy may run while this waits: an emptied ring ends the wait with an error)
         const bool got = c->ring_cv.wait_for(lk, std::chrono::milliseconds(timeout_ms < 0 ? 0 : timeout_ms),
-                                             [&] { return (i = pick()) >= 0; });
+                                             [&] { return c->ring.empty() || (i = pick()) >= 0; });
+        if (c->ring.empty()) return fail(c, HDRTV_ESTATE, "ring destroyed while waiting for a slot");
         if (!got) return fail(c, HDRTV_ESTATE, "no free ring slot within %d ms", timeout_ms);
     }
     c->ring[i].state = 1;
@@ -466,38 +476,54 @@ int hdrtv_ring_commit(hdrtv_ctx *c, int slot, void *stream)
         if (e == hipSuccess) e = hipEventRecord(ev, (hipStream_t)stream);
         if (e != hipSuccess) return fail(c, HDRTV_EHIP, "ring commit failed: %s", hipGetErrorString(e));
         c->ring[slot].state = 2;
+        c->ring[slot].landed = false;
     }
+    return HDRTV_OK;
+}
+
+// Blocks on a committed slot's event OUTSIDE ring_mu.  The event stays alive meanwhile: the call is counted in ring_waiters,
+// and hdrtv_ring_destroy (also reached through hdrtv_ring_create) waits for that count to drop to zero before it frees anything.
+static int ring_sync_slot(hdrtv_ctx *c, int slot, std::unique_lock<std::mutex> &lk, const char *what)
+{
+    hipEvent_t ev = c->ring[slot].ev;
+    ++c->ring_waiters;
+    lk.unlock();
+    const hipError_t e = hipEventSynchronize(ev);
+    lk.lock();
+    --c->ring_waiters;
+    c->ring_cv.notify_all();
+    if (e != hipSuccess) return fail(c, HDRTV_EHIP, "ring %s failed: %s", what, hipGetErrorString(e));
+    if (slot < (int)c->ring.size() && c->ring[slot].ev == ev && c->ring[slot].state == 2) c->ring[slot].landed = true;
     return HDRTV_OK;
 }
 
 int hdrtv_ring_wait(hdrtv_ctx *c, int slot)
 {
     if (!c) return HDRTV_EINVAL;
-    hipEvent_t ev = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(c->ring_mu);
-        if (slot < 0 || slot >= (int)c->ring.size()) return fail(c, HDRTV_EINVAL, "bad ring slot");
-        // an acquired-but-uncommitted slot has no copy in flight: its event was never recorded (or belongs to the slot's
-        // previous frame) and hipEventSynchronize would return at once on stale pixels
-        if (c->ring[slot].state != 2) return fail(c, HDRTV_ESTATE, "ring slot %d is not committed (state %d)", slot, c->ring[slot].state);
-        ev = c->ring[slot].ev;
-    }
-    const hipError_t e = hipEventSynchronize(ev);          // outside the lock: blocks until the copy has landed
-    if (e != hipSuccess) {
-        std::lock_guard<std::mutex> lk(c->ring_mu);
-        return fail(c, HDRTV_EHIP, "ring wait failed: %s", hipGetErrorString(e));
-    }
-    return HDRTV_OK;
+    std::unique_lock<std::mutex> lk(c->ring_mu);
+    if (slot < 0 || slot >= (int)c->ring.size()) return fail(c, HDRTV_EINVAL, "bad ring slot");
+    // an acquired-but-uncommitted slot has no copy in flight: its event was never recorded (or belongs to the slot's
+    // previous frame) and hipEventSynchronize would return at once on stale pixels
+    if (c->ring[slot].state != 2) return fail(c, HDRTV_ESTATE, "ring slot %d is not committed (state %d)", slot, c->ring[slot].state);
+    return ring_sync_slot(c, slot, lk, "wait");
 }
 
 int hdrtv_ring_release(hdrtv_ctx *c, int slot)
 {
     if (!c) return HDRTV_EINVAL;
     {
-        std::lock_guard<std::mutex> lk(c->ring_mu);
+        std::unique_lock<std::mutex> lk(c->ring_mu);
         if (slot < 0 || slot >= (int)c->ring.size()) return fail(c, HDRTV_EINVAL, "bad ring slot");
         if (c->ring[slot].state == 0) return fail(c, HDRTV_ESTATE, "ring slot %d is already free", slot);
+        // a committed slot released without hdrtv_ring_wait: its device -> host copy may still be in flight, and a free slot
+        // is re-acquired and overwritten by the next frame's post kernel -- the copy is waited for here
+        if (c->ring[slot].state == 2 && !c->ring[slot].landed) {
+            const hipEvent_t ev = c->ring[slot].ev;
+            if (int rc = ring_sync_slot(c, slot, lk, "release")) return rc;
+            if (slot >= (int)c->ring.size() || c->ring[slot].ev != ev) return fail(c, HDRTV_ESTATE, "ring destroyed during release");
+        }
         c->ring[slot].state = 0;
+        c->ring[slot].landed = false;
     }
     c->ring_cv.notify_all();
     return HDRTV_OK;
@@ -506,13 +532,16 @@ int hdrtv_ring_release(hdrtv_ctx *c, int slot)
 int hdrtv_ring_destroy(hdrtv_ctx *c)
 {
     if (!c) return HDRTV_OK;
-    std::lock_guard<std::mutex> lk(c->ring_mu);
+    std::unique_lock<std::mutex> lk(c->ring_mu);
+    c->ring_cv.wait(lk, [&] { return c->ring_waiters == 0; });      // threads inside hipEventSynchronize on a slot's event
     for (auto &sl : c->ring) {
         if (sl.ev) (void)hipEventDestroy(sl.ev);
         if (sl.host) (void)hipHostFree(sl.host);
         if (sl.dev) (void)hipFree(sl.dev);
     }
     c->ring.clear();
+    lk.unlock();
+    c->ring_cv.notify_all();               // a producer blocked in hdrtv_ring_acquire sees the empty ring
     return HDRTV_OK;
 }
 
@@ -562,6 +591,14 @@ int hdrtv_profile_get(hdrtv_ctx *c, int i, const char **layer, const char **kern
     return HDRTV_OK;
 }
 
-const char *hdrtv_last_error(const hdrtv_ctx *c) { return c ? c->err.c_str() : "null context"; }
+// the message of the calling thread's view: copied out under err_mu (fail() may run on the producer and the consumer thread at once)
+const char *hdrtv_last_error(const hdrtv_ctx *c)
+{
+    if (!c) return "null context";
+    static thread_local std::string copy;
+    std::lock_guard<std::mutex> lk(c->err_mu);
+    copy = c->err;
+    return copy.c_str();
+}
 
 }  // extern "C"

@@ -45,6 +45,7 @@ import sys
 import threading
 import time
 import traceback
+import uuid
 from multiprocessing import shared_memory
 
 import numpy as np
@@ -171,7 +172,7 @@ class _SyncBody:
         return None
 
 
-def _worker_main(rank, device_index, make_worker, init_args, geom, task_q, done_q, use_numa):
+def _worker_main(rank, device_index, make_worker, init_args, geom, task_q, done_q, use_numa, shm_name=None):
     shm, ins, outs, body = None, None, None, None
     code = 0
     try:
@@ -180,7 +181,9 @@ def _worker_main(rank, device_index, make_worker, init_args, geom, task_q, done_
         # placement first: affinity, then the slots (created and first-touched HERE, on the GPU's node), then the GPU
         from . import numa
         info = numa.pin_to_gpu_node(device_index, apply=bool(use_numa)) if use_numa is not None else {"device": device_index, "numa_node": -1, "cpus": [], "pinned": False}
-        shm = shared_memory.SharedMemory(create=True, size=slots * (in_b + out_b))
+        # the NAME is the parent's (chosen before this process existed): whatever happens to this process, or to the message
+        # below, the parent can unlink the segment
+        shm = shared_memory.SharedMemory(name=shm_name, create=True, size=slots * (in_b + out_b))
         try:        # the parent unlinks the segment (it outlives this process's views); keep this process's tracker out of it
             from multiprocessing import resource_tracker
             resource_tracker.unregister(shm._name, "shared_memory")
@@ -264,6 +267,8 @@ class FrameDispatcher:
         ctx = mp.get_context("spawn")           # fresh interpreters: nothing GPU-related is inherited
         self._in_b, self._out_b = self.h * self.w * 3, self.h * self.w * 6
         self._shm = [None] * self.n             # created by the workers (first touch on their GPU's node), attached below
+        # ... under names chosen HERE, so that close() can unlink a segment whose worker died between creating it and saying so
+        self._shm_names = [f"hdrtv_{os.getpid()}_{uuid.uuid4().hex[:12]}_{r}" for r in range(self.n)]
         self.placement = [None] * self.n
         self._task = [ctx.Queue() for _ in range(self.n)]
         self._done = ctx.Queue()
@@ -271,7 +276,8 @@ class FrameDispatcher:
         self._stop = False
         self._procs = [ctx.Process(target=_worker_main, daemon=True,
                                    args=(r, devices[r], make_worker, dict(init_args or {}),
-                                         (self.h, self.w, self.slots), self._task[r], self._done, bool(numa))) for r in range(self.n)]
+                                         (self.h, self.w, self.slots), self._task[r], self._done, bool(numa), self._shm_names[r]))
+                       for r in range(self.n)]
         for p in self._procs:
             p.start()
         self._ins, self._outs = [None] * self.n, [None] * self.n
@@ -463,11 +469,21 @@ class FrameDispatcher:
         t = getattr(self, "_thread", None)
         if t is not None:
             t.join(timeout=2.0)
+        # the producer threads copy into the slots: they see _stop within 0.1 s; joined BEFORE the views go away (a copy in
+        # flight would otherwise hold a buffer export, and SharedMemory.close() raises BufferError under it)
+        for t in getattr(self, "_producers", None) or []:
+            t.join(timeout=5.0)
         self._ins = self._outs = None
         gc.collect()
-        for s in getattr(self, "_shm", []):
+        shms = list(getattr(self, "_shm", []))
+        for r, name in enumerate(getattr(self, "_shm_names", [])):
+            s = shms[r] if r < len(shms) else None
             if s is None:
-                continue
+                # never attached (start-up failed, or the worker died before / while reporting): the segment may exist all the same
+                try:
+                    s = shared_memory.SharedMemory(name=name)
+                except (FileNotFoundError, OSError, ValueError):
+                    continue
             try:
                 s.close()
             except Exception:  # noqa: BLE001
@@ -477,6 +493,7 @@ class FrameDispatcher:
             except Exception:  # noqa: BLE001
                 pass
         self._shm = []
+        self._shm_names = []
 
     def __enter__(self):
         return self

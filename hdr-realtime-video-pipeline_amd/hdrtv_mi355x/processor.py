@@ -53,6 +53,38 @@ def _load_state(path_or_state, what):
     return {(k[7:] if k.startswith("module.") else k): v for k, v in payload.items()}
 
 
+def kernel_arithmetic(tag):
+    """The arithmetic class of a launch by its profile tag (csrc/api_graph.inc writes the tags): 'int8' = v_mfma_i32_*_i8,
+    'fq-f16' = activation quantiser in registers + fp16 MFMA on dequantised weights, 'fq-f32' = fp32 fake-quant, 'f16'."""
+    t = tag.lower()
+    if "rows<fq>" in t:
+        return "fq-f16"
+    if t.startswith("cls_block<fq>"):
+        return "fq-f32"
+    if "_i8" in t or ",i8" in t or "<i8" in t or "q8" in t or "-i8" in t:
+        return "int8"
+    return "f16"
+
+
+def summarize_profile(profile):
+    """{class: {"launches", "gmac", "ms", "kernels"}} + "text": one sentence for a bench label, taken from what ran."""
+    out = {k: {"launches": 0, "gmac": 0.0, "ms": 0.0, "kernels": set()} for k in ("int8", "fq-f16", "fq-f32", "f16")}
+    for _layer, kern, ms, macs, _bytes in profile:
+        c = out[kernel_arithmetic(kern)]
+        c["launches"] += 1
+        c["gmac"] += macs / 1e9
+        c["ms"] += ms
+        c["kernels"].add(kern.split("<")[0])
+    total = sum(c["gmac"] for c in out.values()) or 1.0
+    names = {"int8": "on int8 MFMA", "fq-f16": "as fake-quant on fp16 MFMA inside the fused LE row kernels",
+             "fq-f32": "as fp32 fake-quant", "f16": "on fp16 MFMA / vector units"}
+    parts = [f"{100 * c['gmac'] / total:.1f} % of the MACs in {c['launches']} launches {names[k]}" for k, c in out.items() if c["launches"]]
+    res = {k: {"launches": c["launches"], "gmac": round(c["gmac"], 2), "ms": round(c["ms"], 3), "kernels": sorted(c["kernels"])}
+           for k, c in out.items()}
+    res["text"] = "; ".join(parts)
+    return res
+
+
 class HDRTVNetMI355X:
     """MI355X-native backend with the ``HDRTVNetTorch`` surface.
 
@@ -183,7 +215,9 @@ class HDRTVNetMI355X:
         self._pin_input = self._pin_output = None
         self._gpu_out = self._gpu_agcm = self._gpu_u8 = None
         print(f"MI355X device : {self.device}")
-        print(f"MI355X precision: {self.precision}{' (W8A8 layers on int8 MFMA)' if self._is_w8_model else ''}  "
+        # which arithmetic a W8A8 layer runs in depends on the kernel the launch sequence picks for it per resolution
+        # (int8 MFMA, or the fake-quant form inside a fused LE row kernel): `execution_summary()` reports it from a profile
+        print(f"MI355X precision: {self.precision}{' (W8A8 layers kept quantised: predequantize off)' if self._is_w8_model else ''}  "
               f"(HG {('W8A8 on int8 MFMA' if self._hg_int8 else 'on') if self._use_hg else 'off'})")
         if self._warmup_passes > 0:
             self._warmup()
@@ -522,6 +556,12 @@ class HDRTVNetMI355X:
                                                   C.byref(macs), C.byref(nbytes)), "hdrtv_profile_get")
             out.append((layer.value.decode(), kern.value.decode(), ms.value, macs.value, nbytes.value))
         return out
+
+    def execution_summary(self, profile=None):
+        """What the last profiled ``infer()`` ran on, by kernel tag: MACs (and launches) on int8 MFMA, as fake-quant on fp16 MFMA
+        (W8A8 layers inside ``le_*_rows<fq>``), as fp32 fake-quant (the AGCM classifier of a full-QAT checkpoint) and on fp16
+        MFMA.  ``profile`` = ``profile_read()`` of a run with profiling enabled (read here when omitted)."""
+        return summarize_profile(profile if profile is not None else self.profile_read())
 
     def infer_stats(self):
         n, m = C.c_int(), C.c_double()

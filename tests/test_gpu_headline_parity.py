@@ -293,3 +293,68 @@ def test_native_int8_hr_with_int8_hg_vs_fake_quant_oracle(torch_cuda, golden_dir
     e = np.abs(out_np - ref_on_base)
     print(f"  HG head on the device's own LE output: max {e.max():.3e} mean {e.mean():.3e}")
     assert e.max() <= 2e-2 and e.mean() <= 5e-4
+
+
+def test_native_int8_default_path_at_3840x2160(torch_cuda, golden_dir, monkeypatch):
+    """configs[4] AT ITS OWN SIZE, on the kernels ``bench.py``'s ``config4_int8`` times: the shipped full-QAT checkpoint with
+    ``predequantize="off"`` and every variant at its default, feeding the W8A8 HG head, on one 3840x2160 frame -- 64 strips x
+    4 segments of the fused LE row kernels in their INT8 form (the steady state of their rings), 8160-tile int8 HG layers.
+      * against the oracle's fake-quant composite (fp32, ATen convolutions = the reference's CPU arithmetic; ~2 min of
+        CPU): the reference's own bars for a re-quantised graph, float MAE <= 0.02 and u8 MAE <= 5
+        (scripts/validate_tensorrt_sources.py:598-609), and ~2x the level this build measures;
+      * against the one-tile-per-workgroup schedule (variant force_ncu, which the small goldens validate): bit for bit,
+        as test_persistent_schedules_do_not_change_results does for fp16."""
+    from hdrtv_mi355x import weights as W
+    from hdrtv_mi355x.processor import HDRTVNetMI355X
+    from oracle import hdrtvnet_oracle as O
+    torch = torch_cuda
+    h, w = 2160, 3840
+    f = W.synthetic_frame(h, w, seed=12, kind="gradient")
+    path = os.path.join(golden_dir, "hr_int8_full_qat.hdrw")
+    qstate = W.seeded_hg_w8a8_state(1234, integer_zero=False)
+    runs = []
+    for force in (None, "4000000"):
+        if force:
+            monkeypatch.setenv("HDRTV_VARIANTS", "force_ncu=" + force)      # read once, by hdrtv_create
+        else:
+            monkeypatch.delenv("HDRTV_VARIANTS", raising=False)
+        p = HDRTVNetMI355X(path, precision="int8-full", predequantize="off", use_hg=True, hg_weights="seeded-w8a8-minmax:1234",
+                           warmup_passes=0)
+        try:
+            assert p._is_w8_model and p._hg_int8
+            if not force:
+                assert p.get_variant("le_rows") == 1 and p.get_variant("le_rows_fq") == 1     # the defaults
+            p.profile_enable(True)
+            out, agcm = p.infer(p.preprocess(f))
+            kern = [k for _, k, *_ in p.profile_read()]
+            p.profile_enable(False)
+            runs.append((out.clone(), agcm.clone(), p.tap("le.out").clone(), p.tap("le.fea0").clone(), p.postprocess(out).copy(), kern))
+        finally:
+            p.close()
+    kern = runs[0][5]
+    print(f"  kernels of the default run: {sorted(set(kern))}")
+    for stem in ("le_head_rows<", "le_rb_rows<", "le_tail_rows<"):          # the fused kernels in an INT8 form, not the fp16 one
+        assert any(k.startswith(stem) for k in kern), (stem, sorted(set(kern)))
+    assert any(k.startswith("conv_pglds_i8") or k.startswith("conv_prw_i8") for k in kern)
+    for name, a, b in zip(("out", "agcm", "le.out", "le.fea0"), runs[0][:4], runs[1][:4]):
+        assert torch.isfinite(a).all(), name
+        assert torch.equal(a, b), (name, int((a != b).sum()))
+    out_np = runs[0][0].float().cpu().numpy()[0]
+    base = runs[0][2].numpy()
+    u8 = runs[0][4]
+    sd = O.w8a8_state(W.load_pack(path))
+    hq = O.w8a8_state(qstate)
+    O.set_threads(min(16, os.cpu_count() or 1))
+    O.use_backend("aten")
+    try:
+        taps = {}
+        ref, _ = O.hg_composite(sd, hq, *O.preprocess(f), taps)
+    finally:
+        O.use_backend("c")
+    _stats("int8-full LE out 2160x3840 vs fake-quant oracle", base, taps["base"])
+    mx, mean = _stats("int8-full HR + int8 HG 2160x3840, final out vs fake-quant composite", out_np, ref)
+    du8 = np.abs(u8.astype(int) - O.postprocess_u8(ref).astype(int))
+    flips = float((O.hg_mask(base) != taps["mask"]).mean())
+    print(f"  u8: max={du8.max()} MAE={du8.mean():.4f} (reference bar: MAE <= 5); mask flips {flips:.4%}")
+    assert mean <= 0.02 and du8.mean() <= 5.0
+    assert mean <= 1.5e-2

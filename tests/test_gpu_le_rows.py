@@ -22,6 +22,8 @@ def torch_cuda():
     return torch
 
 
+# (270, 486): 9 strips x 28 segments of 10 rows -- under the default le_rows_min = 12 no row kernel runs there (the loop below
+# asserts which sizes do); test_short_segments_* forces them on
 def test_fused_rows_are_bit_identical_to_the_per_layer_kernels(torch_cuda, golden_dir):
     from hdrtv_mi355x import weights as W
     from hdrtv_mi355x.processor import HDRTVNetMI355X
@@ -40,8 +42,8 @@ def test_fused_rows_are_bit_identical_to_the_per_layer_kernels(torch_cuda, golde
                 kernels.append({k for _, k, *_ in p.profile_read()})
                 p.profile_enable(False)
                 res.append([out.clone()] + [p.tap(t).clone() for t in taps])
-            if h * w >= 720 * 1280:
-                assert any(k.startswith("le_") and "rows" in k for k in kernels[1]), kernels[1]
+            if h * w >= 540 * 960:
+                assert {"le_head_rows", "le_rb_rows", "le_tail_rows"} <= kernels[1], ((h, w), kernels[1])
             assert not any("rows" in k for k in kernels[0]), kernels[0]
             for other in res[1:]:
                 for name, a, b in zip(("out",) + taps, res[0], other):
@@ -49,6 +51,41 @@ def test_fused_rows_are_bit_identical_to_the_per_layer_kernels(torch_cuda, golde
                     assert torch.equal(a, b), (h, w, name, int((a != b).sum()))
         with pytest.raises(RuntimeError):
             p.set_variant("no_such_variant", 1)
+    finally:
+        p.close()
+
+
+SHORT = (((270, 486), 47), ((136, 242), 51), ((64, 122), 52), ((62, 124), 53), ((46, 182), 54), ((34, 3840), 55))
+
+
+def test_short_segments_and_narrow_last_strips(torch_cuda, golden_dir):
+    """le_rows_min = 1 (hdrtv_set_variant; a device with fewer CUs or a partitioned one reaches the same shapes): segments of
+    1 .. 10 rows -- shorter than the chains' 6-row lag and their 3-step DMA lead, so the prologue's row clamp, `nsteps` and the
+    masked stores all work on rows outside the segment -- last strips 1 and 2 columns wide, and one-row segments of a
+    3840-wide map.  Every size must run all three row kernels and agree bit for bit with the per-layer kernels."""
+    from hdrtv_mi355x import weights as W
+    from hdrtv_mi355x.processor import HDRTVNetMI355X
+    torch = torch_cuda
+    p = HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), use_hg=False, warmup_passes=0)
+    taps = ("le.fea0", "le.fea1a", "le.fea1", "le.t5", "le.out")
+    try:
+        with pytest.raises(RuntimeError):
+            p.set_variant("le_rows_min", 0)           # validated: 1 .. 4096
+        p.set_variant("le_rows_min", 1)
+        for (h, w), seed in SHORT:
+            f = W.synthetic_frame(h, w, seed=seed, kind="gradient" if seed % 2 else "noise")
+            res, kernels = [], []
+            for v in (0, 1):
+                p.set_variant("le_rows", v)
+                p.profile_enable(True)
+                out, _ = p.infer(p.preprocess(f))
+                kernels.append({k for _, k, *_ in p.profile_read()})
+                p.profile_enable(False)
+                res.append([out.clone()] + [p.tap(t).clone() for t in taps])
+            assert {"le_head_rows", "le_rb_rows", "le_tail_rows"} <= kernels[1], ((h, w), kernels[1])
+            for name, a, b in zip(("out",) + taps, res[0], res[1]):
+                assert torch.isfinite(a).all(), (h, w, name)
+                assert torch.equal(a, b), (h, w, name, int((a != b).sum()))
     finally:
         p.close()
 

@@ -174,6 +174,66 @@ def test_dispatcher_detects_a_dead_worker():
     assert d.exit_codes[1] == 3
 
 
+def _startup_failing_worker(rank, device_index, init_args):
+    """make_worker itself fails on rank 1 -- AFTER _worker_main has created (and announced) its slot segment; rank 0 is slow to
+    come up, so the parent is still collecting messages when the error arrives."""
+    import time
+    if rank == 1:
+        raise RuntimeError("no such device")
+    time.sleep(0.5)
+    return lambda frame, out: None
+
+
+def _dies_before_reporting(rank, device_index, init_args):
+    os._exit(5)
+
+
+def test_dispatcher_startup_failure_leaves_no_segment_behind(monkeypatch):
+    """A failed start-up must not leak /dev/shm segments (224 MB per worker at 4K): the parent chose the names, so close()
+    unlinks every segment -- attached or not, announced or not."""
+    from multiprocessing import shared_memory
+    import pytest
+    from hdrtv_mi355x import dispatch
+    for worker, msg in ((_startup_failing_worker, "no such device"), (_dies_before_reporting, "died with exit code 5")):
+        names = []
+        orig = dispatch.uuid.uuid4
+
+        def tagged():
+            u = orig()
+            names.append(u.hex[:12])
+            return u
+
+        monkeypatch.setattr(dispatch.uuid, "uuid4", tagged)
+        with pytest.raises(RuntimeError, match=msg):
+            dispatch.FrameDispatcher(2, 8, 8, lambda i, v: None, make_worker=worker, init_args={}, slots=2, start_timeout=60)
+        monkeypatch.setattr(dispatch.uuid, "uuid4", orig)
+        assert len(names) == 2
+        for r, tag in enumerate(names):
+            with pytest.raises(FileNotFoundError):
+                shared_memory.SharedMemory(name=f"hdrtv_{os.getpid()}_{tag}_{r}")
+
+
+def test_dispatcher_close_joins_the_producer_threads():
+    """close() with submit_async copies still queued: the producer threads are joined before the slot views are dropped (no
+    BufferError from SharedMemory.close, no exception in a producer thread), workers exit 0."""
+    from hdrtv_mi355x.dispatch import FrameDispatcher
+    import threading
+    errors = []
+    old = threading.excepthook
+    threading.excepthook = lambda a: errors.append(a)
+    try:
+        d = FrameDispatcher(2, 64, 64, lambda i, v: None, make_worker=_standin_worker, init_args={"delay": [0.02, 0.02]}, slots=2)
+        frames = [np.full((64, 64, 3), i, np.uint8) for i in range(40)]
+        for f in frames:
+            d.submit_async(f)
+        d.close()
+        assert all(not t.is_alive() for t in d._producers)
+    finally:
+        threading.excepthook = old
+    assert not errors, errors
+    assert d.exit_codes == [0, 0]
+
+
 def test_dispatcher_keeps_two_frames_in_flight_and_zero_copy_submit():
     """begin / finish bodies: the worker loop begins frame i + 1 before it waits for frame i whenever a frame is queued
     (the overlap the product's worker gets from its three streams), and reserve() / commit() feed slots in place."""
