@@ -72,11 +72,44 @@ constexpr int WI = 64;                  // input columns: 2 halo columns each si
 constexpr int YP = 66;                  // pixel pitch of the Y rings (fragment reads of the two unused lanes run to slot 65)
 constexpr int YN = 6, YPH = YN + 2;     // Y ring rows; physical rows: rows 0 and 1 of a lap are kept a second time behind row 5
 constexpr int X_ROWB = WI * 64, C_ROWB = WI * 32, Y_ROWB = YP * 64;
-constexpr int OUT_ROWB = 64 + 16, STRIP = 32 * OUT_ROWB;
 constexpr int BIG = 168;                // multiple of every ring size: keeps (row + BIG) % ring non-negative
 constexpr int SFT_TILE_B = 2 * 2 * 16 * 4;   // bytes of one SFT layer's two head bias tiles (2 lane halves x 16 floats each)
 
-__device__ __forceinline__ int swz32(int v) { return (v >> 2) & 3; }
+// ---- ring layouts.  A ring row holds one pixel per SLOT (64 or 32 bytes) in 16-byte CHUNKS (8 channels); where a pixel's chunk k
+// lies is a per-ring choice -- slot(c) = c with bit 0 flipped by a parity of higher bits of c, chunk position = k ^ s(c), s two
+// parities of bits of c -- made so that EVERY LDS instruction of the ring's readers and writers is free of bank conflicts
+// (tools/lds_bank_model.py restates MI355X_MICROARCH.md's lane groups and bank functions; tools/lds_ring_layouts.py searches the
+// layouts and prints the conflict cycles of every access below: 0).  The accesses (16 bytes per lane throughout):
+//   R1  MFMA fragment reads, lane (l31, lh) reads chunk 2 ks + lh of pixel c0 + l31 + kx (c0 = 0 / 32, kx = 0..2)  [ds_read_b128: 4 x 16 lanes]
+//   S2  the same at stride 2, pixel 2 l31 + kx (the head's down_conv1)
+//   W1  chunk writes / reads, lane (l31, lh) chunk q + ... of pixel c0 + l31 (+ 0..2)                              [ds_write_b128: 8 x 8 lanes]
+//   W2  chunk writes / reads at stride 2, pixel 2 l31 + gh (the tail's PixelShuffle phases)
+// Round 4's layout (s = bits 2..3 of c for every ring) served R1 only: accumulator-layout 8-byte writes and reads were 2-way
+// conflicts by construction (the 16 lanes of a ds_write_b64 group share lh, i.e. use half of the 8-byte slots), the stride-2
+// accesses 2-way, the output strips 2- and 3-way: SQ_LDS_BANK_CONFLICT 23 - 30 % of SQ_LDS_IDX_ACTIVE (profiles/r04_sq_lds_breakdown.txt).
+__device__ __forceinline__ int par(int v) { return __builtin_popcount((unsigned)v) & 1; }
+template <int A0, int S0, int S1> struct Lay64 {            // 64-byte pixels (32 channels f16)
+    static_assert((A0 & 3) == 0, "slot() must be an involution");
+    static __device__ __forceinline__ int slot(int c) { return c ^ par(c & A0); }
+    static __device__ __forceinline__ int sw(int c) { return par(c & S0) | (par(c & S1) << 1); }
+    static __device__ __forceinline__ unsigned at(int c, int k) { return (unsigned)((slot(c) << 6) | ((k ^ sw(c)) << 4)); }
+    // LDS-DMA piece (16 slots; lane i lands at byte 16 i of the piece): the lane's SOURCE pixel and its byte offset in the source row
+    static __device__ __forceinline__ int src_px(int piece, int lane) { return slot(16 * piece + (lane >> 2)); }
+    static __device__ __forceinline__ unsigned src_off(int piece, int lane) { const int c = src_px(piece, lane); return (unsigned)(c * 64 + (((lane & 3) ^ sw(c)) << 4)); }
+};
+template <int A0, int S0> struct Lay32 {                    // 32-byte pixels (the 16-channel condition maps)
+    static_assert((A0 & 7) == 0, "slot() must be an involution");
+    static __device__ __forceinline__ int slot(int c) { return c ^ par(c & A0); }
+    static __device__ __forceinline__ unsigned at(int c, int h) { return (unsigned)((slot(c) << 5) | ((h ^ par(c & S0)) << 4)); }
+    static __device__ __forceinline__ int src_px(int piece, int lane) { return slot(32 * piece + (lane >> 1)); }
+    static __device__ __forceinline__ unsigned src_off(int piece, int lane) { const int c = src_px(piece, lane); return (unsigned)(c * 32 + (((lane & 1) ^ par(c & S0)) << 4)); }
+};
+using LStd = Lay64<0, 4, 10>;        // R1 + W1: every stride-1 ring (x, Y1, Y2, u, Z, the head's Y)
+using LTailY = Lay64<4, 3, 8>;       // R1 + W2: the tail's Y ring (written per PixelShuffle phase, read by HR_conv2)
+using LTailF = Lay64<4, 8, 16>;      // W2: the tail's fea0 ring (DMA in, read per PixelShuffle phase)
+using LHeadF = Lay64<4, 9, 18>;      // W1 + S2: the head's fea0 ring (written by HR_conv1, read by down_conv1 at stride 2)
+using LCond = Lay32<0, 8>;           // condition ring read at stride 1
+using LCondT = Lay32<8, 16>;         // ... at stride 2 (the tail)
 
 // LDS reads while an LDS-DMA is in flight: hipcc's waitcnt pass puts s_waitcnt vmcnt(0) in front of every LDS load that
 // carries NO alias metadata -- in practice loads of HIP's struct vector types (float4 ...), which are aggregate copies
@@ -119,6 +152,35 @@ __device__ __forceinline__ f16x4 bias_cvt4(const f32x16 &acc, int qd, const f32x
 }
 __device__ __forceinline__ f16x4 zero4() { return f16x4{(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f}; }
 __device__ __forceinline__ f32x16 zero16() { return f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; }
+
+// ---- accumulator layout <-> chunk layout.  A 32x32 MFMA leaves lane (l31, lh) with channels 8 qd + 4 lh .. + 3 of pixel l31
+// (QUADS, 8 bytes each); memory and the MFMA B operand want 16-byte CHUNKS (8 consecutive channels).  The two lanes of a pixel
+// trade halves with v_permlane32_swap (lanes 32-63 of the first register <-> lanes 0-31 of the second; tools/permlane_probe.hip):
+// four swaps turn the four quads into chunks lh and 2 + lh -- exactly the fragment of k-step 0 / 1 -- and the same four turn them
+// back.  No LDS round trip, no 8-byte LDS access.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void xhalf(unsigned &a, unsigned &b)
+{
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+}
+__device__ __forceinline__ void quads_to_chunks(const f16x4 (&y)[4], f16x8 &c0, f16x8 &c1)      // c0 = chunk lh, c1 = chunk 2 + lh
+{
+    u32x2 q0 = __builtin_bit_cast(u32x2, y[0]), q1 = __builtin_bit_cast(u32x2, y[1]), q2 = __builtin_bit_cast(u32x2, y[2]), q3 = __builtin_bit_cast(u32x2, y[3]);
+    unsigned a0 = q0[0], a1 = q0[1], b0 = q1[0], b1 = q1[1], d0 = q2[0], d1 = q2[1], e0 = q3[0], e1 = q3[1];
+    xhalf(a0, b0); xhalf(a1, b1); xhalf(d0, e0); xhalf(d1, e1);
+    c0 = __builtin_bit_cast(f16x8, u32x4{a0, a1, b0, b1});
+    c1 = __builtin_bit_cast(f16x8, u32x4{d0, d1, e0, e1});
+}
+__device__ __forceinline__ void chunks_to_quads(const f16x8 &c0, const f16x8 &c1, f16x4 (&y)[4])
+{
+    const u32x4 u = __builtin_bit_cast(u32x4, c0), v = __builtin_bit_cast(u32x4, c1);
+    unsigned a0 = u[0], a1 = u[1], b0 = u[2], b1 = u[3], d0 = v[0], d1 = v[1], e0 = v[2], e1 = v[3];
+    xhalf(a0, b0); xhalf(a1, b1); xhalf(d0, e0); xhalf(d1, e1);
+    y[0] = __builtin_bit_cast(f16x4, u32x2{a0, a1}); y[1] = __builtin_bit_cast(f16x4, u32x2{b0, b1});
+    y[2] = __builtin_bit_cast(f16x4, u32x2{d0, d1}); y[3] = __builtin_bit_cast(f16x4, u32x2{e0, e1});
+}
 
 __device__ __forceinline__ f16x8 lrelu_pack16(const f32x16 &a, int s)
 {
@@ -282,35 +344,32 @@ __device__ __forceinline__ f32x16 conv18(const Bank &w, const unsigned (&va)[3][
     if (PRIO) __builtin_amdgcn_s_setprio(0);
     return acc;
 }
-// this lane's fragment addresses for output slot c of a 64-byte-pixel ring row: input slots c .. c + 2 (row 0, base `b`)
-__device__ __forceinline__ void frag_addr(unsigned (&va)[3][2], unsigned b, int c, int lh)
+// this lane's fragment addresses for output slot c of a ring row in layout L: input slots c .. c + 2 (row 0, base `b`)
+template <class L> __device__ __forceinline__ void frag_addr(unsigned (&va)[3][2], unsigned b, int c, int lh, int stride = 1)
 {
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) va[kx][ks] = b + (unsigned)((c + kx) * 64 + ((((ks << 1) | lh) ^ swz32(c + kx)) << 4));
+        for (int ks = 0; ks < 2; ++ks) va[kx][ks] = b + L::at(stride * c + kx, (ks << 1) | lh);
 }
-// the four channel quads of slot c of a 64-byte-pixel ring row: quad qd (channels 8 qd + 4 lh ..) at vq[qd]
-__device__ __forceinline__ void quad_addr(unsigned (&vq)[4], unsigned b, int c, int lh)
+// this lane's two chunks (lh and 2 + lh, the pair quads_to_chunks produces) of slot c
+template <class L> __device__ __forceinline__ void chunk_addr(unsigned (&vc)[2], unsigned b, int c, int lh)
 {
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) vq[qd] = b + (unsigned)(c * 64 + ((qd ^ swz32(c)) << 4) + 8 * lh);
+    vc[0] = b + L::at(c, lh); vc[1] = b + L::at(c, 2 + lh);
 }
-// One pixel's 16 channels of this lane into a Y ring row at byte offset `off` (and into the row's second copy)
-__device__ __forceinline__ void put_row(const unsigned (&vq)[4], int off, bool mirror, const f16x4 (&y)[4])
+// One pixel's 16 channels of this lane (accumulator layout) into a Y ring row at byte offset `off` (and into the row's second copy)
+__device__ __forceinline__ void put_row(const unsigned (&vc)[2], int off, bool mirror, const f16x4 (&y)[4])
 {
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) lds_wr(vq[qd] + (unsigned)off, y[qd]);
-    if (mirror) {
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) lds_wr(vq[qd] + (unsigned)(off + YN * Y_ROWB), y[qd]);
-    }
+    f16x8 c0, c1;
+    quads_to_chunks(y, c0, c1);
+    lds_wr(vc[0] + (unsigned)off, c0); lds_wr(vc[1] + (unsigned)off, c1);
+    if (mirror) { lds_wr(vc[0] + (unsigned)(off + YN * Y_ROWB), c0); lds_wr(vc[1] + (unsigned)(off + YN * Y_ROWB), c1); }
 }
-// lane constants of the LDS-DMA pieces of a 64-byte-pixel row (piece = 16 pixels) and of a 32-byte-pixel row (32 pixels):
-// byte offset inside the row with the chunk swizzle on the SOURCE side, so that the piece lands in the layout the readers expect
-__device__ __forceinline__ unsigned piece64_lane(int piece, int lane) { const int px = 16 * piece + (lane >> 2); return (unsigned)(px * 64 + (((lane & 3) ^ swz32(px)) << 4)); }
-__device__ __forceinline__ unsigned piece32_lane(int piece, int lane) { const int px = 32 * piece + (lane >> 1); return (unsigned)(px * 32 + (((lane & 1) ^ ((px >> 3) & 1)) << 4)); }
-__device__ __forceinline__ unsigned cond_addr(unsigned b, int c, int lh) { return b + (unsigned)(c * 32 + ((lh ^ ((c >> 3) & 1)) << 4)); }
+// ... and back: slot c of a ring row at byte offset `off` as the lane's four quads
+__device__ __forceinline__ void get_row(const unsigned (&vc)[2], int off, f16x4 (&y)[4])
+{
+    chunks_to_quads(lds_rd<f16x8>(vc[0] + (unsigned)off), lds_rd<f16x8>(vc[1] + (unsigned)off), y);
+}
 
 // ------------------------------------------------------------------------------------------------------------------------
 // Fused ResBlock_with_SFT.  Roles: B (waves 0-3) conv1 + sft2 -- LDS to LDS, not one memory operation; C (waves 4-7) the
@@ -320,8 +379,7 @@ template <int DPF> struct RbGeo {
     static constexpr int XR = 2 * DPF + LAG + 2;             // x ring: fetched 2 DPF rows ahead, read again LAG rows later (the residual)
     static constexpr int CR = 2 * DPF + LAG;                 // condition ring: last read by sft2, 3 rows behind sft1
     static constexpr int OFF_X = 0, OFF_C = OFF_X + XR * X_ROWB, OFF_Y1 = OFF_C + CR * C_ROWB, OFF_Y2 = OFF_Y1 + YPH * Y_ROWB;
-    static constexpr int OFF_ST = OFF_Y2 + YPH * Y_ROWB;
-    static constexpr int OFF_B = OFF_ST + 4 * STRIP;         // the head tiles of sft2, then of sft1, then conv2's bias
+    static constexpr int OFF_B = OFF_Y2 + YPH * Y_ROWB;      // the head tiles of sft2, then of sft1, then conv2's bias
     static constexpr int SMEM = OFF_B + 2 * SFT_TILE_B + 128;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
     static_assert(BIG % XR == 0 && BIG % CR == 0 && BIG % YN == 0, "BIG");
@@ -351,7 +409,7 @@ __global__ __launch_bounds__(512) void le_rb_rows_kernel(RowsRbParams p)
     const int g = wave & 3, gr = g >> 1, gh = g & 1;                   // this wave's 32-pixel group: row gr of the step's pair, column half gh
     const int cx = 32 * gh + l31;                                      // this lane's pixel slot in its group's ring rows
     unsigned va[3][2];                                                 // conv fragments: output slot cx reads input slots cx .. cx + 2
-    frag_addr(va, sm, cx, lh);
+    frag_addr<LStd>(va, sm, cx, lh);
     const bool colfull = x0 >= 2 && x0 + 62 <= W;                      // no column of the strip's halo lies outside the image
 
     if (wave < 4) {
@@ -363,9 +421,9 @@ __global__ __launch_bounds__(512) void le_rb_rows_kernel(RowsRbParams p)
         f32x4 bq[4];
         load_bias(bq, p.b1, lh);
         const unsigned t2 = sm + G::OFF_B + 64 * lh;
-        unsigned vq[4];                                                // Y2 write: channel quad qd of slot cx
-        quad_addr(vq, sm, cx, lh);
-        const unsigned vc2 = cond_addr(sm, cx + 1, lh);                // Y2 slot cx = image column x0 - 1 + cx = condition slot cx + 1
+        unsigned vq[2];                                                // Y2 write: this lane's two chunks of slot cx
+        chunk_addr<LStd>(vq, sm, cx, lh);
+        const unsigned vc2 = sm + LCond::at(cx + 1, lh);               // Y2 slot cx = image column x0 - 1 + cx = condition slot cx + 1
         const bool col2 = (unsigned)(x0 - 1 + cx) < (unsigned)W;
         // ring rows of step s: conv1 + sft2 on rb = 2 s - 3 + gr
         Cur<G::OFF_C, CR, C_ROWB> cb(gr - 3);
@@ -419,15 +477,15 @@ __global__ __launch_bounds__(512) void le_rb_rows_kernel(RowsRbParams p)
         SftW s1;
         load_sft(s1, p.sft1_wfrag, p.sft1_bias, lane, lh);
         const unsigned t1 = sm + G::OFF_B + SFT_TILE_B + 64 * lh;
-        unsigned vq[4];                                                // x read, Y1 write: channel quad qd of slot cx
-        quad_addr(vq, sm, cx, lh);
-        const unsigned vc1 = cond_addr(sm, cx, lh);                    // slot cx = image column x0 - 2 + cx
+        unsigned vq[2];                                                // x read, Y1 write: this lane's two chunks of slot cx
+        chunk_addr<LStd>(vq, sm, cx, lh);
+        const unsigned vc1 = sm + LCond::at(cx, lh);                   // slot cx = image column x0 - 2 + cx
         const bool col1 = (unsigned)(x0 - 2 + cx) < (unsigned)W;
         const dma_rsrc_t rx = dma_rsrc(p.x), rc = dma_rsrc(p.cond);
         // per step: pieces 2 gh, 2 gh + 1 of x row gr (16 pixels x 64 B each) and piece gh of condition row gr (32 pixels x 32 B)
-        const unsigned xl0 = piece64_lane(2 * gh, lane), xl1 = piece64_lane(2 * gh + 1, lane), cl = piece32_lane(gh, lane);
-        const bool xok0 = (unsigned)(x0 - 2 + 32 * gh + (lane >> 2)) < (unsigned)W, xok1 = (unsigned)(x0 - 2 + 32 * gh + 16 + (lane >> 2)) < (unsigned)W;
-        const bool cok = (unsigned)(x0 - 2 + 32 * gh + (lane >> 1)) < (unsigned)W;
+        const unsigned xl0 = LStd::src_off(2 * gh, lane), xl1 = LStd::src_off(2 * gh + 1, lane), cl = LCond::src_off(gh, lane);
+        const bool xok0 = (unsigned)(x0 - 2 + LStd::src_px(2 * gh, lane)) < (unsigned)W, xok1 = (unsigned)(x0 - 2 + LStd::src_px(2 * gh + 1, lane)) < (unsigned)W;
+        const bool cok = (unsigned)(x0 - 2 + LCond::src_px(gh, lane)) < (unsigned)W;
         auto issue = [&](int r, int xo_, int co_) __attribute__((always_inline)) {        // image row r into the ring rows at xo_ / co_
             if (RB_ABL & 1) return;
             const bool rok = (unsigned)r < (unsigned)H && r <= y1 + 1;
@@ -436,26 +494,15 @@ __global__ __launch_bounds__(512) void le_rb_rows_kernel(RowsRbParams p)
             dma16_at(rx, sm + xo_ + (2 * gh + 1) * 1024, (rok && xok1) ? pix * 64u + xl1 : DMA_OOB);
             dma16_at(rc, sm + co_ + gh * 1024, (rok && cok) ? pix * 32u + cl : DMA_OOB);
         };
-        // epilogue: the result + x goes through a wave-private strip and leaves as 16-byte chunks: this lane stores pixels
-        // it * 16 + (lane >> 2) of the group, channel chunk c8 -- one step LATER, in front of the next conv (the strip's
-        // write -> read -> store chain then runs under that conv's MFMAs)
-        const unsigned strip_b = sm + G::OFF_ST + g * STRIP;
-        const int c8 = lane & 3, spx = lane >> 2;
+        // epilogue: the result's quads become this lane's two chunks of its pixel (quads_to_chunks: no LDS round trip), the
+        // residual is added in that form (x of output column x0 + cx: ring slot cx + 2, read as the same two chunks) and the lane
+        // stores 2 x 16 bytes: the two lanes of a pixel write bytes 0-31 with one store instruction, 32-63 with the next
         char *trash = p.trash + tid * 16;
-        unsigned vr[4];                                                // x of output column x0 + cx: ring slot cx + 2
-        quad_addr(vr, sm, cx + 2, lh);
-        const unsigned sw0 = strip_b + l31 * OUT_ROWB + 8 * lh;        // strip write: quad qd at sw0 + 16 qd
-        const unsigned sr0 = strip_b + spx * OUT_ROWB + c8 * 16;       // strip read: pixels spx, 16 + spx
-        const bool cok0 = 32 * gh + spx < WS && x0 + 32 * gh + spx < W, cok1 = 32 * gh + 16 + spx < WS && x0 + 32 * gh + 16 + spx < W;
-        f16 *const dst0 = p.dst + (size_t)(x0 + 32 * gh + spx) * 32 + c8 * 8;
-        auto store_row = [&](int r) __attribute__((always_inline)) {    // the strip holds output row r
-            const bool row_ok = r >= y0 && r < y1;
-            const f16x8 v0 = lds_rd<f16x8>(sr0), v1 = lds_rd<f16x8>(sr0 + 16 * OUT_ROWB);
-            f16 *d = dst0 + (size_t)r * W * 32;
-            if (RB_ABL & 2) { if (v0[0] == (f16)123.25f) *reinterpret_cast<f16x8 *>(trash) = v1; return; }
-            *reinterpret_cast<f16x8 *>((row_ok && cok0) ? d : reinterpret_cast<f16 *>(trash)) = v0;
-            *reinterpret_cast<f16x8 *>((row_ok && cok1) ? d + 16 * 32 : reinterpret_cast<f16 *>(trash)) = v1;
-        };
+        unsigned vr[2];
+        chunk_addr<LStd>(vr, sm, cx + 2, lh);
+        const bool ocol = cx < WS && x0 + cx < W;
+        f16 *const dst0 = p.dst + (size_t)(x0 + cx) * 32 + 8 * lh;
+        const int yend = y1;                                           // (the step loop has a local y1: the sft1 row)
 #pragma unroll
         for (int sq = 0; sq < DPF; ++sq)
             issue(ya + 2 * sq + gr, G::OFF_X + ((2 * sq + gr + BIG) % XR) * X_ROWB, G::OFF_C + ((2 * sq + gr + BIG) % CR) * C_ROWB);
@@ -470,22 +517,19 @@ __global__ __launch_bounds__(512) void le_rb_rows_kernel(RowsRbParams p)
         STAMP_DECL;
         for (int s = 0; s < nsteps; ++s) {
             STAMP(7);
-            store_row(ro_img - 2);                                     // (step 0: a row above the segment, masked)
             issue(ro_img + LAG + 2 * DPF, xd.o, cd.o);
             __builtin_amdgcn_sched_barrier(0);
             STAMP(0);
             if (RB_ABL & 64) {
-                __builtin_amdgcn_s_waitcnt(waitcnt_imm(5 * (DPF - 1), 0));
+                __builtin_amdgcn_s_waitcnt(waitcnt_imm(3 * (DPF - 1), 0));
                 __builtin_amdgcn_s_barrier();
                 xd.step(); cd.step(); ro_img += 2;
                 continue;
             }
             const f16x8 c1 = lds_rd<f16x8>(vc1 + ca.o);
-            f16x4 y1[4], res[4];
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) y1[qd] = lds_rd<f16x4>(vq[qd] + xa.o);
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) res[qd] = lds_rd<f16x4>(vr[qd] + xres.o);
+            f16x4 y1[4];
+            get_row(vq, xa.o, y1);
+            const f16x8 res0 = lds_rd<f16x8>(vr[0] + (unsigned)xres.o), res1 = lds_rd<f16x8>(vr[1] + (unsigned)xres.o);
             const bool row1 = (unsigned)(ro_img + LAG) < (unsigned)H;  // outside the image: conv1's zero padding
             // conv2 on row ro with row ra's whole SFT pass (independent of it) between its MFMAs
             f32x16 h1, sc1, sh1;
@@ -508,19 +552,28 @@ __global__ __launch_bounds__(512) void le_rb_rows_kernel(RowsRbParams p)
 #pragma unroll
                 for (int qd = 0; qd < 4; ++qd) bq[qd] = lds_rd<f32x4>(sm + G::OFF_B + 2 * SFT_TILE_B + 32 * qd + 16 * lh);
             }
+            {
+                f16x4 o[4];
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) lds_wr(sw0 + 16 * qd, bias_cvt4(acc, qd, bq[qd]) + res[qd]);
+                for (int qd = 0; qd < 4; ++qd) o[qd] = bias_cvt4(acc, qd, bq[qd]);
+                f16x8 o0, o1;
+                quads_to_chunks(o, o0, o1);
+                o0 += res0; o1 += res1;                                // x + conv2(..): one f16 rounding per element, as in the per-layer kernel
+                f16 *d = (ocol && ro_img >= y0 && ro_img < yend) ? dst0 + (size_t)ro_img * W * 32 : reinterpret_cast<f16 *>(trash);
+                if (RB_ABL & 2) d = reinterpret_cast<f16 *>(trash);
+                *reinterpret_cast<f16x8 *>(d) = o0;
+                *reinterpret_cast<f16x8 *>(d == reinterpret_cast<f16 *>(trash) ? d : d + 16) = o1;
+            }
             xd.step(); xa.step(); xres.step(); cd.step(); ca.step(); ya1.step(); wn.step();
             ro_img += 2;
             STAMP(3);
-            // per step and wave: two stores, then three DMA pieces (all always issued): the pieces of step s + 1 are older
-            // than the 5 (DPF - 1) operations of the steps since
-            __builtin_amdgcn_s_waitcnt(waitcnt_imm((RB_ABL & 3) ? 0 : 5 * (DPF - 1), 0));
+            // per step and wave: three DMA pieces, then (behind the conv) two stores, all always issued: the pieces that step s + 1
+            // reads were issued at the top of step s + 1 - DPF, in front of 5 (DPF - 1) + 2 younger operations
+            __builtin_amdgcn_s_waitcnt(waitcnt_imm((RB_ABL & 3) ? 0 : 5 * (DPF - 1) + 2, 0));
             STAMP(4);
             if (!(RB_ABL & 16)) __builtin_amdgcn_s_barrier();
             STAMP(5);
         }
-        store_row(ro_img - 2);
         STAMP_DUMP(p);
     }
 }
@@ -583,20 +636,21 @@ __global__ __launch_bounds__(512) void le_tail_rows_kernel(RowsTailParams p)
         f32x4 bq[4];
         load_bias(bq, p.b_up + 32 * g, lh);
         unsigned va[3][2];                                             // half-resolution pixel l31 reads u slots l31 .. l31 + 2
-        frag_addr(va, sm, l31, lh);
+        frag_addr<LStd>(va, sm, l31, lh);
         const int cx = 2 * l31 + gh;                                   // full-resolution slot (image column x0 - 2 + cx) of this lane's pixel
-        unsigned vq[4];                                                // fea0 read, Y write
-        quad_addr(vq, sm, cx, lh);
-        const unsigned vc = cond_addr(sm, cx, lh);
+        unsigned vf[2], vq[2];                                         // fea0 read, Y write: this lane's two chunks of slot cx (stride 2 across the lanes)
+        chunk_addr<LTailF>(vf, sm, cx, lh);
+        chunk_addr<LTailY>(vq, sm, cx, lh);
+        const unsigned vc = sm + LCondT::at(cx, lh);
         const bool col = (unsigned)(x0 - 2 + cx) < (unsigned)W;
         // the DMA: pieces 2 gh, 2 gh + 1 of fea0 row gr, piece gh of condition row gr, (waves 0-2) piece g of the u row and of
         // its second copy, the residual planes of 32 pixels of an output row (lane = plane * 16 + pixel pair) -- always six
         // DMA instructions per step (the unused ones fetch nothing into a trash KiB)
         const dma_rsrc_t rf = dma_rsrc(p.fea0), rc = dma_rsrc(p.cond), ru = dma_rsrc(p.u), rres = dma_rsrc(p.res_planar);
-        const unsigned fl0 = piece64_lane(2 * gh, lane), fl1 = piece64_lane(2 * gh + 1, lane), cl = piece32_lane(gh, lane), ul = piece64_lane(g, lane);
-        const bool fok0 = (unsigned)(x0 - 2 + 32 * gh + (lane >> 2)) < (unsigned)W, fok1 = (unsigned)(x0 - 2 + 32 * gh + 16 + (lane >> 2)) < (unsigned)W;
-        const bool cok = (unsigned)(x0 - 2 + 32 * gh + (lane >> 1)) < (unsigned)W;
-        const bool uok = g < 3 && 16 * g + (lane >> 2) < 34 && (unsigned)(hx0 - 2 + 16 * g + (lane >> 2)) < (unsigned)W1;
+        const unsigned fl0 = LTailF::src_off(2 * gh, lane), fl1 = LTailF::src_off(2 * gh + 1, lane), cl = LCondT::src_off(gh, lane), ul = LStd::src_off(g, lane);
+        const bool fok0 = (unsigned)(x0 - 2 + LTailF::src_px(2 * gh, lane)) < (unsigned)W, fok1 = (unsigned)(x0 - 2 + LTailF::src_px(2 * gh + 1, lane)) < (unsigned)W;
+        const bool cok = (unsigned)(x0 - 2 + LCondT::src_px(gh, lane)) < (unsigned)W;
+        const bool uok = g < 3 && LStd::src_px(g, lane) < 34 && (unsigned)(hx0 - 2 + LStd::src_px(g, lane)) < (unsigned)W1;
         const size_t plane = (size_t)H * W;
         const unsigned rl = (unsigned)((lane >> 4) * plane * 2 + (32 * gh + 2 * (lane & 15)) * 2);     // plane, pixel pair
         const bool rlok = lane < 48 && x0 + 32 * gh + 2 * (lane & 15) < W;
@@ -676,8 +730,7 @@ __global__ __launch_bounds__(512) void le_tail_rows_kernel(RowsTailParams p)
             if (FQ && (p.fq & 1)) fq_u_row(uq, hya + s + 2);
             const f16x8 c2 = lds_rd<f16x8>(vc + ca.o);
             f16x4 sk[4];
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) sk[qd] = lds_rd<f16x4>(vq[qd] + fa.o);
+            get_row(vf, fa.o, sk);
             const bool row = (unsigned)ra_img < (unsigned)H;
             f32x16 h2, sc2, sh2;
             const f32x16 acc = conv18<ROWS_AHEAD_H, U_ROWB, ROWS_PIN_H, (ROWS_PRIO_MASK >> 2) & 1>(wu, va, uw, [&](int st) __attribute__((always_inline)) {
@@ -718,9 +771,10 @@ __global__ __launch_bounds__(512) void le_tail_rows_kernel(RowsTailParams p)
         load_bias(bh, p.b_hr, lh);
         const float bl0 = p.b_last[0], bl1 = p.b_last[1], bl2 = p.b_last[2];
         const int cx = 32 * gh + l31;
-        unsigned va[3][2], vq[4];
-        frag_addr(va, sm, cx, lh);
-        quad_addr(vq, sm, cx, lh);                                     // Z write
+        unsigned va[3][2], vy[3][2], vq[2];
+        frag_addr<LStd>(va, sm, cx, lh);                               // conv_last's fragments of the Z ring
+        frag_addr<LTailY>(vy, sm, cx, lh);                             // HR_conv2's of the Y ring
+        chunk_addr<LStd>(vq, sm, cx, lh);                              // Z write
         const bool colz = (unsigned)(x0 - 1 + cx) < (unsigned)W;       // Z slot cx = image column x0 - 1 + cx
         const unsigned rbuf = sm + G::OFF_R + g * RN * G::R_SLOTB + l31 * 2;
         // output: channels 0..2 of pixel l31 sit in accumulator registers 0..2 of the lanes with lh == 0
@@ -757,7 +811,7 @@ __global__ __launch_bounds__(512) void le_tail_rows_kernel(RowsTailParams p)
             }
             STAMP(1);
             {   // HR_conv2 + ReLU -> Z
-                const f32x16 acc = conv18<ROWS_AHEAD_F, Y_ROWB, ROWS_PIN_F, (ROWS_PRIO_MASK >> 3) & 1>(wh, va, wy.o, [](int) {});
+                const f32x16 acc = conv18<ROWS_AHEAD_F, Y_ROWB, ROWS_PIN_F, (ROWS_PRIO_MASK >> 3) & 1>(wh, vy, wy.o, [](int) {});
                 f16x4 z[4];
                 const bool in = colz && (unsigned)rb_img < (unsigned)H;     // outside the image: conv_last's zero padding
 #pragma unroll
@@ -794,8 +848,7 @@ constexpr int P_SLOTS = 72, P_ROWB = P_SLOTS * 8;            // patch ring: 68 o
 template <int DPF> struct HeadGeo {
     static constexpr int CR = 2 * DPF + 2;
     static constexpr int OFF_P = 0, OFF_C = OFF_P + YPH * P_ROWB, OFF_Y = OFF_C + CR * C_ROWB, OFF_F = OFF_Y + YPH * Y_ROWB;
-    static constexpr int OFF_ST = OFF_F + YPH * Y_ROWB;      // H2's four output strips
-    static constexpr int OFF_B = OFF_ST + 4 * STRIP;         // SFT_layer1's head tiles
+    static constexpr int OFF_B = OFF_F + YPH * Y_ROWB;       // SFT_layer1's head tiles
     static constexpr int SMEM = OFF_B + SFT_TILE_B;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
     static_assert(BIG % CR == 0, "BIG");
@@ -822,9 +875,8 @@ __global__ __launch_bounds__(512) void le_head_rows_kernel(RowsHeadParams p)
     const bool colfull = x0 >= 2 && x0 + 62 <= W;
     const int g = wave & 3, gr = g >> 1, gh = g & 1;
     const int cx = 32 * gh + l31;
-    unsigned va[3][2], vq[4];
-    frag_addr(va, sm, cx, lh);
-    quad_addr(vq, sm, cx, lh);                                         // Y / F write
+    unsigned va[3][2];
+    frag_addr<LStd>(va, sm, cx, lh);                                   // HR_conv1's fragments of the Y ring
 
     if (wave < 4) {
         // ------------------------------------------------------------------ role H1
@@ -838,7 +890,9 @@ __global__ __launch_bounds__(512) void le_head_rows_kernel(RowsHeadParams p)
         load_bank(wd, p.w_down, l31, lh);
         f32x4 bd[4];
         load_bias(bd, p.b_down, lh);
-        const unsigned vc = cond_addr(sm, cx, lh);
+        unsigned vq[2];                                                // Y write
+        chunk_addr<LStd>(vq, sm, cx, lh);
+        const unsigned vc = sm + LCond::at(cx, lh);
         const bool col = (unsigned)(x0 - 2 + cx) < (unsigned)W;
         const unsigned vp = sm + (cx + 2 * lh) * 8;                    // patch pixels cx + 2 lh, + 1 of a kernel row = K slots 8 lh .. 8 lh + 7
         // patch staging: thread t < 136 owns pixel (t / 68, t % 68) of the two new rows
@@ -873,10 +927,7 @@ __global__ __launch_bounds__(512) void le_head_rows_kernel(RowsHeadParams p)
         };
         // down_conv1: half-resolution pixel l31 (column hx0 + l31, 30 used) reads F slots 2 l31 + kx (slot c = image column x0 - 1 + c)
         unsigned vd[3][2];
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) vd[kx][ks] = sm + (unsigned)((2 * l31 + kx) * 64 + ((((ks << 1) | lh) ^ swz32(2 * l31 + kx)) << 4));
+        frag_addr<LHeadF>(vd, sm, l31, lh, 2);
         const bool dcol = l31 < WS / 2 && hx0 + l31 < W1;
         f16 *const d1 = p.fea1 + (size_t)(hx0 + l31) * 32 + 4 * lh;
         for (int e = tid; e < YPH * 4; e += 256)                        // the four pad slots of every patch row stay finite (zero weights read them)
@@ -949,27 +1000,19 @@ __global__ __launch_bounds__(512) void le_head_rows_kernel(RowsHeadParams p)
         load_bias(bh, p.b_hr, lh);
         const bool colf = (unsigned)(x0 - 1 + cx) < (unsigned)W;       // F slot cx = image column x0 - 1 + cx
         const dma_rsrc_t rc = dma_rsrc(p.cond);
-        const unsigned cl = piece32_lane(gh, lane);
-        const bool cok = (unsigned)(x0 - 2 + 32 * gh + (lane >> 1)) < (unsigned)W;
+        const unsigned cl = LCond::src_off(gh, lane);
+        const bool cok = (unsigned)(x0 - 2 + LCond::src_px(gh, lane)) < (unsigned)W;
         auto issue_c = [&](int r, int co) __attribute__((always_inline)) {
             const bool rok = (unsigned)r < (unsigned)H && r <= y1;
             dma16_at(rc, sm + co + gh * 1024, (rok && cok) ? (unsigned)((r * W + x0 - 2) * 32) + cl : DMA_OOB);
         };
-        const unsigned strip_b = sm + G::OFF_ST + g * STRIP;
-        const int c8 = lane & 3, spx = lane >> 2;
+        unsigned vq[2];                                                // F write
+        chunk_addr<LHeadF>(vq, sm, cx, lh);
         char *trash = p.trash + tid * 16;
-        const unsigned sw0 = strip_b + l31 * OUT_ROWB + 8 * lh, sr0 = strip_b + spx * OUT_ROWB + c8 * 16;
-        // the strip holds F slots 32 gh .. (slot c = column x0 - 1 + c): this lane stores slots 32 gh + spx and + 16
-        const int ox0 = 32 * gh + spx - 1, ox1 = ox0 + 16;
-        const bool sok0 = ox0 >= 0 && ox0 < WS && x0 + ox0 < W, sok1 = ox1 < WS && x0 + ox1 < W;
-        f16 *const dst0 = p.fea0 + (size_t)(x0 + ox0) * 32 + c8 * 8;
-        auto store_row = [&](int r) __attribute__((always_inline)) {
-            const bool row_ok = r >= y0 && r < y1;
-            const f16x8 v0 = lds_rd<f16x8>(sr0), v1 = lds_rd<f16x8>(sr0 + 16 * OUT_ROWB);
-            f16 *d = dst0 + (size_t)r * W * 32;
-            *reinterpret_cast<f16x8 *>((row_ok && sok0) ? d : reinterpret_cast<f16 *>(trash)) = v0;
-            *reinterpret_cast<f16x8 *>((row_ok && sok1) ? d + 16 * 32 : reinterpret_cast<f16 *>(trash)) = v1;
-        };
+        // fea0 leaves straight from the registers, as this lane's two chunks of its pixel: F slot cx = image column x0 - 1 + cx
+        const int ox = cx - 1;
+        const bool ocol = ox >= 0 && ox < WS && x0 + ox < W;
+        f16 *const dst0 = p.fea0 + ((ptrdiff_t)x0 + ox) * 32 + 8 * lh;
 #pragma unroll
         for (int sq = 0; sq < DPF; ++sq) issue_c(ya + 2 * sq + gr, G::OFF_C + ((2 * sq + gr + BIG) % CR) * C_ROWB);
         Cur<G::OFF_C, CR, C_ROWB> cd(2 * DPF + gr);
@@ -981,33 +1024,37 @@ __global__ __launch_bounds__(512) void le_head_rows_kernel(RowsHeadParams p)
         STAMP_DECL;
         for (int s = 0; s < nsteps; ++s) {
             STAMP(7);
-            store_row(rb_img - 2);
             issue_c(rb_img + 3 + 2 * DPF, cd.o);
             __builtin_amdgcn_sched_barrier(0);
             STAMP(0);
-            if (RB_ABL & 64) { __builtin_amdgcn_s_waitcnt(waitcnt_imm(3 * (DPF - 1), 0)); __builtin_amdgcn_s_barrier(); cd.step(); rb_img += 2; continue; }
+            if (RB_ABL & 64) { __builtin_amdgcn_s_waitcnt(waitcnt_imm(DPF - 1, 0)); __builtin_amdgcn_s_barrier(); cd.step(); rb_img += 2; continue; }
             const f32x16 acc = conv18<ROWS_AHEAD_F, Y_ROWB, ROWS_PIN_F, (ROWS_PRIO_MASK >> 5) & 1>(wh, va, wy.o, [](int) {});
             STAMP(1);
             f16x4 z[4];
             const bool in = colf && (unsigned)rb_img < (unsigned)H;        // outside the image: down_conv1's zero padding
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                z[qd] = __builtin_elementwise_max(bias_cvt4(acc, qd, bh[qd]), zero4());
-                lds_wr(sw0 + 16 * qd, z[qd]);                             // fea0 as the tail's skip wants it: not quantised
-                if (FQ && (p.fq & 4)) z[qd] = fq4(z[qd], p.fq_f);         // down_conv1 is W8A8: its input quantiser
-                if (!in) z[qd] = zero4();
+            for (int qd = 0; qd < 4; ++qd) z[qd] = __builtin_elementwise_max(bias_cvt4(acc, qd, bh[qd]), zero4());
+            f16x8 z0, z1;
+            quads_to_chunks(z, z0, z1);
+            {   // fea0 as the tail's skip wants it: not quantised
+                f16 *d = (ocol && rb_img >= y0 && rb_img < y1) ? dst0 + (size_t)rb_img * W * 32 : reinterpret_cast<f16 *>(trash);
+                *reinterpret_cast<f16x8 *>(d) = z0;
+                *reinterpret_cast<f16x8 *>(d == reinterpret_cast<f16 *>(trash) ? d : d + 16) = z1;
             }
-            put_row(vq, fw.o, fw.mirrored(), z);
+            if (FQ && (p.fq & 4)) { z0 = fq8(z0, p.fq_f); z1 = fq8(z1, p.fq_f); }     // down_conv1 is W8A8: its input quantiser
+            if (!in) { z0 = f16x8{}; z1 = f16x8{}; }
+            lds_wr(vq[0] + (unsigned)fw.o, z0); lds_wr(vq[1] + (unsigned)fw.o, z1);
+            if (fw.mirrored()) { lds_wr(vq[0] + (unsigned)(fw.o + YN * Y_ROWB), z0); lds_wr(vq[1] + (unsigned)(fw.o + YN * Y_ROWB), z1); }
             cd.step(); wy.step(); fw.step();
             rb_img += 2;
             STAMP(3);
-            // per step and wave: two stores, then one DMA piece: the piece of step s + 1 is older than 3 (DPF - 1) operations
-            __builtin_amdgcn_s_waitcnt(waitcnt_imm(3 * (DPF - 1), 0));
+            // per step and wave: one DMA piece, then (behind the conv) two stores: the piece step s + 1 reads is older than
+            // 3 (DPF - 1) + 2 operations
+            __builtin_amdgcn_s_waitcnt(waitcnt_imm(3 * (DPF - 1) + 2, 0));
             STAMP(4);
             __builtin_amdgcn_s_barrier();
             STAMP(5);
         }
-        store_row(rb_img - 2);
         STAMP_DUMP(p);
     }
 }

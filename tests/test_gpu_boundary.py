@@ -10,7 +10,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-OUT_MAX, OUT_MEAN = 6e-3, 5e-4
+OUT_MAX, OUT_MEAN = 3.7e-3, 2.5e-4      # test_gpu_parity.py's bars (1.5 x measured)
 
 
 def _hr(golden_dir, **kw):

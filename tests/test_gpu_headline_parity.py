@@ -18,7 +18,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-OUT_MAX, OUT_MEAN = 6e-3, 5e-4              # test_gpu_parity.py's float bars for the final output
+OUT_MAX, OUT_MEAN = 3.7e-3, 2.5e-4          # test_gpu_parity.py's float bars for the final output (1.5 x measured)
 # RGB48 against the reference's own integers: 1.5 x the worst case measured on the r04 build over every golden below and the
 # full-size fixtures of test_gpu_fullsize_reference.py (max 151 LSB, mean 9.5 LSB of 65535), not the float bars converted to LSB
 LSB_MAX, LSB_MEAN = 230, 14.5
@@ -222,26 +222,27 @@ def test_uhd_hg_vs_oracle(torch_cuda, golden_dir, hg_state):
         O.hg_generator(hg_state, bp, np.zeros((1, h + ph, w), np.float32), taps)
     finally:
         O.use_backend("c")
-    for name, tol in (("hg.conv2", 1e-2), ("hg.conv5_2", 3e-2), ("hg.conv9", 6e-3)):
+    # 1.5 x measured (3.3e-3 / 1.3e-4, 8.8e-3 / 3.8e-4, 2.1e-3 / 1.9e-4): the bars of test_gpu_parity.py
+    for name, (tol, tol_mean) in (("hg.conv2", (4.9e-3, 2.2e-4)), ("hg.conv5_2", (1.32e-2, 7.0e-4)), ("hg.conv9", (3.1e-3, 3.2e-4))):
         mx, mean = _stats(name + " 2176x3840", dev[name], taps[name])
-        assert mx <= tol and mean <= tol / 20, name
+        assert mx <= tol and mean <= tol_mean, name
     w10 = np.asarray(hg_state["conv10.weight"], np.float32).reshape(3, 128)[:, :64]
     want_part = np.einsum("ok,khw->ohw", w10, taps["hg.up5"]).astype(np.float32)
     mx, mean = _stats("hg.part (ps_dot3 epilogue) 2176x3840", part, want_part)
-    assert mx <= 6e-3 and mean <= 4e-4
+    assert mx <= 1.5e-3 and mean <= 1.5e-4                   # measured 9.8e-4 / 9.8e-5
     tail = taps["hg.tail"][:, :h, :w]
     for r, got, dev_mask in ((0.75, out75, mask75_dev), (0.3, out30, mask30_dev)):
         mask = O.hg_mask(base, r=r)
         assert np.array_equal(dev_mask, mask)
         ref = (mask * tail + base).astype(np.float32)                       # Hallucination_arch.py:136
         mx, mean = _stats(f"hg out 2160x3840, mask_r={r} (mask fraction {mask.mean():.4f})", got, ref)
-        assert mx <= 3e-3 and mean <= 2e-4
+        assert mx <= 1.4e-3 and mean <= 1e-4                 # measured 9.4e-4 / 6.7e-5 (dense mask)
         if r == 0.3:
             assert mask.mean() >= 0.2
             inside = mask[0] > 0
             dd = np.abs(got - ref)[:, inside]
             print(f"  masked-in pixels only ({int(inside.sum())}): max_abs={dd.max():.3e} mean_abs={dd.mean():.3e}")
-            assert dd.max() <= 3e-3
+            assert dd.max() <= 1.4e-3
 
 
 # ------------------------------------------------------------------------------------------ configs[4]: int8 HR + int8 HG
@@ -298,50 +299,51 @@ def test_native_int8_hr_with_int8_hg_vs_fake_quant_oracle(torch_cuda, golden_dir
 def test_native_int8_default_path_at_3840x2160(torch_cuda, golden_dir, monkeypatch):
     """configs[4] AT ITS OWN SIZE, on the kernels ``bench.py``'s ``config4_int8`` times: the shipped full-QAT checkpoint with
     ``predequantize="off"`` and every variant at its default, feeding the W8A8 HG head, on one 3840x2160 frame -- 64 strips x
-    4 segments of the fused LE row kernels in their INT8 form (the steady state of their rings), 8160-tile int8 HG layers.
+    4 segments of the fused LE row kernels in their W8A8 form (the steady state of their rings), 8160-tile int8 HG layers.
       * against the oracle's fake-quant composite (fp32, ATen convolutions = the reference's CPU arithmetic; ~2 min of
         CPU): the reference's own bars for a re-quantised graph, float MAE <= 0.02 and u8 MAE <= 5
         (scripts/validate_tensorrt_sources.py:598-609), and ~2x the level this build measures;
-      * against the one-tile-per-workgroup schedule (variant force_ncu, which the small goldens validate): bit for bit,
-        as test_persistent_schedules_do_not_change_results does for fp16."""
+      * schedule invariance, bit for bit: (a) on 128 instead of 256 workgroups (variant force_ncu = 128: the row kernels cut
+        the frame into 64 strips x 2 segments instead of x 4, every other persistent kernel walks twice the tiles per workgroup);
+        (b) with the W8A8 layers of the fused kernels on the per-layer int8-MFMA kernels (le_rows_fq = 0), the real schedule
+        against one tile per workgroup (force_ncu = 4000000, the schedule the small goldens validate), as
+        test_persistent_schedules_do_not_change_results does for fp16.  (The two forms (a) and (b) differ from each other by
+        design: fake-quant on fp16 MFMA against int8 MFMA -- `execution_summary()` says which ran.)"""
     from hdrtv_mi355x import weights as W
-    from hdrtv_mi355x.processor import HDRTVNetMI355X
+    from hdrtv_mi355x.processor import HDRTVNetMI355X, summarize_profile
     from oracle import hdrtvnet_oracle as O
     torch = torch_cuda
     h, w = 2160, 3840
     f = W.synthetic_frame(h, w, seed=12, kind="gradient")
     path = os.path.join(golden_dir, "hr_int8_full_qat.hdrw")
     qstate = W.seeded_hg_w8a8_state(1234, integer_zero=False)
-    runs = []
-    for force in (None, "4000000"):
-        if force:
-            monkeypatch.setenv("HDRTV_VARIANTS", "force_ncu=" + force)      # read once, by hdrtv_create
-        else:
-            monkeypatch.delenv("HDRTV_VARIANTS", raising=False)
-        p = HDRTVNetMI355X(path, precision="int8-full", predequantize="off", use_hg=True, hg_weights="seeded-w8a8-minmax:1234",
-                           warmup_passes=0)
-        try:
-            assert p._is_w8_model and p._hg_int8
-            if not force:
-                assert p.get_variant("le_rows") == 1 and p.get_variant("le_rows_fq") == 1     # the defaults
+    monkeypatch.delenv("HDRTV_VARIANTS", raising=False)
+    p = HDRTVNetMI355X(path, precision="int8-full", predequantize="off", use_hg=True, hg_weights="seeded-w8a8-minmax:1234", warmup_passes=0)
+    runs = {}
+    try:
+        assert p._is_w8_model and p._hg_int8
+        assert p.get_variant("le_rows") == 1 and p.get_variant("le_rows_fq") == 1 and p.get_variant("force_ncu") == 0     # the defaults
+        for name, fq, ncu in (("default", 1, 0), ("128 workgroups", 1, 128), ("per-layer int8", 0, 0), ("per-layer int8, one tile per workgroup", 0, 4000000)):
+            p.set_variant("le_rows_fq", fq)
+            p.set_variant("force_ncu", ncu)
             p.profile_enable(True)
             out, agcm = p.infer(p.preprocess(f))
-            kern = [k for _, k, *_ in p.profile_read()]
+            prof = p.profile_read()
             p.profile_enable(False)
-            runs.append((out.clone(), agcm.clone(), p.tap("le.out").clone(), p.tap("le.fea0").clone(), p.postprocess(out).copy(), kern))
-        finally:
-            p.close()
-    kern = runs[0][5]
-    print(f"  kernels of the default run: {sorted(set(kern))}")
-    for stem in ("le_head_rows<", "le_rb_rows<", "le_tail_rows<"):          # the fused kernels in an INT8 form, not the fp16 one
+            runs[name] = (out.clone(), agcm.clone(), p.tap("le.out").clone(), p.tap("le.fea0").clone(), p.postprocess(out).copy(), prof)
+    finally:
+        p.close()
+    kern = [k for _, k, *_ in runs["default"][5]]
+    ran = summarize_profile(runs["default"][5])
+    print(f"  default run: {ran['text']}")
+    for stem in ("le_head_rows<", "le_rb_rows<", "le_tail_rows<"):          # the fused kernels in a W8A8 form, not the fp16 one
         assert any(k.startswith(stem) for k in kern), (stem, sorted(set(kern)))
-    assert any(k.startswith("conv_pglds_i8") or k.startswith("conv_prw_i8") for k in kern)
-    for name, a, b in zip(("out", "agcm", "le.out", "le.fea0"), runs[0][:4], runs[1][:4]):
-        assert torch.isfinite(a).all(), name
-        assert torch.equal(a, b), (name, int((a != b).sum()))
-    out_np = runs[0][0].float().cpu().numpy()[0]
-    base = runs[0][2].numpy()
-    u8 = runs[0][4]
+    assert not any("rows" in k for _, k, *_ in runs["per-layer int8"][5])
+    assert ran["int8"]["gmac"] >= 0.9 * sum(v["gmac"] for k, v in ran.items() if k != "text")      # HG + the per-layer LE kernels
+    for a_name, b_name in (("default", "128 workgroups"), ("per-layer int8", "per-layer int8, one tile per workgroup")):
+        for name, a, b in zip(("out", "agcm", "le.out", "le.fea0"), runs[a_name][:4], runs[b_name][:4]):
+            assert torch.isfinite(a).all(), (a_name, name)
+            assert torch.equal(a, b), (a_name, b_name, name, int((a != b).sum()))
     sd = O.w8a8_state(W.load_pack(path))
     hq = O.w8a8_state(qstate)
     O.set_threads(min(16, os.cpu_count() or 1))
@@ -351,10 +353,14 @@ def test_native_int8_default_path_at_3840x2160(torch_cuda, golden_dir, monkeypat
         ref, _ = O.hg_composite(sd, hq, *O.preprocess(f), taps)
     finally:
         O.use_backend("c")
-    _stats("int8-full LE out 2160x3840 vs fake-quant oracle", base, taps["base"])
-    mx, mean = _stats("int8-full HR + int8 HG 2160x3840, final out vs fake-quant composite", out_np, ref)
-    du8 = np.abs(u8.astype(int) - O.postprocess_u8(ref).astype(int))
-    flips = float((O.hg_mask(base) != taps["mask"]).mean())
-    print(f"  u8: max={du8.max()} MAE={du8.mean():.4f} (reference bar: MAE <= 5); mask flips {flips:.4%}")
-    assert mean <= 0.02 and du8.mean() <= 5.0
-    assert mean <= 1.5e-2
+    ru8 = O.postprocess_u8(ref)
+    for name in ("default", "per-layer int8"):
+        out_np = runs[name][0].float().cpu().numpy()[0]
+        base = runs[name][2].numpy()
+        _stats(f"int8-full LE out 2160x3840 vs fake-quant oracle ({name})", base, taps["base"])
+        mx, mean = _stats(f"int8-full HR + int8 HG 2160x3840, final out vs fake-quant composite ({name})", out_np, ref)
+        du8 = np.abs(runs[name][4].astype(int) - ru8.astype(int))
+        flips = float((O.hg_mask(base) != taps["mask"]).mean())
+        print(f"  u8: max={du8.max()} MAE={du8.mean():.4f} (reference bar: MAE <= 5); mask flips {flips:.4%}")
+        assert mean <= 0.02 and du8.mean() <= 5.0
+        assert mean <= 1.5e-2

@@ -4,10 +4,11 @@ vectors.  All tests here need a real MI355X: ``pytest -m gpu``.
 Tolerances (stated once, used below):
   * pre/post quantisers, given identical float inputs: EXACT integers.
   * network floats: the product computes in fp16 storage / fp32 accumulate, the oracle and
-    the goldens are the reference's CPU fp32 path.  Bars (the constants below): AGCM out max_abs <= 2e-3;
-    LE/HG final out max_abs <= 6e-3 and mean_abs <= 5e-4 on O(1) values; u8 within 3 LSB,
-    mean u8 error <= 0.6 LSB.  (The reference's own bar for a re-quantised graph is
-    float MAE <= 0.02 and u8 MAE <= 5, scripts/validate_tensorrt_sources.py:598-609.)
+    the goldens are the reference's CPU fp32 path.  Every bar below is 1.5 x the worst value the round-5 build
+    prints over all tests of this file (gpurun_out/r5_gputest_b.log; values on O(1) tensors): AGCM out max_abs
+    9.0e-4 -> 1.35e-3; LE / final out max_abs 2.46e-3 -> 3.7e-3, mean_abs 1.66e-4 -> 2.5e-4; u8 max 1 -> 2 LSB,
+    mean 0.055 -> 0.09 LSB; per-tap bars next to their tests.  (The reference's own bar for a re-quantised graph
+    is float MAE <= 0.02 and u8 MAE <= 5, scripts/validate_tensorrt_sources.py:598-609.)
 """
 import os
 
@@ -16,9 +17,13 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-AGCM_MAX = 2e-3
-OUT_MAX, OUT_MEAN = 6e-3, 5e-4      # ~3x the worst measured case (profiles/r01_final_layers.txt era)
-U8_MAX, U8_MEAN = 3, 0.6
+AGCM_MAX = 1.35e-3
+OUT_MAX, OUT_MEAN = 3.7e-3, 2.5e-4
+U8_MAX, U8_MEAN = 2, 0.09
+# HG taps against the oracle on the device's own LE output: (max_abs, mean_abs), measured 3.3e-3 / 1.4e-4, 8.8e-3 / 4.7e-4 (conv5_2),
+# 2.1e-3 / 2.1e-4 (conv9) at 96x128 .. 2176x3840
+HG_TAP = {"hg.conv2": (4.9e-3, 2.2e-4), "hg.conv5_2": (1.32e-2, 7.0e-4), "hg.conv9": (3.1e-3, 3.2e-4)}
+HG_OUT_MAX = 1.4e-3                  # final HG output vs the oracle on our base: measured 9.4e-4
 
 
 @pytest.fixture(scope="module")
@@ -150,16 +155,17 @@ def test_hr_golden(proc_hr, golden_dir, hr_state, name):
     bias = proc_hr.tap("agcm.bias").numpy().ravel()
     if "fea6" in d.files:
         mx, _ = _stats("fea6", bias[160:166], d["fea6"])
-        assert mx <= 2e-3
+        assert mx <= 1e-6            # fp32 on both sides (measured 1.3e-8)
     mx, _ = _stats("agcm_out", agcm_np, d["agcm_out"])
     assert mx <= AGCM_MAX
     # LE stage taps against the oracle evaluated on OUR agcm output (isolates LE from AGCM error)
     taps = {}
     O.le(hr_state, agcm_np, taps)
-    for ours, theirs, tol in (("le.cond", "LE.cond_first", 3e-3), ("le.cond1", "LE.CondNet1", 3e-3),
-                              ("le.cond2", "LE.CondNet2", 4e-3), ("le.cond3", "LE.CondNet3", 6e-3),
-                              ("le.cond4", "LE.CondNet4", 1.5e-2), ("le.fea0", None, 4e-3),
-                              ("le.fea1", "LE.recon_trunk1", 5e-3), ("le.fea2", "LE.recon_trunk2", 1.2e-2)):
+    # 1.5 x measured (7.5e-4, 7.8e-4, 1.23e-3, 2.1e-3, 4.8e-3 on values ~1.5, 1.2e-3, 1.6e-3, 3.8e-3)
+    for ours, theirs, tol in (("le.cond", "LE.cond_first", 1.2e-3), ("le.cond1", "LE.CondNet1", 1.2e-3),
+                              ("le.cond2", "LE.CondNet2", 1.9e-3), ("le.cond3", "LE.CondNet3", 3.2e-3),
+                              ("le.cond4", "LE.CondNet4", 7.2e-3), ("le.fea0", None, 1.8e-3),
+                              ("le.fea1", "LE.recon_trunk1", 2.5e-3), ("le.fea2", "LE.recon_trunk2", 5.8e-3)):
         got = proc_hr.tap(ours).numpy()
         if theirs is None:
             want = np.maximum(taps["LE.HR_conv1"], 0)
@@ -194,20 +200,21 @@ def test_hg_golden(proc_hg, golden_dir, hr_state, hg_state, name):
     ref = O.hg_generator(hg_state, np.pad(base, ((0, 0), (0, ph), (0, pw)), mode="reflect"),
                          np.pad(mask, ((0, 0), (0, ph), (0, pw)), mode="reflect"), taps)[:, :h, :w]
     assert np.array_equal(proc_hg.tap("hg.mask").numpy()[:, :h, :w], mask)
-    for ours, tol in (("hg.conv2", 1e-2), ("hg.conv3_2", 1.2e-2), ("hg.conv4_2", 2e-2), ("hg.conv5_2", 2.5e-2),
-                      ("hg.conv_code2", 2e-2), ("hg.conv6", 1e-2), ("hg.conv7", 1e-2), ("hg.conv8", 8e-3),
-                      ("hg.conv9", 6e-3)):
+    # 1.5 x measured (2.9e-3, 4.2e-3, 7.6e-3, 8.2e-3, 6.7e-3, 3.3e-3, 3.0e-3, 2.2e-3, 1.9e-3)
+    for ours, tol in (("hg.conv2", 4.5e-3), ("hg.conv3_2", 6.4e-3), ("hg.conv4_2", 1.15e-2), ("hg.conv5_2", 1.25e-2),
+                      ("hg.conv_code2", 1.0e-2), ("hg.conv6", 5e-3), ("hg.conv7", 4.6e-3), ("hg.conv8", 3.4e-3),
+                      ("hg.conv9", 2.9e-3)):
         mx, _ = _stats(ours, proc_hg.tap(ours).numpy(), taps[ours])
         assert mx <= tol, ours
     mx, mean = _stats("hg_out vs oracle(our base)", out_np, ref)
-    assert mx <= 3e-3 and mean <= 1e-4
+    assert mx <= HG_OUT_MAX and mean <= 2.1e-5               # measured 7.2e-4 / 1.4e-5
     # against the reference's golden output, away from pixels whose mask bit flipped under fp16
     same = (mask == d["mask"])[0]
     print(f"  mask flips vs golden: {int((~same).sum())} of {same.size}")
     assert (~same).mean() <= 0.002
     dd = np.abs(out_np - d["out"])[:, same]
     print(f"  hg_out vs golden: max_abs={dd.max():.3e} mean_abs={dd.mean():.3e}")
-    assert dd.max() <= 8e-3 and dd.mean() <= 6e-4
+    assert dd.max() <= 3.5e-3 and dd.mean() <= 2.6e-4        # measured 2.3e-3 / 1.7e-4
 
 
 def test_mid_size_vs_oracle(proc_hg, hr_state, hg_state):
@@ -227,7 +234,7 @@ def test_mid_size_vs_oracle(proc_hg, hr_state, hg_state):
     ref = O.hg_generator(hg_state, np.pad(base, ((0, 0), (0, ph), (0, pw)), mode="reflect"),
                          np.pad(mask, ((0, 0), (0, ph), (0, pw)), mode="reflect"))[:, :272, :480]
     mx, mean = _stats("hg 272x480", out.cpu().numpy()[0], ref)
-    assert mx <= 3e-3 and mean <= 1e-4
+    assert mx <= HG_OUT_MAX and mean <= 4e-6                 # measured 7.6e-4 / 2.2e-6 (the mask is sparse)
 
 
 @pytest.mark.parametrize("hw", [(1080, 1920), (2160, 3840)])
@@ -339,12 +346,11 @@ def test_full_hd_hg_vs_oracle(proc_hg, hr_state, hg_state):
     taps = {}
     ref = O.hg_generator(hg_state, np.pad(base, ((0, 0), (0, ph), (0, 0)), mode="reflect"),
                          np.pad(mask, ((0, 0), (0, ph), (0, 0)), mode="reflect"), taps)[:, :h, :w]
-    # measured r01: 3.4e-3 / 9.5e-3 / 2.0e-3 max_abs (f16 storage against the fp32 oracle); bounds = 3x that
-    for name, tol in (("hg.conv2", 1e-2), ("hg.conv5_2", 3e-2), ("hg.conv9", 6e-3)):
+    for name, (tol, tol_mean) in HG_TAP.items():
         mx, mean = _stats(name + " 1088x1920", proc_hg.tap(name).numpy(), taps[name])
-        assert mx <= tol and mean <= tol / 20, name
+        assert mx <= tol and mean <= tol_mean, name
     mx, mean = _stats("hg out 1080x1920", out.cpu().numpy()[0], ref)
-    assert mx <= 3e-3 and mean <= 1e-4
+    assert mx <= HG_OUT_MAX and mean <= 1e-6                 # measured 7.1e-4 / 3.3e-8 (0.02 % of the pixels are masked in)
     # LE itself at this size (multi-tile persistent schedule of every LE kernel) against the oracle's whole HR forward
     rt, rc = O.preprocess(f)
     rbase, ragcm = O.hr_forward(hr_state, rt, rc)
@@ -386,13 +392,13 @@ def test_full_hd_hg_tail_dense_mask(proc_hg, hr_state, hg_state):
     w10 = np.asarray(hg_state["conv10.weight"], np.float32).reshape(3, 128)[:, :64]
     want_part = np.einsum("ok,khw->ohw", w10, taps["hg.up5"]).astype(np.float32)
     mx, mean = _stats("hg.part (ps_dot3 epilogue) 1088x1920", part, want_part)
-    assert mx <= 6e-3 and mean <= 4e-4
+    assert mx <= 1.5e-3 and mean <= 1.5e-4                   # measured 9.7e-4 / 9.6e-5
     mx, mean = _stats("hg out, dense mask", out_np, ref)
-    assert mx <= 3e-3 and mean <= 2e-4
+    assert mx <= HG_OUT_MAX and mean <= 1e-4                 # measured 9.3e-4 / 6.5e-5
     inside = mask[0] > 0
     dd = np.abs(out_np - ref)[:, inside]
     print(f"  masked-in pixels only ({int(inside.sum())}): max_abs={dd.max():.3e} mean_abs={dd.mean():.3e}")
-    assert dd.max() <= 3e-3
+    assert dd.max() <= HG_OUT_MAX
 
 
 def test_uhd_le_vs_oracle(proc_hr, hr_state):

@@ -223,8 +223,8 @@ def test_le_rows_step_loops_never_drain_the_dma_queue(tmp_path):
     # kernel -> (MFMAs in the text, counted closing waits of its DMA role(s))
     # (the <.., true> instances -- W8A8 layers as fake-quant -- carry the SFT hidden-layer MFMA twice where a layer's input may
     # or may not be quantised, the mixed recipe: a wave-uniform branch)
-    want = {"le_rb_rows_kernel": ((2 * 18 + 2 * 3, 2 * 18 + 2 * 3 + 4), {10}), "le_tail_rows_kernel": ((3 * 18 + 3, 3 * 18 + 3 + 2), {12}),
-            "le_head_rows_kernel": ((2 * 18 + 3 + 3, 2 * 18 + 3 + 3 + 2), {6})}
+    want = {"le_rb_rows_kernel": ((2 * 18 + 2 * 3, 2 * 18 + 2 * 3 + 4), {12}), "le_tail_rows_kernel": ((3 * 18 + 3, 3 * 18 + 3 + 2), {12}),
+            "le_head_rows_kernel": ((2 * 18 + 3 + 3, 2 * 18 + 3 + 3 + 2), {8})}
     seen = 0
     for name, body in kernels.items():
         key = next((k for k in want if k in name), None)
