@@ -75,6 +75,10 @@ def parse():
                     help="skip the host-fed in-product dispatcher measurement (hdrtv_mi355x/dispatch.py, one worker process) reported "
                          "beside value_pcie_inclusive at N=1")
     ap.add_argument("--dispatcher", action="store_true", help="only the host-fed dispatcher measurement (its own JSON line)")
+    ap.add_argument("--dispatcher-sim", action="store_true",
+                    help="CPU only: the dispatcher's host side over --gpus N stand-in workers (memcpys + device_ms of sleep per frame); no GPU is touched")
+    ap.add_argument("--sim-fps", type=float, nargs="*", help="with --dispatcher-sim: offered rates to run (default: 100 per worker)")
+    ap.add_argument("--sim-numa", action="store_true", help="with --dispatcher-sim: workers pin themselves as they would to their GPU's NUMA node")
     ap.add_argument("--layers", action="store_true", help="print the per-layer profile to stderr")
     return ap.parse_args()
 
@@ -329,14 +333,17 @@ def dispatcher_host_fed(args, frames, device_index, use_hg, steps, warmup=5, n_w
                 put(frames[i % len(frames)])
             d.flush(timeout=100)
             steps *= n_workers
+            before = list(d.frames_per_worker)
             t0 = time.perf_counter()
             for i in range(steps):
                 put(frames[i % len(frames)])
             d.flush(timeout=100)
             el = time.perf_counter() - t0
             placement = d.placement
+            # a worker's own rate: its frames over the time to ITS last frame (a straggling GPU finishes late and shows here)
+            per_worker = [round((d.frames_per_worker[r] - before[r]) / max(d.last_done[r] - t0, 1e-9), 3) for r in range(n_workers)]
         return {"value": round(steps / el, 3), "unit": "frames/s", "frames": steps, "workers": n_workers, "slots": 3, "frames_in_flight": 2,
-                "ms_per_frame": round(el / steps * 1e3, 3), "worker_exit_codes": d.exit_codes,
+                "ms_per_frame": round(el / steps * 1e3, 3), "per_worker_frames_per_s": per_worker, "worker_exit_codes": d.exit_codes,
                 "placement": [{k: (p[k] if k != "cpus" else len(p[k])) for k in ("device", "numa_node", "cpus", "pinned")} for p in placement],
                 "what": "FrameDispatcher: parent memcpy into a pinned shared slot -> worker hipMemcpyAsync H2D -> pre + infer + post_rgb48 "
                         "-> hipMemcpyAsync D2H into a pinned shared slot -> hipEvent -> in-order sink"}
@@ -344,8 +351,61 @@ def dispatcher_host_fed(args, frames, device_index, use_hg, steps, warmup=5, n_w
         return {"error": f"{type(exc).__name__}: {exc}"}
 
 
+def dispatcher_host_sim(args, n_workers, target_fps, seconds=6.0, use_numa=False, device_ms=9.5):
+    """The HOST side of the N-GPU dispatcher without the GPUs (`python bench.py --dispatcher-sim --gpus 8`; CPU only): the real
+    FrameDispatcher -- producer thread per worker, worker-owned shared-memory slots, reorder thread, in-order sink -- over N
+    stand-in workers (dispatch.host_sim_worker: reads the whole input slot, holds the "device" for device_ms per frame with two
+    frames in flight, writes the whole RGB48 slot).  A pacing loop offers frames at target_fps; reported: the rate delivered in
+    order to the sink, per worker, and the CPU seconds per delivered frame of every parent thread."""
+    from hdrtv_mi355x.dispatch import FrameDispatcher, host_sim_worker
+    from hdrtv_mi355x import weights as W
+    H, Wd = args.height, args.width
+    frames = [W.synthetic_frame(H, Wd, seed=1234 + i, kind="noise") for i in range(2)]
+    order = []
+
+    def sink(i, view):
+        order.append(i)
+        _ = int(view[H // 2, Wd // 2, 1])
+
+    n_frames = int(target_fps * seconds)
+    t_main0 = time.thread_time()
+    with FrameDispatcher(n_workers, H, Wd, sink, make_worker=host_sim_worker, init_args={"device_ms": device_ms}, slots=3,
+                         start_timeout=120.0, numa=(True if use_numa else None)) as d:
+        for i in range(2 * n_workers):
+            d.submit_async(frames[i % 2])
+        d.flush(timeout=120)
+        n_warm = len(order)
+        before = list(d.frames_per_worker)
+        t0 = time.perf_counter()
+        for i in range(n_frames):
+            due = t0 + i / target_fps
+            dt = due - time.perf_counter()
+            if dt > 0:
+                time.sleep(dt)
+            d.submit_async(frames[i % 2])
+        t_offered = time.perf_counter() - t0
+        d.flush(timeout=300)
+        el = time.perf_counter() - t0
+        per_worker = [round((d.frames_per_worker[r] - before[r]) / max(d.last_done[r] - t0, 1e-9), 2) for r in range(n_workers)]
+        cpu = {"producer_ms_per_frame": [round(1e3 * c * n_workers / max(n_frames, 1), 3) for c in d.host_cpu_s["producers"]],
+               "reorder_ms_per_frame": round(1e3 * d.host_cpu_s["reorder"] / max(len(order), 1), 4),
+               "submit_thread_ms_per_frame": round(1e3 * (time.thread_time() - t_main0) / max(n_frames, 1), 4)}
+        depth = d.max_reorder_depth
+    in_order = order == list(range(len(order)))
+    return {"target_frames_per_s": target_fps, "delivered_frames_per_s": round(n_frames / el, 2), "offered_over_s": round(t_offered, 2),
+            "frames": n_frames, "workers": n_workers, "device_ms": device_ms, "size": f"{Wd}x{H}", "in_order": in_order and len(order) == n_warm + n_frames,
+            "per_worker_frames_per_s": per_worker, "max_reorder_depth": depth, "parent_cpu": cpu, "worker_exit_codes": d.exit_codes,
+            # host memory traffic per frame: source read 3 + slot write 3 + slot read 3 + RGB48 slot write 6 bytes per pixel
+            "host_bytes_per_frame": H * Wd * 15, "cores": len(os.sched_getaffinity(0)), "numa_pinning": bool(use_numa)}
+
+
 def main():
     args = parse()
+    if args.dispatcher_sim:
+        # CPU only: where the host side of an N-GPU node saturates (DESIGN.md section 7)
+        runs = [dispatcher_host_sim(args, max(1, args.gpus), fps, use_numa=args.sim_numa) for fps in (args.sim_fps or [100.0 * max(1, args.gpus)])]
+        print(json.dumps({"dispatcher_host_sim": runs}), flush=True)
+        return None
     if args.dispatcher:
         # one parent, N worker processes (no torch.distributed): the in-product multi-GPU form
         from hdrtv_mi355x import weights as W

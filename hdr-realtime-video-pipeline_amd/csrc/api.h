@@ -1,6 +1,31 @@
-// hdrtv_api.hip, part 1: weight-pack reader, layer tables, the context, error / variant helpers.
-// (part of hdrtv_api.hip's single translation unit: included there, inside its anonymous namespace where one is open)
-namespace {
+// api.h -- the host side of libhdrtv_mi355x.so: what its translation units share.
+//   hdrtv_api.hip        the exported C ABI (include/hdrtv_mi355x.h), rings, letterbox / metrics / PQ tables
+//   api_util.hip         fail(), the developer-variant table
+//   api_pack.hip         state_dict -> MFMA operand layouts (build_weights); nothing else of it is visible outside
+//   api_workspace.hip    per-resolution workspace (do_reserve), shapes
+//   api_graph.hip        launch sequencing of hdrtv_infer: struct Seq, run_agcm / run_le / run_hg
+//   fp32_graph.hip       precision="fp32": build_weights_f32, run_f32
+// Kernels live in the other .hip files behind launchers.h; no kernel is launched from a header.
+#pragma once
+#include "../../include/hdrtv_mi355x.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "launchers.h"
+
+namespace hdrtv_host {
 
 // ------------------------------------------------------------------------------ weight pack
 struct PackEntry {
@@ -163,7 +188,7 @@ struct Tensor {
     }
 };
 
-struct F32Layer {                            // precision="fp32": one conv layer of fp32_graph.inc
+struct F32Layer {                            // precision="fp32": one conv layer of fp32_graph.hip
     size_t w = 0, b = 0, bn_s = 0, bn_t = 0;
     int cin = 0, cout = 0, cot = 32, ks = 1;
     bool bn = false;
@@ -177,32 +202,33 @@ struct RingSlot {
     bool landed = false;   // state 2: hdrtv_ring_wait has seen the copy land
 };
 
-}  // namespace
+}  // namespace hdrtv_host
 
 struct hdrtv_ctx {
+    // (the types of hdrtv_host are this struct's vocabulary: the public header only names it as an opaque struct)
     int device = 0;
     int n_cu = 256, dev_ncu = 256;        // n_cu: what grids are sized for (variant force_ncu); dev_ncu: the device's
     bool has_hg = false;
-    bool fp32 = false;                    // hdrtv_create_ex(..., HDRTV_PREC_F32): the fp32 graph (fp32_graph.inc) on planar fp32 tensors
-    std::map<std::string, F32Layer> conv32f;
+    bool fp32 = false;                    // hdrtv_create_ex(..., HDRTV_PREC_F32): the fp32 graph (fp32_graph.hip) on planar fp32 tensors
+    std::map<std::string, hdrtv_host::F32Layer> conv32f;
     std::string err;
     mutable std::mutex err_mu;            // fail() runs on the producer and the consumer thread (ring entry points)
-    Arena wts;
-    std::map<std::string, ConvLayer> conv;
-    std::map<std::string, C3Layer> c3;
-    std::map<std::string, ConvI8Layer> conv8;
+    hdrtv_host::Arena wts;
+    std::map<std::string, hdrtv_host::ConvLayer> conv;
+    std::map<std::string, hdrtv_host::C3Layer> c3;
+    std::map<std::string, hdrtv_host::ConvI8Layer> conv8;
     float mask_r = 0.75f;                 // HG_Composite(mask_r=0.75), HG_Composite_arch.py:21
     int cond_mode = 0;                    // 0 AA-bicubic, 1 bilinear (fast_condition_resize), 2 zero (HDRTVNET_ZERO_COND)
     bool hg_i8 = false;                   // the HG pack is a W8A8 checkpoint: 15 layers run on int8 MFMA
     float hg_q0_inv = 0.f, hg_q0_zero = 0.f;   // quantiser of the fp16 -> int8 boundary (conv2's output)
-    std::map<std::string, SftLayer> sft;
+    std::map<std::string, hdrtv_host::SftLayer> sft;
     bool hr_i8 = false;                   // the HR pack holds W8A8 layers: they run on int8 MFMA (predequantize off)
-    std::map<std::string, QLayer> q32, q8;
-    QLastLayer q_trunk6, q_tail2;         // CondNet1.4 / CondNet2.4 as the W8A8 last layer of their fused chains
+    std::map<std::string, hdrtv_host::QLayer> q32, q8;
+    hdrtv_host::QLastLayer q_trunk6, q_tail2;         // CondNet1.4 / CondNet2.4 as the W8A8 last layer of their fused chains
     // fully quantised chains (le_chain_q8.hip) and the fp32 fake-quant of the AGCM classifier / Linear heads
     bool trunk_q8 = false, tail_q8 = false, agcm_q8 = false;
     size_t tq_frag = 0, tq_const = 0, tl_frag = 0, tl_const = 0, ag_frag = 0, ag_P = 0, ag_Q = 0;
-    ActQf tq_q[6], tl_q[2], ag_q[3];
+    hdrtv_host::ActQf tq_q[6], tl_q[2], ag_q[3];
     FakeQ cls_q[6] = {}, lin_q[6] = {};
     std::map<std::string, size_t> f32v;   // raw fp32 vectors/matrices in the weight arena
     size_t zeros_off = 0;                 // 256 B of zeros in the weight arena
@@ -212,8 +238,8 @@ struct hdrtv_ctx {
     size_t hgf_wfrag = 0, hg_w10a = 0;        // fused HG tail: conv1 + conv10(second half) fragments, conv10 first half
     // workspace
     int H = 0, W = 0;
-    Arena ws;
-    std::map<std::string, Tensor> t;
+    hdrtv_host::Arena ws;
+    std::map<std::string, hdrtv_host::Tensor> t;
     int launches = 0;
     double macs = 0.0;
     // per-launch profile (hdrtv_profile_*): event i is recorded after launch i-1
@@ -231,7 +257,7 @@ struct hdrtv_ctx {
     double *mt_dev = nullptr;
     size_t mt_cap = 0;
     // ring
-    std::vector<RingSlot> ring;
+    std::vector<hdrtv_host::RingSlot> ring;
     int ring_next = 0, ring_H = 0, ring_W = 0, ring_waiters = 0;   // ring_waiters: threads blocked on a slot's event outside ring_mu
     std::mutex ring_mu;
     std::condition_variable ring_cv;
@@ -240,3 +266,137 @@ struct hdrtv_ctx {
     // environment on the launch path.
     std::map<std::string, int> var;
 };
+
+namespace hdrtv_host {
+
+// ---- api_util.hip: errors, developer variants
+int fail(hdrtv_ctx *c, int code, const char *fmt, ...);
+bool variant_allowed(const std::string &name, int value);
+void variants_init(hdrtv_ctx *c);              // defaults, then HDRTV_VARIANTS of the creating process
+
+#define HIPCHK(c, expr)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return hdrtv_host::fail(c, HDRTV_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---- api_pack.hip / fp32_graph.hip: the reference's state_dict -> operand layouts in c->wts (hdrtv_create)
+bool build_weights(hdrtv_ctx *c, const Pack &hr, const Pack *hg);
+bool build_weights_f32(hdrtv_ctx *c, const Pack &hr, const Pack *hg);
+
+// ---- api_workspace.hip: the per-resolution workspace (hdrtv_reserve)
+struct Shapes {
+    int H, W, h4, w4;
+    int ch[6], cw[6];        // classifier spatial sizes: [0]=cond, [i]=after block i
+    int H1, W1, H2, W2, H3, W3;
+    int Hp, Wp;
+};
+Shapes shapes_for(int H, int W);
+Tensor &ws_add(hdrtv_ctx *c, const std::string &name, int C, int H, int W, int layout);
+int do_reserve(hdrtv_ctx *c, int H, int W);
+template <typename T>
+T *wsp(hdrtv_ctx *c, const std::string &name)
+{
+    auto it = c->t.find(name);
+    if (it == c->t.end()) { fprintf(stderr, "hdrtv: internal error, no workspace tensor %s\n", name.c_str()); abort(); }
+    return reinterpret_cast<T *>(c->ws.dev + it->second.off);
+}
+template <typename T>
+const T *wtp(hdrtv_ctx *c, size_t off) { return reinterpret_cast<const T *>(c->wts.dev + off); }
+
+// ---- api_graph.hip: launch sequencing of one hdrtv_infer (AGCM, LE, HG); fp32_graph.hip: the fp32 preset's graph
+struct Seq {
+    hdrtv_ctx *c;
+    hipStream_t s;
+    int rc = HDRTV_OK;
+    // conv3x3s2_preg<192> only, consumed by the next conv(): CondNet2's 1x1 tail fused behind its first 64 output channels
+    const f16 *tail_w = nullptr;
+    const float *tail_b = nullptr, *tail_s = nullptr;       // tail_s != null: conv3x3s2_preg<64>'s single-layer tail (CondNet3.4)
+    f16 *tail_out = nullptr;
+    bool ok() const { return rc == HDRTV_OK; }
+    void mark()
+    {
+        if (!c->prof_on) return;
+        const size_t i = c->prof.size();
+        while (c->prof_ev.size() <= i) {
+            hipEvent_t ev;
+            if (hipEventCreate(&ev) != hipSuccess) { c->prof_on = false; return; }
+            c->prof_ev.push_back(ev);
+        }
+        (void)hipEventRecord(c->prof_ev[i], s);
+    }
+    // called after every launch: counts it, checks it and (profiling) closes its event interval
+    void chk(hipError_t e, const char *what, const char *kernel = "", double macs = 0.0, double bytes = 0.0)
+    {
+        ++c->launches;
+        c->macs += macs;
+        if (e != hipSuccess && rc == HDRTV_OK) rc = fail(c, HDRTV_EHIP, "launch %s failed: %s", what, hipGetErrorString(e));
+        if (c->prof_on) {
+            c->prof.push_back({what, kernel, macs, bytes, 0.f});
+            mark();
+        }
+    }
+    // generic conv: src0 (+src1) -> dst
+    void conv(const std::string &key, const f16 *src0, int c0, const f16 *src1, int c1, int Hi, int Wi, int act, int mode, f16 *dst, int dstC, int Hd, int Wd, const f16 *res1 = nullptr, const f16 *res2 = nullptr, f16 *dst_full = nullptr, f16 *dst_planar = nullptr, const f16 *res_planar = nullptr, const float *dotw = nullptr, float *dst_dot = nullptr, int s0_stride = 0);
+    // W8A8 HG layer on int8 MFMA: 3x3 (conv3x3_pglds_i8.hip) or 1x1 (conv_i8_misc.hip)
+    void conv8(const std::string &key, const int8_t *src0, int c0, const int8_t *src1, int c1, int Hi, int Wi, int mode, void *dst, int dstC, int Hd, int Wd, const float *dotw = nullptr, float *dst_dot = nullptr);
+    // W8A8 LE layer on int8 MFMA (conv_q8.hip).  src: f16 NHWC (quantised on load) or this layer's int8 codes; dst: f16, or
+    // (oq != nullptr) the int8 codes of the reading layer's quantiser *oq
+    void convq8(const std::string &key, const void *src, bool src_i8, int src_stride, int Hi, int Wi, int act, void *dst, int dstC, const ActQf *oq);
+    void c3(const std::string &key, const f16 *in, int H, int W, int act, f16 *out, f16 *out_pool, float pool_q_inv = 0.f, float pool_q_zero = 0.f, const f16 *w2frag = nullptr, float *part2 = nullptr);
+    // persistent 32-channel 3x3 conv, optionally with the SFT layer `sft_key` fused in front (conv32p.hip)
+    void conv32(const std::string &key, const f16 *src, const f16 *cond, const std::string &sft_key, int H, int W, int act, int mode, f16 *dst, int dstC, int Hd, int Wd, const f16 *res1 = nullptr, const f16 *res2 = nullptr, f16 *dst_planar = nullptr, const f16 *res_planar = nullptr, const f16 *c3_img = nullptr, const std::string &c3_key = "");
+    // diagnostic builds (make STAMP=1) write per-phase cycle sums of launch number HDRTV_STAMP_LAUNCH (read once) here
+    void *stamp_buf() const
+    {
+#ifdef HDRTV_STAMP
+        static const int stamp_launch = [] { const char *e = getenv("HDRTV_STAMP_LAUNCH"); return e ? atoi(e) : -1; }();
+        return (stamp_launch >= 0 && c->launches == stamp_launch) ? (void *)wsp<f16>(c, "dbg.stamps") : nullptr;
+#else
+        return nullptr;
+#endif
+    }
+    // a conv inside a fused row kernel: its fp16 pack, or (W8A8 layer, variant le_rows_fq) the dequantised pack + its activation quantiser
+    static FqParam fqp(const ActQf &q) { return FqParam{q.inv(), q.zoff(), q.scale, q.asym ? q.zero : -128.f * q.scale}; }
+    const ConvLayer *rows_conv(const std::string &key, FqParam &fq, bool &on) const
+    {
+        on = false;
+        auto it = c->conv.find(key);
+        if (it != c->conv.end()) return &it->second;
+        if (!c->var.at("le_rows_fq")) return nullptr;
+        it = c->conv.find(key + "#fq");
+        if (it == c->conv.end()) return nullptr;
+        auto iq = c->q32.find(key);
+        const ActQf *q = iq != c->q32.end() ? &iq->second.q : nullptr;
+        if (!q) { auto i8 = c->q8.find(key); if (i8 != c->q8.end()) q = &i8->second.q; }
+        if (!q) return nullptr;
+        fq = fqp(*q);
+        on = true;
+        return &it->second;
+    }
+    // its SFT layer: fp16 convs, or all four W8A8 (fake-quant)
+    bool rows_sft(const SftLayer &S, FqParam (&fq)[4], bool &on) const
+    {
+        on = S.q;
+        if (S.q && !c->var.at("le_rows_fq")) return false;
+        for (int i = 0; i < 4; ++i) fq[i] = fqp(S.fq[i]);
+        return true;
+    }
+    // the row-streaming kernels (le_rows.hip) cut a map into 60-column strips x row segments, one workgroup each: worth it
+    // when a segment is long against its 4 .. 6 warm-up rows
+    bool rows_fit(int H, int W) const
+    {
+        const int nstrips = (W + 59) / 60, nseg = std::max(1, c->n_cu / nstrips);
+        return W >= 60 && (H + nseg - 1) / nseg >= c->var.at("le_rows_min");
+    }
+    // ResBlock_with_SFT (arch_util.py:89-95): y = x + conv2(sft2(relu(conv1(sft1(x,c))),c))  [+ extra]; 2 launches
+    void resblock(const std::string &base, const f16 *x, const f16 *cond, int H, int W, f16 *tb, f16 *y, const f16 *extra = nullptr);
+};
+
+int run_agcm(hdrtv_ctx *c, Seq &q, const f16 *rgb, const f16 *cond, f16 *agcm_out);
+int run_le(hdrtv_ctx *c, Seq &q, const f16 *img, f16 *out_planar);
+int run_hg(hdrtv_ctx *c, Seq &q, const f16 *base, void *out, int out_f32);
+int run_f32(hdrtv_ctx *c, Seq &q, bool plan, int H, int W, const float *rgb, const float *cond, float *out, float *agcm_out);
+int f32_plan(hdrtv_ctx *c, int H, int W);      // registers the fp32 graph's tensors (hdrtv_reserve)
+
+}  // namespace hdrtv_host

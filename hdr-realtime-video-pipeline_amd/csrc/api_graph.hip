@@ -1,335 +1,257 @@
-// hdrtv_api.hip, part 4: launch sequencing -- AGCM, LE and HG layer by layer (hdrtv_infer).
-// (part of hdrtv_api.hip's single translation unit: included there, inside its anonymous namespace where one is open)
-// ----------------------------------------------------------------------- launch sequencing
-struct Seq {
-    hdrtv_ctx *c;
-    hipStream_t s;
-    int rc = HDRTV_OK;
-    // conv3x3s2_preg<192> only, consumed by the next conv(): CondNet2's 1x1 tail fused behind its first 64 output channels
-    const f16 *tail_w = nullptr;
-    const float *tail_b = nullptr, *tail_s = nullptr;       // tail_s != null: conv3x3s2_preg<64>'s single-layer tail (CondNet3.4)
-    f16 *tail_out = nullptr;
-    bool ok() const { return rc == HDRTV_OK; }
-    void mark()
-    {
-        if (!c->prof_on) return;
-        const size_t i = c->prof.size();
-        while (c->prof_ev.size() <= i) {
-            hipEvent_t ev;
-            if (hipEventCreate(&ev) != hipSuccess) { c->prof_on = false; return; }
-            c->prof_ev.push_back(ev);
-        }
-        (void)hipEventRecord(c->prof_ev[i], s);
-    }
-    // called after every launch: counts it, checks it and (profiling) closes its event interval
-    void chk(hipError_t e, const char *what, const char *kernel = "", double macs = 0.0, double bytes = 0.0)
-    {
-        ++c->launches;
-        c->macs += macs;
-        if (e != hipSuccess && rc == HDRTV_OK) rc = fail(c, HDRTV_EHIP, "launch %s failed: %s", what, hipGetErrorString(e));
-        if (c->prof_on) {
-            c->prof.push_back({what, kernel, macs, bytes, 0.f});
-            mark();
-        }
-    }
-    // generic conv: src0 (+src1) -> dst
-    void conv(const std::string &key, const f16 *src0, int c0, const f16 *src1, int c1, int Hi, int Wi, int act, int mode,
-              f16 *dst, int dstC, int Hd, int Wd, const f16 *res1 = nullptr, const f16 *res2 = nullptr, f16 *dst_full = nullptr,
-              f16 *dst_planar = nullptr, const f16 *res_planar = nullptr, const float *dotw = nullptr, float *dst_dot = nullptr,
-              int s0_stride = 0)
-    {
-        if (!ok()) return;
-        auto it = c->conv.find(key);
-        if (it == c->conv.end()) { rc = fail(c, HDRTV_ESTATE, "no packed conv %s", key.c_str()); return; }
-        const ConvLayer &L = it->second;
-        ConvParams p;
-        memset(&p, 0, sizeof p);
-        p.src0 = src0; p.src1 = src1; p.c0 = c0; p.c1 = c1;
-        p.s0_stride = s0_stride ? s0_stride : c0; p.s1_stride = c1;
-        p.Hi = Hi; p.Wi = Wi;
-        const int pad = L.ks / 2;
-        p.Ho = (Hi + 2 * pad - L.ks) / L.stride + 1;
-        p.Wo = (Wi + 2 * pad - L.ks) / L.stride + 1;
-        p.wpk = wtp<f16>(c, L.wpk); p.scale = wtp<float>(c, L.scale); p.shift = wtp<float>(c, L.shift);
-        p.CoutPad = L.coutPad; p.Cout = L.cout; p.act = act; p.mode = mode;
-        p.dst = dst; p.dst_full = dst_full; p.dstC = dstC; p.Hd = Hd; p.Wd = Wd;
-        p.res1 = res1; p.res2 = res2; p.dst_planar = dst_planar; p.res_planar = res_planar;
-        p.dotw = dotw; p.dst_dot = dst_dot;
-        if (c0 + c1 != L.cin) { rc = fail(c, HDRTV_ESTATE, "conv %s: channel mismatch", key.c_str()); return; }
-        p.zeros = wtp<f16>(c, c->zeros_off);
-        p.tail_w = tail_w; p.tail_b = tail_b; p.tail_s = tail_s; p.tail_out = tail_out;
-        tail_w = nullptr; tail_b = nullptr; tail_s = nullptr; tail_out = nullptr;
-        const bool g64 = L.stride == 1 && L.cin_t == 64 && L.bn == 128 && !res1 && !res2 && !dst_full && mode != ST_PLANAR3;
-        const bool pglds = g64 && L.ks == 3 && L.cout == L.coutPad;      // HG 3x3 convs: persistent LDS-DMA kernel
-        const bool glds1 = g64 && L.ks == 1 && mode == ST_NHWC && (c0 + c1) >= 128 && L.coutPad <= 512 && (act == ACT_RELU || act == ACT_NONE);   // HG 1x1 fuse convs
-        p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
-        const int nt_slow = c->var.at("pglds_nt_slow");
-        // default: the Up convs (Cout = 4 Cin: 4 .. 16 Cout-tiles per pixel tile) walk Cout-tile slowest -- an XCD then shares one
-        // weight slab instead of re-fetching up to 16 (-17 % L2 misses, profiles/r02_pmc_traffic_tile_order.json); the other
-        // layers walk it fastest so that the blocks of an XCD share halo tiles (+45 .. +75 % misses the other way round)
-        p.nt_slow = nt_slow == 3 ? (mode == ST_PS) : (nt_slow == 2 ? (L.coutPad >= 512) : nt_slow);
-        const bool s2g = L.ks == 3 && L.stride == 2 && L.cin_t == 64 && L.bn == L.coutPad && (L.coutPad == 64 || L.coutPad == 192);
-        // a fused 1x1 tail (run_le sets it and then skips the tail's own launch) exists in conv3x3s2_preg's epilogue only
-        if (p.tail_w && !s2g) { rc = fail(c, HDRTV_ESTATE, "conv %s: a fused CondNet tail was requested but the layer does not run on conv3x3s2_preg", key.c_str()); return; }
-        const bool no_t16 = c->var.at("no_t16") != 0;                         // developer A/B: the generic implicit-GEMM kernel
-        const bool t16 = !no_t16 && L.ks == 3 && L.stride == 2 && L.cin == 32 && L.coutPad == 32 && !src1 && mode == ST_NHWC && !res1 && !res2;
-        // HG 3x3 convs with Cout a multiple of 256: the private-weight schedule (conv3x3_prw.hip); variant prw = 0: conv_pglds
-        // variant "prw": 0 = never, 1 (default) = the cheapest shape per layer, 2 / 3 = 16-row / 8-row tiles wherever it applies
-        const int use_prw_mode = c->var.at("prw");
-        const bool use_prw = use_prw_mode != 0;
-        const bool prw_dot3 = mode == ST_PS_DOT3 && L.coutPad == 256;                // Up_conv5: always the 16-row shape
-        bool prw = pglds && use_prw && (L.coutPad % 256) == 0 && (mode != ST_PS_DOT3 || prw_dot3);
-        int prw_th = 16;
-        if (prw && prw_dot3) {
-        } else if (prw && use_prw_mode == 1) {
-            // Its tiles cover 256 output channels (conv_pglds: 128).  Pick the shape whose tile count wastes least of the last
-            // round on n_cu workgroups: relative cost per unit of work 1.0 (16-row tiles), 1.09 (8-row tiles: twice the weight
-            // bytes per MAC, 1.11x the halo), 1.15 - 1.22 (conv_pglds) -- measured on full rounds, profiles/r03_prw_ab.txt
-            const long tx = (p.Wo + 15) / 16, n = c->n_cu;
-            auto cost = [&](long tiles, double rel) { return (double)(((tiles + n - 1) / n) * n) / (double)tiles * rel; };
-            const double c16 = cost(tx * ((p.Ho + 15) / 16) * (L.coutPad / 256), 1.0);
-            const double c8 = cost(tx * ((p.Ho + 7) / 8) * (L.coutPad / 256), 1.09);
-            const double c0 = cost(tx * ((p.Ho + 15) / 16) * (L.coutPad / 128), 1.22);
-            if (c0 <= c16 && c0 <= c8) prw = false;
-            else prw_th = c8 < c16 ? 8 : 16;
-        } else if (prw && use_prw_mode == 3) {
-            prw_th = 8;
-        }
-        char tag[64];
-        if (t16) snprintf(tag, sizeof tag, "conv_t16<32,3,2>");
-        else if (s2g) snprintf(tag, sizeof tag, p.tail_w ? "conv3x3s2_preg<%d>+tail" : "conv3x3s2_preg<%d>", L.coutPad);
-        else if (pglds) snprintf(tag, sizeof tag, "%s<%s>", prw ? (prw_th == 8 ? "conv_prw8" : "conv_prw") : "conv_pglds", mode == ST_POOL ? "pool" : (mode == ST_PS ? "ps" : (mode == ST_PS_DOT3 ? "ps_dot3" : "nhwc")));
-        else if (glds1) snprintf(tag, sizeof tag, "conv_glds1");
-        else snprintf(tag, sizeof tag, "conv_igemm<%d,%d,%d,%d>", L.cin_t, L.bn, L.ks, L.stride);
-        double macs = (double)p.Ho * p.Wo * L.cin * L.ks * L.ks * L.cout;
-        double bytes = 2.0 * Hi * Wi * L.cin + 2.0 * L.ks * L.ks * L.cin * L.coutPad;
-        if (s2g && p.tail_w) {          // a fused 1x1 tail: + its MACs, 16 channels out instead of the 64 it consumes
-            macs += (double)p.Ho * p.Wo * (p.tail_s ? 64 * 16 : 64 * 64 + 64 * 16);
-            bytes -= 2.0 * p.Ho * p.Wo * (64 - 16);
-        }
-        const double outel = mode == ST_POOL ? (double)Hd * Wd * L.cout + (dst_full ? (double)p.Ho * p.Wo * L.cout : 0.0)
-                                              : (mode == ST_PLANAR3 ? 3.0 * Hd * Wd
-                                                                    : (mode == ST_PS_DOT3 ? 8.0 * Hd * Wd : (double)p.Ho * p.Wo * L.cout));
-        bytes += 2.0 * outel * (1 + (res1 ? 1 : 0) + (res2 ? 1 : 0) + (res_planar ? 1 : 0));
-        chk(t16 ? conv_t16_launch(p, s, c->n_cu) : s2g ? conv3x3s2_preg_launch(p, c->n_cu, s)
-                : (pglds ? (prw ? conv_prw_launch(p, prw_th, c->n_cu, s) : conv_pglds_launch(p, c->n_cu, s))
-                         : (glds1 ? conv_glds1_launch(p, s, c->n_cu, c->var.at("glds1_old") != 0) : conv_igemm_launch(p, L.cin_t, L.bn, L.ks, L.stride, s))),
-            key.c_str(), tag, macs, bytes);
-    }
-    // W8A8 HG layer on int8 MFMA: 3x3 (conv3x3_pglds_i8.hip) or 1x1 (conv_i8_misc.hip)
-    void conv8(const std::string &key, const int8_t *src0, int c0, const int8_t *src1, int c1, int Hi, int Wi, int mode, void *dst,
-               int dstC, int Hd, int Wd, const float *dotw = nullptr, float *dst_dot = nullptr)
-    {
-        if (!ok()) return;
-        auto it = c->conv8.find(key);
-        if (it == c->conv8.end()) { rc = fail(c, HDRTV_ESTATE, "no packed int8 conv %s", key.c_str()); return; }
-        const ConvI8Layer &L = it->second;
-        if (c0 + c1 != L.cin) { rc = fail(c, HDRTV_ESTATE, "conv %s: channel mismatch", key.c_str()); return; }
-        ConvI8Params p;
-        memset(&p, 0, sizeof p);
-        p.src0 = src0; p.src1 = src1; p.c0 = c0; p.c1 = c1; p.Hi = Hi; p.Wi = Wi; p.Ho = Hi; p.Wo = Wi;
-        p.wpk = wtp<int8_t>(c, L.wpk); p.scale = wtp<float>(c, L.scale); p.shift = wtp<float>(c, L.shift);
-        p.Cout = L.cout; p.mode = mode; p.out_f16 = L.out_f16; p.dst = dst; p.dstC = dstC; p.Hd = Hd; p.Wd = Wd;
-        p.padline = wtp<int8_t>(c, L.padline);
-        p.delta = L.has_delta ? wtp<float>(c, L.delta) : nullptr;
-        p.delta_acc = L.has_delta ? wtp<int>(c, L.delta_acc) : nullptr;
-        p.lo_clamp = L.lo_clamp;
-        p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
-        p.dotw = dotw; p.dst_dot = dst_dot;
-        char tag[64];
-        if (L.ks == 3) snprintf(tag, sizeof tag, "conv_pglds_i8<%s%s>", mode == ST_POOL ? "pool" : (mode == ST_PS ? "ps" : (mode == ST_PS_DOT3 ? "ps_dot3" : "nhwc")), c0 == 64 ? ",c64" : "");
-        else snprintf(tag, sizeof tag, "conv1x1_i8%s", L.out_f16 ? "<f16>" : "");
-        const double macs = (double)Hi * Wi * L.cin * L.ks * L.ks * L.cout_real;
-        const double outel = mode == ST_POOL ? (double)Hd * Wd * L.cout_real : (double)Hi * Wi * L.cout_real;
-        const double bytes = (double)Hi * Wi * L.cin + (double)L.ks * L.ks * L.cin * L.cout +
-                             (mode == ST_PS_DOT3 ? 16.0 * Hd * Wd : outel * (L.out_f16 ? 2.0 : 1.0));
-        // the private-weight schedule (conv3x3_prw_i8.hip) and its tile shape, picked as for the fp16 layers (Seq::conv)
-        const int prw_mode = c->var.at("prw");
-        bool prw = prw_mode != 0 && L.ks == 3 && c0 != 64 && (L.cout % 256) == 0 && mode != ST_PS_DOT3 && !L.out_f16;
-        int prw_th = 16;
-        if (prw && prw_mode == 1) {
-            const long tx = (Wi + 15) / 16, n = c->n_cu;
-            auto cost = [&](long tiles, double rel) { return (double)(((tiles + n - 1) / n) * n) / (double)tiles * rel; };
-            const double c16 = cost(tx * ((Hi + 15) / 16) * (L.cout / 256), 1.0), c8 = cost(tx * ((Hi + 7) / 8) * (L.cout / 256), 1.09);
-            const double c0c = cost(tx * ((Hi + 15) / 16) * (L.cout / 128), 1.22);
-            if (c0c <= c16 && c0c <= c8) prw = false;
-            else prw_th = c8 < c16 ? 8 : 16;
-        } else if (prw && prw_mode == 3) {
-            prw_th = 8;
-        }
-        // variant "prw_i8": 0 = never, 1 = only where the 8-row tiles win (the low-resolution layers), 2 = wherever "prw" selects it
-        const int i8_mode = c->var.at("prw_i8");
-        if (i8_mode == 0 || (i8_mode == 1 && prw_th != 8)) prw = false;
-        if (prw) snprintf(tag, sizeof tag, "conv_prw%s_i8<%s>", prw_th == 8 ? "8" : "", mode == ST_POOL ? "pool" : (mode == ST_PS ? "ps" : "nhwc"));
-        chk(L.ks == 3 ? (prw ? conv_prw_i8_launch(p, prw_th, c->n_cu, s) : conv_pglds_i8_launch(p, c->n_cu, s)) : conv1x1_i8_launch(p, s),
-            key.c_str(), tag, macs, bytes);
-    }
-    // W8A8 LE layer on int8 MFMA (conv_q8.hip).  src: f16 NHWC (quantised on load) or this layer's int8 codes; dst: f16, or
-    // (oq != nullptr) the int8 codes of the reading layer's quantiser *oq
-    void convq8(const std::string &key, const void *src, bool src_i8, int src_stride, int Hi, int Wi, int act, void *dst, int dstC,
-                const ActQf *oq)
-    {
-        if (!ok()) return;
-        auto it = c->q8.find(key);
-        if (it == c->q8.end()) { rc = fail(c, HDRTV_ESTATE, "no packed W8A8 conv %s", key.c_str()); return; }
-        const QLayer &L = it->second;
-        ConvQ8Params p;
-        memset(&p, 0, sizeof p);
-        p.src = src; p.src_i8 = src_i8 ? 1 : 0; p.Cin = L.cin; p.src_stride = src_stride; p.Hi = Hi; p.Wi = Wi;
-        p.ks = L.ks; p.stride = L.stride;
-        const int pad = L.ks / 2;
-        p.Ho = (Hi + 2 * pad - L.ks) / L.stride + 1; p.Wo = (Wi + 2 * pad - L.ks) / L.stride + 1;
-        p.wpk8 = wtp<int8_t>(c, L.wpk8); p.scale = wtp<float>(c, L.scale); p.shift = wtp<float>(c, L.shift);
-        p.CoutPad = L.coutPad; p.Cout = L.cout; p.act = act; p.q_inv = L.q.inv(); p.q_zoff = L.q.zoff();
-        p.dst = dst; p.dst_i8 = oq ? 1 : 0; p.dstC = dstC;
-        if (oq) { p.oq_inv = oq->inv(); p.oq_zoff = oq->zoff(); }
-        char tag[64];
-        snprintf(tag, sizeof tag, "conv_q8<%d,%d,%d>", L.cin, L.ks, L.stride);
-        const double macs = (double)p.Ho * p.Wo * L.cin * L.ks * L.ks * L.cout;
-        const double bytes = (double)Hi * Wi * L.cin * (src_i8 ? 1.0 : 2.0) + (double)L.ks * L.ks * L.cin * L.coutPad +
-                             (double)p.Ho * p.Wo * L.cout * (oq ? 1.0 : 2.0);
-        chk(conv_q8_launch(p, s, c->n_cu), key.c_str(), tag, macs, bytes);
-    }
-    void c3(const std::string &key, const f16 *in, int H, int W, int act, f16 *out, f16 *out_pool, float pool_q_inv = 0.f,
-            float pool_q_zero = 0.f, const f16 *w2frag = nullptr, float *part2 = nullptr)
-    {
-        if (!ok()) return;
-        const C3Layer &L = c->c3.at(key);
-        chk(conv_c3_launch(in, H, W, wtp<f16>(c, L.wfrag), wtp<float>(c, L.scale), wtp<float>(c, L.shift), L.cout, act, out,
-                           out_pool, c->n_cu, s, pool_q_inv, pool_q_zero, w2frag, part2), key.c_str(),
-            part2 ? "conv_c3<64,dot3>" : (L.cout == 64 ? "conv_c3<64>" : "conv_c3<32>"), (double)H * W * (27 * L.cout + (part2 ? 192 : 0)),
-            (double)H * W * (6.0 + (out ? 2.0 * L.cout : 0.0) + (out_pool ? (pool_q_inv > 0.f ? 0.25 : 0.5) * L.cout : 0.0) + (part2 ? 16.0 : 0.0)));
-    }
-    // persistent 32-channel 3x3 conv, optionally with the SFT layer `sft_key` fused in front (conv32p.hip)
-    void conv32(const std::string &key, const f16 *src, const f16 *cond, const std::string &sft_key, int H, int W, int act,
-                int mode, f16 *dst, int dstC, int Hd, int Wd, const f16 *res1 = nullptr, const f16 *res2 = nullptr,
-                f16 *dst_planar = nullptr, const f16 *res_planar = nullptr, const f16 *c3_img = nullptr, const std::string &c3_key = "")
-    {
-        if (!ok()) return;
-        auto it = c->conv.find(key);
-        auto iq = c->q32.find(key);
-        if (it == c->conv.end() && iq == c->q32.end()) { rc = fail(c, HDRTV_ESTATE, "no packed conv %s", key.c_str()); return; }
-        const bool i8 = iq != c->q32.end();
-        ConvLayer L;
-        Conv32Params p;
-        memset(&p, 0, sizeof p);
-        if (i8) {             // W8A8 layer: int8 MFMA on the quantised tile
-            const QLayer &Q = iq->second;
-            L.cout = Q.cout; L.coutPad = Q.coutPad;
-            p.wpk8 = wtp<int8_t>(c, Q.wpk8); p.scale = wtp<float>(c, Q.scale); p.shift = wtp<float>(c, Q.shift);
-            p.q_inv = Q.q.inv(); p.q_zoff = Q.q.zoff();
-        } else {
-            L = it->second;
-            p.wpk = wtp<f16>(c, L.wpk); p.scale = wtp<float>(c, L.scale); p.shift = wtp<float>(c, L.shift);
-        }
-        p.src = src; p.cond = cond; p.H = H; p.W = W;
-        bool sq = false;
-        if (cond) {
-            const SftLayer &S = c->sft.at(sft_key);
-            p.sft_wfrag = wtp<f16>(c, S.wfrag); p.sft_bias = wtp<float>(c, S.bias);
-            if (S.q) {        // W8A8 SFT convs: int8 MFMA on the quantised condition pixel
-                sq = true;
-                p.sq_wfrag = wtp<int8_t>(c, S.qfrag); p.sq_const = wtp<float>(c, S.qconst);
-                for (int b = 0; b < 2; ++b) { p.sq_inv[b] = S.inv[b]; p.sq_zoff[b] = S.zoff[b]; p.sq_hzoff[b] = S.hzoff[b]; }
-            }
-        }
-        p.CoutPad = L.coutPad; p.Cout = L.cout; p.act = act; p.mode = mode;
-        p.dst = dst; p.dstC = dstC; p.Hd = Hd; p.Wd = Wd; p.res1 = res1; p.res2 = res2;
-        p.dst_planar = dst_planar; p.res_planar = res_planar; p.zeros = wtp<f16>(c, c->zeros_off);
-        p.dump = reinterpret_cast<f16 *>(stamp_buf());
-        const double npx = (double)H * W;
-        const double macs = npx * 32 * 9 * L.cout + (cond ? npx * 2 * (16 * 16 + 16 * 32) : 0.0) + (c3_img ? npx * 27 * 32 : 0.0);
-        const double outb = mode == ST_PLANAR3 ? 6.0 * npx : 2.0 * npx * L.cout;
-        const double bytes = npx * ((c3_img ? 6 : 64) + (cond ? 32 : 0)) + outb * (1 + (res1 ? 1 : 0) + (res2 ? 1 : 0) + (res_planar ? 1 : 0)) +
-                             (i8 ? 1.0 : 2.0) * 9 * 32 * L.coutPad;
-        p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
-        if (c3_img) {         // conv_first fused in front of SFT_layer1 + HR_conv1: src is the planar image
-            const C3Layer &L3 = c->c3.at(c3_key);
-            p.c3_img = c3_img; p.c3_wfrag = wtp<f16>(c, L3.wfrag);      // bias inside the fragments (pack_c3), no BatchNorm
-        }
-        // single-pass layers run the one-barrier schedule (conv32s.hip); variant "conv32_old" is the developer A/B switch
-        const bool old_sched = c->var.at("conv32_old") != 0;
-        const bool one_barrier = L.coutPad == 32 && !old_sched;
-        char tag[48];
-        snprintf(tag, sizeof tag, "conv32%c<%d,%s%s%s>", one_barrier ? 's' : 'p', L.coutPad / 32, c3_img ? "c3+" : "", cond ? (sq ? "sft-i8" : "sft") : "plain", i8 ? ",i8" : "");
-        if (c3_img && !one_barrier) { rc = fail(c, HDRTV_ESTATE, "conv_first fusion needs the one-barrier schedule"); return; }
-        chk(one_barrier ? conv32s_launch(p, c->n_cu, s, c->var.at("conv32_nosplit") != 0) : conv32p_launch(p, c->n_cu, s, c->var.at("conv32_nw")), key.c_str(), tag, macs, bytes);
-    }
-    // diagnostic builds (make STAMP=1) write per-phase cycle sums of launch number HDRTV_STAMP_LAUNCH (read once) here
-    void *stamp_buf() const
-    {
-#ifdef HDRTV_STAMP
-        static const int stamp_launch = [] { const char *e = getenv("HDRTV_STAMP_LAUNCH"); return e ? atoi(e) : -1; }();
-        return (stamp_launch >= 0 && c->launches == stamp_launch) ? (void *)wsp<f16>(c, "dbg.stamps") : nullptr;
-#else
-        return nullptr;
-#endif
-    }
-    // a conv inside a fused row kernel: its fp16 pack, or (W8A8 layer, variant le_rows_fq) the dequantised pack + its activation quantiser
-    static FqParam fqp(const ActQf &q) { return FqParam{q.inv(), q.zoff(), q.scale, q.asym ? q.zero : -128.f * q.scale}; }
-    const ConvLayer *rows_conv(const std::string &key, FqParam &fq, bool &on) const
-    {
-        on = false;
-        auto it = c->conv.find(key);
-        if (it != c->conv.end()) return &it->second;
-        if (!c->var.at("le_rows_fq")) return nullptr;
-        it = c->conv.find(key + "#fq");
-        if (it == c->conv.end()) return nullptr;
-        auto iq = c->q32.find(key);
-        const ActQf *q = iq != c->q32.end() ? &iq->second.q : nullptr;
-        if (!q) { auto i8 = c->q8.find(key); if (i8 != c->q8.end()) q = &i8->second.q; }
-        if (!q) return nullptr;
-        fq = fqp(*q);
-        on = true;
-        return &it->second;
-    }
-    // its SFT layer: fp16 convs, or all four W8A8 (fake-quant)
-    bool rows_sft(const SftLayer &S, FqParam (&fq)[4], bool &on) const
-    {
-        on = S.q;
-        if (S.q && !c->var.at("le_rows_fq")) return false;
-        for (int i = 0; i < 4; ++i) fq[i] = fqp(S.fq[i]);
-        return true;
-    }
-    // the row-streaming kernels (le_rows.hip) cut a map into 60-column strips x row segments, one workgroup each: worth it
-    // when a segment is long against its 4 .. 6 warm-up rows
-    bool rows_fit(int H, int W) const
-    {
-        const int nstrips = (W + 59) / 60, nseg = std::max(1, c->n_cu / nstrips);
-        return W >= 60 && (H + nseg - 1) / nseg >= c->var.at("le_rows_min");
-    }
-    // ResBlock_with_SFT (arch_util.py:89-95): y = x + conv2(sft2(relu(conv1(sft1(x,c))),c))  [+ extra]; 2 launches
-    void resblock(const std::string &base, const f16 *x, const f16 *cond, int H, int W, f16 *tb, f16 *y,
-                  const f16 *extra = nullptr)
-    {
-        // fp16 block without a second residual, enough rows per segment to amortise the 4-row warm-up: ONE row-streaming
-        // launch (le_rows.hip), the intermediate never leaves LDS; bit-identical to the two launches below
-        if (ok() && c->var.at("le_rows") && !extra && rows_fit(H, W)) {
-            RowsRbParams p;
-            memset(&p, 0, sizeof p);
-            bool q1, q2, qs1, qs2;
-            const ConvLayer *L1 = rows_conv(base + ".conv1", p.fq_c1, q1), *L2 = rows_conv(base + ".conv2", p.fq_c2, q2);
-            const SftLayer &S1 = c->sft.at(base + ".sft1"), &S2 = c->sft.at(base + ".sft2");
-            if (L1 && L2 && rows_sft(S1, p.fq_s1, qs1) && rows_sft(S2, p.fq_s2, qs2)) {
-                p.fq = (q1 ? 1 : 0) | (q2 ? 2 : 0) | (qs1 ? 4 : 0) | (qs2 ? 8 : 0);
-                p.x = x; p.cond = cond; p.H = H; p.W = W; p.dst = y;
-                p.w1 = wtp<f16>(c, L1->wpk); p.w2 = wtp<f16>(c, L2->wpk); p.b1 = wtp<float>(c, L1->shift); p.b2 = wtp<float>(c, L2->shift);
-                p.sft1_wfrag = wtp<f16>(c, S1.wfrag); p.sft1_bias = wtp<float>(c, S1.bias);
-                p.sft2_wfrag = wtp<f16>(c, S2.wfrag); p.sft2_bias = wtp<float>(c, S2.bias);
-                p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
-                p.dump = stamp_buf();
-                const double npx = (double)H * W;
-                chk(le_rb_rows_launch(p, c->n_cu, s), base.c_str(), p.fq ? "le_rb_rows<fq>" : "le_rb_rows",
-                    npx * (2.0 * 32 * 9 * 32 + 4.0 * (16 * 16 + 16 * 32)), npx * (64 + 32 + 64) + 2.0 * 2 * 9 * 32 * 32);
-                return;
-            }
-        }
-        conv32(base + ".conv1", x, cond, base + ".sft1", H, W, ACT_RELU, ST_NHWC, tb, 32, H, W);
-        conv32(base + ".conv2", tb, cond, base + ".sft2", H, W, ACT_NONE, ST_NHWC, y, 32, H, W, x, extra);
-    }
-};
+// api_graph.hip -- launch sequencing of one hdrtv_infer: AGCM, LE and HG layer by layer (struct Seq: api.h).
+#include "api.h"
 
-#include "fp32_graph.inc"
+namespace hdrtv_host {
+
+// ----------------------------------------------------------------------- Seq: one launch per call, counted, checked, profiled
+void Seq::conv(const std::string &key, const f16 *src0, int c0, const f16 *src1, int c1, int Hi, int Wi, int act, int mode, f16 *dst, int dstC, int Hd, int Wd, const f16 *res1, const f16 *res2, f16 *dst_full, f16 *dst_planar, const f16 *res_planar, const float *dotw, float *dst_dot, int s0_stride)
+{
+    if (!ok()) return;
+    auto it = c->conv.find(key);
+    if (it == c->conv.end()) { rc = fail(c, HDRTV_ESTATE, "no packed conv %s", key.c_str()); return; }
+    const ConvLayer &L = it->second;
+    ConvParams p;
+    memset(&p, 0, sizeof p);
+    p.src0 = src0; p.src1 = src1; p.c0 = c0; p.c1 = c1;
+    p.s0_stride = s0_stride ? s0_stride : c0; p.s1_stride = c1;
+    p.Hi = Hi; p.Wi = Wi;
+    const int pad = L.ks / 2;
+    p.Ho = (Hi + 2 * pad - L.ks) / L.stride + 1;
+    p.Wo = (Wi + 2 * pad - L.ks) / L.stride + 1;
+    p.wpk = wtp<f16>(c, L.wpk); p.scale = wtp<float>(c, L.scale); p.shift = wtp<float>(c, L.shift);
+    p.CoutPad = L.coutPad; p.Cout = L.cout; p.act = act; p.mode = mode;
+    p.dst = dst; p.dst_full = dst_full; p.dstC = dstC; p.Hd = Hd; p.Wd = Wd;
+    p.res1 = res1; p.res2 = res2; p.dst_planar = dst_planar; p.res_planar = res_planar;
+    p.dotw = dotw; p.dst_dot = dst_dot;
+    if (c0 + c1 != L.cin) { rc = fail(c, HDRTV_ESTATE, "conv %s: channel mismatch", key.c_str()); return; }
+    p.zeros = wtp<f16>(c, c->zeros_off);
+    p.tail_w = tail_w; p.tail_b = tail_b; p.tail_s = tail_s; p.tail_out = tail_out;
+    tail_w = nullptr; tail_b = nullptr; tail_s = nullptr; tail_out = nullptr;
+    const bool g64 = L.stride == 1 && L.cin_t == 64 && L.bn == 128 && !res1 && !res2 && !dst_full && mode != ST_PLANAR3;
+    const bool pglds = g64 && L.ks == 3 && L.cout == L.coutPad;      // HG 3x3 convs: persistent LDS-DMA kernel
+    const bool glds1 = g64 && L.ks == 1 && mode == ST_NHWC && (c0 + c1) >= 128 && L.coutPad <= 512 && (act == ACT_RELU || act == ACT_NONE);   // HG 1x1 fuse convs
+    p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
+    const int nt_slow = c->var.at("pglds_nt_slow");
+    // default: the Up convs (Cout = 4 Cin: 4 .. 16 Cout-tiles per pixel tile) walk Cout-tile slowest -- an XCD then shares one
+    // weight slab instead of re-fetching up to 16 (-17 % L2 misses, profiles/r02_pmc_traffic_tile_order.json); the other
+    // layers walk it fastest so that the blocks of an XCD share halo tiles (+45 .. +75 % misses the other way round)
+    p.nt_slow = nt_slow == 3 ? (mode == ST_PS) : (nt_slow == 2 ? (L.coutPad >= 512) : nt_slow);
+    const bool s2g = L.ks == 3 && L.stride == 2 && L.cin_t == 64 && L.bn == L.coutPad && (L.coutPad == 64 || L.coutPad == 192);
+    // a fused 1x1 tail (run_le sets it and then skips the tail's own launch) exists in conv3x3s2_preg's epilogue only
+    if (p.tail_w && !s2g) { rc = fail(c, HDRTV_ESTATE, "conv %s: a fused CondNet tail was requested but the layer does not run on conv3x3s2_preg", key.c_str()); return; }
+    const bool no_t16 = c->var.at("no_t16") != 0;                         // developer A/B: the generic implicit-GEMM kernel
+    const bool t16 = !no_t16 && L.ks == 3 && L.stride == 2 && L.cin == 32 && L.coutPad == 32 && !src1 && mode == ST_NHWC && !res1 && !res2;
+    // HG 3x3 convs with Cout a multiple of 256: the private-weight schedule (conv3x3_prw.hip); variant prw = 0: conv_pglds
+    // variant "prw": 0 = never, 1 (default) = the cheapest shape per layer, 2 / 3 = 16-row / 8-row tiles wherever it applies
+    const int use_prw_mode = c->var.at("prw");
+    const bool use_prw = use_prw_mode != 0;
+    const bool prw_dot3 = mode == ST_PS_DOT3 && L.coutPad == 256;                // Up_conv5: always the 16-row shape
+    bool prw = pglds && use_prw && (L.coutPad % 256) == 0 && (mode != ST_PS_DOT3 || prw_dot3);
+    int prw_th = 16;
+    if (prw && prw_dot3) {
+    } else if (prw && use_prw_mode == 1) {
+        // Its tiles cover 256 output channels (conv_pglds: 128).  Pick the shape whose tile count wastes least of the last
+        // round on n_cu workgroups: relative cost per unit of work 1.0 (16-row tiles), 1.09 (8-row tiles: twice the weight
+        // bytes per MAC, 1.11x the halo), 1.15 - 1.22 (conv_pglds) -- measured on full rounds, profiles/r03_prw_ab.txt
+        const long tx = (p.Wo + 15) / 16, n = c->n_cu;
+        auto cost = [&](long tiles, double rel) { return (double)(((tiles + n - 1) / n) * n) / (double)tiles * rel; };
+        const double c16 = cost(tx * ((p.Ho + 15) / 16) * (L.coutPad / 256), 1.0);
+        const double c8 = cost(tx * ((p.Ho + 7) / 8) * (L.coutPad / 256), 1.09);
+        const double c0 = cost(tx * ((p.Ho + 15) / 16) * (L.coutPad / 128), 1.22);
+        if (c0 <= c16 && c0 <= c8) prw = false;
+        else prw_th = c8 < c16 ? 8 : 16;
+    } else if (prw && use_prw_mode == 3) {
+        prw_th = 8;
+    }
+    char tag[64];
+    if (t16) snprintf(tag, sizeof tag, "conv_t16<32,3,2>");
+    else if (s2g) snprintf(tag, sizeof tag, p.tail_w ? "conv3x3s2_preg<%d>+tail" : "conv3x3s2_preg<%d>", L.coutPad);
+    else if (pglds) snprintf(tag, sizeof tag, "%s<%s>", prw ? (prw_th == 8 ? "conv_prw8" : "conv_prw") : "conv_pglds", mode == ST_POOL ? "pool" : (mode == ST_PS ? "ps" : (mode == ST_PS_DOT3 ? "ps_dot3" : "nhwc")));
+    else if (glds1) snprintf(tag, sizeof tag, "conv_glds1");
+    else snprintf(tag, sizeof tag, "conv_igemm<%d,%d,%d,%d>", L.cin_t, L.bn, L.ks, L.stride);
+    double macs = (double)p.Ho * p.Wo * L.cin * L.ks * L.ks * L.cout;
+    double bytes = 2.0 * Hi * Wi * L.cin + 2.0 * L.ks * L.ks * L.cin * L.coutPad;
+    if (s2g && p.tail_w) {          // a fused 1x1 tail: + its MACs, 16 channels out instead of the 64 it consumes
+        macs += (double)p.Ho * p.Wo * (p.tail_s ? 64 * 16 : 64 * 64 + 64 * 16);
+        bytes -= 2.0 * p.Ho * p.Wo * (64 - 16);
+    }
+    const double outel = mode == ST_POOL ? (double)Hd * Wd * L.cout + (dst_full ? (double)p.Ho * p.Wo * L.cout : 0.0)
+                                          : (mode == ST_PLANAR3 ? 3.0 * Hd * Wd
+                                                                : (mode == ST_PS_DOT3 ? 8.0 * Hd * Wd : (double)p.Ho * p.Wo * L.cout));
+    bytes += 2.0 * outel * (1 + (res1 ? 1 : 0) + (res2 ? 1 : 0) + (res_planar ? 1 : 0));
+    chk(t16 ? conv_t16_launch(p, s, c->n_cu) : s2g ? conv3x3s2_preg_launch(p, c->n_cu, s)
+            : (pglds ? (prw ? conv_prw_launch(p, prw_th, c->n_cu, s) : conv_pglds_launch(p, c->n_cu, s))
+                     : (glds1 ? conv_glds1_launch(p, s, c->n_cu, c->var.at("glds1_old") != 0) : conv_igemm_launch(p, L.cin_t, L.bn, L.ks, L.stride, s))),
+        key.c_str(), tag, macs, bytes);
+}
+
+
+void Seq::conv8(const std::string &key, const int8_t *src0, int c0, const int8_t *src1, int c1, int Hi, int Wi, int mode, void *dst, int dstC, int Hd, int Wd, const float *dotw, float *dst_dot)
+{
+    if (!ok()) return;
+    auto it = c->conv8.find(key);
+    if (it == c->conv8.end()) { rc = fail(c, HDRTV_ESTATE, "no packed int8 conv %s", key.c_str()); return; }
+    const ConvI8Layer &L = it->second;
+    if (c0 + c1 != L.cin) { rc = fail(c, HDRTV_ESTATE, "conv %s: channel mismatch", key.c_str()); return; }
+    ConvI8Params p;
+    memset(&p, 0, sizeof p);
+    p.src0 = src0; p.src1 = src1; p.c0 = c0; p.c1 = c1; p.Hi = Hi; p.Wi = Wi; p.Ho = Hi; p.Wo = Wi;
+    p.wpk = wtp<int8_t>(c, L.wpk); p.scale = wtp<float>(c, L.scale); p.shift = wtp<float>(c, L.shift);
+    p.Cout = L.cout; p.mode = mode; p.out_f16 = L.out_f16; p.dst = dst; p.dstC = dstC; p.Hd = Hd; p.Wd = Wd;
+    p.padline = wtp<int8_t>(c, L.padline);
+    p.delta = L.has_delta ? wtp<float>(c, L.delta) : nullptr;
+    p.delta_acc = L.has_delta ? wtp<int>(c, L.delta_acc) : nullptr;
+    p.lo_clamp = L.lo_clamp;
+    p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
+    p.dotw = dotw; p.dst_dot = dst_dot;
+    char tag[64];
+    if (L.ks == 3) snprintf(tag, sizeof tag, "conv_pglds_i8<%s%s>", mode == ST_POOL ? "pool" : (mode == ST_PS ? "ps" : (mode == ST_PS_DOT3 ? "ps_dot3" : "nhwc")), c0 == 64 ? ",c64" : "");
+    else snprintf(tag, sizeof tag, "conv1x1_i8%s", L.out_f16 ? "<f16>" : "");
+    const double macs = (double)Hi * Wi * L.cin * L.ks * L.ks * L.cout_real;
+    const double outel = mode == ST_POOL ? (double)Hd * Wd * L.cout_real : (double)Hi * Wi * L.cout_real;
+    const double bytes = (double)Hi * Wi * L.cin + (double)L.ks * L.ks * L.cin * L.cout +
+                         (mode == ST_PS_DOT3 ? 16.0 * Hd * Wd : outel * (L.out_f16 ? 2.0 : 1.0));
+    // the private-weight schedule (conv3x3_prw_i8.hip) and its tile shape, picked as for the fp16 layers (Seq::conv)
+    const int prw_mode = c->var.at("prw");
+    bool prw = prw_mode != 0 && L.ks == 3 && c0 != 64 && (L.cout % 256) == 0 && mode != ST_PS_DOT3 && !L.out_f16;
+    int prw_th = 16;
+    if (prw && prw_mode == 1) {
+        const long tx = (Wi + 15) / 16, n = c->n_cu;
+        auto cost = [&](long tiles, double rel) { return (double)(((tiles + n - 1) / n) * n) / (double)tiles * rel; };
+        const double c16 = cost(tx * ((Hi + 15) / 16) * (L.cout / 256), 1.0), c8 = cost(tx * ((Hi + 7) / 8) * (L.cout / 256), 1.09);
+        const double c0c = cost(tx * ((Hi + 15) / 16) * (L.cout / 128), 1.22);
+        if (c0c <= c16 && c0c <= c8) prw = false;
+        else prw_th = c8 < c16 ? 8 : 16;
+    } else if (prw && prw_mode == 3) {
+        prw_th = 8;
+    }
+    // variant "prw_i8": 0 = never, 1 = only where the 8-row tiles win (the low-resolution layers), 2 = wherever "prw" selects it
+    const int i8_mode = c->var.at("prw_i8");
+    if (i8_mode == 0 || (i8_mode == 1 && prw_th != 8)) prw = false;
+    if (prw) snprintf(tag, sizeof tag, "conv_prw%s_i8<%s>", prw_th == 8 ? "8" : "", mode == ST_POOL ? "pool" : (mode == ST_PS ? "ps" : "nhwc"));
+    chk(L.ks == 3 ? (prw ? conv_prw_i8_launch(p, prw_th, c->n_cu, s) : conv_pglds_i8_launch(p, c->n_cu, s)) : conv1x1_i8_launch(p, s),
+        key.c_str(), tag, macs, bytes);
+}
+
+
+void Seq::convq8(const std::string &key, const void *src, bool src_i8, int src_stride, int Hi, int Wi, int act, void *dst, int dstC, const ActQf *oq)
+{
+    if (!ok()) return;
+    auto it = c->q8.find(key);
+    if (it == c->q8.end()) { rc = fail(c, HDRTV_ESTATE, "no packed W8A8 conv %s", key.c_str()); return; }
+    const QLayer &L = it->second;
+    ConvQ8Params p;
+    memset(&p, 0, sizeof p);
+    p.src = src; p.src_i8 = src_i8 ? 1 : 0; p.Cin = L.cin; p.src_stride = src_stride; p.Hi = Hi; p.Wi = Wi;
+    p.ks = L.ks; p.stride = L.stride;
+    const int pad = L.ks / 2;
+    p.Ho = (Hi + 2 * pad - L.ks) / L.stride + 1; p.Wo = (Wi + 2 * pad - L.ks) / L.stride + 1;
+    p.wpk8 = wtp<int8_t>(c, L.wpk8); p.scale = wtp<float>(c, L.scale); p.shift = wtp<float>(c, L.shift);
+    p.CoutPad = L.coutPad; p.Cout = L.cout; p.act = act; p.q_inv = L.q.inv(); p.q_zoff = L.q.zoff();
+    p.dst = dst; p.dst_i8 = oq ? 1 : 0; p.dstC = dstC;
+    if (oq) { p.oq_inv = oq->inv(); p.oq_zoff = oq->zoff(); }
+    char tag[64];
+    snprintf(tag, sizeof tag, "conv_q8<%d,%d,%d>", L.cin, L.ks, L.stride);
+    const double macs = (double)p.Ho * p.Wo * L.cin * L.ks * L.ks * L.cout;
+    const double bytes = (double)Hi * Wi * L.cin * (src_i8 ? 1.0 : 2.0) + (double)L.ks * L.ks * L.cin * L.coutPad +
+                         (double)p.Ho * p.Wo * L.cout * (oq ? 1.0 : 2.0);
+    chk(conv_q8_launch(p, s, c->n_cu), key.c_str(), tag, macs, bytes);
+}
+
+
+void Seq::c3(const std::string &key, const f16 *in, int H, int W, int act, f16 *out, f16 *out_pool, float pool_q_inv, float pool_q_zero, const f16 *w2frag, float *part2)
+{
+    if (!ok()) return;
+    const C3Layer &L = c->c3.at(key);
+    chk(conv_c3_launch(in, H, W, wtp<f16>(c, L.wfrag), wtp<float>(c, L.scale), wtp<float>(c, L.shift), L.cout, act, out,
+                       out_pool, c->n_cu, s, pool_q_inv, pool_q_zero, w2frag, part2), key.c_str(),
+        part2 ? "conv_c3<64,dot3>" : (L.cout == 64 ? "conv_c3<64>" : "conv_c3<32>"), (double)H * W * (27 * L.cout + (part2 ? 192 : 0)),
+        (double)H * W * (6.0 + (out ? 2.0 * L.cout : 0.0) + (out_pool ? (pool_q_inv > 0.f ? 0.25 : 0.5) * L.cout : 0.0) + (part2 ? 16.0 : 0.0)));
+}
+
+
+void Seq::conv32(const std::string &key, const f16 *src, const f16 *cond, const std::string &sft_key, int H, int W, int act, int mode, f16 *dst, int dstC, int Hd, int Wd, const f16 *res1, const f16 *res2, f16 *dst_planar, const f16 *res_planar, const f16 *c3_img, const std::string &c3_key)
+{
+    if (!ok()) return;
+    auto it = c->conv.find(key);
+    auto iq = c->q32.find(key);
+    if (it == c->conv.end() && iq == c->q32.end()) { rc = fail(c, HDRTV_ESTATE, "no packed conv %s", key.c_str()); return; }
+    const bool i8 = iq != c->q32.end();
+    ConvLayer L;
+    Conv32Params p;
+    memset(&p, 0, sizeof p);
+    if (i8) {             // W8A8 layer: int8 MFMA on the quantised tile
+        const QLayer &Q = iq->second;
+        L.cout = Q.cout; L.coutPad = Q.coutPad;
+        p.wpk8 = wtp<int8_t>(c, Q.wpk8); p.scale = wtp<float>(c, Q.scale); p.shift = wtp<float>(c, Q.shift);
+        p.q_inv = Q.q.inv(); p.q_zoff = Q.q.zoff();
+    } else {
+        L = it->second;
+        p.wpk = wtp<f16>(c, L.wpk); p.scale = wtp<float>(c, L.scale); p.shift = wtp<float>(c, L.shift);
+    }
+    p.src = src; p.cond = cond; p.H = H; p.W = W;
+    bool sq = false;
+    if (cond) {
+        const SftLayer &S = c->sft.at(sft_key);
+        p.sft_wfrag = wtp<f16>(c, S.wfrag); p.sft_bias = wtp<float>(c, S.bias);
+        if (S.q) {        // W8A8 SFT convs: int8 MFMA on the quantised condition pixel
+            sq = true;
+            p.sq_wfrag = wtp<int8_t>(c, S.qfrag); p.sq_const = wtp<float>(c, S.qconst);
+            for (int b = 0; b < 2; ++b) { p.sq_inv[b] = S.inv[b]; p.sq_zoff[b] = S.zoff[b]; p.sq_hzoff[b] = S.hzoff[b]; }
+        }
+    }
+    p.CoutPad = L.coutPad; p.Cout = L.cout; p.act = act; p.mode = mode;
+    p.dst = dst; p.dstC = dstC; p.Hd = Hd; p.Wd = Wd; p.res1 = res1; p.res2 = res2;
+    p.dst_planar = dst_planar; p.res_planar = res_planar; p.zeros = wtp<f16>(c, c->zeros_off);
+    p.dump = reinterpret_cast<f16 *>(stamp_buf());
+    const double npx = (double)H * W;
+    const double macs = npx * 32 * 9 * L.cout + (cond ? npx * 2 * (16 * 16 + 16 * 32) : 0.0) + (c3_img ? npx * 27 * 32 : 0.0);
+    const double outb = mode == ST_PLANAR3 ? 6.0 * npx : 2.0 * npx * L.cout;
+    const double bytes = npx * ((c3_img ? 6 : 64) + (cond ? 32 : 0)) + outb * (1 + (res1 ? 1 : 0) + (res2 ? 1 : 0) + (res_planar ? 1 : 0)) +
+                         (i8 ? 1.0 : 2.0) * 9 * 32 * L.coutPad;
+    p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
+    if (c3_img) {         // conv_first fused in front of SFT_layer1 + HR_conv1: src is the planar image
+        const C3Layer &L3 = c->c3.at(c3_key);
+        p.c3_img = c3_img; p.c3_wfrag = wtp<f16>(c, L3.wfrag);      // bias inside the fragments (pack_c3), no BatchNorm
+    }
+    // single-pass layers run the one-barrier schedule (conv32s.hip); variant "conv32_old" is the developer A/B switch
+    const bool old_sched = c->var.at("conv32_old") != 0;
+    const bool one_barrier = L.coutPad == 32 && !old_sched;
+    char tag[48];
+    snprintf(tag, sizeof tag, "conv32%c<%d,%s%s%s>", one_barrier ? 's' : 'p', L.coutPad / 32, c3_img ? "c3+" : "", cond ? (sq ? "sft-i8" : "sft") : "plain", i8 ? ",i8" : "");
+    if (c3_img && !one_barrier) { rc = fail(c, HDRTV_ESTATE, "conv_first fusion needs the one-barrier schedule"); return; }
+    chk(one_barrier ? conv32s_launch(p, c->n_cu, s, c->var.at("conv32_nosplit") != 0) : conv32p_launch(p, c->n_cu, s, c->var.at("conv32_nw")), key.c_str(), tag, macs, bytes);
+}
+
+
+void Seq::resblock(const std::string &base, const f16 *x, const f16 *cond, int H, int W, f16 *tb, f16 *y, const f16 *extra)
+{
+    // fp16 block without a second residual, enough rows per segment to amortise the 4-row warm-up: ONE row-streaming
+    // launch (le_rows.hip), the intermediate never leaves LDS; bit-identical to the two launches below
+    if (ok() && c->var.at("le_rows") && !extra && rows_fit(H, W)) {
+        RowsRbParams p;
+        memset(&p, 0, sizeof p);
+        bool q1, q2, qs1, qs2;
+        const ConvLayer *L1 = rows_conv(base + ".conv1", p.fq_c1, q1), *L2 = rows_conv(base + ".conv2", p.fq_c2, q2);
+        const SftLayer &S1 = c->sft.at(base + ".sft1"), &S2 = c->sft.at(base + ".sft2");
+        if (L1 && L2 && rows_sft(S1, p.fq_s1, qs1) && rows_sft(S2, p.fq_s2, qs2)) {
+            p.fq = (q1 ? 1 : 0) | (q2 ? 2 : 0) | (qs1 ? 4 : 0) | (qs2 ? 8 : 0);
+            p.x = x; p.cond = cond; p.H = H; p.W = W; p.dst = y;
+            p.w1 = wtp<f16>(c, L1->wpk); p.w2 = wtp<f16>(c, L2->wpk); p.b1 = wtp<float>(c, L1->shift); p.b2 = wtp<float>(c, L2->shift);
+            p.sft1_wfrag = wtp<f16>(c, S1.wfrag); p.sft1_bias = wtp<float>(c, S1.bias);
+            p.sft2_wfrag = wtp<f16>(c, S2.wfrag); p.sft2_bias = wtp<float>(c, S2.bias);
+            p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
+            p.dump = stamp_buf();
+            const double npx = (double)H * W;
+            chk(le_rb_rows_launch(p, c->n_cu, s), base.c_str(), p.fq ? "le_rb_rows<fq>" : "le_rb_rows",
+                npx * (2.0 * 32 * 9 * 32 + 4.0 * (16 * 16 + 16 * 32)), npx * (64 + 32 + 64) + 2.0 * 2 * 9 * 32 * 32);
+            return;
+        }
+    }
+    conv32(base + ".conv1", x, cond, base + ".sft1", H, W, ACT_RELU, ST_NHWC, tb, 32, H, W);
+    conv32(base + ".conv2", tb, cond, base + ".sft2", H, W, ACT_NONE, ST_NHWC, y, 32, H, W, x, extra);
+}
+
 
 int f32_plan(hdrtv_ctx *c, int H, int W)
 {
@@ -727,3 +649,4 @@ int run_hg(hdrtv_ctx *c, Seq &q, const f16 *base, void *out, int out_f32)
     return q.rc;
 }
 
+}  // namespace hdrtv_host

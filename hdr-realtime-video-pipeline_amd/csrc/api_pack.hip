@@ -1,5 +1,10 @@
-// hdrtv_api.hip, part 2: the reference's state_dict -> MFMA operand layouts (hdrtv_create).
-// (part of hdrtv_api.hip's single translation unit: included there, inside its anonymous namespace where one is open)
+// api_pack.hip -- the reference's state_dict -> MFMA operand layouts in the weight arena (hdrtv_create).
+// Only build_weights() is visible to the other translation units (api.h); the per-layer packers are file-local.
+#include "api.h"
+
+namespace hdrtv_host {
+namespace {
+
 // ------------------------------------------------------------------------- weight repacking
 // Implicit-GEMM conv: [Co][Ci][K][K] f32 -> wpk [K*K][Ci/CT][CoPad][CT] f16, per-channel scale/shift.
 // ps_cps > 0: output channels are re-ordered for a fused PixelShuffle(2): packed row
@@ -667,6 +672,8 @@ bool put_f32(hdrtv_ctx *c, const Pack &pk, const std::string &key, const std::st
     return true;
 }
 
+}  // namespace
+
 bool build_weights(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
 {
     {
@@ -887,3 +894,4 @@ bool build_weights(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
     return true;
 }
 
+}  // namespace hdrtv_host

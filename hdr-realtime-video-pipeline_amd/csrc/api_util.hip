@@ -1,5 +1,7 @@
-// hdrtv_api.hip, part 1b: error and variant helpers.
-// (part of hdrtv_api.hip's single translation unit: included there, inside its anonymous namespace)
+// api_util.hip -- error reporting and the developer-variant table of a context (api.h).
+#include "api.h"
+
+namespace hdrtv_host {
 
 int fail(hdrtv_ctx *c, int code, const char *fmt, ...)
 {
@@ -14,6 +16,7 @@ int fail(hdrtv_ctx *c, int code, const char *fmt, ...)
 
 // ---- developer variants: name -> default.  hdrtv_set_variant changes one on a context; HDRTV_VARIANTS="a=1,b=0" seeds them at
 // hdrtv_create.  The launch path reads c->var only.
+namespace {
 const std::pair<const char *, int> k_variants[] = {
     {"le_rows", 1},          // fused row-streaming LE kernels (le_rows.hip); 0 = the per-layer 16x16-tile kernels
     {"le_rows_min", 12},     // ... when a strip segment has at least this many rows (it pays 4 .. 6 warm-up rows)
@@ -34,10 +37,12 @@ const std::pair<const char *, int> k_variants[] = {
     {"pre_split", 0},        // 1: preprocess as two kernels (unpack, condition resize)
     {"force_ncu", 0},        // > 0: pretend the device has this many CUs (persistent grids)
     {"f32_narrow_below", 0}, // precision="fp32": workgroups per CU below which conv_f32 runs 8 channels per lane (0 = 3)
+    {"f32_mfma", 1},         // precision="fp32": 3x3 / stride-1 layers on v_mfma_f32_32x32x2_f32 (conv_f32_mfma); 0 = every layer on the vector-FMA kernel
 };
 // variants whose non-default settings select kernels that exist in the A/B library only (make AB=1 -> libhdrtv_mi355x_ab.so):
 // superseded schedules kept as bit-identity yardsticks of the shipped ones
 const char *const k_ab_only[] = {"conv32_old", "conv32_nosplit", "conv32_nw", "glds1_old", "final_recompute"};
+}  // namespace
 bool variant_allowed(const std::string &name, int value)
 {
 #ifdef HDRTV_AB
@@ -69,9 +74,4 @@ void variants_init(hdrtv_ctx *c)
     }
 }
 
-#define HIPCHK(c, expr)                                                                         \
-    do {                                                                                        \
-        hipError_t e_ = (expr);                                                                 \
-        if (e_ != hipSuccess) return fail(c, HDRTV_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
-
+}  // namespace hdrtv_host

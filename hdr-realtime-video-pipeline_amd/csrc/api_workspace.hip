@@ -1,7 +1,13 @@
-// hdrtv_api.hip, part 3: the per-resolution workspace (hdrtv_reserve).
-// (part of hdrtv_api.hip's single translation unit: included there, inside its anonymous namespace where one is open)
+// api_workspace.hip -- the per-resolution workspace arena: every intermediate a named tensor (hdrtv_reserve, hdrtv_get_tap).
+#include "api.h"
+
+namespace hdrtv_host {
+
 // ------------------------------------------------------------------------------- workspace
+namespace {
 inline int half_up(int n) { return (n - 1) / 2 + 1; }
+
+}  // namespace
 
 Tensor &ws_add(hdrtv_ctx *c, const std::string &name, int C, int H, int W, int layout)
 {
@@ -12,16 +18,7 @@ Tensor &ws_add(hdrtv_ctx *c, const std::string &name, int C, int H, int W, int l
     return c->t[name];
 }
 
-template <typename T>
-T *wsp(hdrtv_ctx *c, const std::string &name)
-{
-    auto it = c->t.find(name);
-    if (it == c->t.end()) { fprintf(stderr, "hdrtv: internal error, no workspace tensor %s\n", name.c_str()); abort(); }
-    return reinterpret_cast<T *>(c->ws.dev + it->second.off);
-}
-template <typename T>
-const T *wtp(hdrtv_ctx *c, size_t off) { return reinterpret_cast<const T *>(c->wts.dev + off); }
-
+namespace {
 // ATen _upsample_bicubic2d_aa tap table for scale 4 (see oracle/hdrtv_oracle.c aa_weights)
 float cubic_aa(float x)
 {
@@ -55,12 +52,8 @@ void aa_table(int in, int out, std::vector<float> &w, std::vector<int> &mn, std:
     }
 }
 
-struct Shapes {
-    int H, W, h4, w4;
-    int ch[6], cw[6];        // classifier spatial sizes: [0]=cond, [i]=after block i
-    int H1, W1, H2, W2, H3, W3;
-    int Hp, Wp;
-};
+}  // namespace
+
 Shapes shapes_for(int H, int W)
 {
     Shapes s;
@@ -74,8 +67,6 @@ Shapes shapes_for(int H, int W)
     s.Hp = (H + 31) / 32 * 32; s.Wp = (W + 31) / 32 * 32;
     return s;
 }
-
-int f32_plan(hdrtv_ctx *c, int H, int W);   // fp32_graph.inc: registers the fp32 graph's tensors
 
 int do_reserve(hdrtv_ctx *c, int H, int W)
 {
@@ -199,3 +190,4 @@ int do_reserve(hdrtv_ctx *c, int H, int W)
     return HDRTV_OK;
 }
 
+}  // namespace hdrtv_host

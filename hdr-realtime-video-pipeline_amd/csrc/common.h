@@ -301,6 +301,7 @@ struct F32ConvParams {
     float slope;
     int ps;                          // store through PixelShuffle(2): y is [cout/4][2Ho][2Wo]
     int narrow_below;                // developer A/B: workgroups per CU below which a layer runs 8 channels per lane (0 = default)
+    int no_mfma;                     // developer A/B (variant f32_mfma = 0): every layer on the vector-FMA kernel
 };
 struct F32GfmParams {
     const float *w[6], *b[6];        // cond_scale_{first,HR,last}, cond_shift_{first,HR,last}: Linear(6 -> n)

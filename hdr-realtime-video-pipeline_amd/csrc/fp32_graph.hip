@@ -1,11 +1,15 @@
-// precision="fp32": weights and the layer graph (included by hdrtv_api.hip inside its anonymous namespace; kernels: fp32_ops.hip).
+// fp32_graph.hip -- precision="fp32": weights and the layer graph (kernels: fp32_ops.hip; interface: api.h).
 //
 // The reference's fp32 preset (hdrtvnet_torch.py:1694-1712) runs the very same modules on fp32 tensors.  Here the graph is
 // spelled out layer by layer on planar CHW fp32 tensors -- one generic convolution kernel with the per-layer epilogue the
 // module applies (BatchNorm / GFM / activation / residual / PixelShuffle), plus a handful of element-wise kernels -- in the
 // reference's operation order, so that the result tracks the reference's own CPU fp32 run to fp32 rounding
 // (tests/test_gpu_fp32.py: floats <= 2e-5, almost every RGB48 integer identical).
+#include "api.h"
 
+namespace hdrtv_host {
+
+namespace {
 struct F32T {
     float *p = nullptr;
     int C = 0, H = 0, W = 0;
@@ -66,6 +70,8 @@ bool pack_f32(hdrtv_ctx *c, const Pack &pk, const std::string &prefix)
     return true;
 }
 
+}  // namespace
+
 bool build_weights_f32(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
 {
     const std::vector<unsigned char> z(256, 0);
@@ -84,6 +90,7 @@ bool build_weights_f32(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
     return true;
 }
 
+namespace {
 struct F32Run {
     hdrtv_ctx *c;
     Seq *q;
@@ -148,9 +155,11 @@ struct F32Run {
         if (L.bn) { p.bn_s = wtp<float>(c, L.bn_s); p.bn_t = wtp<float>(c, L.bn_t); }
         p.gfm_s = o.gfm_s; p.gfm_t = o.gfm_t; p.res = o.res; p.y = y.p;
         p.narrow_below = c->var.at("f32_narrow_below");
+        p.no_mfma = c->var.at("f32_mfma") ? 0 : 1;
         p.cout = L.cout; p.cot = L.cot; p.pad = pad; p.act = o.act; p.slope = o.slope; p.ps = o.ps ? 1 : 0;
         const double macs = (double)L.cout * L.cin * L.ks * L.ks * Ho * Wo;
-        q->chk(conv_f32_launch(p, L.ks, o.stride, c->n_cu, q->s), layer.c_str(), "conv_f32", macs,
+        const bool mfma = L.ks == 3 && o.stride == 1 && conv_f32_on_mfma(p, c->n_cu);
+        q->chk(conv_f32_launch(p, L.ks, o.stride, c->n_cu, q->s), layer.c_str(), mfma ? "conv_f32_mfma" : "conv_f32", macs,
                4.0 * ((double)L.cin * x.H * x.W + (double)L.cout * Ho * Wo));
         return y;
     }
@@ -367,6 +376,8 @@ void f32_hg(F32Run &r, const F32T &base, float mask_r, float *out)
 }
 
 // the whole fp32 graph; plan = true registers its tensors in the workspace (hdrtv_reserve), false launches it
+}  // namespace
+
 int run_f32(hdrtv_ctx *c, Seq &q, bool plan, int H, int W, const float *rgb, const float *cond, float *out, float *agcm_out)
 {
     F32Run r{c, &q, plan};
@@ -384,3 +395,5 @@ int run_f32(hdrtv_ctx *c, Seq &q, bool plan, int H, int W, const float *rgb, con
     }
     return q.rc;
 }
+
+}  // namespace hdrtv_host

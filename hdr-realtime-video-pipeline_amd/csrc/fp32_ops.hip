@@ -2,9 +2,14 @@
 //
 // The fp16 path is the product's speed path (hand-fused MFMA kernels, NHWC f16).  This file serves the reference's "maximum
 // precision" preset: every tensor is planar CHW fp32 as in the reference, every layer is one generic kernel, the graph is
-// hdrtv_api.hip: fp32_graph.inc.  fp32 has no fast matrix path on gfx950 (fp32 MFMA = vector rate, 157 TFLOP/s), so the
-// convolution is a vector-FMA kernel: a lane owns one output pixel and COT output channels, the filter is read through
-// the scalar cache (wave-uniform addresses -> s_load), one coalesced pixel load feeds COT FMAs.
+// fp32_graph.hip.  Two convolution kernels:
+//   * conv_f32_mfma (round 5): the 3x3 / stride-1 layers whose channel counts are multiples of 32 / 16 -- 97 % of the MACs -- as an
+//     implicit GEMM on the fp32 MATRIX pipe, v_mfma_f32_32x32x2_f32: exact fp32 products and sums (an fmaf chain per output
+//     element, MI355X_MICROARCH.md "Matrix cores"), 64 FLOP / clock / SIMD = the vector rate, but one instruction per 4096
+//     FLOPs instead of per 128, so the issue slots, the scalar cache and the register file stop being the limit;
+//   * conv_f32 (round 4): everything else (1x1, stride 2, 3 input or output channels, maps too small to fill the chip) as a
+//     vector-FMA kernel: a lane owns one output pixel and COT output channels, the filter arrives through the scalar cache.
+// Both accumulate in the order (input channel, tap) from zero and add the bias behind the sum.
 #include "common.h"
 #include "launchers.h"
 
@@ -74,6 +79,129 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(F32ConvParams p)
             p.y[(size_t)co * oplane + (size_t)oy * p.Wo + ox] = v;
         }
     }
+}
+
+// ---------------------------------------------------------------- conv2d 3x3 / stride 1 / pad 1 on the fp32 matrix pipe
+// GEMM view: M = 32 MT output channels, N = a tile of 8 rows x 32 columns (wave w owns row w: one 32-pixel N tile and MT
+// accumulator tiles), K = (input channel, tap) in that order, 2 per v_mfma_f32_32x32x2_f32: lane (n, kk) of a wave feeds
+// B[k0 + kk][n] = the pixel of column n for tap k0 + kk, and A[m][k0 + kk] = the weight of channel m -- the host's layout
+// [cout group][cin][tap][32] IS that fragment order, so a chunk's weights are one contiguous copy.  Input channels go through
+// LDS in chunks of 16 (halo tile 16 x 10 x 34 floats + MT x 144 x 32 weights, double-buffered, one barrier per chunk): the next
+// chunk's global loads are issued in front of this chunk's 144 MT MFMAs and written to LDS behind them.
+constexpr int MF_CIB = 16, MF_TR = 8, MF_TC = 32, MF_HR = MF_TR + 2, MF_HC = MF_TC + 2;
+constexpr int MF_HALO = MF_CIB * MF_HR * MF_HC;                 // 5440 floats
+constexpr int MF_KQ = MF_CIB * 9 / 2;                           // 72 MFMAs per chunk and accumulator tile
+template <int MT> struct MfGeo {
+    static constexpr int WCH = MT * MF_CIB * 9 * 32;            // floats of a chunk's weights
+    static constexpr int SMEM = 2 * (MF_HALO + WCH) * 4;        // 117 248 B (MT = 2) / 80 384 B (MT = 1)
+    static constexpr int NH = (MF_HALO + 511) / 512, NW4 = (WCH / 4 + 511) / 512;
+};
+
+template <int MT>
+__global__ __launch_bounds__(512) void conv_f32_mfma_kernel(F32ConvParams p)
+{
+    using G = MfGeo<MT>;
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    float *const sX = smf, *const sW = smf + 2 * MF_HALO;
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, kk = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ox0 = blockIdx.x * MF_TC, oy0 = blockIdx.y * MF_TR, g0 = blockIdx.z * MT;
+    const int cin = p.c0 + p.c1, nch = cin / MF_CIB;
+    const size_t plane = (size_t)p.Hi * p.Wi;
+    // ---- staging: this thread's elements of a chunk (halo: element e = ((channel, row), column); weights: float4 number e)
+    int hoff[G::NH];                       // offset inside a plane, or -1 outside the image (zero padding)
+    int hcl[G::NH];
+#pragma unroll
+    for (int i = 0; i < G::NH; ++i) {
+        const int e = tid + 512 * i;
+        const int cl = e / (MF_HR * MF_HC), r = (e - cl * (MF_HR * MF_HC)) / MF_HC, c = e - cl * (MF_HR * MF_HC) - r * MF_HC;
+        const int iy = oy0 - 1 + r, ix = ox0 - 1 + c;
+        hcl[i] = cl;
+        hoff[i] = (e < MF_HALO && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? iy * p.Wi + ix : -1;
+    }
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+    const int xb = wv * MF_HC + n;                                   // this lane's pixel in row `wv` of the halo tile (tap 0)
+    // pass ch = -1 only stages chunk 0; pass ch fetches chunk ch + 1 into registers, runs chunk ch's MFMAs, writes the registers to
+    // the other buffer (whose readers all passed the previous barrier)
+    for (int ch = -1; ch < nch; ++ch) {
+        const int buf = ch & 1, nx = ch + 1;
+        float hv[G::NH];
+        f32x4 wv4[G::NW4];                                       // (clang vectors: arrays of HIP's float4 struct end up in scratch)
+        if (nx < nch) {
+#pragma unroll
+            for (int i = 0; i < G::NH; ++i) {
+                const int ci = nx * MF_CIB + hcl[i];
+                const float *pl = ci < p.c0 ? p.x0 + (size_t)ci * plane : p.x1 + (size_t)(ci - p.c0) * plane;
+                hv[i] = hoff[i] >= 0 ? pl[hoff[i]] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < G::NW4; ++i) {
+                int e = tid + 512 * i;                                // float4 index inside the chunk: [mt][1152]
+                e = e < G::WCH / 4 ? e : 0;                           // (past the end: any valid address; not staged)
+                const int mt = e / (MF_CIB * 9 * 8), r = e - mt * (MF_CIB * 9 * 8);
+                wv4[i] = *reinterpret_cast<const f32x4 *>(p.w + ((size_t)(g0 + mt) * cin + (size_t)nx * MF_CIB) * 288 + (size_t)r * 4);
+            }
+        }
+        if (ch >= 0) {
+            const float *bx = sX + buf * MF_HALO + xb, *bw = sW + buf * G::WCH + lane;
+#pragma unroll
+            for (int q = 0; q < MF_KQ; ++q) {
+                // k = 2 q + kk -> (channel, tap): compile-time for either lane half
+                const int k0 = 2 * q, k1 = 2 * q + 1;
+                const int o0 = ((k0 / 9) * MF_HR + (k0 % 9) / 3) * MF_HC + (k0 % 9) % 3, o1 = ((k1 / 9) * MF_HR + (k1 % 9) / 3) * MF_HC + (k1 % 9) % 3;
+                const float b = bx[kk ? o1 : o0];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[(mt * MF_KQ + q) * 64], b, acc[mt], 0, 0, 0);
+            }
+        }
+        if (nx < nch) {
+            const int nb = nx & 1;
+#pragma unroll
+            for (int i = 0; i < G::NH; ++i) { const int e = tid + 512 * i; if (e < MF_HALO) sX[nb * MF_HALO + e] = hv[i]; }
+#pragma unroll
+            for (int i = 0; i < G::NW4; ++i) { const int e = tid + 512 * i; if (e < G::WCH / 4) reinterpret_cast<f32x4 *>(sW + nb * G::WCH)[e] = wv4[i]; }
+        }
+        __syncthreads();
+    }
+    // ---- epilogue, in the reference's op order (see conv_f32_kernel): register r of tile mt = channel 32 (g0 + mt) + 8 (r >> 2) + 4 kk + (r & 3)
+    const int oy = oy0 + wv, ox = ox0 + n;
+    if (oy >= p.Ho || ox >= p.Wo) return;
+    const size_t oplane = (size_t)p.Ho * p.Wo;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = (g0 + mt) * 32 + 8 * (r >> 2) + 4 * kk + (r & 3);
+            float v = __fadd_rn(acc[mt][r], p.bias[co]);
+            if (p.bn_s) v = __fadd_rn(__fmul_rn(v, p.bn_s[co]), p.bn_t[co]);
+            if (p.gfm_s) v = __fadd_rn(__fadd_rn(__fmul_rn(v, p.gfm_s[co]), p.gfm_t[co]), v);
+            if (p.act == 1) v = v > 0.f ? v : 0.f;
+            else if (p.act == 2) v = v >= 0.f ? v : __fmul_rn(v, p.slope);
+            if (p.res) v = __fadd_rn(p.res[(size_t)co * oplane + (size_t)oy * p.Wo + ox], v);
+            if (p.ps) {
+                const int c = co >> 2, dy = (co >> 1) & 1, dx = co & 1;
+                p.y[((size_t)c * (2 * p.Ho) + 2 * oy + dy) * (size_t)(2 * p.Wo) + 2 * ox + dx] = v;
+            } else {
+                p.y[(size_t)co * oplane + (size_t)oy * p.Wo + ox] = v;
+            }
+        }
+}
+
+template <int MT> hipError_t conv_f32_mfma_go(const F32ConvParams &p, hipStream_t s)
+{
+    static DevOnce once;
+    auto kern = conv_f32_mfma_kernel<MT>;
+    if (once.need()) {
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, MfGeo<MT>::SMEM)) return e;
+        once.done();
+    }
+    hipLaunchKernelGGL(kern, dim3((p.Wo + MF_TC - 1) / MF_TC, (p.Ho + MF_TR - 1) / MF_TR, p.cout / (32 * MT)), dim3(512), MfGeo<MT>::SMEM, s, p);
+    return hipGetLastError();
 }
 
 template <int KS, int STRIDE>
@@ -295,10 +423,28 @@ inline dim3 ew_grid_f32(size_t n)
 
 }  // namespace
 
+// which layers run on the matrix pipe: 3x3 / stride 1 / pad 1, filter packed in groups of 32, whole groups of output channels and
+// whole chunks of input channels on either side of a concat, at least 64 input channels, and enough tiles to give at least a
+// quarter of the CUs a workgroup
+bool conv_f32_on_mfma(const F32ConvParams &p, int n_cu)
+{
+    if (p.no_mfma || p.pad != 1 || p.cot != 32 || p.cout % 32 || p.c0 % MF_CIB || p.c1 % MF_CIB || p.Hi != p.Ho || p.Wi != p.Wo) return false;
+    // 32 input channels are two chunks: prologue, barriers and epilogue then weigh as much as the MFMAs (LE's 32 -> 32 layers measured
+    // 52 TFLOP/s here against 74 on the vector kernel, profiles/r05_fp32_layers.txt)
+    if (p.c0 + p.c1 < 64) return false;
+    const long tiles = (long)((p.Wo + MF_TC - 1) / MF_TC) * ((p.Ho + MF_TR - 1) / MF_TR) * (p.cout / 32);
+    return tiles * 4 >= n_cu;
+}
+
 hipError_t conv_f32_launch(const F32ConvParams &p, int ks, int stride, int n_cu, hipStream_t s)
 {
     if (p.Ho <= 0 || p.Wo <= 0 || p.cout <= 0 || p.c0 <= 0 || (p.cot != 8 && p.cot != 32)) return hipErrorInvalidValue;
     if (ks == 1 && stride == 1) return conv_f32_pick<1, 1>(p, n_cu, s);
+    if (ks == 3 && stride == 1 && conv_f32_on_mfma(p, n_cu)) {
+        const long tiles = (long)((p.Wo + MF_TC - 1) / MF_TC) * ((p.Ho + MF_TR - 1) / MF_TR);
+        // two 32-channel groups per workgroup (each pixel fragment feeds two MFMAs) while that still leaves two workgroups per CU
+        return (p.cout % 64 == 0 && tiles * (p.cout / 64) >= 2L * n_cu) ? conv_f32_mfma_go<2>(p, s) : conv_f32_mfma_go<1>(p, s);
+    }
     if (ks == 3 && stride == 1) return conv_f32_pick<3, 1>(p, n_cu, s);
     if (ks == 3 && stride == 2) return conv_f32_pick<3, 2>(p, n_cu, s);
     if (ks == 1 && stride == 2) return conv_f32_pick<1, 2>(p, n_cu, s);

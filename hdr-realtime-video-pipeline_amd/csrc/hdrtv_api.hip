@@ -1,33 +1,9 @@
-// hdrtv_api.hip -- C ABI of libhdrtv_mi355x.so (see include/hdrtv_mi355x.h).
-// Host side only: weight-pack parsing, repacking into MFMA operand layouts, workspace
-// management and the per-frame launch sequence.  No kernel lives in this file.
-#include "../../include/hdrtv_mi355x.h"
+// hdrtv_api.hip -- the exported C ABI of libhdrtv_mi355x.so (include/hdrtv_mi355x.h): argument checks, the context's life cycle,
+// the RGB48 ring, letterbox / metrics / PQ tables.  Packing, workspace and launch sequencing are their own translation units
+// (api.h).  No kernel lives in this file.
+#include "api.h"
 
-#include <algorithm>
-#include <cfloat>
-#include <chrono>
-#include <cmath>
-#include <condition_variable>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <map>
-#include <mutex>
-#include <string>
-#include <vector>
-
-#include "launchers.h"
-
-// One translation unit, split by concern (the parts share the context and a few dozen small helpers):
-#include "api_ctx.inc"          // weight-pack reader, layer tables, struct hdrtv_ctx
-
-namespace {
-#include "api_util.inc"         // fail(), the variant table
-#include "api_pack.inc"         // state_dict -> MFMA operand layouts (hdrtv_create)
-#include "api_workspace.inc"    // per-resolution workspace (hdrtv_reserve)
-#include "api_graph.inc"        // launch sequencing: AGCM, LE, HG (hdrtv_infer); includes fp32_graph.inc
-}  // namespace
-
+using namespace hdrtv_host;
 // =========================================================================== exported C ABI
 extern "C" {
 

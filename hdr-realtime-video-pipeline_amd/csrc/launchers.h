@@ -110,6 +110,7 @@ int metrics_blocks(int H, int W);
 
 // precision="fp32" (fp32_ops.hip)
 hipError_t conv_f32_launch(const F32ConvParams &p, int ks, int stride, int n_cu, hipStream_t s);
+bool conv_f32_on_mfma(const F32ConvParams &p, int n_cu);      // whether conv_f32_launch runs the layer on the fp32 matrix pipe (3x3 / stride 1 only)
 hipError_t ew_f32_launch(int op, const float *a, const float *b, const float *c, float *y, size_t n, hipStream_t s);
 hipError_t avgpool3s2_leaky_f32_launch(const float *x, float *y, int C, int H, int W, float slope, hipStream_t s);
 hipError_t instnorm_f32_launch(float *x, const float *gamma, const float *beta, int C, int n, float eps, hipStream_t s);

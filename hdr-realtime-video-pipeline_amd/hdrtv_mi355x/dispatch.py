@@ -153,6 +153,53 @@ def mi355x_worker(rank, device_index, init_args):
     return _Mi355xWorker(rank, device_index, init_args)
 
 
+class _HostSimWorker:
+    """CPU stand-in for one GPU worker, for measuring the HOST side of the dispatcher without a node of GPUs
+    (``bench.py --dispatcher-sim``, tests): it does what the host sees of a real worker -- the whole input slot is read
+    (the H2D copy's source traffic) and the whole output slot written (the D2H copy's destination traffic), with plain memcpys on
+    the worker's core where a real worker's DMA engines would move them -- and a frame occupies the "device" for ``device_ms``
+    (two frames in flight, as ``_Mi355xWorker``).  Pessimistic for the workers' CPU time, faithful for the parent's producers,
+    the slot hand-off, the reorder stage and the memory traffic through the host."""
+
+    depth = 2
+
+    def __init__(self, rank, device_index, init_args):
+        self.rank = rank
+        self.device_ms = float(init_args.get("device_ms", 9.5))
+        self._staged = None
+        self._result = None
+        self._busy_until = 0.0
+        self.cpu_s = 0.0
+
+    def begin(self, frame, out):
+        t0 = time.thread_time()
+        if self._staged is None or self._staged.shape != frame.shape:
+            self._staged = np.empty_like(frame)
+            self._result = np.empty(out.shape, out.dtype)
+            self._result[...] = 257 * (self.rank + 1)
+        np.copyto(self._staged, frame)                     # "H2D": the slot's 24.9 MB (4K) leave host memory
+        self._result[0, 0, 0] = int(frame[0, 0, 0]) * 257  # (so that a test can tell the frames apart)
+        self._result[0, 0, 1] = self.rank
+        start = max(time.perf_counter(), self._busy_until)
+        self._busy_until = start + self.device_ms * 1e-3   # the device works on one frame at a time
+        self.cpu_s += time.thread_time() - t0
+        return (out, self._busy_until, int(self._result[0, 0, 0]))
+
+    def finish(self, token):
+        out, t_done, tag = token
+        dt = t_done - time.perf_counter()
+        if dt > 0:
+            time.sleep(dt)
+        t0 = time.thread_time()
+        np.copyto(out, self._result)                       # "D2H": 49.8 MB (4K) land in host memory
+        out[0, 0, 0] = tag
+        self.cpu_s += time.thread_time() - t0
+
+
+def host_sim_worker(rank, device_index, init_args):
+    return _HostSimWorker(rank, device_index, init_args)
+
+
 class _SyncBody:
     """Adapter: a plain ``process(frame, out)`` function as a depth-1 begin / finish body."""
 
@@ -293,6 +340,9 @@ class FrameDispatcher:
         self._error = None
         self._emitted = threading.Condition()
         self.max_reorder_depth = 0
+        self.frames_per_worker = [0] * self.n                 # frames each worker has delivered (a straggler shows here)
+        self.last_done = [0.0] * self.n                       # perf_counter() of each worker's last delivered frame
+        self.host_cpu_s = {"producers": [0.0] * self.n, "reorder": 0.0}      # CPU seconds of the parent's own threads
         ready, t_end = 0, time.monotonic() + start_timeout
         while ready < self.n:
             try:
@@ -376,6 +426,7 @@ class FrameDispatcher:
 
     def _produce(self, r):
         while not self._stop:
+            self.host_cpu_s["producers"][r] = time.thread_time()
             try:
                 i, frame = self._prod_q[r].get(timeout=0.1)
             except _queue.Empty:
@@ -437,6 +488,9 @@ class FrameDispatcher:
                 continue
             if kind != "frame":
                 continue
+            self.frames_per_worker[rank] += 1
+            self.last_done[rank] = time.perf_counter()
+            self.host_cpu_s["reorder"] = time.thread_time()
             self._held[idx] = (rank, payload)
             self.max_reorder_depth = max(self.max_reorder_depth, len(self._held))
             while self._next_emit in self._held:            # release strictly in source order

@@ -54,7 +54,7 @@ def _load_state(path_or_state, what):
 
 
 def kernel_arithmetic(tag):
-    """The arithmetic class of a launch by its profile tag (csrc/api_graph.inc writes the tags): 'int8' = v_mfma_i32_*_i8,
+    """The arithmetic class of a launch by its profile tag (csrc/api_graph.hip writes the tags): 'int8' = v_mfma_i32_*_i8,
     'fq-f16' = activation quantiser in registers + fp16 MFMA on dequantised weights, 'fq-f32' = fp32 fake-quant, 'f16'."""
     t = tag.lower()
     if "rows<fq>" in t:
@@ -124,7 +124,7 @@ class HDRTVNetMI355X:
         self.device = self._resolve_device(device)
         self.precision = self._resolve_precision(precision)
         self._use_cuda = True
-        # fp32: the reference's maximum-precision preset -- the same graph on fp32 tensors (csrc/fp32_ops.hip, fp32_graph.inc)
+        # fp32: the reference's maximum-precision preset -- the same graph on fp32 tensors (csrc/fp32_ops.hip, fp32_graph.hip)
         self._fp32 = self.precision == "fp32"
         self._dtype = torch.float32 if self._fp32 else torch.float16
         self._compiled = False          # nothing is JIT-compiled; warmup_compile() is a no-op

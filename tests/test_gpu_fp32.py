@@ -1,5 +1,5 @@
 """``precision="fp32"`` (HDRTVNetTorch's maximum-precision preset, hdrtvnet_torch.py:1694-1712) on the device: the fp32 graph
-(csrc/fp32_ops.hip + fp32_graph.inc) against what the reference's OWN fp32 run produced (tests/golden/*.npz: CPU fp32).
+(csrc/fp32_ops.hip + fp32_graph.hip) against what the reference's OWN fp32 run produced (tests/golden/*.npz: CPU fp32).
 
 Both sides compute every product and sum in fp32; they differ only in summation order (ATen / oneDNN blocking vs one FMA
 chain per output here).  Measured: every LE tensor within 3.7e-6, every HG tensor within 2.2e-5 (conv_code2, sums over 9216
@@ -243,3 +243,43 @@ def test_create_ex_argument_checks(torch_cuda, golden_dir):
     torch_cuda.cuda.synchronize()
     assert bool(torch_cuda.isfinite(out).all())
     lib.hdrtv_destroy(ctx)
+
+
+def test_fp32_matrix_pipe_convs_against_the_vector_kernel(torch_cuda, golden_dir):
+    """conv_f32_mfma (3x3 / stride-1 layers on v_mfma_f32_32x32x2_f32) against conv_f32 (one fmaf chain per output element on the
+    vector ALUs; variant f32_mfma = 0): the same products, the same order of accumulation (input channel, tap) from zero, the bias
+    behind the sum -- an fp32 MFMA is itself an fmaf chain (MI355X_MICROARCH.md), so the two graphs must agree to the last bit
+    or, should the matrix pipe associate its two products per instruction the other way round, to an ulp or two per layer.
+    Printed: the fraction of identical output values; asserted: <= 2e-6 everywhere, the profile names the kernels, and the
+    layers that must stay on the vector kernel (1x1, stride 2, 3-channel ends, maps too small for the chip) do."""
+    from hdrtv_mi355x import weights as W
+    from hdrtv_mi355x.processor import HDRTVNetMI355X
+    torch = torch_cuda
+    p = HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), precision="fp32", use_hg=True, hg_weights="seeded:1234", warmup_passes=0)
+    try:
+        assert p.get_variant("f32_mfma") == 1
+        for (h, w), seed in (((272, 480), 3), ((1080, 1920), 4), ((61, 103), 5)):
+            f = W.synthetic_frame(h, w, seed=seed, kind="gradient")
+            res, kern = [], []
+            for v in (0, 1):
+                p.set_variant("f32_mfma", v)
+                p.profile_enable(True)
+                out, agcm = p.infer(p.preprocess(f))
+                prof = p.profile_read()
+                p.profile_enable(False)
+                kern.append(prof)
+                res.append((out.clone(), agcm.clone()))
+            assert not any(k == "conv_f32_mfma" for _, k, *_ in kern[0])
+            on = [(l, m) for l, k, _, m, _ in kern[1] if k == "conv_f32_mfma"]
+            off = [(l, m) for l, k, _, m, _ in kern[1] if k == "conv_f32"]
+            share = sum(m for _, m in on) / max(1.0, sum(m for _, m in on + off))
+            d = (res[0][0] - res[1][0]).abs()
+            same = float((d == 0).float().mean())
+            print(f"  {w}x{h}: {len(on)} layers ({share:.1%} of the conv MACs) on the matrix pipe, {len(off)} on the vector kernel; "
+                  f"out identical on {same:.3%} of the values, max |delta| {float(d.max()):.2e}")
+            assert float(d.max()) <= 2e-6
+            if h >= 1080:
+                assert share >= 0.9
+            assert float((res[0][1] - res[1][1]).abs().max()) <= 2e-6
+    finally:
+        p.close()

@@ -274,3 +274,19 @@ def test_prw_dot3_strip_reads_stay_behind_the_flag_poll(tmp_path):
     j = next(k for k in range(polls[1], len(lines)) if lines[k].startswith("s_cbranch_execnz"))
     nxt = lines[j + 1:j + 40]
     assert sum(ln.startswith("ds_read_b96") or ln.startswith("ds_read_b128") for ln in nxt) >= 4, nxt      # (x, y, z of a float4: b96)
+
+
+def test_fp32_matrix_pipe_conv_issues_its_mfmas_and_spills_nothing(tmp_path):
+    """conv_f32_mfma (fp32_ops.hip): 72 v_mfma_f32_32x32x2_f32 per 16-channel chunk and accumulator tile in the unrolled chunk loop,
+    staged through registers without scratch (an array of HIP's float4 struct for the weight staging landed in scratch: clang
+    vectors only)."""
+    kernels = _asm("fp32_ops.hip", tmp_path)
+    seen = 0
+    for name, body in kernels.items():
+        if "conv_f32_mfma_kernel" not in name:
+            continue
+        mt = 2 if "ILi2E" in name else 1
+        assert len(re.findall(r"v_mfma_f32_32x32x2_f32", body)) == 72 * mt, name
+        assert "scratch_" not in body, name
+        seen += 1
+    assert seen == 2
