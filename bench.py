@@ -177,6 +177,35 @@ def cpu_baseline(args, use_hg):
     return out
 
 
+# profile tag -> the source file whose change invalidates a committed counter figure for that kernel (besides common.h / launchers.h)
+KERNEL_SOURCE = (("conv_prw8_i8", "conv3x3_prw_i8.hip"), ("conv_prw_i8", "conv3x3_prw_i8.hip"), ("conv_prw", "conv3x3_prw.hip"), ("conv_pglds_i8", "conv3x3_pglds_i8.hip"), ("conv_pglds", "conv3x3_pglds.hip"), ("conv_glds1", "conv1x1_glds.hip"),
+                 ("le_rb_rows", "le_rows.hip"), ("le_tail_rows", "le_rows.hip"), ("le_head_rows", "le_rows.hip"), ("conv32s", "conv32s.hip"),
+                 ("conv32p", "conv32p.hip"), ("conv3x3s2_preg", "conv3x3s2_preg.hip"), ("conv1x1_i8", "conv_i8_misc.hip"), ("le_cond_trunk", "le_fused.hip"),
+                 ("conv_c3", "le_hg_misc.hip"), ("hg_final", "le_hg_misc.hip"), ("agcm_mlp", "agcm.hip"), ("conv_q8", "conv_q8.hip"))
+
+
+def traffic_for(kern, measured, doc, doc_path, build_id=None, source_hash=None):
+    """(traffic, note): a committed PMC figure is reported only for the code it was measured on -- the library's build id equals
+    the file's stamp, or at least the kernel's own source file and the shared headers hash as they did when it was measured
+    (tools/pmc_to_json.py records both); otherwise (None, why)."""
+    from hdrtv_mi355x import lib as L
+    build_id = build_id or L.build_id
+    source_hash = source_hash or L.source_hash
+    stamp, srcs = doc.get("build_id"), doc.get("sources") or {}
+    if not stamp:
+        return None, f"{doc_path} carries no build stamp (measured before round 5): not reported"
+    try:
+        if stamp == build_id():
+            return measured, None
+        src = next((f for tag, f in KERNEL_SOURCE if kern.startswith(tag)), None)
+        files = [src, "common.h", "launchers.h"] if src else []
+        if src and all(srcs.get(f) == source_hash(f) for f in files):
+            return measured, f"library rebuilt since {doc_path} was measured (build {stamp}); {src} and the shared headers are unchanged"
+        return None, f"{doc_path} was measured on library build {stamp}, this is {build_id()} and {src or 'the kernel source'} differs: re-run tools/r05_final.sh"
+    except OSError as exc:
+        return None, f"cannot verify {doc_path} against the sources: {exc}"
+
+
 def int8_extra(args, dev, dev_frames, steps=20, warmup=3, recipe="full"):
     """BASELINE configs[4] beside the headline, same frames, same timing method (never `value`): HR from the INT8-QAT
     checkpoint with predequantize off, HG head W8A8; the label states what ran from the launch profile.  `python bench.py --int8` is the full run."""
@@ -629,10 +658,12 @@ def main():
         infer_ms = sum(v[0] for v in agg.values()) / nprof
         # HBM bytes per launch from the PMC counters: collected by rocprofv3 in separate --pmc passes of this same
         # command (tools/r04_final.sh, tools/pmc_to_json.py) and committed
+        pmc_file = os.path.join("profiles", "pmc_traffic_int8.json" if args.int8 else "pmc_traffic.json")
         try:
-            pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic_int8.json" if args.int8 else "pmc_traffic.json")))["kernels"]
+            pmc_doc = json.load(open(os.path.join(REPO, pmc_file)))
+            pmc = pmc_doc["kernels"]
         except (OSError, KeyError, ValueError):
-            pmc = {}
+            pmc_doc, pmc = {}, {}
         # profile tag -> kernel name in the rocprofv3 counter CSV (template argument = store mode, common.h)
         pmc_key = {"conv_prw<nhwc>": "conv_prw_kernel<0, 16>", "conv_prw<ps>": "conv_prw_kernel<1, 16>", "conv_prw<pool>": "conv_prw_kernel<2, 16>",
                    "conv_prw<ps_dot3>": "conv_prw_kernel<4, 16>", "conv_prw8<nhwc>": "conv_prw_kernel<0, 8>", "conv_prw8<ps>": "conv_prw_kernel<1, 8>",
@@ -661,12 +692,12 @@ def main():
             its algorithmic intensity vs the machine balance (peak FLOP/s / 8 TB/s)."""
             avg_ms = ms / n
             tflops = 2.0 * macs / n / (avg_ms * 1e-3) / 1e12
-            traffic = None
+            traffic, why = None, None
             key = pmc_key.get(kern, kern)
             if (H, Wd) == (2160, 3840) and use_hg:
                 hit = [v for k, v in pmc.items() if k == key or k.endswith(key) or (len(key) > 12 and key in k)]
                 if hit:
-                    traffic = hit[0]["hbm_bytes_per_launch"]
+                    traffic, why = traffic_for(kern, hit[0]["hbm_bytes_per_launch"], pmc_doc, pmc_file)
             peak = MFMA_F16_DENSE_PEAK_TFLOPS * (2.0 if "_i8" in kern else 1.0)       # int8 MFMA: twice the K per instruction
             if 2.0 * macs / max(nbytes, 1.0) >= peak * 1e12 / (HBM_PEAK_GBS * 1e9):
                 r = {"kernel": kern, "bound": "mfma", "achieved": round(tflops, 2), "peak": peak,
@@ -675,6 +706,8 @@ def main():
                 gbs = nbytes / n / (avg_ms * 1e-3) / 1e9
                 r = {"kernel": kern, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic}
+            if why:
+                r["traffic_note"] = why
             r.update({"algorithmic_bytes_per_launch": round(nbytes / n), "launches_per_frame": n // nprof,
                       "avg_launch_ms": round(avg_ms, 4), "share_of_infer_time": round(ms / nprof / infer_ms, 3)})
             return r
@@ -683,7 +716,7 @@ def main():
         kern, (ms, macs, nbytes, n) = ranked[0]
         roof = roof_of(kern, ms, macs, nbytes, n)
         roof.update({
-                "traffic_source": ("profiles/pmc_traffic_int8.json" if args.int8 else "profiles/pmc_traffic.json") + " (rocprofv3 --pmc passes of this command, corrected as MI355X_MICROARCH.md prescribes; not re-measured in this run)" if roof["traffic"] is not None else None,
+                "traffic_source": pmc_file + f" (rocprofv3 --pmc passes of this command on library build {pmc_doc.get('build_id', '?')}, corrected as MI355X_MICROARCH.md prescribes; not re-measured in this run)" if roof["traffic"] is not None else None,
                 "flop_per_launch": 2.0 * macs / n, "infer_ms_profiled": round(infer_ms, 3)})
         # the same figures for the next kernels by time (never `roofline`: the dominant kernel is the one above)
         roof_next = [roof_of(k, *v) for k, v in ranked[1:7] if v[1] > 0 or v[2] > 0]

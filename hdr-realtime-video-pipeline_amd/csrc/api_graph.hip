@@ -226,6 +226,29 @@ void Seq::conv32(const std::string &key, const f16 *src, const f16 *cond, const 
 
 void Seq::resblock(const std::string &base, const f16 *x, const f16 *cond, int H, int W, f16 *tb, f16 *y, const f16 *extra)
 {
+    // every layer of the block W8A8 (the full-QAT recipe): the row-streaming kernel on int8 MFMA (le_rows_i8.hip), the rings hold
+    // the layers' int8 codes; bit-identical to the two conv32s<sft-i8, i8> launches at the bottom (variant le_rows_i8 = 0: the
+    // fake-quant form below, or those launches)
+    if (ok() && c->var.at("le_rows") && c->var.at("le_rows_i8") && !extra && rows_fit(H, W)) {
+        auto q1 = c->q32.find(base + ".conv1"), q2 = c->q32.find(base + ".conv2");
+        const SftLayer &S1 = c->sft.at(base + ".sft1"), &S2 = c->sft.at(base + ".sft2");
+        if (q1 != c->q32.end() && q2 != c->q32.end() && S1.q && S2.q && q1->second.coutPad == 32 && q2->second.coutPad == 32) {
+            RowsRbI8Params p;
+            memset(&p, 0, sizeof p);
+            auto cv = [&](const QLayer &Q) { return RowsConvI8{wtp<int8_t>(c, Q.wpk8), wtp<float>(c, Q.scale), wtp<float>(c, Q.shift), Q.q.inv(), Q.q.zoff()}; };
+            auto sv = [&](const SftLayer &S) {
+                RowsSftI8 r{wtp<int8_t>(c, S.qfrag), wtp<float>(c, S.qconst), {S.inv[0], S.inv[1]}, {S.zoff[0], S.zoff[1]}, {S.hzoff[0], S.hzoff[1]}};
+                return r;
+            };
+            p.x = x; p.cond = cond; p.c1 = cv(q1->second); p.c2 = cv(q2->second); p.s1 = sv(S1); p.s2 = sv(S2);
+            p.slope1 = act_slope(ACT_RELU);
+            p.dst = y; p.trash = const_cast<char *>(wtp<char>(c, c->dump_off)); p.H = H; p.W = W;
+            const double npx = (double)H * W;
+            chk(le_rb_rows_i8_launch(p, c->n_cu, s), base.c_str(), "le_rb_rows<i8>",
+                npx * (2.0 * 32 * 9 * 32 + 4.0 * (16 * 16 + 16 * 32)), npx * (64 + 32 + 64) + 2.0 * 9 * 32 * 32);
+            return;
+        }
+    }
     // fp16 block without a second residual, enough rows per segment to amortise the 4-row warm-up: ONE row-streaming
     // launch (le_rows.hip), the intermediate never leaves LDS; bit-identical to the two launches below
     if (ok() && c->var.at("le_rows") && !extra && rows_fit(H, W)) {

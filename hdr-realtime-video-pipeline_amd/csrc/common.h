@@ -242,6 +242,23 @@ struct RowsRbParams {
     FqParam fq_c1, fq_c2, fq_s1[4], fq_s2[4];
 };
 
+// The same chains with EVERY layer W8A8 on int8 MFMA (le_rows_i8.hip): a conv is conv32s<.., i8>'s operand set (pack_conv32_i8:
+// wpk8 [9][32][32] int8, byte 16 h + 4 qd + k of a row = input channel 8 qd + 4 h + k; scale [32]; shift [16 border classes][32];
+// the input quantiser q_inv / q_zoff), an SFT layer its SQ set (pack_sft: three int8 A fragments, 192 dequantisation constants,
+// the two condition quantisers and the two hidden-layer zero offsets)
+struct RowsConvI8 { const int8_t *wpk8; const float *scale, *shift; float q_inv, q_zoff; };
+struct RowsSftI8 { const int8_t *wfrag; const float *konst; float inv[2], zoff[2], hzoff[2]; };
+struct RowsRbI8Params {
+    const f16 *x, *cond;   // NHWC 32 / 16 [H][W]
+    RowsConvI8 c1, c2;
+    RowsSftI8 s1, s2;
+    float slope1;          // act_slope of conv1's activation (ReLU: 0), a runtime value as in conv32s
+    f16 *dst;
+    char *trash;
+    int H, W;
+    int nstrips, rows_per_seg;
+};
+
 // Parameter block of the row-streaming fused tail of the LE net (le_rows.hip):
 // out = res + conv_last(relu(HR_conv2(sft(relu(shuffle(up_conv(u))) + skip, cond))))
 struct RowsTailParams {

@@ -158,7 +158,7 @@ struct F32Run {
         p.no_mfma = c->var.at("f32_mfma") ? 0 : 1;
         p.cout = L.cout; p.cot = L.cot; p.pad = pad; p.act = o.act; p.slope = o.slope; p.ps = o.ps ? 1 : 0;
         const double macs = (double)L.cout * L.cin * L.ks * L.ks * Ho * Wo;
-        const bool mfma = L.ks == 3 && o.stride == 1 && conv_f32_on_mfma(p, c->n_cu);
+        const bool mfma = o.stride == 1 && conv_f32_on_mfma(p, L.ks, c->n_cu);
         q->chk(conv_f32_launch(p, L.ks, o.stride, c->n_cu, q->s), layer.c_str(), mfma ? "conv_f32_mfma" : "conv_f32", macs,
                4.0 * ((double)L.cin * x.H * x.W + (double)L.cout * Ho * Wo));
         return y;

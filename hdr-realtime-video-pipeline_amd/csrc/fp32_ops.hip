@@ -3,7 +3,7 @@
 // The fp16 path is the product's speed path (hand-fused MFMA kernels, NHWC f16).  This file serves the reference's "maximum
 // precision" preset: every tensor is planar CHW fp32 as in the reference, every layer is one generic kernel, the graph is
 // fp32_graph.hip.  Two convolution kernels:
-//   * conv_f32_mfma (round 5): the 3x3 / stride-1 layers whose channel counts are multiples of 32 / 16 -- 97 % of the MACs -- as an
+//   * conv_f32_mfma (round 5): the 3x3 and 1x1 / stride-1 layers whose channel counts are multiples of 32 / 16 -- 97 % of the MACs -- as an
 //     implicit GEMM on the fp32 MATRIX pipe, v_mfma_f32_32x32x2_f32: exact fp32 products and sums (an fmaf chain per output
 //     element, MI355X_MICROARCH.md "Matrix cores"), 64 FLOP / clock / SIMD = the vector rate, but one instruction per 4096
 //     FLOPs instead of per 128, so the issue slots, the scalar cache and the register file stop being the limit;
@@ -88,19 +88,24 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(F32ConvParams p)
 // [cout group][cin][tap][32] IS that fragment order, so a chunk's weights are one contiguous copy.  Input channels go through
 // LDS in chunks of 16 (halo tile 16 x 10 x 34 floats + MT x 144 x 32 weights, double-buffered, one barrier per chunk): the next
 // chunk's global loads are issued in front of this chunk's 144 MT MFMAs and written to LDS behind them.
-constexpr int MF_CIB = 16, MF_TR = 8, MF_TC = 32, MF_HR = MF_TR + 2, MF_HC = MF_TC + 2;
-constexpr int MF_HALO = MF_CIB * MF_HR * MF_HC;                 // 5440 floats
-constexpr int MF_KQ = MF_CIB * 9 / 2;                           // 72 MFMAs per chunk and accumulator tile
-template <int MT> struct MfGeo {
-    static constexpr int WCH = MT * MF_CIB * 9 * 32;            // floats of a chunk's weights
-    static constexpr int SMEM = 2 * (MF_HALO + WCH) * 4;        // 117 248 B (MT = 2) / 80 384 B (MT = 1)
-    static constexpr int NH = (MF_HALO + 511) / 512, NW4 = (WCH / 4 + 511) / 512;
+// The 1x1 layers (KS = 1: the condition nets' 64 -> 64 convs over the full-resolution map, the HG head's 1x1 fuse convs over a
+// channel concat) are the same GEMM without a halo, in chunks of 32 input channels (16 MFMAs per chunk and accumulator tile).
+constexpr int MF_TR = 8, MF_TC = 32;
+template <int MT, int KS> struct MfGeo {
+    static constexpr int TAPS = KS * KS, CIB = KS == 3 ? 16 : 32;    // input channels per chunk
+    static constexpr int HR = MF_TR + KS - 1, HC = MF_TC + KS - 1;
+    static constexpr int HALO = CIB * HR * HC;                        // 5440 / 8192 floats
+    static constexpr int KQ = CIB * TAPS / 2;                         // 72 / 16 MFMAs per chunk and accumulator tile
+    static constexpr int WCH = MT * CIB * TAPS * 32;                  // floats of a chunk's weights
+    static constexpr int SMEM = 2 * (HALO + WCH) * 4;                 // KS = 3: 117 248 B (MT = 2) / 80 384 B; KS = 1: 81 920 B / 73 728 B
+    static constexpr int NH = (HALO + 511) / 512, NW4 = (WCH / 4 + 511) / 512;
 };
 
-template <int MT>
+template <int MT, int KS>
 __global__ __launch_bounds__(512) void conv_f32_mfma_kernel(F32ConvParams p)
 {
-    using G = MfGeo<MT>;
+    using G = MfGeo<MT, KS>;
+    constexpr int MF_CIB = G::CIB, MF_HR = G::HR, MF_HC = G::HC, MF_HALO = G::HALO, MF_KQ = G::KQ, TAPS = G::TAPS;
     extern __shared__ __attribute__((aligned(16))) float smf[];
     float *const sX = smf, *const sW = smf + 2 * MF_HALO;
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, kk = lane >> 5;
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(512) void conv_f32_mfma_kernel(F32ConvParams p)
     for (int i = 0; i < G::NH; ++i) {
         const int e = tid + 512 * i;
         const int cl = e / (MF_HR * MF_HC), r = (e - cl * (MF_HR * MF_HC)) / MF_HC, c = e - cl * (MF_HR * MF_HC) - r * MF_HC;
-        const int iy = oy0 - 1 + r, ix = ox0 - 1 + c;
+        const int iy = oy0 - KS / 2 + r, ix = ox0 - KS / 2 + c;
         hcl[i] = cl;
         hoff[i] = (e < MF_HALO && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) ? iy * p.Wi + ix : -1;
     }
@@ -142,8 +147,8 @@ __global__ __launch_bounds__(512) void conv_f32_mfma_kernel(F32ConvParams p)
             for (int i = 0; i < G::NW4; ++i) {
                 int e = tid + 512 * i;                                // float4 index inside the chunk: [mt][1152]
                 e = e < G::WCH / 4 ? e : 0;                           // (past the end: any valid address; not staged)
-                const int mt = e / (MF_CIB * 9 * 8), r = e - mt * (MF_CIB * 9 * 8);
-                wv4[i] = *reinterpret_cast<const f32x4 *>(p.w + ((size_t)(g0 + mt) * cin + (size_t)nx * MF_CIB) * 288 + (size_t)r * 4);
+                const int mt = e / (MF_CIB * TAPS * 8), r = e - mt * (MF_CIB * TAPS * 8);
+                wv4[i] = *reinterpret_cast<const f32x4 *>(p.w + ((size_t)(g0 + mt) * cin + (size_t)nx * MF_CIB) * (TAPS * 32) + (size_t)r * 4);
             }
         }
         if (ch >= 0) {
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(512) void conv_f32_mfma_kernel(F32ConvParams p)
             for (int q = 0; q < MF_KQ; ++q) {
                 // k = 2 q + kk -> (channel, tap): compile-time for either lane half
                 const int k0 = 2 * q, k1 = 2 * q + 1;
-                const int o0 = ((k0 / 9) * MF_HR + (k0 % 9) / 3) * MF_HC + (k0 % 9) % 3, o1 = ((k1 / 9) * MF_HR + (k1 % 9) / 3) * MF_HC + (k1 % 9) % 3;
+                const int o0 = ((k0 / TAPS) * MF_HR + (k0 % TAPS) / KS) * MF_HC + (k0 % TAPS) % KS, o1 = ((k1 / TAPS) * MF_HR + (k1 % TAPS) / KS) * MF_HC + (k1 % TAPS) % KS;
                 const float b = bx[kk ? o1 : o0];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
@@ -192,16 +197,23 @@ __global__ __launch_bounds__(512) void conv_f32_mfma_kernel(F32ConvParams p)
         }
 }
 
-template <int MT> hipError_t conv_f32_mfma_go(const F32ConvParams &p, hipStream_t s)
+template <int MT, int KS> hipError_t conv_f32_mfma_go(const F32ConvParams &p, hipStream_t s)
 {
     static DevOnce once;
-    auto kern = conv_f32_mfma_kernel<MT>;
+    auto kern = conv_f32_mfma_kernel<MT, KS>;
+    constexpr int smem = MfGeo<MT, KS>::SMEM;
     if (once.need()) {
-        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, MfGeo<MT>::SMEM)) return e;
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem)) return e;
         once.done();
     }
-    hipLaunchKernelGGL(kern, dim3((p.Wo + MF_TC - 1) / MF_TC, (p.Ho + MF_TR - 1) / MF_TR, p.cout / (32 * MT)), dim3(512), MfGeo<MT>::SMEM, s, p);
+    hipLaunchKernelGGL(kern, dim3((p.Wo + MF_TC - 1) / MF_TC, (p.Ho + MF_TR - 1) / MF_TR, p.cout / (32 * MT)), dim3(512), smem, s, p);
     return hipGetLastError();
+}
+// two 32-channel groups per workgroup (each pixel fragment feeds two MFMAs) while that still leaves two workgroups per CU
+template <int KS> hipError_t conv_f32_mfma_pick(const F32ConvParams &p, int n_cu, hipStream_t s)
+{
+    const long tiles = (long)((p.Wo + MF_TC - 1) / MF_TC) * ((p.Ho + MF_TR - 1) / MF_TR);
+    return (p.cout % 64 == 0 && tiles * (p.cout / 64) >= 2L * n_cu) ? conv_f32_mfma_go<2, KS>(p, s) : conv_f32_mfma_go<1, KS>(p, s);
 }
 
 template <int KS, int STRIDE>
@@ -423,12 +435,13 @@ inline dim3 ew_grid_f32(size_t n)
 
 }  // namespace
 
-// which layers run on the matrix pipe: 3x3 / stride 1 / pad 1, filter packed in groups of 32, whole groups of output channels and
+// which layers run on the matrix pipe: 3x3 or 1x1 / stride 1 / same size, filter packed in groups of 32, whole groups of output channels and
 // whole chunks of input channels on either side of a concat, at least 64 input channels, and enough tiles to give at least a
 // quarter of the CUs a workgroup
-bool conv_f32_on_mfma(const F32ConvParams &p, int n_cu)
+bool conv_f32_on_mfma(const F32ConvParams &p, int ks, int n_cu)
 {
-    if (p.no_mfma || p.pad != 1 || p.cot != 32 || p.cout % 32 || p.c0 % MF_CIB || p.c1 % MF_CIB || p.Hi != p.Ho || p.Wi != p.Wo) return false;
+    const int cib = ks == 3 ? 16 : 32;
+    if ((ks != 1 && ks != 3) || p.no_mfma || p.pad != ks / 2 || p.cot != 32 || p.cout % 32 || p.c0 % cib || p.c1 % cib || p.Hi != p.Ho || p.Wi != p.Wo) return false;
     // 32 input channels are two chunks: prologue, barriers and epilogue then weigh as much as the MFMAs (LE's 32 -> 32 layers measured
     // 52 TFLOP/s here against 74 on the vector kernel, profiles/r05_fp32_layers.txt)
     if (p.c0 + p.c1 < 64) return false;
@@ -439,12 +452,8 @@ bool conv_f32_on_mfma(const F32ConvParams &p, int n_cu)
 hipError_t conv_f32_launch(const F32ConvParams &p, int ks, int stride, int n_cu, hipStream_t s)
 {
     if (p.Ho <= 0 || p.Wo <= 0 || p.cout <= 0 || p.c0 <= 0 || (p.cot != 8 && p.cot != 32)) return hipErrorInvalidValue;
+    if (stride == 1 && conv_f32_on_mfma(p, ks, n_cu)) return ks == 3 ? conv_f32_mfma_pick<3>(p, n_cu, s) : conv_f32_mfma_pick<1>(p, n_cu, s);
     if (ks == 1 && stride == 1) return conv_f32_pick<1, 1>(p, n_cu, s);
-    if (ks == 3 && stride == 1 && conv_f32_on_mfma(p, n_cu)) {
-        const long tiles = (long)((p.Wo + MF_TC - 1) / MF_TC) * ((p.Ho + MF_TR - 1) / MF_TR);
-        // two 32-channel groups per workgroup (each pixel fragment feeds two MFMAs) while that still leaves two workgroups per CU
-        return (p.cout % 64 == 0 && tiles * (p.cout / 64) >= 2L * n_cu) ? conv_f32_mfma_go<2>(p, s) : conv_f32_mfma_go<1>(p, s);
-    }
     if (ks == 3 && stride == 1) return conv_f32_pick<3, 1>(p, n_cu, s);
     if (ks == 3 && stride == 2) return conv_f32_pick<3, 2>(p, n_cu, s);
     if (ks == 1 && stride == 2) return conv_f32_pick<1, 2>(p, n_cu, s);

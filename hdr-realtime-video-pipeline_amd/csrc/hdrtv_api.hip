@@ -7,7 +7,11 @@ using namespace hdrtv_host;
 // =========================================================================== exported C ABI
 extern "C" {
 
-const char *hdrtv_version(void) { return "hdrtv_mi355x 0.1 gfx950 (MFMA f16 implicit-GEMM, hand-written HIP)"; }
+#ifndef HDRTV_BUILD_ID
+#define HDRTV_BUILD_ID "unstamped"
+#endif
+// "... build <id>": <id> = the first 12 hex digits of the SHA-1 over the library's sources (csrc/Makefile)
+const char *hdrtv_version(void) { return "hdrtv_mi355x 0.1 gfx950 (MFMA f16 implicit-GEMM, hand-written HIP) build " HDRTV_BUILD_ID; }
 
 int hdrtv_create(const void *hr_pack, size_t hr_bytes, const void *hg_pack, size_t hg_bytes, int device_id, hdrtv_ctx **out)
 {

@@ -21,6 +21,7 @@ hipError_t conv1x1_i8_launch(ConvI8Params p, hipStream_t stream);
 hipError_t conv32p_launch(Conv32Params p, int n_cu, hipStream_t stream, int nw = 0);
 hipError_t conv32s_launch(Conv32Params p, int n_cu, hipStream_t stream, bool nosplit = false);   // the single-pass (CoutPad == 32) layers
 hipError_t le_rb_rows_launch(RowsRbParams p, int n_cu, hipStream_t stream);   // fused ResBlock_with_SFT, row-streaming (le_rows.hip)
+hipError_t le_rb_rows_i8_launch(RowsRbI8Params p, int n_cu, hipStream_t stream);   // ... every layer W8A8 on int8 MFMA (le_rows_i8.hip)
 hipError_t le_tail_rows_launch(RowsTailParams p, int n_cu, hipStream_t stream);   // up_conv3 .. conv_last in one launch (le_rows.hip)
 hipError_t le_head_rows_launch(RowsHeadParams p, int n_cu, hipStream_t stream);   // conv_first .. down_conv1 in one launch (le_rows.hip)
 hipError_t conv_t16_launch(ConvParams p, hipStream_t stream, int n_cu);
@@ -110,7 +111,7 @@ int metrics_blocks(int H, int W);
 
 // precision="fp32" (fp32_ops.hip)
 hipError_t conv_f32_launch(const F32ConvParams &p, int ks, int stride, int n_cu, hipStream_t s);
-bool conv_f32_on_mfma(const F32ConvParams &p, int n_cu);      // whether conv_f32_launch runs the layer on the fp32 matrix pipe (3x3 / stride 1 only)
+bool conv_f32_on_mfma(const F32ConvParams &p, int ks, int n_cu);      // whether conv_f32_launch runs a stride-1 layer on the fp32 matrix pipe
 hipError_t ew_f32_launch(int op, const float *a, const float *b, const float *c, float *y, size_t n, hipStream_t s);
 hipError_t avgpool3s2_leaky_f32_launch(const float *x, float *y, int C, int H, int W, float slope, hipStream_t s);
 hipError_t instnorm_f32_launch(float *x, const float *gamma, const float *beta, int C, int n, float eps, hipStream_t s);

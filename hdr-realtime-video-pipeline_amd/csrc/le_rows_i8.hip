@@ -1,0 +1,317 @@
+// le_rows_i8.hip -- the row-streaming fused LE kernels (le_rows.hip) for chains whose layers are ALL W8A8, on int8 MFMA (gfx950).
+//
+//   le_rb_rows_i8   ResBlock_with_SFT.forward (arch_util.py:89-95) with conv1, conv2 and the eight 1x1 convs of its two SFT layers as
+//                   W8A8Conv2d (hdrtvnet_torch.py:296-364): the full-QAT recipe's ResBlocks at 1/2 and 1/4 resolution
+//
+// Same schedule as le_rb_rows (strips of 60 columns x row segments, two rows per step, stages skewed across steps, one barrier
+// per step, LDS-DMA three steps ahead; le_rows.hip's header), but what lives in the rings between the stages are the layers' int8
+// CODES, not f16 values:
+//   * a stage's epilogue applies the NEXT conv's activation quantiser once per element (one FMA + v_cvt_pk_u8_f32 per value,
+//     common.h quant4) and writes the lane's 16 codes of its pixel as ONE 16-byte LDS store: a code pixel is 32 bytes, its two
+//     halves hold the channels of the two lane halves in accumulator order (8 qd + 4 lh + k at byte 16 lh + 4 qd + k) -- the K order
+//     pack_conv32_i8 gives the weights -- so there is no cross-lane exchange and no 8-byte access at all;
+//   * a 3x3 conv is 9 v_mfma_i32_32x32x32_i8 (one tap of 32 channels = one K step) on 9 fragment reads: half the MFMAs, half the
+//     LDS reads and half the ring bytes of the f16 form; the filter bank is 36 VGPRs instead of 72;
+//   * the reference pads with zeros AFTER dequantisation: out-of-image ring slots hold code 0 and the conv's epilogue picks the
+//     shift of the output pixel's border class (16 classes x 32 channels, pack_conv32_i8 / q_tables);
+//   * the SFT layers' four 1x1 convs run as conv32s's SQ pass does: the condition pixel quantised per branch, one block-diagonal
+//     K = 32 MFMA for both hidden layers, dequantise + LeakyReLU + re-quantise in registers, two MFMAs for the heads, constants
+//     from LDS.
+// Arithmetic, operand order and every rounding point are those of the per-layer int8 kernels conv32s<sft-i8, i8> (variant
+// le_rows_i8 = 0): outputs are bit-identical to them (tests/test_gpu_le_rows.py), so the per-layer path's parity evidence against
+// the reference's fake-quant arithmetic carries over, and the result no longer depends on whether a map is large enough for the
+// fused kernels.
+#include "le_rows.h"
+
+namespace {
+
+constexpr int Y8_ROWB = YP * 32;                    // a code ring row: 66 slots x 32 bytes
+using L8Std = Lay32<0, 12>;                         // R1 + W1 for 32-byte pixels (tools/lds_ring_layouts.py)
+
+struct Bank8 { i32x4 f[9]; };                       // a 3x3 32 -> 32 int8 filter bank: tap t, lane (n = l31, half lh) = bytes 16 lh .. of row n
+__device__ __forceinline__ void load_bank8(Bank8 &b, const int8_t *wpk8, int l31, int lh)
+{
+#pragma unroll
+    for (int t = 0; t < 9; ++t) b.f[t] = *reinterpret_cast<const i32x4 *>(wpk8 + (t * 32 + l31) * 32 + 16 * lh);
+}
+__device__ __forceinline__ i32x16 izero16() { return i32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; }
+
+// 3x3 conv of one 32-pixel group out of a mirrored code ring: va[kx] = this lane's fragment address for kernel column kx in ring
+// row 0 (buffer base included), `win` the byte offset of the window's first row; reads run AHEAD taps in front of the MFMAs
+template <int AHEAD, class Hook>
+__device__ __forceinline__ i32x16 conv9(const Bank8 &w, const unsigned (&va)[3], int win, Hook hook)
+{
+    i32x4 x[9];
+    i32x16 acc;
+    auto ld = [&](int t) __attribute__((always_inline)) { x[t] = lds_rd<i32x4>(va[t % 3] + (unsigned)(win + (t / 3) * Y8_ROWB)); };
+#pragma unroll
+    for (int t = 0; t < AHEAD; ++t) ld(t);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        if (t + AHEAD < 9) ld(t + AHEAD);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w.f[t], x[t], t == 0 ? izero16() : acc, 0, 0, 0);
+        hook(t);
+    }
+    return acc;
+}
+
+// An SFT layer's W8A8 operands (pack_sft, SftLayer.q*): fragments in registers, the 192 constants in LDS at `kb` (this lane half's
+// 16-float rows start at kb + 64 lh: ka, kb, k2, k3, k4, k5 at byte offsets 0, 128, .. 640)
+struct Sft8 { i32x4 a0, a1s, a1t; float inv, zoff, hz0, hz1; unsigned kb; };
+__device__ __forceinline__ void load_sft8(Sft8 &s, const RowsSftI8 &p, unsigned k_lds, int lane, int lh)
+{
+    const i32x4 *fr = reinterpret_cast<const i32x4 *>(p.wfrag);
+    s.a0 = fr[lane]; s.a1s = fr[64 + lane]; s.a1t = fr[128 + lane];
+    s.inv = p.inv[lh]; s.zoff = p.zoff[lh]; s.hz0 = p.hzoff[0]; s.hz1 = p.hzoff[1];
+    s.kb = k_lds + 64 * lh;
+}
+// conv32s.hip's SQ pass, step by step (same expressions: the results are its bits)
+__device__ __forceinline__ i32x16 sft8_hidden(const Sft8 &s, const f16x8 &c0, const f16x8 &c1)
+{
+    i32x4 cb;
+    cb[0] = (int)quant4((float)c0[0], (float)c0[1], (float)c0[2], (float)c0[3], s.inv, s.zoff);
+    cb[1] = (int)quant4((float)c0[4], (float)c0[5], (float)c0[6], (float)c0[7], s.inv, s.zoff);
+    cb[2] = (int)quant4((float)c1[0], (float)c1[1], (float)c1[2], (float)c1[3], s.inv, s.zoff);
+    cb[3] = (int)quant4((float)c1[4], (float)c1[5], (float)c1[6], (float)c1[7], s.inv, s.zoff);
+    return __builtin_amdgcn_mfma_i32_32x32x32_i8(s.a0, cb, izero16(), 0, 0, 0);
+}
+__device__ __forceinline__ void sft8_mid(const Sft8 &s, const i32x16 &hacc, i32x4 &hs, i32x4 &ht)
+{
+    float t[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 ka = lds_rd<f32x4>(s.kb + 16 * g), kb = lds_rd<f32x4>(s.kb + 128 + 16 * g);
+        const float zo = (g >> 1) ? s.hz1 : s.hz0;
+        const float u0 = (float)hacc[4 * g + 0] * ka[0] + kb[0], u1 = (float)hacc[4 * g + 1] * ka[1] + kb[1],
+                    u2 = (float)hacc[4 * g + 2] * ka[2] + kb[2], u3 = (float)hacc[4 * g + 3] * ka[3] + kb[3];
+        t[4 * g + 0] = fmaxf(u0, 0.1f * u0) + zo; t[4 * g + 1] = fmaxf(u1, 0.1f * u1) + zo;
+        t[4 * g + 2] = fmaxf(u2, 0.1f * u2) + zo; t[4 * g + 3] = fmaxf(u3, 0.1f * u3) + zo;
+    }
+    hs = i32x4{(int)quant4u(t[0], t[1], t[2], t[3]), (int)quant4u(t[4], t[5], t[6], t[7]), 0, 0};
+    ht = i32x4{(int)quant4u(t[8], t[9], t[10], t[11]), (int)quant4u(t[12], t[13], t[14], t[15]), 0, 0};
+}
+__device__ __forceinline__ void sft8_heads(const Sft8 &s, const i32x4 &hs, const i32x4 &ht, f16x4 (&s1p)[4], f16x4 (&s0p)[4])
+{
+    const i32x16 a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(s.a1s, hs, izero16(), 0, 0, 0);
+    const i32x16 a2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(s.a1t, ht, izero16(), 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 k2 = lds_rd<f32x4>(s.kb + 256 + 16 * g), k3 = lds_rd<f32x4>(s.kb + 384 + 16 * g);
+        const f32x4 k4 = lds_rd<f32x4>(s.kb + 512 + 16 * g), k5 = lds_rd<f32x4>(s.kb + 640 + 16 * g);
+        const float sc0 = (float)a1[4 * g + 0] * k2[0] + k3[0], sc1 = (float)a1[4 * g + 1] * k2[1] + k3[1],
+                    sc2 = (float)a1[4 * g + 2] * k2[2] + k3[2], sc3 = (float)a1[4 * g + 3] * k2[3] + k3[3];
+        const float sh0 = (float)a2[4 * g + 0] * k4[0] + k5[0], sh1 = (float)a2[4 * g + 1] * k4[1] + k5[1],
+                    sh2 = (float)a2[4 * g + 2] * k4[2] + k5[2], sh3 = (float)a2[4 * g + 3] * k4[3] + k5[3];
+        s1p[g] = cvt4(sc0, sc1, sc2, sc3);
+        s0p[g] = cvt4(sh0, sh1, sh2, sh3);
+    }
+}
+// y = x * (scale + 1) + shift in packed f16, then the reading conv's quantiser: this lane's 16 codes of its pixel (0 outside the image)
+__device__ __forceinline__ i32x4 modulate_quant(const f16x4 (&x)[4], const f16x4 (&s1p)[4], const f16x4 (&s0p)[4], float q_inv, float q_zoff, bool inimg)
+{
+    i32x4 codes;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+        const f16x4 y = x[qd] * s1p[qd] + s0p[qd];
+        const unsigned w = quant4((float)y[0], (float)y[1], (float)y[2], (float)y[3], q_inv, q_zoff);
+        codes[qd] = inimg ? (int)w : 0;
+    }
+    return codes;
+}
+__device__ __forceinline__ void put_codes(unsigned a, int off, bool mirror, const i32x4 &codes)
+{
+    lds_wr(a + (unsigned)off, codes);
+    if (mirror) lds_wr(a + (unsigned)(off + YN * Y8_ROWB), codes);
+}
+// conv epilogue of conv32s<.., i8>: o = f16(act(acc * scale[c] + shift[class][c])) on this lane's 16 channels
+__device__ __forceinline__ void dequant_act(const i32x16 &iacc, const f32x4 (&scq)[4], unsigned shift_tab, int bcls, int lh, float slope, f16x4 (&o)[4])
+{
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+        const f32x4 sh = lds_rd<f32x4>(shift_tab + (unsigned)(bcls * 128 + 32 * qd + 16 * lh));
+        const float v0 = (float)iacc[4 * qd + 0] * scq[qd][0] + sh[0], v1 = (float)iacc[4 * qd + 1] * scq[qd][1] + sh[1],
+                    v2 = (float)iacc[4 * qd + 2] * scq[qd][2] + sh[2], v3 = (float)iacc[4 * qd + 3] * scq[qd][3] + sh[3];
+        o[qd] = f16x4{(f16)act_fast(v0, slope), (f16)act_fast(v1, slope), (f16)act_fast(v2, slope), (f16)act_fast(v3, slope)};
+    }
+}
+__device__ __forceinline__ void table_to_lds(char *dst, const RowsConvI8 &c, int tid)       // [scale 32][shift 16 x 32] floats
+{
+    for (int e = tid; e < 17 * 32; e += 512) reinterpret_cast<float *>(dst)[e] = e < 32 ? c.scale[e] : c.shift[e - 32];
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+template <int DPF> struct Rb8Geo {
+    static constexpr int LAG = 6;
+    static constexpr int XR = 2 * DPF + LAG + 2, CR = 2 * DPF + LAG;
+    static constexpr int OFF_X = 0, OFF_C = OFF_X + XR * X_ROWB, OFF_Y1 = OFF_C + CR * C_ROWB, OFF_Y2 = OFF_Y1 + YPH * Y8_ROWB;
+    static constexpr int OFF_T = OFF_Y2 + YPH * Y8_ROWB;       // conv1's table (2176 B), then conv2's
+    static constexpr int OFF_K = OFF_T + 2 * 2176;             // sft2's constants (768 B), then sft1's
+    static constexpr int SMEM = OFF_K + 2 * 768;
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+    static_assert(BIG % XR == 0 && BIG % CR == 0 && BIG % YN == 0, "BIG");
+};
+
+template <int DPF>
+__global__ __launch_bounds__(512) void le_rb_rows_i8_kernel(RowsRbI8Params p)
+{
+    using G = Rb8Geo<DPF>;
+    constexpr int LAG = G::LAG, XR = G::XR, CR = G::CR;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned sm = lds_off(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int strip = blockIdx.x % p.nstrips, seg = blockIdx.x / p.nstrips;
+    const int x0 = strip * WS;
+    const int y0 = seg * p.rows_per_seg, yend = min(y0 + p.rows_per_seg, p.H);
+    const int ya = y0 - 2;                                             // image row of ring row 0
+    const int nsteps = (yend - ya + LAG - 1) / 2 + 1;
+    const int H = p.H, W = p.W;
+    table_to_lds(smem + G::OFF_T, p.c1, tid);
+    table_to_lds(smem + G::OFF_T + 2176, p.c2, tid);
+    for (int e = tid; e < 384; e += 512) reinterpret_cast<float *>(smem + G::OFF_K)[e] = e < 192 ? p.s2.konst[e] : p.s1.konst[e - 192];
+
+    const int g = wave & 3, gr = g >> 1, gh = g & 1;                   // this wave's 32-pixel group: row gr of the step's pair, column half gh
+    const int cx = 32 * gh + l31;                                      // this lane's pixel slot in its group's ring rows
+    unsigned va[3];                                                    // conv fragments: output slot cx reads code slots cx .. cx + 2, half lh
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) va[kx] = sm + L8Std::at(cx + kx, lh);
+    const unsigned vw = sm + L8Std::at(cx, lh);                        // code write: this lane's half of slot cx
+
+    if (wave < 4) {
+        // ------------------------------------------------------------------ role B: conv1 (int8) -> ReLU -> sft2 -> conv2's codes
+        Bank8 w1;
+        load_bank8(w1, p.c1.wpk8, l31, lh);
+        Sft8 s2;
+        load_sft8(s2, p.s2, sm + G::OFF_K, lane, lh);
+        f32x4 scq[4];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) scq[qd] = *reinterpret_cast<const f32x4 *>(p.c1.scale + 8 * qd + 4 * lh);
+        const unsigned tab = sm + G::OFF_T + 128;                      // conv1's shift classes
+        const unsigned vc0 = sm + LCond::at(cx + 1, 0), vc1 = sm + LCond::at(cx + 1, 1);      // Y2 slot cx = image column x0 - 1 + cx = condition slot cx + 1
+        const int ox = x0 - 1 + cx;
+        const bool col2 = (unsigned)ox < (unsigned)W;
+        const int ccls = (ox == 0 ? 1 : 0) | (ox == W - 1 ? 2 : 0);
+        const float q_inv = p.c2.q_inv, q_zoff = p.c2.q_zoff, slope = p.slope1;
+        // ring rows of step s: conv1 + sft2 on rb = 2 s - 3 + gr
+        Cur<G::OFF_C, CR, C_ROWB> cb(gr - 3);
+        Cur<G::OFF_Y1, YN, Y8_ROWB> wn(gr - 4);
+        Cur<G::OFF_Y2, YN, Y8_ROWB> yb2(gr - 3);
+        int rb_img = ya + gr - 3;
+        __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));
+        __builtin_amdgcn_s_barrier();
+        for (int s = 0; s < nsteps; ++s) {
+            const f16x8 c0 = lds_rd<f16x8>(vc0 + cb.o), c1 = lds_rd<f16x8>(vc1 + cb.o);
+            const bool in2 = col2 && (unsigned)rb_img < (unsigned)H;   // outside the image: conv2's zero padding = code 0
+            const int bcls = (((rb_img == 0 ? 1 : 0) | (rb_img == H - 1 ? 2 : 0)) << 2) | ccls;
+            i32x16 hacc;
+            i32x4 hs, ht;
+            f16x4 s1p[4], s0p[4];
+            const i32x16 iacc = conv9<4>(w1, va, wn.o, [&](int t) __attribute__((always_inline)) {
+                if (t == 0) hacc = sft8_hidden(s2, c0, c1);
+                if (t == 3) sft8_mid(s2, hacc, hs, ht);
+                if (t == 6) sft8_heads(s2, hs, ht, s1p, s0p);
+            });
+            f16x4 o[4];
+            dequant_act(iacc, scq, tab, bcls, lh, slope, o);
+            put_codes(vw, yb2.o, yb2.mirrored(), modulate_quant(o, s1p, s0p, q_inv, q_zoff, in2));
+            cb.step(); wn.step(); yb2.step();
+            rb_img += 2;
+            __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
+        // ------------------------------------------------------------------ role C: the DMA, sft1 -> conv1's codes, conv2 (int8) + x, stores
+        Bank8 w2;
+        load_bank8(w2, p.c2.wpk8, l31, lh);
+        Sft8 s1;
+        load_sft8(s1, p.s1, sm + G::OFF_K + 768, lane, lh);
+        f32x4 scq[4];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) scq[qd] = *reinterpret_cast<const f32x4 *>(p.c2.scale + 8 * qd + 4 * lh);
+        const unsigned tab = sm + G::OFF_T + 2176 + 128;               // conv2's shift classes
+        unsigned vq[2], vr[2];                                         // x of slot cx (sft1's input) and of slot cx + 2 (the residual): this lane's two chunks
+        chunk_addr<LStd>(vq, sm, cx, lh);
+        chunk_addr<LStd>(vr, sm, cx + 2, lh);
+        const unsigned vc0 = sm + LCond::at(cx, 0), vc1 = sm + LCond::at(cx, 1);             // slot cx = image column x0 - 2 + cx
+        const bool col1 = (unsigned)(x0 - 2 + cx) < (unsigned)W;
+        const int ox = x0 + cx;
+        const int ccls = (ox == 0 ? 1 : 0) | (ox == W - 1 ? 2 : 0);
+        const float q_inv = p.c1.q_inv, q_zoff = p.c1.q_zoff;
+        const dma_rsrc_t rx = dma_rsrc(p.x), rc = dma_rsrc(p.cond);
+        // per step: pieces 2 gh, 2 gh + 1 of x row gr (16 pixels x 64 B each) and piece gh of condition row gr (32 pixels x 32 B)
+        const unsigned xl0 = LStd::src_off(2 * gh, lane), xl1 = LStd::src_off(2 * gh + 1, lane), cl = LCond::src_off(gh, lane);
+        const bool xok0 = (unsigned)(x0 - 2 + LStd::src_px(2 * gh, lane)) < (unsigned)W, xok1 = (unsigned)(x0 - 2 + LStd::src_px(2 * gh + 1, lane)) < (unsigned)W;
+        const bool cok = (unsigned)(x0 - 2 + LCond::src_px(gh, lane)) < (unsigned)W;
+        auto issue = [&](int r, int xo_, int co_) __attribute__((always_inline)) {        // image row r into the ring rows at xo_ / co_
+            const bool rok = (unsigned)r < (unsigned)H && r <= yend + 1;
+            const unsigned pix = (unsigned)(r * W + x0 - 2);
+            dma16_at(rx, sm + xo_ + (2 * gh) * 1024, (rok && xok0) ? pix * 64u + xl0 : DMA_OOB);
+            dma16_at(rx, sm + xo_ + (2 * gh + 1) * 1024, (rok && xok1) ? pix * 64u + xl1 : DMA_OOB);
+            dma16_at(rc, sm + co_ + gh * 1024, (rok && cok) ? pix * 32u + cl : DMA_OOB);
+        };
+        char *trash = p.trash + tid * 16;
+        const bool ocol = cx < WS && x0 + cx < W;
+        f16 *const dst0 = p.dst + (size_t)(x0 + cx) * 32 + 8 * lh;
+#pragma unroll
+        for (int sq = 0; sq < DPF; ++sq)
+            issue(ya + 2 * sq + gr, G::OFF_X + ((2 * sq + gr + BIG) % XR) * X_ROWB, G::OFF_C + ((2 * sq + gr + BIG) % CR) * C_ROWB);
+        // ring rows of step s: DMA into 2 (s + DPF) + gr; sft1 on ra = 2 s + gr; conv2 + residual on ro = ra - LAG
+        Cur<G::OFF_X, XR, X_ROWB> xd(2 * DPF + gr), xa(gr), xres(gr - LAG);
+        Cur<G::OFF_C, CR, C_ROWB> cd(2 * DPF + gr), ca(gr);
+        Cur<G::OFF_Y1, YN, Y8_ROWB> ya1(gr);
+        Cur<G::OFF_Y2, YN, Y8_ROWB> wn(gr - LAG - 1);
+        int ro_img = ya + gr - LAG;
+        __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));
+        __builtin_amdgcn_s_barrier();
+        for (int s = 0; s < nsteps; ++s) {
+            issue(ro_img + LAG + 2 * DPF, xd.o, cd.o);
+            __builtin_amdgcn_sched_barrier(0);
+            const f16x8 c0 = lds_rd<f16x8>(vc0 + ca.o), c1 = lds_rd<f16x8>(vc1 + ca.o);
+            f16x4 xq[4];
+            get_row(vq, xa.o, xq);
+            const f16x8 res0 = lds_rd<f16x8>(vr[0] + (unsigned)xres.o), res1 = lds_rd<f16x8>(vr[1] + (unsigned)xres.o);
+            const bool in1 = col1 && (unsigned)(ro_img + LAG) < (unsigned)H;   // outside the image: conv1's zero padding = code 0
+            const int bcls = (((ro_img == 0 ? 1 : 0) | (ro_img == H - 1 ? 2 : 0)) << 2) | ccls;
+            // conv2 on row ro with row ra's whole SFT pass (independent of it) between its MFMAs
+            i32x16 hacc;
+            i32x4 hs, ht;
+            f16x4 s1p[4], s0p[4];
+            const i32x16 iacc = conv9<4>(w2, va, wn.o, [&](int t) __attribute__((always_inline)) {
+                if (t == 0) hacc = sft8_hidden(s1, c0, c1);
+                if (t == 3) sft8_mid(s1, hacc, hs, ht);
+                if (t == 6) sft8_heads(s1, hs, ht, s1p, s0p);
+            });
+            put_codes(vw, ya1.o, ya1.mirrored(), modulate_quant(xq, s1p, s0p, q_inv, q_zoff, in1));
+            {
+                f16x4 o[4];
+                dequant_act(iacc, scq, tab, bcls, lh, 1.f, o);         // no activation behind conv2 (act_fast(v, 1) = v)
+                f16x8 o0, o1;
+                quads_to_chunks(o, o0, o1);
+                o0 += res0; o1 += res1;                                // x + conv2(..): one f16 rounding per element, as conv32s's epilogue
+                f16 *d = (ocol && ro_img >= y0 && ro_img < yend) ? dst0 + (size_t)ro_img * W * 32 : reinterpret_cast<f16 *>(trash);
+                *reinterpret_cast<f16x8 *>(d) = o0;
+                *reinterpret_cast<f16x8 *>(d == reinterpret_cast<f16 *>(trash) ? d : d + 16) = o1;
+            }
+            xd.step(); xa.step(); xres.step(); cd.step(); ca.step(); ya1.step(); wn.step();
+            ro_img += 2;
+            // per step and wave: three DMA pieces, then two stores, all always issued: the pieces that step s + 1 reads were issued
+            // at the top of step s + 1 - DPF, in front of 5 (DPF - 1) + 2 younger operations
+            __builtin_amdgcn_s_waitcnt(waitcnt_imm(5 * (DPF - 1) + 2, 0));
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t le_rb_rows_i8_launch(RowsRbI8Params p, int n_cu, hipStream_t s)
+{
+    if ((size_t)p.H * p.W * 64 >= 0x7f000000ull || !p.trash) return hipErrorInvalidValue;
+    static DevOnce once;
+    int nseg;
+    strips(p, n_cu, false, nseg);
+    if (hipError_t e = set_lds(le_rb_rows_i8_kernel<3>, Rb8Geo<3>::SMEM, once)) return e;
+    hipLaunchKernelGGL((le_rb_rows_i8_kernel<3>), dim3(p.nstrips * nseg), dim3(512), Rb8Geo<3>::SMEM, s, p);
+    return hipGetLastError();
+}

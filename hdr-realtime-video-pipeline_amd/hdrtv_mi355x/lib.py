@@ -76,6 +76,19 @@ def load(ab=False):
     return lib
 
 
+def build_id(ab=False):
+    """The library's build id: the hash over its sources that csrc/Makefile stamps into hdrtv_version() ("... build <id>")."""
+    v = load(ab).hdrtv_version().decode()
+    return v.rsplit(" build ", 1)[1] if " build " in v else "unstamped"
+
+
+def source_hash(name):
+    """First 12 hex digits of the SHA-1 of csrc/<name>: what tools/pmc_to_json.py records per source file."""
+    import hashlib
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc", name), "rb") as f:
+        return hashlib.sha1(f.read()).hexdigest()[:12]
+
+
 class HdrtvError(RuntimeError):
     pass
 

@@ -70,3 +70,28 @@ def test_bench_self_launches_its_ranks(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["max_over_ranks"] == 2.0
     assert "torch.distributed.run" in r.stderr and "--nproc-per-node=2" in r.stderr
+
+
+def test_committed_counter_figures_are_reported_only_for_the_code_they_were_measured_on():
+    """bench.py's `roofline.traffic` comes from a committed rocprofv3 --pmc file: it must carry the library's build stamp, and a
+    figure is printed only when the stamp matches the loaded library or the kernel's own source (and the shared headers) hash as
+    they did at measurement time; otherwise `traffic` is null and `traffic_note` says why."""
+    import bench
+    doc = {"build_id": "aaaaaaaaaaaa", "sources": {"conv3x3_prw.hip": "111", "common.h": "222", "launchers.h": "333", "le_rows.hip": "444"}}
+    same = {"conv3x3_prw.hip": "111", "common.h": "222", "launchers.h": "333", "le_rows.hip": "changed"}
+    t, why = bench.traffic_for("conv_prw<pool>", 123, doc, "profiles/x.json", build_id=lambda: "aaaaaaaaaaaa", source_hash=same.__getitem__)
+    assert (t, why) == (123, None)
+    t, why = bench.traffic_for("conv_prw<pool>", 123, doc, "profiles/x.json", build_id=lambda: "bbbbbbbbbbbb", source_hash=same.__getitem__)
+    assert t == 123 and "unchanged" in why
+    t, why = bench.traffic_for("le_tail_rows", 123, doc, "profiles/x.json", build_id=lambda: "bbbbbbbbbbbb", source_hash=same.__getitem__)
+    assert t is None and "le_rows.hip differs" in why
+    t, why = bench.traffic_for("conv_prw<pool>", 123, {"kernels": {}}, "profiles/x.json", build_id=lambda: "bbbbbbbbbbbb", source_hash=same.__getitem__)
+    assert t is None and "no build stamp" in why
+    assert bench.traffic_for("conv_prw8_i8<ps>", 1, doc, "p", build_id=lambda: "b", source_hash=lambda f: "zzz")[0] is None
+
+
+def test_library_version_carries_a_build_stamp():
+    from hdrtv_mi355x import lib
+    bid = lib.build_id()
+    assert len(bid) == 12 and all(c in "0123456789abcdef" for c in bid), bid
+    assert lib.source_hash("common.h") and len(lib.source_hash("common.h")) == 12

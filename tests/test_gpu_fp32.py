@@ -279,7 +279,7 @@ def test_fp32_matrix_pipe_convs_against_the_vector_kernel(torch_cuda, golden_dir
                   f"out identical on {same:.3%} of the values, max |delta| {float(d.max()):.2e}")
             assert float(d.max()) <= 2e-6
             if h >= 1080:
-                assert share >= 0.9
+                assert share >= 0.8              # 3x3 layers with >= 64 input channels + the 64 -> 64 / concat 1x1 layers
             assert float((res[0][1] - res[1][1]).abs().max()) <= 2e-6
     finally:
         p.close()

@@ -277,16 +277,17 @@ def test_prw_dot3_strip_reads_stay_behind_the_flag_poll(tmp_path):
 
 
 def test_fp32_matrix_pipe_conv_issues_its_mfmas_and_spills_nothing(tmp_path):
-    """conv_f32_mfma (fp32_ops.hip): 72 v_mfma_f32_32x32x2_f32 per 16-channel chunk and accumulator tile in the unrolled chunk loop,
-    staged through registers without scratch (an array of HIP's float4 struct for the weight staging landed in scratch: clang
-    vectors only)."""
+    """conv_f32_mfma (fp32_ops.hip): 72 (3x3, 16-channel chunks) / 16 (1x1, 32-channel chunks) v_mfma_f32_32x32x2_f32 per chunk and
+    accumulator tile in the unrolled chunk loop, staged through registers without scratch (an array of HIP's float4 struct for the
+    weight staging landed in scratch: clang vectors only)."""
     kernels = _asm("fp32_ops.hip", tmp_path)
     seen = 0
     for name, body in kernels.items():
-        if "conv_f32_mfma_kernel" not in name:
+        m = re.search(r"conv_f32_mfma_kernelILi(\d)ELi(\d)E", name)
+        if not m:
             continue
-        mt = 2 if "ILi2E" in name else 1
-        assert len(re.findall(r"v_mfma_f32_32x32x2_f32", body)) == 72 * mt, name
+        mt, ks = int(m.group(1)), int(m.group(2))
+        assert len(re.findall(r"v_mfma_f32_32x32x2_f32", body)) == (72 if ks == 3 else 16) * mt, name
         assert "scratch_" not in body, name
         seen += 1
-    assert seen == 2
+    assert seen == 4

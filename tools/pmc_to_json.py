@@ -5,7 +5,23 @@ profiles/pmc_traffic.json: HBM bytes per launch and kernel, corrected as
     bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024
 (FETCH_SIZE counts 128-byte requests of a wide coalesced stream at 64 B -> doubled; both counters are in KiB).
 usage: pmc_to_json.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> <note>"""
-import collections, csv, json, re, sys
+import collections, csv, hashlib, json, os, re, sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(REPO, "hdr-realtime-video-pipeline_amd", "csrc")
+
+
+def stamps():
+    """What the figures were measured on: the library's build id (hdrtv_version()) and a hash per source file."""
+    sys.path.insert(0, os.path.join(REPO, "hdr-realtime-video-pipeline_amd"))
+    try:
+        from hdrtv_mi355x import lib
+        build = lib.build_id()
+    except Exception as exc:  # noqa: BLE001
+        build = f"unknown ({exc})"
+    src = {f: hashlib.sha1(open(os.path.join(CSRC, f), "rb").read()).hexdigest()[:12] for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))}
+    return build, src
+
 
 def per_kernel(path, counter):
     acc = collections.defaultdict(list)
@@ -18,7 +34,8 @@ def per_kernel(path, counter):
 
 f = per_kernel(sys.argv[1], "FETCH_SIZE")
 w = per_kernel(sys.argv[2], "WRITE_SIZE")
-out = {"note": sys.argv[4] if len(sys.argv) > 4 else "", "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 bytes, mean per launch",
+build_id, sources = stamps()
+out = {"note": sys.argv[4] if len(sys.argv) > 4 else "", "build_id": build_id, "sources": sources, "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 bytes, mean per launch",
        "kernels": {}}
 for k in sorted(set(f) & set(w)):
     out["kernels"][k] = {"fetch_kib": round(f[k][0], 1), "write_kib": round(w[k][0], 1), "launches_sampled": f[k][1],
