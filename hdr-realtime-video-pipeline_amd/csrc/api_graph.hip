@@ -553,6 +553,27 @@ int run_le(hdrtv_ctx *c, Seq &q, const f16 *img, f16 *out_planar)
     q.resblock("LE.recon_trunk5.0", up2, cond2, s.H1, s.W1, l1b, t5);
     // the full-resolution tail: one row-streaming launch (le_rows.hip) when the shapes are even and every layer is fp16 or a W8A8
     // layer the kernel runs as fake-quant, else per layer
+    if (q.ok() && c->var.at("le_rows") && c->var.at("le_rows_i8") && !(H & 1) && !(W & 1) && s.H1 * 2 == H && s.W1 * 2 == W && q.rows_fit(H, W)) {
+        // every layer of the tail W8A8 (the full-QAT recipe): the row kernel on int8 MFMA (le_rows_i8.hip), bit-identical to the three
+        // per-layer int8 launches at the bottom
+        auto qu = c->q32.find("LE.up_conv3.0"), qh = c->q32.find("LE.HR_conv2"), ql = c->q32.find("LE.conv_last");
+        const SftLayer &S2 = c->sft.at("LE.SFT_layer2");
+        if (qu != c->q32.end() && qh != c->q32.end() && ql != c->q32.end() && S2.q && qu->second.coutPad == 128 &&
+            qh->second.coutPad == 32 && ql->second.coutPad == 32) {
+            RowsTailI8Params p;
+            memset(&p, 0, sizeof p);
+            auto cv = [&](const QLayer &Q) { return RowsConvI8{wtp<int8_t>(c, Q.wpk8), wtp<float>(c, Q.scale), wtp<float>(c, Q.shift), Q.q.inv(), Q.q.zoff()}; };
+            p.u = t5; p.fea0 = fea0; p.cond = cond1; p.res_planar = img; p.dst_planar = out_planar; p.H = H; p.W = W;
+            p.up = cv(qu->second); p.hr = cv(qh->second); p.last = cv(ql->second);
+            p.s = RowsSftI8{wtp<int8_t>(c, S2.qfrag), wtp<float>(c, S2.qconst), {S2.inv[0], S2.inv[1]}, {S2.zoff[0], S2.zoff[1]}, {S2.hzoff[0], S2.hzoff[1]}};
+            p.slope_relu = act_slope(ACT_RELU);
+            p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
+            const double npx = (double)H * W;
+            q.chk(le_tail_rows_i8_launch(p, c->n_cu, q.s), "LE.tail", "le_tail_rows<i8>",
+                  npx * (32.0 * 9 * 128 / 4 + 2.0 * (16 * 16 + 16 * 32) + 32.0 * 9 * 32 + 32.0 * 9 * 3), npx * (16 + 64 + 32 + 6 + 6) + 9.0 * 32 * (128 + 32 + 32));
+            return q.rc;
+        }
+    }
     if (q.ok() && c->var.at("le_rows") && !(H & 1) && !(W & 1) && s.H1 * 2 == H && s.W1 * 2 == W && q.rows_fit(H, W)) {
         RowsTailParams p;
         memset(&p, 0, sizeof p);

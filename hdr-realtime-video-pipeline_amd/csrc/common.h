@@ -259,6 +259,19 @@ struct RowsRbI8Params {
     int nstrips, rows_per_seg;
 };
 
+// ... the full-resolution tail with up_conv3 (wpk8 [9][128][32], PixelShuffle row order; scale [128]; shift [16][128]), SFT_layer2,
+// HR_conv2 and conv_last all W8A8
+struct RowsTailI8Params {
+    const f16 *u, *fea0, *cond, *res_planar;
+    f16 *dst_planar;
+    RowsConvI8 up, hr, last;
+    RowsSftI8 s;
+    float slope_relu;      // act_slope(ACT_RELU), a runtime value as in conv32p / conv32s
+    char *trash;
+    int H, W;
+    int nstrips, rows_per_seg;
+};
+
 // Parameter block of the row-streaming fused tail of the LE net (le_rows.hip):
 // out = res + conv_last(relu(HR_conv2(sft(relu(shuffle(up_conv(u))) + skip, cond))))
 struct RowsTailParams {

@@ -69,7 +69,7 @@ template <int A0, int S0, int S1> struct Lay64 {            // 64-byte pixels (3
     static __device__ __forceinline__ unsigned src_off(int piece, int lane) { const int c = src_px(piece, lane); return (unsigned)(c * 64 + (((lane & 3) ^ sw(c)) << 4)); }
 };
 template <int A0, int S0> struct Lay32 {                    // 32-byte pixels (the 16-channel condition maps)
-    static_assert((A0 & 7) == 0, "slot() must be an involution");
+    static_assert((A0 & 1) == 0, "slot() must be an involution");
     static __device__ __forceinline__ int slot(int c) { return c ^ par(c & A0); }
     static __device__ __forceinline__ unsigned at(int c, int h) { return (unsigned)((slot(c) << 5) | ((h ^ par(c & S0)) << 4)); }
     static __device__ __forceinline__ int src_px(int piece, int lane) { return slot(32 * piece + (lane >> 1)); }

@@ -2,6 +2,7 @@
 //
 //   le_rb_rows_i8   ResBlock_with_SFT.forward (arch_util.py:89-95) with conv1, conv2 and the eight 1x1 convs of its two SFT layers as
 //                   W8A8Conv2d (hdrtvnet_torch.py:296-364): the full-QAT recipe's ResBlocks at 1/2 and 1/4 resolution
+//   le_tail_rows_i8 HDRUNet3T1_arch.py:196-206 with up_conv3, SFT_layer2, HR_conv2 and conv_last W8A8
 //
 // Same schedule as le_rb_rows (strips of 60 columns x row segments, two rows per step, stages skewed across steps, one barrier
 // per step, LDS-DMA three steps ahead; le_rows.hip's header), but what lives in the rings between the stages are the layers' int8
@@ -29,21 +30,21 @@ constexpr int Y8_ROWB = YP * 32;                    // a code ring row: 66 slots
 using L8Std = Lay32<0, 12>;                         // R1 + W1 for 32-byte pixels (tools/lds_ring_layouts.py)
 
 struct Bank8 { i32x4 f[9]; };                       // a 3x3 32 -> 32 int8 filter bank: tap t, lane (n = l31, half lh) = bytes 16 lh .. of row n
-__device__ __forceinline__ void load_bank8(Bank8 &b, const int8_t *wpk8, int l31, int lh)
+__device__ __forceinline__ void load_bank8(Bank8 &b, const int8_t *wpk8, int l31, int lh, int coutp = 32, int n0 = 0)
 {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) b.f[t] = *reinterpret_cast<const i32x4 *>(wpk8 + (t * 32 + l31) * 32 + 16 * lh);
+    for (int t = 0; t < 9; ++t) b.f[t] = *reinterpret_cast<const i32x4 *>(wpk8 + (t * coutp + n0 + l31) * 32 + 16 * lh);
 }
 __device__ __forceinline__ i32x16 izero16() { return i32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; }
 
 // 3x3 conv of one 32-pixel group out of a mirrored code ring: va[kx] = this lane's fragment address for kernel column kx in ring
 // row 0 (buffer base included), `win` the byte offset of the window's first row; reads run AHEAD taps in front of the MFMAs
-template <int AHEAD, class Hook>
+template <int AHEAD, int ROWB = Y8_ROWB, class Hook>
 __device__ __forceinline__ i32x16 conv9(const Bank8 &w, const unsigned (&va)[3], int win, Hook hook)
 {
     i32x4 x[9];
     i32x16 acc;
-    auto ld = [&](int t) __attribute__((always_inline)) { x[t] = lds_rd<i32x4>(va[t % 3] + (unsigned)(win + (t / 3) * Y8_ROWB)); };
+    auto ld = [&](int t) __attribute__((always_inline)) { x[t] = lds_rd<i32x4>(va[t % 3] + (unsigned)(win + (t / 3) * ROWB)); };
 #pragma unroll
     for (int t = 0; t < AHEAD; ++t) ld(t);
 #pragma unroll
@@ -118,25 +119,29 @@ __device__ __forceinline__ i32x4 modulate_quant(const f16x4 (&x)[4], const f16x4
     }
     return codes;
 }
+// (LAP: bytes from a ring row to its second copy = the ring's logical size)
+template <int LAP = YN * Y8_ROWB>
 __device__ __forceinline__ void put_codes(unsigned a, int off, bool mirror, const i32x4 &codes)
 {
     lds_wr(a + (unsigned)off, codes);
-    if (mirror) lds_wr(a + (unsigned)(off + YN * Y8_ROWB), codes);
+    if (mirror) lds_wr(a + (unsigned)(off + LAP), codes);
 }
 // conv epilogue of conv32s<.., i8>: o = f16(act(acc * scale[c] + shift[class][c])) on this lane's 16 channels
+// (shift_tab: LDS address of class 0's row for this wave's 32 channels; CLSB: bytes from one class's row to the next)
+template <int CLSB = 128>
 __device__ __forceinline__ void dequant_act(const i32x16 &iacc, const f32x4 (&scq)[4], unsigned shift_tab, int bcls, int lh, float slope, f16x4 (&o)[4])
 {
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
-        const f32x4 sh = lds_rd<f32x4>(shift_tab + (unsigned)(bcls * 128 + 32 * qd + 16 * lh));
+        const f32x4 sh = lds_rd<f32x4>(shift_tab + (unsigned)(bcls * CLSB + 32 * qd + 16 * lh));
         const float v0 = (float)iacc[4 * qd + 0] * scq[qd][0] + sh[0], v1 = (float)iacc[4 * qd + 1] * scq[qd][1] + sh[1],
                     v2 = (float)iacc[4 * qd + 2] * scq[qd][2] + sh[2], v3 = (float)iacc[4 * qd + 3] * scq[qd][3] + sh[3];
         o[qd] = f16x4{(f16)act_fast(v0, slope), (f16)act_fast(v1, slope), (f16)act_fast(v2, slope), (f16)act_fast(v3, slope)};
     }
 }
-__device__ __forceinline__ void table_to_lds(char *dst, const RowsConvI8 &c, int tid)       // [scale 32][shift 16 x 32] floats
+__device__ __forceinline__ void table_to_lds(char *dst, const RowsConvI8 &c, int tid, int coutp = 32)       // [scale coutp][shift 16 x coutp] floats
 {
-    for (int e = tid; e < 17 * 32; e += 512) reinterpret_cast<float *>(dst)[e] = e < 32 ? c.scale[e] : c.shift[e - 32];
+    for (int e = tid; e < 17 * coutp; e += 512) reinterpret_cast<float *>(dst)[e] = e < coutp ? c.scale[e] : c.shift[e - coutp];
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -303,6 +308,260 @@ __global__ __launch_bounds__(512) void le_rb_rows_i8_kernel(RowsRbI8Params p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The full-resolution tail (le_tail_rows) with up_conv3, SFT_layer2, HR_conv2 and conv_last all W8A8.  Per-layer form: conv32p<4,
+// plain, i8> (quantise u, up-conv, ReLU, PixelShuffle, + fea0), conv32s<sft-i8, i8> (SFT_layer2, quantise, HR_conv2, ReLU) and
+// conv32s<plain, i8, planar> (quantise, conv_last, + the AGCM residual).  Here:
+//     step s:  role T1 (waves 0-3; wave b = PixelShuffle phase (b >> 1, b & 1)): LDS-DMA of fea0 / cond rows 2s+6, 2s+7, of the f16 u
+//                   row s+5 and of the residual planes; the u row s+2 (landed: issued five steps ago) quantised ONCE into the u code
+//                   ring (9 of its 34 pixels per wave); up_conv3 bank b on u code rows s-1 .. s+1 -> ReLU, + fea0, SFT_layer2 (its
+//                   int8 MLPs inside the conv's MFMA stream), HR_conv2's quantiser -> Y code rows 2s, 2s+1
+//              role T2 (waves 4-7, group (g >> 1, g & 1)): HR_conv2 + ReLU + conv_last's quantiser -> Z code rows 2s-3, 2s-2;
+//                   conv_last + residual -> output rows 2s-6, 2s-5 (planar)
+constexpr int U8_SLOTS = 48, U16_ROWB = U8_SLOTS * 64, U8_ROWB = U8_SLOTS * 32, UN16 = 6, UN8 = 6, UPH8 = UN8 + 2;
+using L8TailY = Lay32<4, 8>;                        // R1 + W2 for 32-byte pixels: written per PixelShuffle phase, read by HR_conv2
+template <int DPF> struct Tail8Geo {
+    static constexpr int LAG = 6;
+    static constexpr int FR = 2 * DPF + 2;                   // fea0 / cond rings: fetched 2 DPF rows ahead of their one use
+    static_assert(DPF + 3 <= UN16, "u ring: rows s + 2 (being quantised) .. s + DPF + 2 (DMA target)");
+    static constexpr int OFF_U = 0, OFF_U8 = OFF_U + UN16 * U16_ROWB, OFF_F = OFF_U8 + UPH8 * U8_ROWB, OFF_C = OFF_F + FR * X_ROWB;
+    static constexpr int OFF_Y = OFF_C + FR * C_ROWB, OFF_Z = OFF_Y + YPH * Y8_ROWB, OFF_TR = OFF_Z + YPH * Y8_ROWB;      // TR: 1 KiB the unused u piece lands in
+    static constexpr int R_SLOTB = 256, RN = DPF + 1;        // residual planes: per group RN slots of [3 planes][32 px] f16
+    static constexpr int OFF_R = OFF_TR + 1024;
+    static constexpr int OFF_TU = OFF_R + 4 * RN * R_SLOTB;  // up_conv3: scale [128], shift [16][128]
+    static constexpr int OFF_TH = OFF_TU + 17 * 128 * 4, OFF_TL = OFF_TH + 2176, OFF_K = OFF_TL + 2176;
+    static constexpr int SMEM = OFF_K + 768;
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+    static_assert(BIG % FR == 0 && BIG % UN16 == 0 && BIG % UN8 == 0, "BIG");
+};
+
+template <int DPF>
+__global__ __launch_bounds__(512) void le_tail_rows_i8_kernel(RowsTailI8Params p)
+{
+    using G = Tail8Geo<DPF>;
+    constexpr int FR = G::FR, LAG = G::LAG, RN = G::RN;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned sm = lds_off(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int strip = blockIdx.x % p.nstrips, seg = blockIdx.x / p.nstrips;
+    const int x0 = strip * WS, hx0 = x0 >> 1;
+    const int y0 = seg * p.rows_per_seg, yend = min(y0 + p.rows_per_seg, p.H);    // rows_per_seg is even
+    const int ya = y0 - 2, hya = ya >> 1;                              // image row of ring row 0 (even); its half-resolution row
+    const int nsteps = (yend - ya + LAG - 1) / 2 + 1;
+    const int H = p.H, W = p.W, H1 = H >> 1, W1 = W >> 1;
+    table_to_lds(smem + G::OFF_TU, p.up, tid, 128);
+    table_to_lds(smem + G::OFF_TH, p.hr, tid);
+    table_to_lds(smem + G::OFF_TL, p.last, tid);
+    for (int e = tid; e < 192; e += 512) reinterpret_cast<float *>(smem + G::OFF_K)[e] = p.s.konst[e];
+    const int g = wave & 3, gr = g >> 1, gh = g & 1;
+
+    if (wave < 4) {
+        // ------------------------------------------------------------------ role T1
+        Bank8 wu;
+        load_bank8(wu, p.up.wpk8, l31, lh, 128, 32 * g);
+        Sft8 s2;
+        load_sft8(s2, p.s, sm + G::OFF_K, lane, lh);
+        f32x4 scq[4];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) scq[qd] = *reinterpret_cast<const f32x4 *>(p.up.scale + 32 * g + 8 * qd + 4 * lh);
+        const unsigned tab = sm + G::OFF_TU + 128 * 4 + 32 * g * 4;    // up_conv3's shift classes, this phase's 32 channels
+        unsigned va[3];                                                // half-resolution pixel l31 reads u code slots l31 .. l31 + 2
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) va[kx] = sm + L8Std::at(l31 + kx, lh);
+        const int cx = 2 * l31 + gh;                                   // full-resolution slot (image column x0 - 2 + cx) of this lane's pixel
+        unsigned vf[2];                                                // fea0 read: this lane's two chunks of slot cx (stride 2 across the lanes)
+        chunk_addr<LTailF>(vf, sm, cx, lh);
+        const unsigned vw = sm + L8TailY::at(cx, lh);                  // Y code write
+        const unsigned vc0 = sm + LCondT::at(cx, 0), vc1 = sm + LCondT::at(cx, 1);
+        const bool col = (unsigned)(x0 - 2 + cx) < (unsigned)W;
+        const int hcol = hx0 - 1 + l31;                                // this lane's half-resolution output column
+        const int ccls = (hcol == 0 ? 1 : 0) | (hcol == W1 - 1 ? 2 : 0);
+        const float q_inv = p.hr.q_inv, q_zoff = p.hr.q_zoff, slope = p.slope_relu, uq_inv = p.up.q_inv, uq_zoff = p.up.q_zoff;
+        // the DMA: pieces 2 gh, 2 gh + 1 of fea0 row gr, piece gh of condition row gr, (waves 0-2) piece g of the f16 u row, the
+        // residual planes of 32 pixels of an output row (lane = plane * 16 + pixel pair) -- always five DMA instructions per step
+        const dma_rsrc_t rf = dma_rsrc(p.fea0), rc = dma_rsrc(p.cond), ru = dma_rsrc(p.u), rres = dma_rsrc(p.res_planar);
+        const unsigned fl0 = LTailF::src_off(2 * gh, lane), fl1 = LTailF::src_off(2 * gh + 1, lane), cl = LCondT::src_off(gh, lane), ul = LStd::src_off(g, lane);
+        const bool fok0 = (unsigned)(x0 - 2 + LTailF::src_px(2 * gh, lane)) < (unsigned)W, fok1 = (unsigned)(x0 - 2 + LTailF::src_px(2 * gh + 1, lane)) < (unsigned)W;
+        const bool cok = (unsigned)(x0 - 2 + LCondT::src_px(gh, lane)) < (unsigned)W;
+        const bool uok = g < 3 && LStd::src_px(g, lane) < 34 && (unsigned)(hx0 - 2 + LStd::src_px(g, lane)) < (unsigned)W1;
+        const size_t plane = (size_t)H * W;
+        const unsigned rl = (unsigned)((lane >> 4) * plane * 2 + (32 * gh + 2 * (lane & 15)) * 2);     // plane, pixel pair
+        const bool rlok = lane < 48 && x0 + 32 * gh + 2 * (lane & 15) < W;
+        const unsigned tr = sm + G::OFF_TR, rbuf = sm + G::OFF_R + g * RN * G::R_SLOTB;
+        auto issue_fc = [&](int r, int fo, int co) __attribute__((always_inline)) {
+            const bool rok = (unsigned)r < (unsigned)H && r <= yend + 1;
+            const unsigned pix = (unsigned)(r * W + x0 - 2);
+            dma16_at(rf, sm + fo + (2 * gh) * 1024, (rok && fok0) ? pix * 64u + fl0 : DMA_OOB);
+            dma16_at(rf, sm + fo + (2 * gh + 1) * 1024, (rok && fok1) ? pix * 64u + fl1 : DMA_OOB);
+            dma16_at(rc, sm + co + gh * 1024, (rok && cok) ? pix * 32u + cl : DMA_OOB);
+        };
+        auto issue_u = [&](int hr, int uo) __attribute__((always_inline)) {               // half-resolution image row hr into the f16 ring row at uo
+            const bool rok = (unsigned)hr < (unsigned)H1 && hr <= ((yend + 1) >> 1) + 1;
+            dma16_at(ru, g < 3 ? sm + uo + g * 1024 : tr, (rok && uok) ? (unsigned)((hr * W1 + hx0 - 2) * 64) + ul : DMA_OOB);
+        };
+        auto issue_r = [&](int r, int slot) __attribute__((always_inline)) {              // residual of output row r (32 pixels of column half gh)
+            const bool rok = r >= y0 && r < yend;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rres, (__attribute__((address_space(3))) void *)(uintptr_t)(rbuf + slot * G::R_SLOTB), 4,
+                                                     (rok && rlok) ? (unsigned)((r * W + x0) * 2) + rl : DMA_OOB, 0, 0, 0);
+        };
+        // up_conv3's input quantiser, once per element: f16 u row (ring row at uo) -> u code row (at qo; rows 0 / 1 of a lap also into
+        // their second copy).  This wave: pixels 9 g .. 9 g + 8 of the 34, lane = (pixel, half); out-of-image pixels are code 0
+        const int qpx = 9 * g + (lane >> 1), qh = lane & 1;
+        const bool qact = lane < 18 && qpx < 34;
+        const bool qcol = (unsigned)(hx0 - 2 + qpx) < (unsigned)W1;
+        unsigned qsrc[4];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) qsrc[qd] = sm + LStd::at(qpx, qd) + 8 * qh;
+        const unsigned qdst = sm + L8Std::at(qpx, qh);
+        auto quant_u_row = [&](int uo, int qo, int hr) __attribute__((always_inline)) {   // hr: the row's half-resolution image row
+            if (qact) {
+                const bool in = qcol && (unsigned)hr < (unsigned)H1;
+                i32x4 codes;
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const f16x4 v = lds_rd<f16x4>(qsrc[qd] + (unsigned)uo);
+                    const unsigned w = quant4((float)v[0], (float)v[1], (float)v[2], (float)v[3], uq_inv, uq_zoff);
+                    codes[qd] = in ? (int)w : 0;
+                }
+                put_codes<UN8 * U8_ROWB>(qdst, qo, qo < G::OFF_U8 + 2 * U8_ROWB, codes);
+            }
+        };
+        // u rows -1 .. DPF + 1 (the ring's six rows), fea0 / cond / residual rows of the first DPF steps
+#pragma unroll
+        for (int ur = -1; ur <= DPF + 1; ++ur) issue_u(hya + ur, G::OFF_U + ((ur + BIG) % UN16) * U16_ROWB);
+#pragma unroll
+        for (int sq = 0; sq < DPF; ++sq) {
+            issue_fc(ya + 2 * sq + gr, G::OFF_F + ((2 * sq + gr + BIG) % FR) * X_ROWB, G::OFF_C + ((2 * sq + gr + BIG) % FR) * C_ROWB);
+            issue_r(ya + 2 * sq - LAG + gr, sq % RN);
+        }
+        // ring rows of step s: this wave produces Y row ra = 2 s + gr (from fea0 / cond row ra, u code rows s - 1 .. s + 1); DMA into
+        // fea0 / cond row 2 (s + DPF) + gr, f16 u row s + DPF + 2, residual slot (s + DPF) % RN; quantises u row s + 2
+        Cur<G::OFF_F, FR, X_ROWB> fa(gr), fd(2 * DPF + gr);
+        Cur<G::OFF_C, FR, C_ROWB> ca(gr), cd(2 * DPF + gr);
+        Cur<G::OFF_Y, YN, Y8_ROWB> yw(gr);
+        int uw = G::OFF_U8 + ((-1 + BIG) % UN8) * U8_ROWB;             // window start (code ring)
+        int uq8 = G::OFF_U8 + ((2 + BIG) % UN8) * U8_ROWB, uq16 = G::OFF_U + ((2 + BIG) % UN16) * U16_ROWB;
+        int ud = G::OFF_U + ((DPF + 2 + BIG) % UN16) * U16_ROWB, rs = DPF % RN;
+        int ra_img = ya + gr;
+        __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));
+        __builtin_amdgcn_s_barrier();                                  // every wave's prologue pieces have landed
+#pragma unroll
+        for (int ur = -1; ur <= 1; ++ur)
+            quant_u_row(G::OFF_U + ((ur + BIG) % UN16) * U16_ROWB, G::OFF_U8 + ((ur + BIG) % UN8) * U8_ROWB, hya + ur);
+        __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));
+        __builtin_amdgcn_s_barrier();
+        for (int s = 0; s < nsteps; ++s) {
+            issue_fc(ra_img + 2 * DPF, fd.o, cd.o);
+            issue_u(hya + s + DPF + 2, ud);
+            issue_r(ra_img + 2 * DPF - LAG, rs);
+            __builtin_amdgcn_sched_barrier(0);
+            quant_u_row(uq16, uq8, hya + s + 2);
+            const f16x8 c0 = lds_rd<f16x8>(vc0 + ca.o), c1 = lds_rd<f16x8>(vc1 + ca.o);
+            f16x4 sk[4];
+            get_row(vf, fa.o, sk);
+            const bool in = col && (unsigned)ra_img < (unsigned)H;     // outside the image: HR_conv2's zero padding = code 0
+            const int hrow = ra_img >> 1;
+            const int bcls = (((hrow == 0 ? 1 : 0) | (hrow == H1 - 1 ? 2 : 0)) << 2) | ccls;
+            i32x16 hacc;
+            i32x4 hs, ht;
+            f16x4 s1p[4], s0p[4];
+            const i32x16 iacc = conv9<4, U8_ROWB>(wu, va, uw, [&](int t) __attribute__((always_inline)) {
+                if (t == 0) hacc = sft8_hidden(s2, c0, c1);
+                if (t == 3) sft8_mid(s2, hacc, hs, ht);
+                if (t == 6) sft8_heads(s2, hs, ht, s1p, s0p);
+            });
+            f16x4 y[4];
+            dequant_act<128 * 4>(iacc, scq, tab, bcls, lh, slope, y);
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) y[qd] = y[qd] + sk[qd];     // relu(shuffle(up_conv3(u))) + fea0: conv32p's residual add in f16
+            put_codes(vw, yw.o, yw.mirrored(), modulate_quant(y, s1p, s0p, q_inv, q_zoff, in));
+            fa.step(); fd.step(); ca.step(); cd.step(); yw.step();
+            uw += U8_ROWB; if (uw >= G::OFF_U8 + UN8 * U8_ROWB) uw -= UN8 * U8_ROWB;
+            uq8 += U8_ROWB; if (uq8 >= G::OFF_U8 + UN8 * U8_ROWB) uq8 -= UN8 * U8_ROWB;
+            uq16 += U16_ROWB; if (uq16 >= G::OFF_U + UN16 * U16_ROWB) uq16 -= UN16 * U16_ROWB;
+            ud += U16_ROWB; if (ud >= G::OFF_U + UN16 * U16_ROWB) ud -= UN16 * U16_ROWB;
+            rs = rs + 1 == RN ? 0 : rs + 1;
+            ra_img += 2;
+            // per step and wave five DMA instructions and nothing else: those of step s + 1 are older than the 5 (DPF - 1) since
+            __builtin_amdgcn_s_waitcnt(waitcnt_imm(5 * (DPF - 1), 0));
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
+        // ------------------------------------------------------------------ role T2
+        Bank8 wh, wl;
+        load_bank8(wh, p.hr.wpk8, l31, lh);
+        load_bank8(wl, p.last.wpk8, l31, lh);
+        f32x4 scq[4];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) scq[qd] = *reinterpret_cast<const f32x4 *>(p.hr.scale + 8 * qd + 4 * lh);
+        const f32x4 scl = *reinterpret_cast<const f32x4 *>(p.last.scale);
+        const unsigned tab_h = sm + G::OFF_TH + 128, tab_l = sm + G::OFF_TL + 128;
+        const int cx = 32 * gh + l31;
+        unsigned va[3], vy[3];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) { va[kx] = sm + L8Std::at(cx + kx, lh); vy[kx] = sm + L8TailY::at(cx + kx, lh); }
+        const unsigned vw = sm + L8Std::at(cx, lh);                    // Z code write
+        const int oxz = x0 - 1 + cx, oxo = x0 + cx;                    // Z slot cx = image column x0 - 1 + cx; the output pixel's column
+        const bool colz = (unsigned)oxz < (unsigned)W;
+        const int cclz = (oxz == 0 ? 1 : 0) | (oxz == W - 1 ? 2 : 0), cclo = (oxo == 0 ? 1 : 0) | (oxo == W - 1 ? 2 : 0);
+        const float q_inv = p.last.q_inv, q_zoff = p.last.q_zoff, slope = p.slope_relu;
+        const unsigned rbuf = sm + G::OFF_R + g * RN * G::R_SLOTB + l31 * 2;
+        // output: channels 0..2 of pixel l31 sit in accumulator registers 0..2 of the lanes with lh == 0
+        char *trash = p.trash + tid * 16;
+        const size_t plane = (size_t)H * W;
+        const bool cok = lh == 0 && cx < WS && x0 + cx < W;
+        // ring rows of step s: HR_conv2 on rb = 2 s - 3 + gr (window rb - 1 ..), conv_last on ro = rb - 3
+        Cur<G::OFF_Y, YN, Y8_ROWB> wy(gr - 4);
+        Cur<G::OFF_Z, YN, Y8_ROWB> zw(gr - 3), wz(gr - LAG - 1);
+        int rb_img = ya + gr - 3, rs = 0;
+        __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();                                  // (role T1's quantiser pass over the first u rows)
+        for (int s = 0; s < nsteps; ++s) {
+            const int r = rb_img - 3;                                  // the output row
+            f16 res[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) res[ch] = lds_rd<f16>(rbuf + rs * G::R_SLOTB + ch * 64);
+            {   // conv_last + residual -> the three output planes (conv32s<plain, i8, planar>'s epilogue)
+                const i32x16 iacc = conv9<6>(wl, va, wz.o, [](int) {});
+                const int bcls = (((r == 0 ? 1 : 0) | (r == H - 1 ? 2 : 0)) << 2) | cclo;
+                const f32x4 sh = lds_rd<f32x4>(tab_l + (unsigned)(bcls * 128));
+                const float o[3] = {act_fast((float)iacc[0] * scl[0] + sh[0], 1.f), act_fast((float)iacc[1] * scl[1] + sh[1], 1.f),
+                                    act_fast((float)iacc[2] * scl[2] + sh[2], 1.f)};
+                const bool ok = cok && r >= y0 && r < yend;
+                f16 *d = p.dst_planar + (size_t)r * W + x0 + cx;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    // the conv result is rounded to f16, the residual added in fp32 and the sum rounded again
+                    const float v = (float)(f16)o[ch] + (float)res[ch];
+                    *(ok ? d + ch * plane : reinterpret_cast<f16 *>(trash)) = (f16)v;
+                }
+            }
+            {   // HR_conv2 + ReLU, conv_last's quantiser -> Z codes
+                const i32x16 iacc = conv9<6>(wh, vy, wy.o, [](int) {});
+                const bool in = colz && (unsigned)rb_img < (unsigned)H;     // outside the image: conv_last's zero padding = code 0
+                const int bcls = (((rb_img == 0 ? 1 : 0) | (rb_img == H - 1 ? 2 : 0)) << 2) | cclz;
+                f16x4 z[4];
+                dequant_act(iacc, scq, tab_h, bcls, lh, slope, z);
+                i32x4 codes;
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const unsigned w = quant4((float)z[qd][0], (float)z[qd][1], (float)z[qd][2], (float)z[qd][3], q_inv, q_zoff);
+                    codes[qd] = in ? (int)w : 0;
+                }
+                put_codes(vw, zw.o, zw.mirrored(), codes);
+            }
+            wy.step(); zw.step(); wz.step();
+            rb_img += 2;
+            rs = rs + 1 == RN ? 0 : rs + 1;
+            __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));            // stores are never waited for
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+}
+
 }  // namespace
 
 hipError_t le_rb_rows_i8_launch(RowsRbI8Params p, int n_cu, hipStream_t s)
@@ -313,5 +572,17 @@ hipError_t le_rb_rows_i8_launch(RowsRbI8Params p, int n_cu, hipStream_t s)
     strips(p, n_cu, false, nseg);
     if (hipError_t e = set_lds(le_rb_rows_i8_kernel<3>, Rb8Geo<3>::SMEM, once)) return e;
     hipLaunchKernelGGL((le_rb_rows_i8_kernel<3>), dim3(p.nstrips * nseg), dim3(512), Rb8Geo<3>::SMEM, s, p);
+    return hipGetLastError();
+}
+
+// H, W even; u is [H/2][W/2][32]
+hipError_t le_tail_rows_i8_launch(RowsTailI8Params p, int n_cu, hipStream_t s)
+{
+    if ((size_t)p.H * p.W * 64 >= 0x7f000000ull || !p.trash || (p.H & 1) || (p.W & 1)) return hipErrorInvalidValue;
+    static DevOnce once;
+    int nseg;
+    strips(p, n_cu, true, nseg);
+    if (hipError_t e = set_lds(le_tail_rows_i8_kernel<3>, Tail8Geo<3>::SMEM, once)) return e;
+    hipLaunchKernelGGL((le_tail_rows_i8_kernel<3>), dim3(p.nstrips * nseg), dim3(512), Tail8Geo<3>::SMEM, s, p);
     return hipGetLastError();
 }

@@ -123,6 +123,8 @@ def test_int8_row_kernels_are_bit_identical_to_the_per_layer_int8_kernels(torch_
             if h * w >= 720 * 1280:
                 assert "le_rb_rows<i8>" in kernels[1] and "le_rb_rows<i8>" in kernels[2], ((h, w), kernels[1])
                 assert "le_rb_rows<fq>" not in kernels[2]
+            if h * w >= 540 * 960 and h % 2 == 0 and w % 2 == 0:
+                assert "le_tail_rows<i8>" in kernels[1] and "le_tail_rows<fq>" not in kernels[2], ((h, w), kernels[1])
             for name, a, b in zip(("out",) + taps, res[0], res[1]):
                 assert torch.isfinite(a).all(), (h, w, name)
                 assert torch.equal(a, b), (h, w, name, int((a != b).sum()))
