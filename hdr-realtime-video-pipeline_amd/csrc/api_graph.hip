@@ -478,7 +478,28 @@ int run_le(hdrtv_ctx *c, Seq &q, const f16 *img, f16 *out_planar)
     bool head_fused = false;
     // conv_first .. down_conv1 in one row-streaming launch (le_rows.hip) when the shapes are even and every layer is fp16 or a W8A8
     // layer the kernel runs as fake-quant (variant le_rows_fq)
-    if (q.ok() && c->var.at("le_rows") && !c->var.at("no_c3fuse") && !c->var.at("conv32_old") && !(H & 1) && !(W & 1) && q.rows_fit(H, W)) {
+    // every layer of the head W8A8 (the full-QAT recipe): the row kernel on int8 MFMA (le_rows_i8.hip), bit-identical to conv_c3_q8 +
+    // conv32s<sft-i8, i8> + conv_q8<32,3,2>
+    if (q.ok() && c->var.at("le_rows") && c->var.at("le_rows_i8") && !c->var.at("no_c3q8") && !(H & 1) && !(W & 1) && q.rows_fit(H, W)) {
+        auto qc = c->q8.find("LE.conv_first#c3");
+        auto qh = c->q32.find("LE.HR_conv1"), qd = c->q32.find("LE.down_conv1#rows8");
+        const SftLayer &S1 = c->sft.at("LE.SFT_layer1");
+        if (qc != c->q8.end() && qh != c->q32.end() && qd != c->q32.end() && S1.q && qh->second.coutPad == 32 && qd->second.coutPad == 32) {
+            RowsHeadI8Params p;
+            memset(&p, 0, sizeof p);
+            auto cv = [&](const QLayer &Q) { return RowsConvI8{wtp<int8_t>(c, Q.wpk8), wtp<float>(c, Q.scale), wtp<float>(c, Q.shift), Q.q.inv(), Q.q.zoff()}; };
+            p.img = img; p.cond = cond1; p.fea0 = fea0; p.fea1 = wsp<f16>(c, "le.fea1a"); p.H = H; p.W = W;
+            p.cf = cv(qc->second); p.hr = cv(qh->second); p.dn = cv(qd->second);
+            p.s = RowsSftI8{wtp<int8_t>(c, S1.qfrag), wtp<float>(c, S1.qconst), {S1.inv[0], S1.inv[1]}, {S1.zoff[0], S1.zoff[1]}, {S1.hzoff[0], S1.hzoff[1]}};
+            p.slope_relu = act_slope(ACT_RELU);
+            p.trash = const_cast<char *>(wtp<char>(c, c->dump_off));
+            const double npx = (double)H * W;
+            q.chk(le_head_rows_i8_launch(p, c->n_cu, q.s), "LE.head", "le_head_rows<i8>",
+                  npx * (27.0 * 32 + 2.0 * (16 * 16 + 16 * 32) + 32.0 * 9 * 32 + 32.0 * 9 * 32 / 4), npx * (6 + 32 + 64 + 16) + 2.0 * 9 * 32 * 32);
+            head_fused = true;
+        }
+    }
+    if (!head_fused && q.ok() && c->var.at("le_rows") && !c->var.at("no_c3fuse") && !c->var.at("conv32_old") && !(H & 1) && !(W & 1) && q.rows_fit(H, W)) {
         RowsHeadParams p;
         memset(&p, 0, sizeof p);
         bool qh, qd, qs, qi = isq8("LE.conv_first");

@@ -230,7 +230,7 @@ void q_tables(const QRaw &r, int co, int ci, int ks, int coP, const std::vector<
 }
 // 3x3 / stride 1 / 32 input channels -> conv32p<.., i8>: wpk8 [9][coP][32], byte 16h + 4qd + k of a row = input channel
 // 8qd + 4h + k (the order in which conv32p's per-tile pass produces a pixel's codes); ps: PixelShuffle row permutation
-bool pack_conv32_i8(hdrtv_ctx *c, const Pack &pk, const std::string &key, int co, int ps_cps)
+bool pack_conv32_i8(hdrtv_ctx *c, const Pack &pk, const std::string &key, int co, int ps_cps, const std::string &store_as = "", int stride = 1)
 {
     QRaw r;
     if (!read_qraw(c, pk, key, co, 32 * 9, r)) return false;
@@ -247,11 +247,11 @@ bool pack_conv32_i8(hdrtv_ctx *c, const Pack &pk, const std::string &key, int co
     std::vector<float> scale, shift;
     q_tables(r, co, 32, 3, coP, rowmap, scale, shift);
     QLayer L;
-    L.q = r.q; L.cin = 32; L.cout = co; L.coutPad = coP; L.ks = 3; L.stride = 1;
+    L.q = r.q; L.cin = 32; L.cout = co; L.coutPad = coP; L.ks = 3; L.stride = stride;
     L.wpk8 = c->wts.put(wp.data(), wp.size());
     L.scale = c->wts.put(scale.data(), scale.size() * 4);
     L.shift = c->wts.put(shift.data(), shift.size() * 4);
-    c->q32[key] = L;
+    c->q32[store_as.empty() ? key : store_as] = L;
     return true;
 }
 // any other W8A8 LE conv -> conv_q8: wpk8 [ks*ks][coP][ci], natural channel order
@@ -779,6 +779,9 @@ bool build_weights(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
         if (isq(s.name)) {
             if (s.ks == 3 && s.stride == 1 ? !pack_conv32_i8(c, hr, s.name, s.co, s.ps) : !pack_conv_q8(c, hr, s.name, s.co, s.ci, s.ks, s.stride))
                 return false;
+            // down_conv1 inside the int8 head row kernel (le_rows_i8.hip) reads the code ring HR_conv1's epilogue writes: the K order
+            // of pack_conv32_i8 (its tables are conv_q8's: the same taps fall outside the image per border class)
+            if (std::string(s.name) == "LE.down_conv1" && !pack_conv32_i8(c, hr, s.name, s.co, 0, "LE.down_conv1#rows8", 2)) return false;
             // ... and, for the fused row kernels (le_rows.hip), its dequantised weights as an fp16 layer "<name>#fq": they apply the
             // layer's activation quantiser in registers and convolve in fp16 -- W8A8Conv2d.forward's own arithmetic
             if (s.ci == 32 && s.ks == 3 && !pack_conv(c, hr, std::string(s.name) + "#fq", s.name, s.co, s.ci, s.ks, s.stride, "", s.ps)) return false;

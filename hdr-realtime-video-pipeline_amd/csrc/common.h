@@ -272,6 +272,20 @@ struct RowsTailI8Params {
     int nstrips, rows_per_seg;
 };
 
+// ... the full-resolution head with conv_first (cf: conv_c3_q8's operands -- two int8 A fragments per lane, K = (kernel row | kernel
+// column, channel)), SFT_layer1, HR_conv1 and down_conv1 (dn: its weights in pack_conv32_i8's K order, "LE.down_conv1#rows8") all W8A8
+struct RowsHeadI8Params {
+    const f16 *img;        // f16 [3][H][W]
+    const f16 *cond;       // NHWC 16 [H][W]
+    f16 *fea0, *fea1;      // NHWC 32 [H][W] / [H/2][W/2]
+    RowsConvI8 cf, hr, dn;
+    RowsSftI8 s;
+    float slope_relu;
+    char *trash;
+    int H, W;
+    int nstrips, rows_per_seg;
+};
+
 // Parameter block of the row-streaming fused tail of the LE net (le_rows.hip):
 // out = res + conv_last(relu(HR_conv2(sft(relu(shuffle(up_conv(u))) + skip, cond))))
 struct RowsTailParams {

@@ -23,6 +23,7 @@ hipError_t conv32s_launch(Conv32Params p, int n_cu, hipStream_t stream, bool nos
 hipError_t le_rb_rows_launch(RowsRbParams p, int n_cu, hipStream_t stream);   // fused ResBlock_with_SFT, row-streaming (le_rows.hip)
 hipError_t le_rb_rows_i8_launch(RowsRbI8Params p, int n_cu, hipStream_t stream);   // ... every layer W8A8 on int8 MFMA (le_rows_i8.hip)
 hipError_t le_tail_rows_i8_launch(RowsTailI8Params p, int n_cu, hipStream_t stream);
+hipError_t le_head_rows_i8_launch(RowsHeadI8Params p, int n_cu, hipStream_t stream);
 hipError_t le_tail_rows_launch(RowsTailParams p, int n_cu, hipStream_t stream);   // up_conv3 .. conv_last in one launch (le_rows.hip)
 hipError_t le_head_rows_launch(RowsHeadParams p, int n_cu, hipStream_t stream);   // conv_first .. down_conv1 in one launch (le_rows.hip)
 hipError_t conv_t16_launch(ConvParams p, hipStream_t stream, int n_cu);

@@ -3,6 +3,7 @@
 //   le_rb_rows_i8   ResBlock_with_SFT.forward (arch_util.py:89-95) with conv1, conv2 and the eight 1x1 convs of its two SFT layers as
 //                   W8A8Conv2d (hdrtvnet_torch.py:296-364): the full-QAT recipe's ResBlocks at 1/2 and 1/4 resolution
 //   le_tail_rows_i8 HDRUNet3T1_arch.py:196-206 with up_conv3, SFT_layer2, HR_conv2 and conv_last W8A8
+//   le_head_rows_i8 HDRUNet3T1_arch.py:168-172 with conv_first, SFT_layer1, HR_conv1 and down_conv1 W8A8
 //
 // Same schedule as le_rb_rows (strips of 60 columns x row segments, two rows per step, stages skewed across steps, one barrier
 // per step, LDS-DMA three steps ahead; le_rows.hip's header), but what lives in the rings between the stages are the layers' int8
@@ -562,6 +563,228 @@ __global__ __launch_bounds__(512) void le_tail_rows_i8_kernel(RowsTailI8Params p
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The full-resolution head (le_head_rows) with conv_first, SFT_layer1, HR_conv1 and down_conv1 all W8A8.  Per-layer form:
+// conv_c3_q8 (image quantised while its patch is staged; two int8 MFMAs per 32 pixels), conv32s<sft-i8, i8> (SFT_layer1,
+// quantise, HR_conv1, ReLU -> fea0) and conv_q8<32,3,2> (quantise fea0, down_conv1, ReLU -> fea1).  Here:
+//     step s:  role H1 (waves 0-3, group (g >> 1, g & 1)): image rows 2s+3, 2s+4 into registers, staged as 4-byte code pixels
+//                   {r, g, b, pad} at the end of the step; conv_first + ReLU + SFT_layer1 + HR_conv1's quantiser -> Y code rows 2s,
+//                   2s+1; wave (s & 3): down_conv1 (stride 2) on F code rows 2s-7 .. 2s-5 -> fea1 row s-3
+//              role H2 (waves 4-7): LDS-DMA of cond rows 2s+6, 2s+7; HR_conv1 + ReLU -> fea0 (stored from registers) and, through
+//                   down_conv1's quantiser, F code rows 2s-3, 2s-2
+constexpr int P8_SLOTS = 72, P8_ROWB = P8_SLOTS * 4;         // patch code ring: 68 of 72 pixel slots used (image columns x0 - 3 .. x0 + 64)
+using L8HeadF = Lay32<8, 20>;                                // S2 + W1 for 32-byte pixels: written by HR_conv1, read by down_conv1 at stride 2
+template <int DPF> struct Head8Geo {
+    static constexpr int CR = 2 * DPF + 2;
+    static constexpr int OFF_P = 0, OFF_C = OFF_P + YPH * P8_ROWB, OFF_Y = OFF_C + CR * C_ROWB, OFF_F = OFF_Y + YPH * Y8_ROWB;
+    static constexpr int OFF_T = OFF_F + YPH * Y8_ROWB;     // tables: conv_first, HR_conv1, down_conv1 (2176 B each)
+    static constexpr int OFF_K = OFF_T + 3 * 2176;
+    static constexpr int SMEM = OFF_K + 768;
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+    static_assert(BIG % CR == 0, "BIG");
+};
+
+template <int DPF>
+__global__ __launch_bounds__(512) void le_head_rows_i8_kernel(RowsHeadI8Params p)
+{
+    using G = Head8Geo<DPF>;
+    constexpr int CR = G::CR;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned sm = lds_off(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int strip = blockIdx.x % p.nstrips, seg = blockIdx.x / p.nstrips;
+    const int x0 = strip * WS, hx0 = x0 >> 1;
+    const int y0 = seg * p.rows_per_seg, yend = min(y0 + p.rows_per_seg, p.H);    // rows_per_seg is even
+    const int ya = y0 - 2, hya = ya >> 1;
+    const int nsteps = (yend - ya + 1) / 2 + 3;
+    const int H = p.H, W = p.W, W1 = (W + 1) >> 1;
+    table_to_lds(smem + G::OFF_T, p.cf, tid);
+    table_to_lds(smem + G::OFF_T + 2176, p.hr, tid);
+    table_to_lds(smem + G::OFF_T + 2 * 2176, p.dn, tid);
+    for (int e = tid; e < 192; e += 512) reinterpret_cast<float *>(smem + G::OFF_K)[e] = p.s.konst[e];
+    const int g = wave & 3, gr = g >> 1, gh = g & 1;
+    const int cx = 32 * gh + l31;
+    const float slope = p.slope_relu;
+
+    if (wave < 4) {
+        // ------------------------------------------------------------------ role H1
+        const i32x4 *wq = reinterpret_cast<const i32x4 *>(p.cf.wpk8);
+        const i32x4 cw0 = wq[lane], cw1 = wq[64 + lane];               // conv_first: kernel rows 0 | 1 in the two lane halves, then row 2 | zero
+        f32x4 scf[4], scd[4];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            scf[qd] = *reinterpret_cast<const f32x4 *>(p.cf.scale + 8 * qd + 4 * lh);
+            scd[qd] = *reinterpret_cast<const f32x4 *>(p.dn.scale + 8 * qd + 4 * lh);
+        }
+        const unsigned tab_f = sm + G::OFF_T + 128, tab_d = sm + G::OFF_T + 2 * 2176 + 128;
+        Sft8 s1;
+        load_sft8(s1, p.s, sm + G::OFF_K, lane, lh);
+        Bank8 wd;
+        load_bank8(wd, p.dn.wpk8, l31, lh);
+        const unsigned vw = sm + L8Std::at(cx, lh);                    // Y code write
+        const unsigned vc0 = sm + LCond::at(cx, 0), vc1 = sm + LCond::at(cx, 1);
+        const int oxf = x0 - 2 + cx;                                   // Y slot cx = image column x0 - 2 + cx
+        const bool col = (unsigned)oxf < (unsigned)W;
+        const int cclf = (oxf == 0 ? 1 : 0) | (oxf == W - 1 ? 2 : 0);
+        const float q_inv = p.hr.q_inv, q_zoff = p.hr.q_zoff, iq_inv = p.cf.q_inv, iq_zoff = p.cf.q_zoff;
+        const unsigned vp = sm + (unsigned)cx * 4;                     // patch pixels cx .. cx + 3 of a row: kernel columns 0 .. 2 (+ the zero-weight slot)
+        // patch staging: thread t < 136 owns pixel (t / 68, t % 68) of the two new rows
+        const int pr = tid / 68, pc = tid - pr * 68;
+        const bool pth = tid < 136, pcol = pth && (unsigned)(x0 - 3 + pc) < (unsigned)W;
+        const size_t plane = (size_t)H * W;
+        const f16 *pimg = p.img + (x0 - 3 + pc);
+        f16 pv[3] = {(f16)0.f, (f16)0.f, (f16)0.f};
+        bool pin_img = false;
+        auto patch_fetch = [&](int r0) __attribute__((always_inline)) {      // image rows r0, r0 + 1
+            const int r = r0 + pr;
+            const bool ok = pcol && (unsigned)r < (unsigned)H && r <= yend + 1;
+            pin_img = ok;
+            const f16 *src = ok ? pimg + (size_t)r * W : p.img;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                pv[ch] = src[ch * plane];
+                if (!ok) pv[ch] = (f16)0.f;
+            }
+        };
+        auto patch_stage = [&](int m0) __attribute__((always_inline)) {       // ring slots m0 (this thread's pr == 0) and m0 + 1
+            if (pth) {
+                int ms = m0 + pr;
+                if (ms >= YN) ms -= YN;
+                const unsigned a = sm + G::OFF_P + ms * P8_ROWB + pc * 4;
+                // conv_c3_q8's staging: the pixel's three codes + the pad slot's (a zero weight meets it); outside the image code 0
+                const int v = pin_img ? (int)quant4((float)pv[0], (float)pv[1], (float)pv[2], 0.f, iq_inv, iq_zoff) : 0;
+                lds_wr(a, v);
+                if (ms < 2) lds_wr(a + YN * P8_ROWB, v);                        // the second copy of a lap's rows 0 and 1
+            }
+        };
+        // down_conv1: half-resolution pixel l31 (column hx0 + l31, 30 used) reads F code slots 2 l31 + kx (slot c = image column x0 - 1 + c)
+        unsigned vd[3];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) vd[kx] = sm + L8HeadF::at(2 * l31 + kx, lh);
+        const int hcol = hx0 + l31;
+        const bool dcol = l31 < WS / 2 && hcol < W1;
+        const int ccld = (2 * hcol - 1 < 0 ? 1 : 0) | (2 * hcol + 1 >= W ? 2 : 0);
+        f16 *const d1 = p.fea1 + (size_t)hcol * 32 + 4 * lh;
+        for (int e = tid; e < YPH * 4; e += 256)                        // the four pad slots of every patch row hold a defined code
+            lds_wr(sm + G::OFF_P + (e >> 2) * P8_ROWB + (68 + (e & 3)) * 4, 0);
+        patch_fetch(ya - 1); patch_stage(YN - 1);                      // ring rows -1, 0
+        patch_fetch(ya + 1); patch_stage(1);                           // ring rows 1, 2
+        // ring rows of step s: Y row ra = 2 s + gr from patch rows ra - 1 .. ra + 1 and cond row ra; staging of patch rows 2 s + 3, + 4;
+        // down_conv1 on F rows 2 s - 7 .. 2 s - 5
+        Cur<G::OFF_C, CR, C_ROWB> ca(gr);
+        Cur<G::OFF_P, YN, P8_ROWB> pw(gr - 1);
+        Cur<G::OFF_Y, YN, Y8_ROWB> yw(gr);
+        Cur<G::OFF_F, YN, Y8_ROWB> wf(-7);
+        int ps = 3;                                                    // staging slot of ring row 2 s + 3 (3, 5, 1, ..)
+        int ra_img = ya + gr;
+        __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));
+        __builtin_amdgcn_s_barrier();
+        for (int s = 0; s < nsteps; ++s) {
+            patch_fetch(ya + 2 * s + 3);
+            const f16x8 c0 = lds_rd<f16x8>(vc0 + ca.o), c1 = lds_rd<f16x8>(vc1 + ca.o);
+            // conv_first (conv_c3_q8): B = four code pixels of patch row ra - 1 + lh, then of row ra + 1
+            const unsigned a0 = vp + (unsigned)(pw.o + lh * P8_ROWB), a1 = vp + (unsigned)(pw.o + 2 * P8_ROWB);
+            const i32x4 b0 = {lds_rd<int>(a0), lds_rd<int>(a0 + 4), lds_rd<int>(a0 + 8), lds_rd<int>(a0 + 12)};
+            const i32x4 b1 = {lds_rd<int>(a1), lds_rd<int>(a1 + 4), lds_rd<int>(a1 + 8), lds_rd<int>(a1 + 12)};
+            const bool in = col && (unsigned)ra_img < (unsigned)H;     // outside the image: HR_conv1's zero padding = code 0
+            const int bcls = (((ra_img == 0 ? 1 : 0) | (ra_img == H - 1 ? 2 : 0)) << 2) | cclf;
+            const i32x16 hacc = sft8_hidden(s1, c0, c1);
+            i32x16 iacc = __builtin_amdgcn_mfma_i32_32x32x32_i8(cw0, b0, izero16(), 0, 0, 0);
+            iacc = __builtin_amdgcn_mfma_i32_32x32x32_i8(cw1, b1, iacc, 0, 0, 0);
+            i32x4 hs, ht;
+            sft8_mid(s1, hacc, hs, ht);
+            f16x4 s1p[4], s0p[4];
+            sft8_heads(s1, hs, ht, s1p, s0p);
+            f16x4 f0[4];
+            dequant_act(iacc, scf, tab_f, bcls, lh, slope, f0);
+            put_codes(vw, yw.o, yw.mirrored(), modulate_quant(f0, s1p, s0p, q_inv, q_zoff, in));
+            if (wave == (s & 3)) {
+                const int hr = hya + s - 3;                            // down_conv1 on half-resolution row s - 3
+                const i32x16 dacc = conv9<6>(wd, vd, wf.o, [](int) {});
+                const int bcd = (((2 * hr - 1 < 0 ? 1 : 0) | (2 * hr + 1 >= H ? 2 : 0)) << 2) | ccld;
+                f16x4 o[4];
+                dequant_act(dacc, scd, tab_d, bcd, lh, slope, o);
+                if (dcol && hr >= (y0 >> 1) && hr < ((yend + 1) >> 1)) {
+                    f16 *d = d1 + (size_t)hr * W1 * 32;
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) *reinterpret_cast<f16x4 *>(d + 8 * qd) = o[qd];
+                }
+            }
+            patch_stage(ps);                                           // rows 2 s + 3, 2 s + 4 (fetched at the top of the step)
+            ca.step(); pw.step(); yw.step(); wf.step();
+            ps = ps + 2 >= YN ? ps + 2 - YN : ps + 2;
+            ra_img += 2;
+            __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
+        // ------------------------------------------------------------------ role H2
+        Bank8 wh;
+        load_bank8(wh, p.hr.wpk8, l31, lh);
+        f32x4 scq[4];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) scq[qd] = *reinterpret_cast<const f32x4 *>(p.hr.scale + 8 * qd + 4 * lh);
+        const unsigned tab_h = sm + G::OFF_T + 2176 + 128;
+        unsigned va[3];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) va[kx] = sm + L8Std::at(cx + kx, lh);
+        const unsigned vw = sm + L8HeadF::at(cx, lh);                  // F code write
+        const int oxh = x0 - 1 + cx;                                   // F slot cx = image column x0 - 1 + cx
+        const bool colf = (unsigned)oxh < (unsigned)W;
+        const int cclh = (oxh == 0 ? 1 : 0) | (oxh == W - 1 ? 2 : 0);
+        const float q_inv = p.dn.q_inv, q_zoff = p.dn.q_zoff;
+        const dma_rsrc_t rc = dma_rsrc(p.cond);
+        const unsigned cl = LCond::src_off(gh, lane);
+        const bool cok = (unsigned)(x0 - 2 + LCond::src_px(gh, lane)) < (unsigned)W;
+        auto issue_c = [&](int r, int co) __attribute__((always_inline)) {
+            const bool rok = (unsigned)r < (unsigned)H && r <= yend;
+            dma16_at(rc, sm + co + gh * 1024, (rok && cok) ? (unsigned)((r * W + x0 - 2) * 32) + cl : DMA_OOB);
+        };
+        char *trash = p.trash + tid * 16;
+        const int ox = cx - 1;
+        const bool ocol = ox >= 0 && ox < WS && x0 + ox < W;
+        f16 *const dst0 = p.fea0 + ((ptrdiff_t)x0 + ox) * 32 + 8 * lh;
+#pragma unroll
+        for (int sq = 0; sq < DPF; ++sq) issue_c(ya + 2 * sq + gr, G::OFF_C + ((2 * sq + gr + BIG) % CR) * C_ROWB);
+        Cur<G::OFF_C, CR, C_ROWB> cd(2 * DPF + gr);
+        Cur<G::OFF_Y, YN, Y8_ROWB> wy(gr - 4);
+        Cur<G::OFF_F, YN, Y8_ROWB> fw(gr - 3);
+        int rb_img = ya + gr - 3;
+        __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));
+        __builtin_amdgcn_s_barrier();
+        for (int s = 0; s < nsteps; ++s) {
+            issue_c(rb_img + 3 + 2 * DPF, cd.o);
+            __builtin_amdgcn_sched_barrier(0);
+            const i32x16 iacc = conv9<6>(wh, va, wy.o, [](int) {});
+            const bool in = colf && (unsigned)rb_img < (unsigned)H;        // outside the image: down_conv1's zero padding = code 0
+            const int bcls = (((rb_img == 0 ? 1 : 0) | (rb_img == H - 1 ? 2 : 0)) << 2) | cclh;
+            f16x4 z[4];
+            dequant_act(iacc, scq, tab_h, bcls, lh, slope, z);
+            {   // fea0, as the tail's skip reads it: the f16 tensor
+                f16x8 z0, z1;
+                quads_to_chunks(z, z0, z1);
+                f16 *d = (ocol && rb_img >= y0 && rb_img < yend) ? dst0 + (size_t)rb_img * W * 32 : reinterpret_cast<f16 *>(trash);
+                *reinterpret_cast<f16x8 *>(d) = z0;
+                *reinterpret_cast<f16x8 *>(d == reinterpret_cast<f16 *>(trash) ? d : d + 16) = z1;
+            }
+            i32x4 codes;                                               // conv_q8 quantises fea0 on load: the same f16 values
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const unsigned w = quant4((float)z[qd][0], (float)z[qd][1], (float)z[qd][2], (float)z[qd][3], q_inv, q_zoff);
+                codes[qd] = in ? (int)w : 0;
+            }
+            put_codes(vw, fw.o, fw.mirrored(), codes);
+            cd.step(); wy.step(); fw.step();
+            rb_img += 2;
+            // per step and wave: one DMA piece, then two stores: the piece step s + 1 reads is older than 3 (DPF - 1) + 2 operations
+            __builtin_amdgcn_s_waitcnt(waitcnt_imm(3 * (DPF - 1) + 2, 0));
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+}
+
 }  // namespace
 
 hipError_t le_rb_rows_i8_launch(RowsRbI8Params p, int n_cu, hipStream_t s)
@@ -584,5 +807,17 @@ hipError_t le_tail_rows_i8_launch(RowsTailI8Params p, int n_cu, hipStream_t s)
     strips(p, n_cu, true, nseg);
     if (hipError_t e = set_lds(le_tail_rows_i8_kernel<3>, Tail8Geo<3>::SMEM, once)) return e;
     hipLaunchKernelGGL((le_tail_rows_i8_kernel<3>), dim3(p.nstrips * nseg), dim3(512), Tail8Geo<3>::SMEM, s, p);
+    return hipGetLastError();
+}
+
+// H, W even (strips start on even columns: the half-resolution map is cut at x0 / 2); fea1 is [H/2][W/2][32]
+hipError_t le_head_rows_i8_launch(RowsHeadI8Params p, int n_cu, hipStream_t s)
+{
+    if ((size_t)p.H * p.W * 64 >= 0x7f000000ull || !p.trash || (p.W & 1) || (p.H & 1)) return hipErrorInvalidValue;
+    static DevOnce once;
+    int nseg;
+    strips(p, n_cu, true, nseg);
+    if (hipError_t e = set_lds(le_head_rows_i8_kernel<3>, Head8Geo<3>::SMEM, once)) return e;
+    hipLaunchKernelGGL((le_head_rows_i8_kernel<3>), dim3(p.nstrips * nseg), dim3(512), Head8Geo<3>::SMEM, s, p);
     return hipGetLastError();
 }
