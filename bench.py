@@ -179,6 +179,7 @@ def cpu_baseline(args, use_hg):
 
 # profile tag -> the source file whose change invalidates a committed counter figure for that kernel (besides common.h / launchers.h)
 KERNEL_SOURCE = (("conv_prw8_i8", "conv3x3_prw_i8.hip"), ("conv_prw_i8", "conv3x3_prw_i8.hip"), ("conv_prw", "conv3x3_prw.hip"), ("conv_pglds_i8", "conv3x3_pglds_i8.hip"), ("conv_pglds", "conv3x3_pglds.hip"), ("conv_glds1", "conv1x1_glds.hip"),
+                 ("le_rb_rows<i8>", "le_rows_i8.hip"), ("le_tail_rows<i8>", "le_rows_i8.hip"), ("le_head_rows<i8>", "le_rows_i8.hip"),
                  ("le_rb_rows", "le_rows.hip"), ("le_tail_rows", "le_rows.hip"), ("le_head_rows", "le_rows.hip"), ("conv32s", "conv32s.hip"),
                  ("conv32p", "conv32p.hip"), ("conv3x3s2_preg", "conv3x3s2_preg.hip"), ("conv1x1_i8", "conv_i8_misc.hip"), ("le_cond_trunk", "le_fused.hip"),
                  ("conv_c3", "le_hg_misc.hip"), ("hg_final", "le_hg_misc.hip"), ("agcm_mlp", "agcm.hip"), ("conv_q8", "conv_q8.hip"))
@@ -677,6 +678,7 @@ def main():
                    "le_rb_rows": "le_rb_rows_kernel<3, false>", "le_tail_rows": "le_tail_rows_kernel<3, false>",
                    "le_head_rows": "le_head_rows_kernel<3, false>", "le_rb_rows<fq>": "le_rb_rows_kernel<3, true>",
                    "le_tail_rows<fq>": "le_tail_rows_kernel<3, true>", "le_head_rows<fq>": "le_head_rows_kernel<3, true>",
+                   "le_rb_rows<i8>": "le_rb_rows_i8_kernel<3>", "le_tail_rows<i8>": "le_tail_rows_i8_kernel<3>", "le_head_rows<i8>": "le_head_rows_i8_kernel<3>",
                    "conv_pglds_i8<nhwc>": "conv_pglds_i8_kernel<0, false>", "conv_pglds_i8<ps>": "conv_pglds_i8_kernel<1, false>",
                    "conv_pglds_i8<pool>": "conv_pglds_i8_kernel<2, false>", "conv_pglds_i8<nhwc,c64>": "conv_pglds_i8_kernel<0, true>",
                    "conv_pglds_i8<ps_dot3,c64>": "conv_pglds_i8_kernel<4, true>", "conv1x1_i8": "conv1x1_i8_kernel<false>",

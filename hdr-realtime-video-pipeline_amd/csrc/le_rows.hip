@@ -408,11 +408,11 @@ __global__ __launch_bounds__(512) void le_rb_rows_kernel(RowsRbParams p)
 //                   the conv's MFMA stream) -> Y rows 2s, 2s+1
 //              role T2 (waves 4-7, group (g >> 1, g & 1)): HR_conv2 + ReLU -> Z rows 2s-3, 2s-2; conv_last + residual -> output
 //                   rows 2s-6, 2s-5 (planar)
-constexpr int U_SLOTS = 48, U_ROWB = U_SLOTS * 64, UN = 6, UPH = UN + 2;
+constexpr int U_SLOTS = 48, U_ROWB = U_SLOTS * 64, UN = 8, UPH = UN + 2;
 template <int DPF> struct TailGeo {
     static constexpr int LAG = 6;
     static constexpr int FR = 2 * DPF + 2;                   // fea0 / cond rings: fetched 2 DPF rows ahead of their one use
-    static_assert(DPF + 3 <= UN, "u ring");
+    static_assert(DPF + 4 <= UN, "u ring: the window's three rows, the row being quantised in place (W8A8 up_conv), DPF rows in flight");
     static constexpr int OFF_U = 0, OFF_F = OFF_U + UPH * U_ROWB, OFF_C = OFF_F + FR * X_ROWB, OFF_Y = OFF_C + FR * C_ROWB;
     static constexpr int OFF_Z = OFF_Y + YPH * Y_ROWB, OFF_TR = OFF_Z + YPH * Y_ROWB;       // TR: 4 x 1 KiB the unused mirror DMAs land in
     static constexpr int R_SLOTB = 256, RN = DPF + 1;        // residual planes: per group RN slots of [3 planes][32 px] f16
@@ -494,8 +494,11 @@ __global__ __launch_bounds__(512) void le_tail_rows_kernel(RowsTailParams p)
             const int m = (-1 + BIG) % UN;
             issue_u(hya - 1, G::OFF_U + m * U_ROWB, m < 2);
         }
+        // (UA: with a W8A8 up_conv the u rows are fetched one step further ahead -- a row is quantised in place one step before its
+        // first window, and must have LANDED by then: the pieces a step may rely on are those issued DPF or more steps earlier)
+        constexpr int UA = FQ ? 1 : 0;
 #pragma unroll
-        for (int sq = 0; sq <= DPF; ++sq) {
+        for (int sq = 0; sq <= DPF + UA; ++sq) {
             const int m = (sq + BIG) % UN;
             issue_u(hya + sq, G::OFF_U + m * U_ROWB, m < 2);
             if (sq < DPF) {
@@ -508,10 +511,11 @@ __global__ __launch_bounds__(512) void le_tail_rows_kernel(RowsTailParams p)
         Cur<G::OFF_F, FR, X_ROWB> fa(gr), fd(2 * DPF + gr);
         Cur<G::OFF_C, FR, C_ROWB> ca(gr), cd(2 * DPF + gr);
         Cur<G::OFF_Y, YN, Y_ROWB> yw(gr);
-        int uw = G::OFF_U + ((-1 + BIG) % UN) * U_ROWB, ud = G::OFF_U + ((DPF + 1 + BIG) % UN) * U_ROWB, rs = DPF % RN;
+        int uw = G::OFF_U + ((-1 + BIG) % UN) * U_ROWB, ud = G::OFF_U + ((DPF + 1 + UA + BIG) % UN) * U_ROWB, rs = DPF % RN;
         int ra_img = ya + gr;
         // W8A8 up_conv: its input quantiser runs ONCE per element over a landed u row, in place (a quarter of the row per wave: 34 of
-        // the row's 136 16-byte chunks), two steps before the row's first window; rows 0 / 1 of a lap also into their second copy
+        // the row's 136 16-byte chunks), one step before the row's first window (row s + 2 at step s: issued at step s - DPF);
+        // rows 0 / 1 of a lap also into their second copy
         auto fq_u_row = [&](int uo, int hr) __attribute__((always_inline)) {       // hr: the row's half-resolution image row
             const int upx = (34 * g + lane) >> 2;
             if (lane < 34 && (unsigned)hr < (unsigned)H1 && (unsigned)(hx0 - 2 + upx) < (unsigned)W1) {
@@ -534,7 +538,7 @@ __global__ __launch_bounds__(512) void le_tail_rows_kernel(RowsTailParams p)
         for (int s = 0; s < nsteps; ++s) {
             STAMP(7);
             issue_fc(ra_img + 2 * DPF, fd.o, cd.o);
-            issue_u(hya + s + DPF + 1, ud, ud < G::OFF_U + 2 * U_ROWB);
+            issue_u(hya + s + DPF + 1 + UA, ud, ud < G::OFF_U + 2 * U_ROWB);
             issue_r(ra_img + 2 * DPF - LAG, rs);
             __builtin_amdgcn_sched_barrier(0);
             STAMP(0);

@@ -138,7 +138,8 @@ def test_int8_row_kernels_are_bit_identical_to_the_per_layer_int8_kernels(torch_
 
 @pytest.mark.parametrize("tag", ["full", "mixed"])
 def test_w8a8_layers_as_fake_quant_in_the_fused_kernels(torch_cuda, golden_dir, tag):
-    """W8A8 layers inside the fused kernels (variant le_rows_fq, the default): the layer's activation quantiser is applied in
+    """W8A8 layers inside the fused kernels in their fake-quant form (variant le_rows_fq: the default for chains that mix W8A8 with
+    other layers -- the mixed recipe; chains whose layers are ALL W8A8 run on int8 MFMA, le_rows_i8): the layer's activation quantiser is applied in
     registers (u8 code and back, common.h FqParam) and the convolution runs in fp16 on the dequantised weights -- the
     arithmetic of the reference's ``W8A8Conv2d.forward`` itself (hdrtvnet_torch.py:351-364: fake-quant, then F.conv2d in the
     compute dtype).  Against the fake-quant oracle (fp32, ATen) at 1920x1080 it must be no further away than the int8-MFMA
@@ -152,6 +153,7 @@ def test_w8a8_layers_as_fake_quant_in_the_fused_kernels(torch_cuda, golden_dir, 
     p = HDRTVNetMI355X(os.path.join(golden_dir, f"hr_int8_{tag}_qat.hdrw"), precision=f"int8-{tag}", predequantize="off", use_hg=False, warmup_passes=0)
     got = {}
     try:
+        p.set_variant("le_rows_i8", 0)        # (full recipe: the int8 row kernels would take every chain; this test is about the fake-quant form)
         for v in (1, 0):
             p.set_variant("le_rows_fq", v)
             p.profile_enable(True)

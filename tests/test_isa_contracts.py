@@ -291,3 +291,36 @@ def test_fp32_matrix_pipe_conv_issues_its_mfmas_and_spills_nothing(tmp_path):
         assert "scratch_" not in body, name
         seen += 1
     assert seen == 4
+
+
+def test_le_rows_i8_step_loops_keep_their_counted_waits(tmp_path):
+    """le_rows_i8.hip: the DMA-issuing role of each kernel closes its step with exactly the counted vmcnt (never a drain), every
+    role's step loop holds its int8 MFMAs (9 per conv, 3 per SFT layer, 2 for conv_first), nothing spills."""
+    kernels = _asm("le_rows_i8.hip", tmp_path)
+    want = {"le_rb_rows_i8_kernel": (2 * (9 + 3), {12}), "le_tail_rows_i8_kernel": (9 + 3 + 2 * 9, {10}), "le_head_rows_i8_kernel": (2 + 3 + 9 + 9, {8})}
+    seen = 0
+    for name, body in kernels.items():
+        key = next((k for k in want if k in name), None)
+        if key is None:
+            continue
+        n_mfma, counted = want[key]
+        assert "scratch_" not in body and "global_load_lds" not in body, name
+        assert len(re.findall(r"v_mfma_i32_32x32x32_i8", body)) == n_mfma, (name, len(re.findall(r"v_mfma_i32_32x32x32_i8", body)))
+        lines = [ln for ln in body.split("\n") if ln.strip() and not ln.strip().startswith(";")]
+        groups, cur = {}, None
+        for ln in lines:
+            lm = re.match(r"\.L(BB\d+_\d+):", ln)
+            if lm:
+                hm = re.search(r"Header=(BB\d+_\d+)", ln)
+                cur = hm.group(1) if hm else (lm.group(1) if "Loop Header" in ln else None)
+            if cur:
+                groups.setdefault(cur, []).append(ln)
+        loops = [g for g in groups.values() if any(re.match(r"\s*s_barrier", ln) for ln in g)]
+        assert len(loops) == 2, (name, len(loops))
+        waits = set()
+        for loop in loops:
+            if any("buffer_load" in ln and " lds" in ln for ln in loop):          # the role that issues LDS-DMA
+                waits |= {int(v) for ln in loop for v in re.findall(r"s_waitcnt vmcnt\((\d+)\)", ln)}
+        assert waits == counted, (name, sorted(waits), sorted(counted))
+        seen += 1
+    assert seen == 3
