@@ -19,7 +19,8 @@ int fail(hdrtv_ctx *c, int code, const char *fmt, ...)
 namespace {
 const std::pair<const char *, int> k_variants[] = {
     {"le_rows", 1},          // fused row-streaming LE kernels (le_rows.hip); 0 = the per-layer 16x16-tile kernels
-    {"le_rows_min", 12},     // ... when a strip segment has at least this many rows (it pays 4 .. 6 warm-up rows)
+    {"le_rows_min", 8},      // ... when a strip segment has at least this many rows (it pays 4 .. 6 warm-up rows; 8: the 1/8-resolution ResBlocks of a
+                             // 3840x2160 frame -- 9-row segments -- still gain 10 - 15 % over their two per-layer launches, profiles/r05_le_rows_min_ab.txt)
     {"le_rows_i8", 1},       // ... chains whose layers are all W8A8 on the int8-MFMA row kernels (le_rows_i8.hip); 0 = the fake-quant form (le_rows_fq) or the per-layer int8 kernels
     {"le_rows_fq", 1},       // ... also for W8A8 layers (fake-quant in registers, fp16 MFMA); 0 = those layers on the int8-MFMA per-layer kernels
     {"prw", 1},              // HG 3x3 convs on conv_prw: 0 never (conv_pglds), 1 the cheapest shape per layer, 2 / 3 16-row / 8-row tiles wherever it applies

@@ -22,8 +22,8 @@ def torch_cuda():
     return torch
 
 
-# (270, 486): 9 strips x 28 segments of 10 rows -- under the default le_rows_min = 12 no row kernel runs there (the loop below
-# asserts which sizes do); test_short_segments_* forces them on
+# (270, 486): 9 strips x 28 segments of 10 rows at full resolution, 5 rows at half resolution: with le_rows_min = 8 the head and the
+# tail run there, the ResBlocks do not (the loop below asserts the larger sizes); test_short_segments_* forces everything on
 def test_fused_rows_are_bit_identical_to_the_per_layer_kernels(torch_cuda, golden_dir):
     from hdrtv_mi355x import weights as W
     from hdrtv_mi355x.processor import HDRTVNetMI355X
@@ -42,7 +42,7 @@ def test_fused_rows_are_bit_identical_to_the_per_layer_kernels(torch_cuda, golde
                 kernels.append({k for _, k, *_ in p.profile_read()})
                 p.profile_enable(False)
                 res.append([out.clone()] + [p.tap(t).clone() for t in taps])
-            # which row kernels a size reaches (256 CUs, le_rows_min = 12): the head and the tail need even sizes (PixelShuffle /
+            # which row kernels a size reaches at the least (256 CUs, le_rows_min = 8): the head and the tail need even sizes (PixelShuffle /
             # stride-2 pairs); the ResBlocks run at half and quarter resolution, where 540x960 leaves 9-row segments
             want = set()
             if h * w >= 540 * 960 and h % 2 == 0 and w % 2 == 0:
