@@ -1,9 +1,12 @@
 #!/bin/bash
 # Round-5 evidence (run from the repo root on the GPU box): bench lines + per-layer tables, rocprofv3 kernel stats, PMC traffic
 # passes (fp16 and INT8), MFMA-busy / effective clock and the SQ wave-cycle breakdown of every kernel.
+# usage: tools/r05_final.sh bench   (the bench lines and per-layer tables)   |   tools/r05_final.sh prof   (rocprofv3 passes + summaries)
+# (two gpurun calls: together they exceed one call's 20-minute limit)
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 B="--steps 20 --warmup 5"
+if [ "${1:-bench}" = bench ]; then
 python3 $R/bench.py $B --layers > $O/r05_bench_default.json 2> $O/r05_layers.txt; echo "bench default $?"
 HDRTV_VARIANTS=le_rows=0 python3 $R/bench.py $B --layers --no-cpu-baseline --no-dispatcher --no-int8-extra > $O/r05_bench_le_rows_off.json 2> $O/r05_layers_le_rows_off.txt; echo "bench le_rows=0 $?"
 python3 $R/bench.py --int8 $B --layers --no-cpu-baseline --no-dispatcher > $O/r05_int8_bench.json 2> $O/r05_int8_layers.txt; echo "bench int8 full $?"
@@ -15,6 +18,8 @@ python3 $R/bench.py --height 1080 --width 1920 $B --no-cpu-baseline --no-dispatc
 python3 $R/bench.py --steps 1500 --warmup 5 --no-cpu-baseline --no-dispatcher --no-int8-extra > $O/r05_soak_1500.json 2> /dev/null; echo "soak $?"
 python3 $R/tools/fp32_layers.py --variant f32_mfma=0,1 --top 40 > $O/r05_fp32_layers.txt 2>&1; echo "fp32 layers $?"
 python3 $R/tools/fp32_layers.py --size 2160x3840 --variant f32_mfma=1 --top 12 > $O/r05_fp32_layers_4k.txt 2>&1; echo "fp32 layers 4K $?"
+exit 0
+fi
 cd /tmp && export TMPDIR=/tmp
 Q="--no-cpu-baseline --no-int8-extra --no-dispatcher"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r05f_kt -o p -- python3 $R/bench.py $B $Q > $O/r05f_kt.json 2> $O/r05f_kt.err; echo "kt $?"
