@@ -21,7 +21,7 @@ python3 $R/tools/fp32_layers.py --size 2160x3840 --variant f32_mfma=1 --top 12 >
 exit 0
 fi
 cd /tmp && export TMPDIR=/tmp
-Q="--no-cpu-baseline --no-int8-extra --no-dispatcher"
+Q="--no-cpu-baseline --no-int8-extra --no-dispatcher --no-latency-tail"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r05f_kt -o p -- python3 $R/bench.py $B $Q > $O/r05f_kt.json 2> $O/r05f_kt.err; echo "kt $?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r05f_kt_i8 -o p -- python3 $R/bench.py --int8 $B $Q > $O/r05f_kt_i8.json 2> $O/r05f_kt_i8.err; echo "kt i8 $?"
 for ctr in FETCH_SIZE WRITE_SIZE; do
@@ -39,4 +39,6 @@ python3 tools/mfma_util.py $(f r05f_mfma counter_collection.csv) $(f r05f_mfma k
 python3 tools/sq_breakdown.py $(f r05f_sq counter_collection.csv) $(f r05f_sq kernel_trace.csv) > $O/r05_sq_breakdown.txt
 python3 tools/sq_breakdown.py $(f r05f_sq2 counter_collection.csv) $(f r05f_sq2 kernel_trace.csv) > $O/r05_sq_lds_breakdown.txt
 cp $(f r05f_kt kernel_stats.csv) $O/r05_kernel_stats.csv; cp $(f r05f_kt_i8 kernel_stats.csv) $O/r05_int8_kernel_stats.csv
+cp $O/r05f_kt.json $O/r05_bench_under_rocprof.json       # the bench line of the run r05_kernel_stats.csv was taken from (compare roofline.avg_launch_ms)
+rm -rf $O/r05f_*                                          # the raw traces: gpurun copies back at most 64 MiB
 head -5 $O/r05_mfma_util.txt; head -6 $O/r05_sq_breakdown.txt
