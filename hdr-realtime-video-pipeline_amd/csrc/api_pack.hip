@@ -737,8 +737,11 @@ bool build_weights(hdrtv_ctx *c, const Pack &hr, const Pack *hg)
     }
 
     // ---- LE
-    // A W8A8 layer (weight_int8 + x_scale in the pack: the reference's `predequantize` off) runs on int8 MFMA when a
-    // kernel exists for it; the pack is rejected otherwise -- there is no silent fake-quant or fp16 substitute.
+    // A W8A8 layer (weight_int8 + x_scale in the pack: the reference's `predequantize` off) is packed for the int8-MFMA kernel that
+    // serves it; the pack is rejected when there is none -- no layer is silently computed in fp16 without its quantiser.  The 3x3
+    // 32-channel layers are ALSO packed as dequantised fp16 weights ("#fq"): a fused LE chain that mixes W8A8 and other layers (the
+    // mixed recipe) runs them in W8A8Conv2d.forward's own fake-quant form (le_rows.hip, variant le_rows_fq); chains whose layers are
+    // all W8A8 run on int8 MFMA (le_rows_i8.hip).  Which form ran is on the launch profile (kernel tags <i8> / <fq>), never assumed.
     auto isq = [&](const std::string &L) { return hr.is_w8a8(L); };
     {
         const std::string suf = ".x_scale";
