@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--no-hg", action="store_true", help="debug: AGCM+LE only (not the headline config)")
+    ap.add_argument("--lanes", type=int, default=2, choices=(1, 2, 3, 4),
+                    help="frames in flight on the device (hdrtv_set_lanes): frame i runs on lane i mod LANES, each lane with its own activation "
+                         "workspace and HIP stream, as the dispatcher's worker does; 1 = one compute stream (the one-lane rate is reported either way)")
     ap.add_argument("--int8", action="store_true",
                     help="BASELINE configs[4] instead of the headline fp16 configuration: HR from the reference's INT8-QAT checkpoint "
                          "with its W8A8 layers kept quantised (predequantize off) and the HG head as a W8A8 checkpoint (seeded + calibrated: the "
@@ -76,6 +79,8 @@ def parse():
                     help="skip the host-fed in-product dispatcher measurement (hdrtv_mi355x/dispatch.py, one worker process) reported "
                          "beside value_pcie_inclusive at N=1")
     ap.add_argument("--dispatcher", action="store_true", help="only the host-fed dispatcher measurement (its own JSON line)")
+    ap.add_argument("--dispatcher-depth", type=int, default=2, help="dispatcher worker: frames in flight (upload + compute + download)")
+    ap.add_argument("--dispatcher-slots", type=int, default=3, help="dispatcher: input / output slots per worker")
     ap.add_argument("--dispatcher-sim", action="store_true",
                     help="CPU only: the dispatcher's host side over --gpus N stand-in workers (memcpys + device_ms of sleep per frame); no GPU is touched")
     ap.add_argument("--sim-fps", type=float, nargs="*", help="with --dispatcher-sim: offered rates to run (default: 100 per worker)")
@@ -219,30 +224,30 @@ def int8_extra(args, dev, dev_frames, steps=20, warmup=3, recipe="full"):
         H, Wd = args.height, args.width
         with contextlib.redirect_stdout(sys.stderr):
             proc = HDRTVNetMI355X(os.path.join(REPO, "tests", "golden", f"hr_int8_{recipe}_qat.hdrw"), device=str(dev),
-                                  precision=f"int8-{recipe}", predequantize="off", use_hg=True, hg_weights="seeded-w8a8:1234", warmup_passes=0)
+                                  precision=f"int8-{recipe}", predequantize="off", use_hg=True, hg_weights="seeded-w8a8:1234", warmup_passes=0,
+                                  lanes=args.lanes)
         proc._ensure_buffers(H, Wd)
         lib, ctx = proc._lib, proc._ctx
-        rgb48 = torch.empty((H, Wd, 3), dtype=torch.uint16, device=dev)
+        rgb48 = [torch.empty((H, Wd, 3), dtype=torch.uint16, device=dev) for _ in range(args.lanes)]
 
-        def step(i):
-            st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            fr = dev_frames[i % len(dev_frames)]
-            proc._chk(lib.hdrtv_preprocess(ctx, st, fr.data_ptr(), H, Wd, proc._gpu_input.data_ptr(), proc._gpu_cond.data_ptr()), "preprocess")
-            proc._chk(lib.hdrtv_infer(ctx, st, proc._gpu_input.data_ptr(), proc._gpu_cond.data_ptr(), H, Wd,
-                                      proc._gpu_out.data_ptr(), L.F32, proc._gpu_agcm.data_ptr()), "infer")
-            proc._chk(lib.hdrtv_post_rgb48(ctx, st, proc._gpu_out.data_ptr(), L.F32, H, Wd, rgb48.data_ptr()), "post_rgb48")
+        def step(i, lanes=args.lanes):
+            proc.enqueue_frame(i % lanes, dev_frames[i % len(dev_frames)].data_ptr(), H, Wd, rgb48[i % lanes].data_ptr())
 
-        for i in range(warmup):
-            step(i)
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for i in range(steps):
-            step(i)
-        torch.cuda.synchronize(dev)
-        el = time.perf_counter() - t0
+        def timed(lanes):
+            for i in range(warmup):
+                step(i, lanes)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for i in range(steps):
+                step(i, lanes)
+            torch.cuda.synchronize(dev)
+            return time.perf_counter() - t0
+
+        el = timed(args.lanes)
+        el_one = timed(1) if args.lanes > 1 else el
         # what ran, from the kernel tags of one profiled frame behind the timed region (never a constant string)
         proc.profile_enable(True)
-        step(0)
+        step(0, 1)
         torch.cuda.synchronize(dev)
         ran = proc.execution_summary()
         proc.profile_enable(False)
@@ -250,6 +255,7 @@ def int8_extra(args, dev, dev_frames, steps=20, warmup=3, recipe="full"):
         return {"metric": f"frames/sec, INT8-QAT HDRTVNet++ (HR: the shipped {recipe}-QAT checkpoint, predequantize off; HG: W8A8 stand-in), same frames; "
                           f"executed: {ran['text']}",
                 "value": round(steps / el, 3), "unit": "frames/s", "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
+                "lanes": args.lanes, "value_one_lane": round(steps / el_one, 3),
                 "dtype": "i8+f16", "executed": {k: v for k, v in ran.items() if k != "text"}}
     except Exception as exc:  # noqa: BLE001  (an extra: never take the headline line down with it)
         return {"error": f"{type(exc).__name__}: {exc}"}
@@ -358,13 +364,13 @@ def dispatcher_host_fed(args, frames, device_index, use_hg, steps, warmup=5, n_w
         seen["sum"] += int(view[H // 2, Wd // 2, 1])            # touch the frame: the view is only valid during the call
 
     init = {"model_path": os.path.join(REPO, "tests", "golden", "hr_weights.hdrw"), "use_hg": use_hg,
-            "hg_weights": "seeded:1234" if use_hg else None}
+            "hg_weights": "seeded:1234" if use_hg else None, "frames_in_flight": args.dispatcher_depth, "lanes": min(args.lanes, args.dispatcher_depth)}
     try:
         # (bounded waits: an extra must never push a default run past the driver's limit)
         devices = [device_index] if n_workers == 1 else list(range(n_workers))
         if os.environ.get("HDRTV_BENCH_ONE_DEVICE"):
             devices = [0] * n_workers                    # rehearsal on a box with fewer GPUs than workers
-        with FrameDispatcher(n_workers, H, Wd, sink, init_args=init, devices=devices, slots=3, start_timeout=150.0) as d:
+        with FrameDispatcher(n_workers, H, Wd, sink, init_args=init, devices=devices, slots=args.dispatcher_slots, start_timeout=150.0) as d:
             # one producer thread per worker copies the frames in (submit_async); with one worker the caller's thread does
             put = d.submit if n_workers == 1 else d.submit_async
             for i in range(warmup * n_workers):
@@ -380,7 +386,8 @@ def dispatcher_host_fed(args, frames, device_index, use_hg, steps, warmup=5, n_w
             placement = d.placement
             # a worker's own rate: its frames over the time to ITS last frame (a straggling GPU finishes late and shows here)
             per_worker = [round((d.frames_per_worker[r] - before[r]) / max(d.last_done[r] - t0, 1e-9), 3) for r in range(n_workers)]
-        return {"value": round(steps / el, 3), "unit": "frames/s", "frames": steps, "workers": n_workers, "slots": 3, "frames_in_flight": 2,
+        return {"value": round(steps / el, 3), "unit": "frames/s", "frames": steps, "workers": n_workers, "slots": args.dispatcher_slots, "frames_in_flight": args.dispatcher_depth,
+                "lanes": min(args.lanes, args.dispatcher_depth),
                 "ms_per_frame": round(el / steps * 1e3, 3), "per_worker_frames_per_s": per_worker, "worker_exit_codes": d.exit_codes,
                 "placement": [{k: (p[k] if k != "cpus" else len(p[k])) for k in ("device", "numa_node", "cpus", "pinned")} for p in placement],
                 "what": "FrameDispatcher: parent memcpy into a pinned shared slot -> worker hipMemcpyAsync H2D -> pre + infer + post_rgb48 "
@@ -494,7 +501,7 @@ def main():
                               device=f"cuda:{local_rank}", precision=f"int8-{args.int8_recipe}" if args.int8 else "auto",
                               predequantize="auto" if (args.int8_predequantize or not args.int8) else "off",
                               use_hg=use_hg, hg_weights=("seeded-w8a8:1234" if args.int8 else "seeded:1234") if use_hg else None,
-                              warmup_passes=0)
+                              warmup_passes=0, lanes=args.lanes)
     proc._ensure_buffers(H, Wd)
     lib, ctx = proc._lib, proc._ctx
 
@@ -524,20 +531,29 @@ def main():
 
     # ---- the path north_star names: frames resident in HBM -> pre + infer + RGB48 post -> the pinned host ring
     # (hipMemcpyAsync on a copy stream + hipEvent per slot; the consumer waits and releases one frame behind).
-    proc._chk(lib.hdrtv_ring_create(ctx, 3, H, Wd), "ring_create")
+    # Frame i runs on lane i mod LANES (its own activation workspace and HIP stream, processor.enqueue_frame): with two lanes the
+    # device starts frame i + 1's kernels in the tails of frame i's.  The ring keeps the order: slots are committed and consumed
+    # in frame order whatever order the lanes finish in.
+    proc._chk(lib.hdrtv_ring_create(ctx, 2 + args.lanes, H, Wd), "ring_create")
     dn_stream = torch.cuda.Stream(dev)
     pending = []
 
-    def ring_step(i):
+    def ring_step(i, lanes=args.lanes, ev=None):
         hp, dp = C.c_void_p(), C.c_void_p()
         slot = proc._chk(lib.hdrtv_ring_acquire(ctx, 250, C.byref(hp), C.byref(dp)), "ring_acquire")
-        step(i, dp.value)                                       # RGB48 into the slot's device buffer
+        lane = i % lanes
+        ls = proc.lane_stream(lane)
+        if ev is not None:
+            ev[0].record(ls)
+        proc.enqueue_frame(lane, dev_frames[i % nfr].data_ptr(), H, Wd, dp.value, stream=ls)   # RGB48 into the slot's device buffer
+        if ev is not None:
+            ev[1].record(ls)
         done = torch.cuda.Event()
-        done.record(torch.cuda.current_stream(dev))
+        done.record(ls)
         dn_stream.wait_event(done)
         proc._chk(lib.hdrtv_ring_commit(ctx, slot, C.c_void_p(dn_stream.cuda_stream)), "ring_commit")
         pending.append(slot)
-        if len(pending) == 2:                                   # consumer side: wait + release one frame behind
+        if len(pending) == 1 + lanes:                           # consumer side: wait + release `lanes` frames behind
             s0 = pending.pop(0)
             lib.hdrtv_ring_wait(ctx, s0)
             lib.hdrtv_ring_release(ctx, s0)
@@ -559,9 +575,7 @@ def main():
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        evs[i][0].record()
-        ring_step(i)
-        evs[i][1].record()
+        ring_step(i, ev=evs[i])
     ring_drain()
     torch.cuda.synchronize(dev)
     elapsed_own = time.perf_counter() - t0          # this rank's own K frames (per_rank_frames_per_s)
@@ -571,7 +585,11 @@ def main():
     p50 = per_frame_ms[len(per_frame_ms) // 2]
     p99 = per_frame_ms[min(len(per_frame_ms) - 1, int(len(per_frame_ms) * 0.99))]
     # 1 % low as main.py:599-604: mean of the lowest 1 % of the per-frame fps samples (at least one sample)
-    fps_samples = sorted(1000.0 / max(ms, 1e-6) for ms in per_frame_ms)
+    # frame TIMES (main.py:586-604 samples the time from one presented frame to the next): the intervals between consecutive frames'
+    # last kernels -- with one lane that is the frame's own duration, with two it is what a consumer of the ring sees
+    def frame_intervals(pairs):
+        return [max(pairs[j - 1][1].elapsed_time(pairs[j][1]), 1e-6) for j in range(1, len(pairs))]
+    fps_samples = sorted(1000.0 / ms for ms in frame_intervals(evs))
     one_pct_low = float(np.mean(fps_samples[:max(1, len(fps_samples) // 100)]))
     per_rank_fps, per_rank_node = [round(args.steps / elapsed_own, 3)], [place["numa_node"]]
     if world > 1:
@@ -595,32 +613,51 @@ def main():
         n_tail = 300
         tev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_tail)]
         for i in range(n_tail):
-            tev[i][0].record()
-            ring_step(i)
-            tev[i][1].record()
+            ring_step(i, ev=tev[i])
         ring_drain()
         torch.cuda.synchronize(dev)
         tms = sorted(a.elapsed_time(b) for a, b in tev)
-        tfps = sorted(1000.0 / max(ms, 1e-6) for ms in tms)
+        tfps = sorted(1000.0 / ms for ms in frame_intervals(tev))
         tail_stats = {"frames": n_tail, "rank": rank, "p50_ms": round(tms[n_tail // 2], 3), "p99_ms": round(tms[int(n_tail * 0.99)], 3),
                       "max_ms": round(tms[-1], 3), "one_percent_low_fps": round(float(np.mean(tfps[:max(1, n_tail // 100)])), 3),
-                      "what": "the timed region's step repeated for 300 more frames behind it (per-frame HIP events): the population p99 / 1 % low need"}
+                      "what": "the timed region's step repeated for 300 more frames behind it (per-frame HIP events): the population p99 / 1 % low need; "
+                              "p50 / p99 / max are a frame's first kernel to its last, the 1 % low is over the intervals between consecutive frames' completions"}
+    # ---- the same K ring steps with ONE frame in flight (everything on lane 0's stream: the reference's frame-at-a-time order),
+    # reported beside `value` with its per-frame latency: what the second lane buys and what it costs
+    one_lane = None
+    if args.lanes > 1:
+        ev1 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        for i in range(2):
+            ring_step(i, lanes=1)
+        ring_drain()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            ring_step(i, lanes=1, ev=ev1[i])
+        ring_drain()
+        torch.cuda.synchronize(dev)
+        el1 = time.perf_counter() - t1
+        ms1 = sorted(a.elapsed_time(b) for a, b in ev1)
+        one_lane = {"value": round(args.steps / el1, 3), "unit": "frames/s", "p50_ms": round(ms1[len(ms1) // 2], 3),
+                    "p99_ms": round(ms1[min(len(ms1) - 1, int(len(ms1) * 0.99))], 3), "rank": rank}
     lib.hdrtv_ring_destroy(ctx)
 
     # ---- the same K steps with the RGB48 frame left in device memory (no ring): reported at N = 1, never `value`
     device_only = None
     if world == 1:
         torch.cuda.synchronize(dev)
+        u16 = [torch.empty((H, Wd, 3), dtype=torch.uint16, device=dev) for _ in range(args.lanes)]
         t1 = time.perf_counter()
         for i in range(args.steps):
-            step(i)
+            proc.enqueue_frame(i % args.lanes, dev_frames[i % nfr].data_ptr(), H, Wd, u16[i % args.lanes].data_ptr())
         torch.cuda.synchronize(dev)
         device_only = args.steps / (time.perf_counter() - t1)
+        del u16
 
     # ---- PCIe-inclusive variant (pinned H2D in, RGB48 out through the pinned host ring): reported, never `value`
     pcie = None
     if rank == 0 and world == 1:
-        proc._chk(lib.hdrtv_ring_create(ctx, 3, H, Wd), "ring_create")
+        proc._chk(lib.hdrtv_ring_create(ctx, 2 + args.lanes, H, Wd), "ring_create")
         pin = [torch.from_numpy(f).pin_memory() for f in frames]
         torch.cuda.synchronize(dev)
         n2, nwarm = max(20, args.steps), 3
@@ -648,15 +685,15 @@ def main():
             slot = proc._chk(lib.hdrtv_ring_acquire(ctx, 250, C.byref(hp), C.byref(dp)), "ring_acquire")
             if i + 1 < n2 + nwarm:
                 upload(i + 1)
-            main = torch.cuda.current_stream(dev)
+            main = proc.lane_stream(i % args.lanes)
             main.wait_event(up_ev[i % nfr])
-            step(i, dp.value)                                       # RGB48 into the slot's device buffer
+            proc.enqueue_frame(i % args.lanes, dev_frames[i % nfr].data_ptr(), H, Wd, dp.value, stream=main)   # RGB48 into the slot's device buffer
             done_ev[i % nfr] = torch.cuda.Event()
             done_ev[i % nfr].record(main)
             dn_stream.wait_event(done_ev[i % nfr])
             proc._chk(lib.hdrtv_ring_commit(ctx, slot, C.c_void_p(dn_stream.cuda_stream)), "ring_commit")
             pending.append(slot)
-            if len(pending) == 2:                      # consumer side: wait + release one frame behind
+            if len(pending) == 1 + args.lanes:         # consumer side: wait + release `lanes` frames behind
                 s0 = pending.pop(0)
                 lib.hdrtv_ring_wait(ctx, s0)
                 lib.hdrtv_ring_release(ctx, s0)
@@ -764,6 +801,7 @@ def main():
             "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "p50_ms": round(p50, 3), "p99_ms": round(p99, 3),
             "one_percent_low_fps": round(one_pct_low, 3), "latency_tail": tail_stats,
+            "lanes": args.lanes, "one_lane": one_lane,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i8+f16" if args.int8 else "f16",
             "world_size": dist.get_world_size() if world > 1 else 1, "backend": (backend if backend != "nccl" else "nccl (RCCL)") if world > 1 else None,
             "per_rank_frames_per_s": per_rank_fps, "per_rank_numa_node": per_rank_node,
@@ -777,11 +815,14 @@ def main():
                                     f"configs[2]: full HDRTVNet++ fp16 {Wd}x{H} + fused RGB48 post, 1 frame per GPU per step")
                        if use_hg else f"DEBUG no-HG {Wd}x{H}",
                        "frames_per_step": world, "sharding": "frame i -> GPU i mod N, no collective",
+                       "frames_in_flight_per_gpu": args.lanes,
                        "launches_per_frame": launches, "gmac_per_frame": round(macs_frame / 1e9, 1)},
             "tflops_end_to_end": round(2 * macs_frame * value / world / 1e12, 1),
             "value_device_only": round(device_only, 3) if device_only else None,
             "value_pcie_inclusive": round(pcie, 3) if pcie else None,
-            "value_is": "u8 frames resident in HBM -> pre_fused + infer + post_rgb48 -> pinned host RGB48 ring (hipMemcpyAsync + hipEvent); "
+            "value_is": f"u8 frames resident in HBM -> pre_fused + infer + post_rgb48 -> pinned host RGB48 ring (hipMemcpyAsync + hipEvent), {args.lanes} frame(s) in "
+                        "flight per GPU (frame i on lane i mod LANES: own workspace and stream; p50_ms / p99_ms are one frame's first kernel to its last "
+                        "with the other lane's frame sharing the device; `one_lane` is the same K steps one frame at a time); "
                         "value_device_only leaves the RGB48 frame in HBM; value_pcie_inclusive also uploads each frame from pinned host memory",
             "roofline": roof,
             "roofline_next": roof_next,

@@ -238,7 +238,9 @@ struct hdrtv_ctx {
     size_t hgf_wfrag = 0, hg_w10a = 0;        // fused HG tail: conv1 + conv10(second half) fragments, conv10 first half
     // workspace
     int H = 0, W = 0;
-    hdrtv_host::Arena ws;
+    hdrtv_host::Arena ws;                 // ws.dev: the workspace of the lane being launched (lane 0 outside hdrtv_infer_lane)
+    int lanes = 1;                        // hdrtv_set_lanes: one activation workspace per frame in flight
+    std::vector<unsigned char *> lane_ws; // [lanes] after hdrtv_reserve; lane_ws[0] == ws.dev
     std::map<std::string, hdrtv_host::Tensor> t;
     int launches = 0;
     double macs = 0.0;
@@ -294,6 +296,7 @@ struct Shapes {
 Shapes shapes_for(int H, int W);
 Tensor &ws_add(hdrtv_ctx *c, const std::string &name, int C, int H, int W, int layout);
 int do_reserve(hdrtv_ctx *c, int H, int W);
+void free_workspaces(hdrtv_ctx *c);            // every lane's; leaves no reserved size behind
 template <typename T>
 T *wsp(hdrtv_ctx *c, const std::string &name)
 {

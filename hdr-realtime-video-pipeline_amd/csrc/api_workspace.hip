@@ -68,6 +68,15 @@ Shapes shapes_for(int H, int W)
     return s;
 }
 
+void free_workspaces(hdrtv_ctx *c)
+{
+    for (unsigned char *p : c->lane_ws)
+        if (p) (void)hipFree(p);
+    c->lane_ws.clear();
+    c->ws.dev = nullptr;
+    c->H = c->W = 0;
+}
+
 int do_reserve(hdrtv_ctx *c, int H, int W)
 {
     if (c->H == H && c->W == W && c->ws.dev) return HDRTV_OK;
@@ -85,8 +94,7 @@ int do_reserve(hdrtv_ctx *c, int H, int W)
         return fail(c, HDRTV_EINVAL, "frame %dx%d too small for the HG head's reflect padding to a multiple of 32", W, H);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipDeviceSynchronize());
-    c->H = c->W = 0;                       // no valid workspace until every step below has succeeded
-    if (c->ws.dev) { (void)hipFree(c->ws.dev); c->ws.dev = nullptr; }
+    free_workspaces(c);                    // no valid workspace until every step below has succeeded
     c->ws = Arena();
     c->t.clear();
     // resize tables
@@ -169,11 +177,15 @@ int do_reserve(hdrtv_ctx *c, int H, int W)
         if (!c->hg_i8) ws_add(c, "hg.conv9", 64, Hp / 2, Wp / 2, 0);
     }
     }
-    if (hipMalloc((void **)&c->ws.dev, c->ws.size + 4096) != hipSuccess) {
-        c->ws.dev = nullptr;
-        c->H = c->W = 0;
-        return fail(c, HDRTV_ENOMEM, "workspace allocation of %zu bytes failed", c->ws.size);
-    }
+    // one workspace per lane (hdrtv_set_lanes): lane 0 is initialised, the others start as copies of it
+    c->lane_ws.assign((size_t)c->lanes, nullptr);
+    for (int l = 0; l < c->lanes; ++l)
+        if (hipMalloc((void **)&c->lane_ws[l], c->ws.size + 4096) != hipSuccess) {
+            c->lane_ws[l] = nullptr;
+            free_workspaces(c);
+            return fail(c, HDRTV_ENOMEM, "workspace allocation of %d x %zu bytes failed", c->lanes, c->ws.size);
+        }
+    c->ws.dev = c->lane_ws[0];
     hipError_t e = hipMemset(c->ws.dev, 0, c->ws.size + 4096);
     auto up = [&](const char *name, const void *src, size_t bytes) {
         if (e == hipSuccess) e = hipMemcpy(wsp<char>(c, name), src, bytes, hipMemcpyHostToDevice);
@@ -181,9 +193,9 @@ int do_reserve(hdrtv_ctx *c, int H, int W)
     up("aa.wx", wx.data(), wx.size() * 4); up("aa.wy", wy.data(), wy.size() * 4);
     up("aa.xmn", xmn.data(), xmn.size() * 4); up("aa.xns", xns.data(), xns.size() * 4);
     up("aa.ymn", ymn.data(), ymn.size() * 4); up("aa.yns", yns.data(), yns.size() * 4);
+    for (int l = 1; l < c->lanes && e == hipSuccess; ++l) e = hipMemcpy(c->lane_ws[l], c->ws.dev, c->ws.size + 4096, hipMemcpyDeviceToDevice);
     if (e != hipSuccess) {                 // leave no half-initialised workspace behind a size that looks reserved
-        (void)hipFree(c->ws.dev);
-        c->ws.dev = nullptr;
+        free_workspaces(c);
         return fail(c, HDRTV_EHIP, "workspace initialisation failed: %s", hipGetErrorString(e));
     }
     c->H = H; c->W = W;

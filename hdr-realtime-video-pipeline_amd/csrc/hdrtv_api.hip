@@ -68,7 +68,7 @@ int hdrtv_destroy(hdrtv_ctx *c)
     if (c->pq_bnd) (void)hipFree(c->pq_bnd);
     if (c->lb_dev) (void)hipFree(c->lb_dev);
     if (c->mt_dev) (void)hipFree(c->mt_dev);
-    if (c->ws.dev) (void)hipFree(c->ws.dev);
+    free_workspaces(c);
     if (c->wts.dev) (void)hipFree(c->wts.dev);
     delete c;
     return HDRTV_OK;
@@ -153,11 +153,40 @@ int hdrtv_preprocess(hdrtv_ctx *c, void *stream, const uint8_t *bgr, int H, int 
     return q.rc;
 }
 
+int hdrtv_set_lanes(hdrtv_ctx *c, int lanes)
+{
+    if (!c) return HDRTV_EINVAL;
+    if (lanes < 1 || lanes > 4) return fail(c, HDRTV_EINVAL, "lanes must be 1 .. 4");
+    if (lanes == c->lanes) return HDRTV_OK;
+    if (c->ws.dev) {                      // the reservation goes with the old lane count
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipDeviceSynchronize());
+        free_workspaces(c);
+    }
+    c->lanes = lanes;
+    return HDRTV_OK;
+}
+
+int hdrtv_get_lanes(const hdrtv_ctx *c) { return c ? c->lanes : 0; }
+
 int hdrtv_infer(hdrtv_ctx *c, void *stream, const void *rgb, const void *cond, int H, int W, void *out, int out_dtype,
                 void *agcm_out)
 {
+    return hdrtv_infer_lane(c, 0, stream, rgb, cond, H, W, out, out_dtype, agcm_out);
+}
+
+int hdrtv_infer_lane(hdrtv_ctx *c, int lane, void *stream, const void *rgb, const void *cond, int H, int W, void *out, int out_dtype,
+                     void *agcm_out)
+{
     if (!c || !rgb || !cond || !out) return fail(c, HDRTV_EINVAL, "null argument");
     if (c->H != H || c->W != W || !c->ws.dev) return fail(c, HDRTV_ESTATE, "call hdrtv_reserve(%d,%d) first", H, W);
+    if (lane < 0 || lane >= c->lanes) return fail(c, HDRTV_EINVAL, "lane %d of %d (hdrtv_set_lanes)", lane, c->lanes);
+    // every workspace tensor of this call resolves inside the lane's buffer; taps and hdrtv_preprocess's tables stay on lane 0
+    struct LaneScope {
+        hdrtv_ctx *c;
+        LaneScope(hdrtv_ctx *c_, int l) : c(c_) { c->ws.dev = c->lane_ws[(size_t)l]; }
+        ~LaneScope() { c->ws.dev = c->lane_ws[0]; }
+    } lane_scope(c, lane);
     if (out_dtype != HDRTV_F16 && out_dtype != HDRTV_F32) return fail(c, HDRTV_EINVAL, "bad out_dtype");
     if (c->fp32 && out_dtype != HDRTV_F32) return fail(c, HDRTV_EINVAL, "an fp32 context takes and returns f32 tensors");
     if (!c->fp32 && !c->has_hg && out_dtype != HDRTV_F16) return fail(c, HDRTV_EINVAL, "the no-HG model returns f16");

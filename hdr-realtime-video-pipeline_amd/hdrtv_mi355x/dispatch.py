@@ -52,7 +52,8 @@ import numpy as np
 
 
 class _Mi355xWorker:
-    """One processor on ``cuda:<device_index>``; two frames in flight over three streams."""
+    """One processor on ``cuda:<device_index>``; two frames in flight: an upload stream, a download stream and one compute
+    stream (and activation workspace: a lane) per frame in flight."""
 
     depth = 2
 
@@ -66,6 +67,9 @@ class _Mi355xWorker:
         self._C, self._torch, self._L = C, torch, L
         kw = dict(init_args)
         model = kw.pop("model_path")
+        # frames in flight (uploads, compute, downloads together) and, of those, frames computing at once (lanes)
+        self.depth = max(1, int(kw.pop("frames_in_flight", self.depth)))
+        kw.setdefault("lanes", min(2, self.depth))
         torch.cuda.set_device(device_index)
         with contextlib.redirect_stdout(sys.stderr):   # a worker's banner must not land on the parent's stdout (bench.py's one JSON line)
             self.proc = HDRTVNetMI355X(model, device=f"cuda:{device_index}", warmup_passes=0, **kw)
@@ -105,12 +109,15 @@ class _Mi355xWorker:
             self._hw = (h, w)
 
     def begin(self, frame, out):
-        C, torch, L, p = self._C, self._torch, self._L, self.proc
+        torch, p = self._torch, self.proc
         h, w = frame.shape[:2]
         self._buffers(h, w)
         k = self._n % self.depth
+        # frame n runs on lane n mod lanes: its own workspace and compute stream, so that the device overlaps the tail of one
+        # frame's kernels with the next frame's (processor.enqueue_frame); one lane = the single compute stream of before
+        lane = self._n % p.lanes
         self._n += 1
-        main = torch.cuda.current_stream(self.dev)
+        main = p.lane_stream(lane)
         if self._comp_ev[k] is not None:
             self._up.wait_event(self._comp_ev[k])              # the frame that last used raw[k] has been unpacked
         rc = self._hip.hipMemcpyAsync(self._raw[k].data_ptr(), frame.ctypes.data, frame.nbytes, 1, self._up.cuda_stream)
@@ -120,13 +127,7 @@ class _Mi355xWorker:
         main.wait_event(self._up_ev[k])
         if self._dn_ev[k] is not None:
             main.wait_event(self._dn_ev[k])                    # u16[k]'s previous frame has left the device
-        st = C.c_void_p(main.cuda_stream)
-        p._chk(p._lib.hdrtv_preprocess(p._ctx, st, self._raw[k].data_ptr(), h, w, p._gpu_input.data_ptr(),
-                                       p._gpu_cond.data_ptr()), "hdrtv_preprocess")
-        dt = L.F32 if (p._use_hg or getattr(p, "_fp32", False)) else L.F16
-        p._chk(p._lib.hdrtv_infer(p._ctx, st, p._gpu_input.data_ptr(), p._gpu_cond.data_ptr(), h, w, p._gpu_out.data_ptr(), dt,
-                                  p._gpu_agcm.data_ptr()), "hdrtv_infer")
-        p._chk(p._lib.hdrtv_post_rgb48(p._ctx, st, p._gpu_out.data_ptr(), dt, h, w, self._u16[k].data_ptr()), "hdrtv_post_rgb48")
+        p.enqueue_frame(lane, self._raw[k].data_ptr(), h, w, self._u16[k].data_ptr(), stream=main)
         self._comp_ev[k] = torch.cuda.Event()
         self._comp_ev[k].record(main)
         self._dn.wait_event(self._comp_ev[k])

@@ -31,6 +31,9 @@ SYMBOLS = [
     ("hdrtv_reserve", _I, [_VP, _I, _I]),
     ("hdrtv_preprocess", _I, [_VP, _VP, _VP, _I, _I, _VP, _VP]),
     ("hdrtv_infer", _I, [_VP, _VP, _VP, _VP, _I, _I, _VP, _I, _VP]),
+    ("hdrtv_set_lanes", _I, [_VP, _I]),
+    ("hdrtv_get_lanes", _I, [_VP]),
+    ("hdrtv_infer_lane", _I, [_VP, _I, _VP, _VP, _VP, _I, _I, _VP, _I, _VP]),
     ("hdrtv_post_u8", _I, [_VP, _VP, _VP, _I, _I, _I, _VP]),
     ("hdrtv_post_rgb48", _I, [_VP, _VP, _VP, _I, _I, _I, _VP]),
     ("hdrtv_post_pq_rgb48", _I, [_VP, _VP, _VP, _I, _I, _I, C.c_float, _VP]),

@@ -106,14 +106,20 @@ class HDRTVNetMI355X:
     ``use_cuda_graphs=True`` replays ``infer`` from a captured hipGraph (2306-2331).  ``fast_condition_resize=True`` (or
     ``HDRTVNET_FAST_COND_RESIZE=1``) derives the condition map with the bilinear 0.25x resize, ``HDRTVNET_ZERO_COND=1``
     zeroes it (1539-1543, 2262-2276).
+    ``lanes`` (no reference counterpart; 1 .. 4, default 1): frames in flight on the device.  Each lane has its own activation
+    workspace, boundary tensors and HIP stream (``enqueue_frame``); the reference-shaped calls (``process`` / ``preprocess`` /
+    ``infer`` / ``postprocess``) always run on lane 0 and the caller's current stream.
     """
 
     def __init__(self, model_path, device="auto", precision="auto",
                  compile_model=True, force_compile=False, compile_mode="auto",
                  use_cuda_graphs=False, force_channels_last=False,
                  predequantize="auto", hg_weights=None, use_hg=True,
-                 warmup_passes=3, fast_condition_resize=False, _ab_library=False):
+                 warmup_passes=3, fast_condition_resize=False, lanes=1, _ab_library=False):
         self.model_path = model_path
+        self._lanes = int(lanes)
+        if not 1 <= self._lanes <= 4:
+            raise ValueError("lanes must be 1 .. 4")
         self._warmup_passes = int(warmup_passes)
         env_true = lambda n: str(os.environ.get(n, "")).strip().lower() in ("1", "true", "yes", "on")   # noqa: E731
         self._fast_condition_resize = bool(fast_condition_resize) or env_true("HDRTVNET_FAST_COND_RESIZE")
@@ -208,6 +214,9 @@ class HDRTVNetMI355X:
                 raise ValueError(f"model backend failed - {msg}")
             raise RuntimeError(f"model backend failed - {msg}")
 
+        if self._lanes > 1:
+            self._chk(self._lib.hdrtv_set_lanes(self._ctx, self._lanes), "hdrtv_set_lanes")
+        self._lane_bufs, self._lane_streams = [], []
         if self._fast_zero_condition or self._fast_condition_resize:
             self._chk(self._lib.hdrtv_set_cond_mode(self._ctx, 2 if self._fast_zero_condition else 1), "hdrtv_set_cond_mode")
         self._buf_hw = None
@@ -287,7 +296,41 @@ class HDRTVNetMI355X:
             self._gpu_agcm = torch.empty((1, 3, h, w), dtype=self._dtype, device=dev)
             self._pin_input = torch.empty((h, w, 3), dtype=torch.uint8, pin_memory=True)
             self._pin_output = torch.empty((h, w, 3), dtype=torch.uint8, pin_memory=True)
+            # lane l > 0: its own boundary tensors (input, cond, out, agcm) and stream; lane 0 is the set above
+            self._lane_bufs = [(self._gpu_input, self._gpu_cond, self._gpu_out, self._gpu_agcm)]
+            for _ in range(1, self._lanes):
+                self._lane_bufs.append((torch.empty_like(self._gpu_input), torch.empty_like(self._gpu_cond),
+                                        torch.empty_like(self._gpu_out), torch.empty_like(self._gpu_agcm)))
+            if len(self._lane_streams) != self._lanes:
+                self._lane_streams = [torch.cuda.Stream(dev) for _ in range(self._lanes)]
         self._buf_hw = (h, w)
+
+    # ------------------------------------------------------------------ lanes
+    @property
+    def lanes(self):
+        return self._lanes
+
+    def lane_stream(self, lane):
+        """The HIP stream lane ``lane``'s frames are enqueued on (a ``torch.cuda.Stream``; valid after the first
+        ``_ensure_buffers``)."""
+        return self._lane_streams[lane]
+
+    def enqueue_frame(self, lane, src_bgr_ptr, h, w, dst_rgb48_ptr, stream=None):
+        """One frame of the hot path on lane ``lane``, stream-ordered and without any host synchronisation: u8 BGR frame in
+        device memory at ``src_bgr_ptr`` -> hdrtv_preprocess -> hdrtv_infer_lane -> hdrtv_post_rgb48 -> u16 RGB48 at the device
+        address ``dst_rgb48_ptr``.  ``stream``: a ``torch.cuda.Stream`` (default: the lane's own).  Frames enqueued on different
+        lanes may overlap on the device; the bytes written do not depend on the lane (tests/test_gpu_lanes.py).  The caller
+        orders the use of ``src`` / ``dst`` against the stream (events), as with any asynchronous launch."""
+        if not 0 <= lane < self._lanes:
+            raise ValueError(f"lane {lane} of {self._lanes}")
+        self._ensure_buffers(h, w)
+        st = C.c_void_p((stream if stream is not None else self._lane_streams[lane]).cuda_stream)
+        tin, tcond, tout, tagcm = self._lane_bufs[lane]
+        dt = _L.F32 if (self._use_hg or self._fp32) else _L.F16
+        self._chk(self._lib.hdrtv_preprocess(self._ctx, st, src_bgr_ptr, h, w, tin.data_ptr(), tcond.data_ptr()), "hdrtv_preprocess")
+        self._chk(self._lib.hdrtv_infer_lane(self._ctx, lane, st, tin.data_ptr(), tcond.data_ptr(), h, w, tout.data_ptr(), dt,
+                                             tagcm.data_ptr()), "hdrtv_infer_lane")
+        self._chk(self._lib.hdrtv_post_rgb48(self._ctx, st, tout.data_ptr(), dt, h, w, dst_rgb48_ptr), "hdrtv_post_rgb48")
 
     # ------------------------------------------------------------------ API
     @torch.inference_mode()

@@ -94,6 +94,19 @@ int hdrtv_preprocess(hdrtv_ctx *ctx, void *stream, const uint8_t *dev_bgr_hwc, i
 int hdrtv_infer(hdrtv_ctx *ctx, void *stream, const void *dev_rgb_chw, const void *dev_cond, int H,
                 int W, void *dev_out, int out_dtype, void *dev_agcm_out);
 
+/* Frames in flight (no reference counterpart: the reference's worker processes one frame at a time and hides its copies
+ * behind streams, gui_pipeline_worker_feeders.py:125-249).  A context holds `lanes` activation workspaces (1 .. 4, default
+ * 1; weights are shared); hdrtv_infer_lane(ctx, l, stream_l, ...) is hdrtv_infer on workspace l, so calls with different
+ * lanes on different streams may overlap on the device: the tail of one frame's kernel fills with the next frame's
+ * workgroups (about +4.5 % frames/s at 3840x2160 with two lanes; a frame's own latency grows towards lanes x).
+ * Results do not depend on the lane.  hdrtv_set_lanes drops the reservation when the count changes (call hdrtv_reserve
+ * again; it synchronises the device); hdrtv_infer is lane 0.  Calls on one context are made by one host thread at a time,
+ * as before: lanes make the DEVICE work concurrent, not the entry points re-entrant.  hdrtv_get_tap addresses lane 0. */
+int hdrtv_set_lanes(hdrtv_ctx *ctx, int lanes);
+int hdrtv_get_lanes(const hdrtv_ctx *ctx);
+int hdrtv_infer_lane(hdrtv_ctx *ctx, int lane, void *stream, const void *dev_rgb_chw, const void *dev_cond, int H,
+                     int W, void *dev_out, int out_dtype, void *dev_agcm_out);
+
 /* Replaces HDRTVNetTorch.postprocess's device half (hdrtvnet_torch.py:2357-2361):
  * trunc(clamp(x,0,1)*255 + 0.5) in the tensor's dtype semantics, RGB planar -> u8 [H][W][3] BGR. */
 int hdrtv_post_u8(hdrtv_ctx *ctx, void *stream, const void *dev_out, int dtype, int H, int W,

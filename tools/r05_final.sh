@@ -8,6 +8,7 @@ O=$R/gpurun_out
 B="--steps 20 --warmup 5"
 if [ "${1:-bench}" = bench ]; then
 python3 $R/bench.py $B --layers > $O/r05_bench_default.json 2> $O/r05_layers.txt; echo "bench default $?"
+python3 $R/bench.py $B --lanes 1 --no-cpu-baseline --no-dispatcher --no-int8-extra > $O/r05_bench_one_lane.json 2> /dev/null; echo "bench one lane $?"
 HDRTV_VARIANTS=le_rows=0 python3 $R/bench.py $B --layers --no-cpu-baseline --no-dispatcher --no-int8-extra > $O/r05_bench_le_rows_off.json 2> $O/r05_layers_le_rows_off.txt; echo "bench le_rows=0 $?"
 python3 $R/bench.py --int8 $B --layers --no-cpu-baseline --no-dispatcher > $O/r05_int8_bench.json 2> $O/r05_int8_layers.txt; echo "bench int8 full $?"
 python3 $R/bench.py --int8 --int8-recipe mixed $B --no-cpu-baseline --no-dispatcher > $O/r05_int8_mixed_bench.json 2> /dev/null; echo "bench int8 mixed $?"
@@ -21,8 +22,13 @@ python3 $R/tools/fp32_layers.py --size 2160x3840 --variant f32_mfma=1 --top 12 >
 exit 0
 fi
 cd /tmp && export TMPDIR=/tmp
-Q="--no-cpu-baseline --no-int8-extra --no-dispatcher --no-latency-tail"
+# per-kernel figures (stats that must agree with the roofline leg, every counter pass) are taken with ONE frame in flight: with two
+# lanes a kernel's begin-to-end time includes the share of the device the other lane's kernel holds.  The default command (two
+# lanes) is traced as well: r05_kernel_stats_2lanes.csv shows that stretch.
+Q2="--no-cpu-baseline --no-int8-extra --no-dispatcher --no-latency-tail"
+Q="$Q2 --lanes 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r05f_kt -o p -- python3 $R/bench.py $B $Q > $O/r05f_kt.json 2> $O/r05f_kt.err; echo "kt $?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/r05f_kt2 -o p -- python3 $R/bench.py $B $Q2 > $O/r05f_kt2.json 2> $O/r05f_kt2.err; echo "kt, two lanes $?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r05f_kt_i8 -o p -- python3 $R/bench.py --int8 $B $Q > $O/r05f_kt_i8.json 2> $O/r05f_kt_i8.err; echo "kt i8 $?"
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $O/r05f_pmc_$ctr -o p -- python3 $R/bench.py --steps 3 --warmup 1 $Q > $O/r05f_pmc_$ctr.log 2>&1; echo "pmc $ctr $?"
@@ -33,12 +39,13 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d $O/r05f_sq2 -o p -- python3 $R/bench.py --steps 3 --warmup 1 $Q > $O/r05f_sq2.log 2>&1; echo "pmc sq2 $?"
 cd $R
 f() { find $O/$1 -name "*$2" | head -1; }
-python3 tools/pmc_to_json.py $(f r05f_pmc_FETCH_SIZE counter_collection.csv) $(f r05f_pmc_WRITE_SIZE counter_collection.csv) $O/pmc_traffic.json "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of \`bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-int8-extra --no-dispatcher\`, r05 final build" > /dev/null
+python3 tools/pmc_to_json.py $(f r05f_pmc_FETCH_SIZE counter_collection.csv) $(f r05f_pmc_WRITE_SIZE counter_collection.csv) $O/pmc_traffic.json "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of \`bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-int8-extra --no-dispatcher --lanes 1\`, r05 final build" > /dev/null
 python3 tools/pmc_to_json.py $(f r05f_pmc_i8_FETCH_SIZE counter_collection.csv) $(f r05f_pmc_i8_WRITE_SIZE counter_collection.csv) $O/pmc_traffic_int8.json "the same passes of \`bench.py --int8 ...\`, r05 final build" > /dev/null
 python3 tools/mfma_util.py $(f r05f_mfma counter_collection.csv) $(f r05f_mfma kernel_trace.csv) $O/r05_mfma_util.json > $O/r05_mfma_util.txt
 python3 tools/sq_breakdown.py $(f r05f_sq counter_collection.csv) $(f r05f_sq kernel_trace.csv) > $O/r05_sq_breakdown.txt
 python3 tools/sq_breakdown.py $(f r05f_sq2 counter_collection.csv) $(f r05f_sq2 kernel_trace.csv) > $O/r05_sq_lds_breakdown.txt
 cp $(f r05f_kt kernel_stats.csv) $O/r05_kernel_stats.csv; cp $(f r05f_kt_i8 kernel_stats.csv) $O/r05_int8_kernel_stats.csv
+cp $(f r05f_kt2 kernel_stats.csv) $O/r05_kernel_stats_2lanes.csv; cp $O/r05f_kt2.json $O/r05_bench_under_rocprof_2lanes.json
 cp $O/r05f_kt.json $O/r05_bench_under_rocprof.json       # the bench line of the run r05_kernel_stats.csv was taken from (compare roofline.avg_launch_ms)
 rm -rf $O/r05f_*                                          # the raw traces: gpurun copies back at most 64 MiB
 head -5 $O/r05_mfma_util.txt; head -6 $O/r05_sq_breakdown.txt
