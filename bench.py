@@ -81,6 +81,7 @@ def parse():
     ap.add_argument("--dispatcher", action="store_true", help="only the host-fed dispatcher measurement (its own JSON line)")
     ap.add_argument("--dispatcher-depth", type=int, default=2, help="dispatcher worker: frames in flight (upload + compute + download)")
     ap.add_argument("--dispatcher-slots", type=int, default=3, help="dispatcher: input / output slots per worker")
+    ap.add_argument("--dispatcher-lanes", type=int, default=1, help="dispatcher worker: compute lanes (the worker's default is 1)")
     ap.add_argument("--dispatcher-sim", action="store_true",
                     help="CPU only: the dispatcher's host side over --gpus N stand-in workers (memcpys + device_ms of sleep per frame); no GPU is touched")
     ap.add_argument("--sim-fps", type=float, nargs="*", help="with --dispatcher-sim: offered rates to run (default: 100 per worker)")
@@ -364,7 +365,7 @@ def dispatcher_host_fed(args, frames, device_index, use_hg, steps, warmup=5, n_w
         seen["sum"] += int(view[H // 2, Wd // 2, 1])            # touch the frame: the view is only valid during the call
 
     init = {"model_path": os.path.join(REPO, "tests", "golden", "hr_weights.hdrw"), "use_hg": use_hg,
-            "hg_weights": "seeded:1234" if use_hg else None, "frames_in_flight": args.dispatcher_depth, "lanes": min(args.lanes, args.dispatcher_depth)}
+            "hg_weights": "seeded:1234" if use_hg else None, "frames_in_flight": args.dispatcher_depth, "lanes": args.dispatcher_lanes}
     try:
         # (bounded waits: an extra must never push a default run past the driver's limit)
         devices = [device_index] if n_workers == 1 else list(range(n_workers))
@@ -373,22 +374,32 @@ def dispatcher_host_fed(args, frames, device_index, use_hg, steps, warmup=5, n_w
         with FrameDispatcher(n_workers, H, Wd, sink, init_args=init, devices=devices, slots=args.dispatcher_slots, start_timeout=150.0) as d:
             # one producer thread per worker copies the frames in (submit_async); with one worker the caller's thread does
             put = d.submit if n_workers == 1 else d.submit_async
+            if os.environ.get("HDRTV_BENCH_ZERO_COPY"):          # experiment: a decoder that writes in place (reserve / commit), slots filled once
+                filled = set()
+                def put(frame):
+                    i, view = d.reserve()
+                    if id(view) not in filled and len(filled) < 64:
+                        np.copyto(view, frame)
+                        filled.add(id(view))
+                    d.commit()
             for i in range(warmup * n_workers):
                 put(frames[i % len(frames)])
             d.flush(timeout=100)
             steps *= n_workers
             before = list(d.frames_per_worker)
+            d.worker_stats(reset=True)
             t0 = time.perf_counter()
             for i in range(steps):
                 put(frames[i % len(frames)])
             d.flush(timeout=100)
             el = time.perf_counter() - t0
+            wstats = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in st.items() if k != "since"} if st else None for st in d.worker_stats()]
             placement = d.placement
             # a worker's own rate: its frames over the time to ITS last frame (a straggling GPU finishes late and shows here)
             per_worker = [round((d.frames_per_worker[r] - before[r]) / max(d.last_done[r] - t0, 1e-9), 3) for r in range(n_workers)]
         return {"value": round(steps / el, 3), "unit": "frames/s", "frames": steps, "workers": n_workers, "slots": args.dispatcher_slots, "frames_in_flight": args.dispatcher_depth,
-                "lanes": min(args.lanes, args.dispatcher_depth),
-                "ms_per_frame": round(el / steps * 1e3, 3), "per_worker_frames_per_s": per_worker, "worker_exit_codes": d.exit_codes,
+                "lanes": args.dispatcher_lanes,
+                "ms_per_frame": round(el / steps * 1e3, 3), "per_worker_frames_per_s": per_worker, "worker_loop_s": wstats, "worker_exit_codes": d.exit_codes,
                 "placement": [{k: (p[k] if k != "cpus" else len(p[k])) for k in ("device", "numa_node", "cpus", "pinned")} for p in placement],
                 "what": "FrameDispatcher: parent memcpy into a pinned shared slot -> worker hipMemcpyAsync H2D -> pre + infer + post_rgb48 "
                         "-> hipMemcpyAsync D2H into a pinned shared slot -> hipEvent -> in-order sink"}

@@ -69,7 +69,9 @@ class _Mi355xWorker:
         model = kw.pop("model_path")
         # frames in flight (uploads, compute, downloads together) and, of those, frames computing at once (lanes)
         self.depth = max(1, int(kw.pop("frames_in_flight", self.depth)))
-        kw.setdefault("lanes", min(2, self.depth))
+        # compute lanes: 1 by default -- host-fed, the second lane's device-side gain (bench.py `one_lane` vs `value`) has not shown
+        # through the upload / download hand-offs in this loop; init_args["lanes"] = 2 turns it on
+        kw.setdefault("lanes", 1)
         torch.cuda.set_device(device_index)
         with contextlib.redirect_stdout(sys.stderr):   # a worker's banner must not land on the parent's stdout (bench.py's one JSON line)
             self.proc = HDRTVNetMI355X(model, device=f"cuda:{device_index}", warmup_passes=0, **kw)
@@ -252,20 +254,31 @@ def _worker_main(rank, device_index, make_worker, init_args, geom, task_q, done_
         backlog = collections.deque()
         inflight = collections.deque()
         stopping = False
+        # where this worker's wall time goes (FrameDispatcher.worker_stats): starved = blocked with nothing in flight and nothing
+        # it could start (no frame offered, or every output slot still with the sink); finish = blocked on the oldest frame
+        stats = {"frames": 0, "starved_s": 0.0, "begin_s": 0.0, "finish_s": 0.0, "since": time.perf_counter()}
         done_q.put(("ready", rank, None, None))
         while True:
             # messages: block only when there is nothing else to do
             block = not stopping and not inflight and not (backlog and free_out)
             while True:
+                t_blk = time.perf_counter() if block else None
                 try:
                     msg = task_q.get(block=block)
                 except _queue.Empty:
                     break
+                if t_blk is not None:
+                    stats["starved_s"] += time.perf_counter() - t_blk
                 block = False
                 if msg[0] == "stop":
                     stopping = True
                 elif msg[0] == "release":
                     free_out.append(msg[1])
+                elif msg[0] == "stats":
+                    now = time.perf_counter()
+                    done_q.put(("stats", rank, None, dict(stats, wall_s=now - stats["since"], inflight=len(inflight), backlog=len(backlog))))
+                    if msg[1:] and msg[1]:                 # ("stats", True): start a new interval
+                        stats = {"frames": 0, "starved_s": 0.0, "begin_s": 0.0, "finish_s": 0.0, "since": now}
                 else:
                     backlog.append(msg)
             if stopping:
@@ -274,10 +287,16 @@ def _worker_main(rank, device_index, make_worker, init_args, geom, task_q, done_
             while backlog and free_out and len(inflight) < depth:
                 _, idx, in_slot = backlog.popleft()
                 out_slot = free_out.pop(0)
+                t_b = time.perf_counter()
                 inflight.append((body.begin(ins[in_slot], outs[out_slot]), idx, in_slot, out_slot))
+                stats["begin_s"] += time.perf_counter() - t_b
             if inflight:
                 token, idx, in_slot, out_slot = inflight.popleft()
+                stats["depth_sum"] = stats.get("depth_sum", 0) + len(inflight) + 1      # frames in flight when the loop turns to wait
+                t_b = time.perf_counter()
                 body.finish(token)
+                stats["finish_s"] += time.perf_counter() - t_b
+                stats["frames"] += 1
                 done_q.put(("frame", rank, idx, (in_slot, out_slot)))
             elif stopping:
                 break
@@ -341,6 +360,7 @@ class FrameDispatcher:
         self._error = None
         self._emitted = threading.Condition()
         self.max_reorder_depth = 0
+        self._stats = {}
         self.frames_per_worker = [0] * self.n                 # frames each worker has delivered (a straggler shows here)
         self.last_done = [0.0] * self.n                       # perf_counter() of each worker's last delivered frame
         self.host_cpu_s = {"producers": [0.0] * self.n, "reorder": 0.0}      # CPU seconds of the parent's own threads
@@ -453,6 +473,21 @@ class FrameDispatcher:
                     raise TimeoutError("dispatcher flush timed out")
         self._raise_if_failed()
 
+    def worker_stats(self, reset=False, timeout=5.0):
+        """Per worker, since start (or the last ``reset``): frames delivered and the seconds its loop spent ``starved`` (nothing in
+        flight and nothing startable: no frame offered or no free output slot), in ``begin`` (enqueueing a frame) and blocked in
+        ``finish`` (waiting for its oldest frame), of ``wall_s``.  A GPU-bound worker is mostly in ``finish``; a starved one says
+        the host side is the limit."""
+        with self._emitted:
+            self._stats = {}
+        for q in self._task:
+            q.put(("stats", bool(reset)))
+        t_end = time.monotonic() + timeout
+        with self._emitted:
+            while len(self._stats) < self.n and time.monotonic() < t_end:
+                self._emitted.wait(timeout=0.1)
+            return [self._stats.get(r) for r in range(self.n)]
+
     def _dead_worker(self):
         """A worker that is gone without having been asked to stop (GPU fault, abort, OOM kill, SIGSEGV: it posts nothing)."""
         if self._stop:
@@ -485,6 +520,11 @@ class FrameDispatcher:
             if kind == "error":
                 self._error = payload
                 with self._emitted:
+                    self._emitted.notify_all()
+                continue
+            if kind == "stats":
+                with self._emitted:
+                    self._stats[rank] = payload
                     self._emitted.notify_all()
                 continue
             if kind != "frame":

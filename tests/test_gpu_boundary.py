@@ -201,11 +201,13 @@ def test_ring_exhaustion_falls_back_and_feeder_errors_surface(golden_dir, tmp_pa
     w.close()
 
 
-def test_dispatcher_on_the_device(golden_dir):
+@pytest.mark.parametrize("worker_opts,slots", [({}, 2), ({"lanes": 2, "frames_in_flight": 3}, 4)])
+def test_dispatcher_on_the_device(golden_dir, worker_opts, slots):
     """hdrtv_mi355x/dispatch.py with the product's worker body: two worker processes (both on this box's one GPU), frames
     round-robin, two frames in flight per worker (upload / compute / download on three streams, DMA straight from and into
     the page-locked shared slots), RGB48 frames back in order and bit-identical to an in-process processor's -- at 1920x1080,
-    where the persistent kernels walk many tiles and the copies are long enough to overlap compute."""
+    where the persistent kernels walk many tiles and the copies are long enough to overlap compute.  Second case: the worker
+    with two compute lanes and three frames in flight (frame n on lane n mod 2, buffers n mod 3)."""
     import ctypes as C
     import torch
     from hdrtv_mi355x import lib as L, weights as W
@@ -222,8 +224,8 @@ def test_dispatcher_on_the_device(golden_dir):
         want.append(u16.cpu().numpy().copy())
     p.close()
     got = {}
-    args = {"model_path": os.path.join(golden_dir, "hr_weights.hdrw"), "use_hg": True, "hg_weights": "seeded:1234"}
-    with FrameDispatcher(2, h, w, lambda i, v: got.__setitem__(i, v.copy()), init_args=args, devices=[0, 0], slots=2) as d:
+    args = dict({"model_path": os.path.join(golden_dir, "hr_weights.hdrw"), "use_hg": True, "hg_weights": "seeded:1234"}, **worker_opts)
+    with FrameDispatcher(2, h, w, lambda i, v: got.__setitem__(i, v.copy()), init_args=args, devices=[0, 0], slots=slots) as d:
         for f in frames:
             d.submit(f)
         d.flush(timeout=120)
