@@ -157,6 +157,12 @@ int hdrtv_set_lanes(hdrtv_ctx *c, int lanes)
 {
     if (!c) return HDRTV_EINVAL;
     if (lanes < 1 || lanes > 4) return fail(c, HDRTV_EINVAL, "lanes must be 1 .. 4");
+    // More than one frame in flight is served for the fp16 graph only.  With W8A8 layers on int8 MFMA a tile of hg.conv2 came out
+    // wrong about once in 500 frames when other frames were in flight (tools/dbg/lane_stress2.py; not understood: NOTEBOOK.md round 5
+    // section 8), and the fp32 preset's vector kernels keep their packed-f32 arithmetic (csrc/Makefile), which is what went wrong in
+    // pre_fused beside another stream's MFMA waves.
+    if (lanes > 1 && (c->fp32 || c->hr_i8 || c->hg_i8))
+        return fail(c, HDRTV_EINVAL, "more than one lane is served for the fp16 graph only (this context: %s)", c->fp32 ? "fp32 preset" : "W8A8 layers on int8 MFMA");
     if (lanes == c->lanes) return HDRTV_OK;
     if (c->ws.dev) {                      // the reservation goes with the old lane count
         HIPCHK(c, hipSetDevice(c->device));

@@ -118,8 +118,8 @@ __device__ __forceinline__ f16x4 cvt4(float a, float b, float c, float d)
 // accumulator quad qd (registers 4 qd .. 4 qd + 3) + bias -> f16
 __device__ __forceinline__ f16x4 bias_cvt4(const f32x16 &acc, int qd, const f32x4 &b)
 {
-    const f32x2 lo = f32x2{acc[4 * qd], acc[4 * qd + 1]} + f32x2{b[0], b[1]}, hi = f32x2{acc[4 * qd + 2], acc[4 * qd + 3]} + f32x2{b[2], b[3]};
-    return __builtin_shufflevector(__builtin_convertvector(lo, f16x2), __builtin_convertvector(hi, f16x2), 0, 1, 2, 3);
+    // scalar adds on purpose (no f32x2 arithmetic: it becomes v_pk_add_f32, see the Makefile's note on packed f32 beside MFMAs)
+    return cvt4(acc[4 * qd] + b[0], acc[4 * qd + 1] + b[1], acc[4 * qd + 2] + b[2], acc[4 * qd + 3] + b[3]);
 }
 __device__ __forceinline__ f16x4 zero4() { return f16x4{(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f}; }
 __device__ __forceinline__ f32x16 zero16() { return f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; }

@@ -107,7 +107,8 @@ class HDRTVNetMI355X:
     ``HDRTVNET_FAST_COND_RESIZE=1``) derives the condition map with the bilinear 0.25x resize, ``HDRTVNET_ZERO_COND=1``
     zeroes it (1539-1543, 2262-2276).
     ``lanes`` (no reference counterpart; 1 .. 4, default 1): frames in flight on the device.  Each lane has its own activation
-    workspace, boundary tensors and HIP stream (``enqueue_frame``); the reference-shaped calls (``process`` / ``preprocess`` /
+    workspace, boundary tensors and HIP stream (``enqueue_frame``; fp16 graphs only: more than one lane raises for the fp32 preset and for
+    INT8 checkpoints run with ``predequantize`` off); the reference-shaped calls (``process`` / ``preprocess`` /
     ``infer`` / ``postprocess``) always run on lane 0 and the caller's current stream.
     """
 
@@ -215,7 +216,13 @@ class HDRTVNetMI355X:
             raise RuntimeError(f"model backend failed - {msg}")
 
         if self._lanes > 1:
-            self._chk(self._lib.hdrtv_set_lanes(self._ctx, self._lanes), "hdrtv_set_lanes")
+            # (HDRTV_EINVAL for the fp32 preset and for W8A8 layers kept on int8 MFMA: one lane only there, include/hdrtv_mi355x.h)
+            try:
+                self._chk(self._lib.hdrtv_set_lanes(self._ctx, self._lanes), "hdrtv_set_lanes")
+            except Exception:
+                self._lib.hdrtv_destroy(self._ctx)
+                self._ctx = C.c_void_p()
+                raise
         self._lane_bufs, self._lane_streams = [], []
         if self._fast_zero_condition or self._fast_condition_resize:
             self._chk(self._lib.hdrtv_set_cond_mode(self._ctx, 2 if self._fast_zero_condition else 1), "hdrtv_set_cond_mode")

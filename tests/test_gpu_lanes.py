@@ -28,7 +28,7 @@ def _make(golden_dir, int8, lanes):
     return HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), use_hg=True, hg_weights="seeded:1234", warmup_passes=0, lanes=lanes)
 
 
-@pytest.mark.parametrize("int8,size", [(False, (2160, 3840)), (False, (540, 962)), (True, (2160, 3840))])
+@pytest.mark.parametrize("int8,size", [(False, (2160, 3840)), (False, (540, 962))])
 def test_overlapping_lanes_write_the_bytes_of_one_frame_at_a_time(torch_cuda, golden_dir, int8, size):
     from hdrtv_mi355x import weights as W
     torch = torch_cuda
@@ -112,26 +112,52 @@ def test_lane_count_is_part_of_the_reservation(torch_cuda, golden_dir):
         HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), use_hg=False, warmup_passes=0, lanes=5)
 
 
-def test_fp32_preset_lanes(torch_cuda, golden_dir):
-    from hdrtv_mi355x import weights as W
+def test_more_than_one_lane_is_refused_outside_the_fp16_graph(torch_cuda, golden_dir):
+    """W8A8 layers on int8 MFMA and the fp32 preset run one frame at a time: hdrtv_set_lanes(2) is HDRTV_EINVAL there (about one
+    frame in 500 came out with wrong hg.conv2 tiles when int8 frames overlapped -- tools/dbg/lane_stress2.py, not understood --
+    and the fp32 vector kernels keep the packed-f32 arithmetic that failed beside another stream's MFMA waves)."""
     from hdrtv_mi355x.processor import HDRTVNetMI355X
+    with pytest.raises(RuntimeError, match="fp16 graph only"):
+        _make(golden_dir, True, lanes=2)
+    with pytest.raises(RuntimeError, match="fp16 graph only"):
+        HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), precision="fp32", use_hg=False, warmup_passes=0, lanes=2)
+    # an INT8 checkpoint run the reference's ROCm way (dequantised at load: fp16 compute) is an fp16 graph
+    p = HDRTVNetMI355X(os.path.join(golden_dir, "hr_int8_mixed_qat.hdrw"), precision="int8-mixed", use_hg=False, warmup_passes=0, lanes=2)
+    assert p.lanes == 2
+    p.close()
+    p = _make(golden_dir, True, lanes=1)
+    assert p.lanes == 1
+    p.close()
+
+
+@pytest.mark.parametrize("int8", [False])
+def test_a_lane_is_not_disturbed_by_the_frames_in_flight_beside_it(torch_cuda, golden_dir, int8):
+    """Rounds of lane 0 = one fixed frame with OTHER frames enqueued on lanes 1 and 2 around it: lane 0's RGB48 bytes and its
+    condition map are those of the quiet run every time.  (Round 5: packed-f32 arithmetic in pre_fused -- v_pk_mul / add / fma_f32
+    from the SLP vectoriser -- read a stale operand when its waves shared a SIMD with conv1x1_i8's MFMA waves of another lane's
+    frame: a handful of wrong condition-map values per disturbed call, 4 .. 14 of 40 such rounds; the library is built without
+    packed f32 since, tests/test_isa_contracts.py.  72 lane-frames here; tools/dbg/lane_stress2.py ran 7500 of them clean.)"""
+    from hdrtv_mi355x import weights as W
     torch = torch_cuda
-    h, w = 272, 480
-    p = HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), precision="fp32", use_hg=True, hg_weights="seeded:1234", warmup_passes=0, lanes=2)
+    h, w = 2160, 3840
+    p = _make(golden_dir, int8, lanes=3)
     try:
         dev = p.device
-        frames = [torch.from_numpy(W.synthetic_frame(h, w, seed=90 + i, kind="noise" if i else "gradient")).to(dev) for i in range(2)]
-        want = []
-        for f in frames:
-            o = torch.empty((h, w, 3), dtype=torch.uint16, device=dev)
-            p.enqueue_frame(0, f.data_ptr(), h, w, o.data_ptr())
-            torch.cuda.synchronize(dev)
-            want.append(o)
-        outs = [torch.zeros((h, w, 3), dtype=torch.uint16, device=dev) for _ in range(6)]
-        for i in range(6):
-            p.enqueue_frame(i % 2, frames[(i // 2 + i) % 2].data_ptr(), h, w, outs[i].data_ptr())
+        frames = [torch.from_numpy(W.synthetic_frame(h, w, seed=70 + i, kind=("noise", "gradient", "noise", "gradient")[i])).to(dev) for i in range(4)]
+        outs = [torch.empty((h, w, 3), dtype=torch.uint16, device=dev) for _ in range(3)]
+        p.enqueue_frame(0, frames[2].data_ptr(), h, w, outs[0].data_ptr())
         torch.cuda.synchronize(dev)
-        for i in range(6):
-            assert torch.equal(outs[i], want[(i // 2 + i) % 2]), i
+        ref_out, ref_cond = outs[0].clone(), p._lane_bufs[0][1].clone()
+        bad = []
+        for r in range(24):
+            order = (0, 1, 2) if r % 2 == 0 else (2, 1, 0)
+            for rep in range(2):
+                for l in order:
+                    p.enqueue_frame(l, frames[2 if l == 0 else (l + r + rep) % 4].data_ptr(), h, w, outs[l].data_ptr())
+            torch.cuda.synchronize(dev)
+            nc, no = int((p._lane_bufs[0][1] != ref_cond).sum()), int((outs[0] != ref_out).sum())
+            if nc or no:
+                bad.append((r, nc, no))
+        assert not bad, bad
     finally:
         p.close()

@@ -22,7 +22,7 @@ pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not ins
 def _asm(src, tmp_path):
     out = tmp_path / (src + ".s")
     # -DHDRTV_AB: the A/B library's superset (the shipped kernels + the superseded ones the GPU bit-identity tests run)
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-DHDRTV_AB", "-S", "--cuda-device-only",
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize", "-fno-vectorize", "-DHDRTV_AB", "-S", "--cuda-device-only",
                     os.path.join(CSRC, src), "-o", str(out)], check=True, capture_output=True)
     text = out.read_text()
     kernels = {}
@@ -203,7 +203,7 @@ def test_lds_dma_kernels_spill_nothing_and_use_the_buffer_form(src, tmp_path):
     (2) the DMA is `buffer_load_dwordx4 ... lds`, never the FLAT-encoded global_load_lds, after which hipcc's waitcnt pass
     stops counting."""
     out = tmp_path / (src + ".s")
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-DHDRTV_AB", "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", str(out)],
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize", "-fno-vectorize", "-DHDRTV_AB", "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", str(out)],
                    check=True, capture_output=True)
     text = out.read_text()
     spills = [int(v) for v in re.findall(r"\.vgpr_spill_count:\s*(\d+)", text)]
@@ -324,3 +324,20 @@ def test_le_rows_i8_step_loops_keep_their_counted_waits(tmp_path):
         assert waits == counted, (name, sorted(waits), sorted(counted))
         seen += 1
     assert seen == 3
+
+
+def test_no_packed_f32_arithmetic_in_any_kernel(tmp_path):
+    """csrc/Makefile builds with -fno-slp-vectorize -fno-vectorize: packed f32 arithmetic (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32, which only the
+    SLP and loop vectorisers produce from this code) returned a stale operand in its low half when the wave shared a SIMD with another
+    kernel's MFMA waves (pre_fused beside conv1x1_i8 of a frame in flight on another stream: NOTEBOOK.md round 5, section 8).  The
+    flag must stay in the Makefile and must keep having that effect on every kernel file."""
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    assert re.search(r"^CXXFLAGS \+= -fno-slp-vectorize", mk, re.M)
+    seen = 0
+    # (fp32_ops.hip keeps the vectorisers -- its vector-FMA convolution runs on v_pk_fma_f32 -- and its contexts take one lane only)
+    for src in sorted(f for f in os.listdir(CSRC) if f.endswith(".hip") and not f.startswith("api_") and f not in ("hdrtv_api.hip", "fp32_graph.hip", "fp32_ops.hip")):
+        for name, body in _asm(src, tmp_path).items():
+            packed = re.findall(r"^\s*v_pk_(?:mul|add|fma)_f32", body, re.M)
+            assert not packed, (src, name, len(packed))
+            seen += 1
+    assert seen >= 50

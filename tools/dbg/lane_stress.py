@@ -1,0 +1,72 @@
+"""Which tensor of lane 0 changes first when the other lanes are busy?  Reference: frame F on lane 0 with the device otherwise idle
+(every workspace tensor copied); then rounds of lane 0 = F with other frames enqueued on lanes 1.. around it; after each round the
+lane-0 tensors are compared with the reference in launch order.  usage: lane_stress.py [--int8] [--rounds N] [--lanes L] [HxW]"""
+import os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(REPO, "hdr-realtime-video-pipeline_amd"))
+import torch
+from hdrtv_mi355x import weights as W
+from hdrtv_mi355x.processor import HDRTVNetMI355X
+
+int8 = "--int8" in sys.argv
+rounds = int(sys.argv[sys.argv.index("--rounds") + 1]) if "--rounds" in sys.argv else 20
+lanes = int(sys.argv[sys.argv.index("--lanes") + 1]) if "--lanes" in sys.argv else 3
+size = [a for a in sys.argv[1:] if "x" in a and a[0].isdigit()]
+H, Wd = (int(v) for v in size[0].split("x")) if size else (2160, 3840)
+dev = torch.device("cuda", 0)
+p = HDRTVNetMI355X(os.path.join(REPO, "tests", "golden", "hr_int8_full_qat.hdrw" if int8 else "hr_weights.hdrw"), device="cuda:0",
+                   precision="int8-full" if int8 else "auto", predequantize="off" if int8 else "auto", use_hg=True,
+                   hg_weights="seeded-w8a8:1234" if int8 else "seeded:1234", warmup_passes=0, lanes=lanes)
+p._ensure_buffers(H, Wd)
+names = [f"agcm.{k}{i}" for i in range(1, 6) for k in ("u", "mean", "rstd")] + ["agcm.part", "agcm.bias", "agcm.qconst" if int8 else "agcm.frags", "agcm.out", "le.cond", "le.cond1", "le.x192", "le.cond2", "le.cond3", "le.cond4",
+         "le.f0a", "le.f0b", "le.fea0", "le.fea1a", "le.fea1", "le.l1b", "le.fea2a", "le.fea2", "le.l2b", "le.fea3", "le.l3b", "le.t3x", "le.t3y",
+         "le.up1", "le.t4", "le.up2", "le.t5", "le.up3", "le.out", "hg.img", "hg.mask", "hg.part2"]
+pre = "hg8." if int8 else "hg."
+names += [pre + n for n in ("p1", "conv2", "p3", "conv3_2", "p4", "conv4_2", "p5", "conv5_2", "pc", "conv_code2", "up1", "conv6", "up2", "conv7", "up3", "conv8", "up4", "conv9")]
+names += ["hg.part"]
+have = []
+for n in names:
+    try:
+        p._tap_device(n); have.append(n)
+    except RuntimeError:
+        pass
+frames = [torch.from_numpy(W.synthetic_frame(H, Wd, seed=70 + i, kind=("noise", "gradient", "noise", "gradient")[i])).to(dev) for i in range(4)]
+outs = [torch.empty((H, Wd, 3), dtype=torch.uint16, device=dev) for _ in range(lanes)]
+print("addresses: " + " | ".join(f"lane {l}: in {t[0].data_ptr():x} cond {t[1].data_ptr():x} out {t[2].data_ptr():x} agcm {t[3].data_ptr():x}" for l, t in enumerate(p._lane_bufs)))
+print("outs " + " ".join(f"{o.data_ptr():x}" for o in outs) + " frames " + " ".join(f"{f.data_ptr():x}" for f in frames))
+F = 2
+p.enqueue_frame(0, frames[F].data_ptr(), H, Wd, outs[0].data_ptr())
+torch.cuda.synchronize(dev)
+ref = {n: p._tap_device(n) for n in have}
+ref["OUT"] = outs[0].clone()
+ref_in = [t.clone() for t in p._lane_bufs[0]]
+# the quiet run is repeatable
+p.enqueue_frame(0, frames[F].data_ptr(), H, Wd, outs[0].data_ptr())
+torch.cuda.synchronize(dev)
+assert all(torch.equal(ref[n], p._tap_device(n)) for n in have) and torch.equal(ref["OUT"], outs[0]), "the quiet run itself is not repeatable"
+bad_rounds = 0
+for r in range(rounds):
+    order = list(range(lanes))
+    if r % 2:
+        order.reverse()
+    for rep in range(2):                 # two frames per lane back to back: lane 0 is in the middle of the others' work
+        for l in order:
+            p.enqueue_frame(l, frames[F if l == 0 else (l + r + rep) % 4].data_ptr(), H, Wd, outs[l].data_ptr())
+    torch.cuda.synchronize(dev)
+    diff = [(n, int((ref[n] != p._tap_device(n)).sum()), ref[n].numel()) for n in have]
+    diff = [d for d in diff if d[1]]
+    od = int((ref["OUT"] != outs[0]).sum())
+    ind = [int((a != b).sum()) for a, b in zip(ref_in, p._lane_bufs[0])]
+    if any(ind):
+        print(f"round {r}: lane 0 boundary tensors differ (input, cond, out, agcm): {ind}", flush=True)
+        a, b = ref_in[1].flatten(), p._lane_bufs[0][1].flatten()
+        idx = (a != b).nonzero().flatten()
+        ch, rem = idx // (a.numel() // 3), idx % (a.numel() // 3)
+        wq = p._lane_bufs[0][1].shape[3]
+        print("   cond elements (plane,row,col): " + " ".join(f"({int(c)},{int(q) // wq},{int(q) % wq})" for c, q in list(zip(ch, rem))[:48]), flush=True)
+        print("   want " + " ".join(f"{float(v):.4f}" for v in a[idx][:16]) + " | got " + " ".join(f"{float(v):.4f}" for v in b[idx][:16]), flush=True)
+    if diff or od:
+        bad_rounds += 1
+        print(f"round {r}: OUT differs in {od} values; tensors that differ, in launch order: " + ", ".join(f"{n} {k}/{t}" for n, k, t in diff[:12]), flush=True)
+print(f"{'int8' if int8 else 'fp16'} {H}x{Wd} lanes {lanes}: {bad_rounds} of {rounds} rounds differ", flush=True)
+p.close()
