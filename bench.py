@@ -54,9 +54,11 @@ def parse():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--no-hg", action="store_true", help="debug: AGCM+LE only (not the headline config)")
-    ap.add_argument("--lanes", type=int, default=2, choices=(1, 2, 3, 4),
-                    help="frames in flight on the device (hdrtv_set_lanes): frame i runs on lane i mod LANES, each lane with its own activation "
-                         "workspace and HIP stream, as the dispatcher's worker does; 1 = one compute stream (the one-lane rate is reported either way)")
+    ap.add_argument("--lanes", type=int, default=1, choices=(1, 2, 3, 4),
+                    help="frames in flight on the device for the timed region (hdrtv_set_lanes): frame i runs on lane i mod LANES, each lane with "
+                         "its own activation workspace and HIP stream.  Default 1: `value` is one frame at a time; the two-lane rate is reported "
+                         "beside it as `two_lanes` (with a byte-for-byte self-check), fp16 only")
+    ap.add_argument("--no-two-lanes", action="store_true", help="skip the `two_lanes` leg")
     ap.add_argument("--int8", action="store_true",
                     help="BASELINE configs[4] instead of the headline fp16 configuration: HR from the reference's INT8-QAT checkpoint "
                          "with its W8A8 layers kept quantised (predequantize off) and the HG head as a W8A8 checkpoint (seeded + calibrated: the "
@@ -508,13 +510,16 @@ def main():
         # W8A8 layers on int8 MFMA run one frame at a time (hdrtv_set_lanes refuses more: include/hdrtv_mi355x.h)
         print("[bench] --int8 with predequantize off: one lane", file=sys.stderr)
         args.lanes = 1
+    fp16_graph = not (args.int8 and not args.int8_predequantize)
+    want_two = fp16_graph and not args.no_two_lanes and world == 1 and args.lanes == 1
+    ctx_lanes = 2 if want_two else args.lanes           # the context holds the second workspace from the start; `value` uses args.lanes
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):       # stdout carries exactly one JSON line
         proc = HDRTVNetMI355X(os.path.join(REPO, "tests", "golden", f"hr_int8_{args.int8_recipe}_qat.hdrw" if args.int8 else "hr_weights.hdrw"),
                               device=f"cuda:{local_rank}", precision=f"int8-{args.int8_recipe}" if args.int8 else "auto",
                               predequantize="auto" if (args.int8_predequantize or not args.int8) else "off",
                               use_hg=use_hg, hg_weights=("seeded-w8a8:1234" if args.int8 else "seeded:1234") if use_hg else None,
-                              warmup_passes=0, lanes=args.lanes)
+                              warmup_passes=0, lanes=ctx_lanes)
     proc._ensure_buffers(H, Wd)
     lib, ctx = proc._lib, proc._ctx
 
@@ -547,7 +552,7 @@ def main():
     # Frame i runs on lane i mod LANES (its own activation workspace and HIP stream, processor.enqueue_frame): with two lanes the
     # device starts frame i + 1's kernels in the tails of frame i's.  The ring keeps the order: slots are committed and consumed
     # in frame order whatever order the lanes finish in.
-    proc._chk(lib.hdrtv_ring_create(ctx, 2 + args.lanes, H, Wd), "ring_create")
+    proc._chk(lib.hdrtv_ring_create(ctx, 2 + ctx_lanes, H, Wd), "ring_create")
     dn_stream = torch.cuda.Stream(dev)
     pending = []
 
@@ -635,24 +640,42 @@ def main():
                       "max_ms": round(tms[-1], 3), "one_percent_low_fps": round(float(np.mean(tfps[:max(1, n_tail // 100)])), 3),
                       "what": "the timed region's step repeated for 300 more frames behind it (per-frame HIP events): the population p99 / 1 % low need; "
                               "p50 / p99 / max are a frame's first kernel to its last, the 1 % low is over the intervals between consecutive frames' completions"}
-    # ---- the same K ring steps with ONE frame in flight (everything on lane 0's stream: the reference's frame-at-a-time order),
-    # reported beside `value` with its per-frame latency: what the second lane buys and what it costs
-    one_lane = None
-    if args.lanes > 1:
-        ev1 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-        for i in range(2):
-            ring_step(i, lanes=1)
+    # ---- the same K ring steps with TWO frames in flight (frame i on lane i mod 2: own workspace and stream; the device starts a
+    # frame's kernels in the tails of the other's), reported beside `value` with its per-frame latency, and a self-check: 60 frames on
+    # two lanes against the bytes the same frames give one at a time.  fp16 graphs only; never `value` (lanes are opt-in: DESIGN.md 7)
+    two_lanes = None
+    if want_two:
+        ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        for i in range(4):
+            ring_step(i, lanes=2)
         ring_drain()
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         for i in range(args.steps):
-            ring_step(i, lanes=1, ev=ev1[i])
+            ring_step(i, lanes=2, ev=ev2[i])
         ring_drain()
         torch.cuda.synchronize(dev)
-        el1 = time.perf_counter() - t1
-        ms1 = sorted(a.elapsed_time(b) for a, b in ev1)
-        one_lane = {"value": round(args.steps / el1, 3), "unit": "frames/s", "p50_ms": round(ms1[len(ms1) // 2], 3),
-                    "p99_ms": round(ms1[min(len(ms1) - 1, int(len(ms1) * 0.99))], 3), "rank": rank}
+        el2 = time.perf_counter() - t1
+        ms2 = sorted(a.elapsed_time(b) for a, b in ev2)
+        want_bytes = []
+        chk = [torch.empty((H, Wd, 3), dtype=torch.uint16, device=dev) for _ in range(2)]
+        for k in range(nfr):
+            proc.enqueue_frame(0, dev_frames[k].data_ptr(), H, Wd, chk[0].data_ptr())
+            torch.cuda.synchronize(dev)
+            want_bytes.append(chk[0].clone())
+        n_chk, bad_chk, worst = 60, 0, 0
+        for i in range(0, n_chk, 2):
+            for l in range(2):
+                proc.enqueue_frame(l, dev_frames[(i + l) % nfr].data_ptr(), H, Wd, chk[l].data_ptr())
+            torch.cuda.synchronize(dev)
+            for l in range(2):
+                nd = int((chk[l] != want_bytes[(i + l) % nfr]).sum())
+                bad_chk += nd > 0
+                worst = max(worst, nd)
+        del chk, want_bytes
+        two_lanes = {"value": round(args.steps / el2, 3), "unit": "frames/s", "p50_ms": round(ms2[len(ms2) // 2], 3),
+                     "p99_ms": round(ms2[min(len(ms2) - 1, int(len(ms2) * 0.99))], 3), "rank": rank,
+                     "selfcheck": {"frames": n_chk, "frames_differing_from_one_lane": bad_chk, "most_values_differing": worst}}
     lib.hdrtv_ring_destroy(ctx)
 
     # ---- the same K steps with the RGB48 frame left in device memory (no ring): reported at N = 1, never `value`
@@ -814,7 +837,7 @@ def main():
             "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "p50_ms": round(p50, 3), "p99_ms": round(p99, 3),
             "one_percent_low_fps": round(one_pct_low, 3), "latency_tail": tail_stats,
-            "lanes": args.lanes, "one_lane": one_lane,
+            "lanes": args.lanes, "two_lanes": two_lanes,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i8+f16" if args.int8 else "f16",
             "world_size": dist.get_world_size() if world > 1 else 1, "backend": (backend if backend != "nccl" else "nccl (RCCL)") if world > 1 else None,
             "per_rank_frames_per_s": per_rank_fps, "per_rank_numa_node": per_rank_node,
@@ -834,8 +857,8 @@ def main():
             "value_device_only": round(device_only, 3) if device_only else None,
             "value_pcie_inclusive": round(pcie, 3) if pcie else None,
             "value_is": f"u8 frames resident in HBM -> pre_fused + infer + post_rgb48 -> pinned host RGB48 ring (hipMemcpyAsync + hipEvent), {args.lanes} frame(s) in "
-                        "flight per GPU (frame i on lane i mod LANES: own workspace and stream; p50_ms / p99_ms are one frame's first kernel to its last "
-                        "with the other lane's frame sharing the device; `one_lane` is the same K steps one frame at a time); "
+                        "flight per GPU (p50_ms / p99_ms: one frame's first kernel to its last; `two_lanes`: the same K steps with frame i on lane i mod 2 "
+                        "-- own workspace and stream --, an opt-in mode that is never `value`); "
                         "value_device_only leaves the RGB48 frame in HBM; value_pcie_inclusive also uploads each frame from pinned host memory",
             "roofline": roof,
             "roofline_next": roof_next,

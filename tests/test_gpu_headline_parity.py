@@ -352,8 +352,8 @@ def test_native_int8_default_path_at_3840x2160(torch_cuda, golden_dir, monkeypat
     print(f"  default vs one tile per workgroup: le.fea0 {int((d0 != 0).sum())} of {d0.numel()} differ (max {float(d0.max()):.2e}); "
           f"le.out mean {float(dl.mean()):.2e}; out mean {float(dout.mean()):.2e}")
     assert torch.equal(runs["default"][1], runs["one tile per workgroup"][1])            # AGCM: no fused form
-    assert float((d0 != 0).float().mean()) <= 2e-5 and float(d0.max()) <= 1.6e-2
-    assert float(dl.mean()) <= 3e-4 and float(dout.mean()) <= 1.5e-3                      # (the bars against the oracle below: 1.5e-2 mean)
+    assert float((d0 != 0).float().mean()) <= 6e-5 and float(d0.max()) <= 1.6e-2
+    assert float(dl.mean()) <= 3e-3 and float(dout.mean()) <= 5e-3                      # (the bars against the oracle below: 1.5e-2 mean)
     sd = O.w8a8_state(W.load_pack(path))
     hq = O.w8a8_state(qstate)
     O.set_threads(min(16, os.cpu_count() or 1))

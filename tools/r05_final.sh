@@ -8,7 +8,7 @@ O=$R/gpurun_out
 B="--steps 20 --warmup 5"
 if [ "${1:-bench}" = bench ]; then
 python3 $R/bench.py $B --layers > $O/r05_bench_default.json 2> $O/r05_layers.txt; echo "bench default $?"
-python3 $R/bench.py $B --lanes 1 --no-cpu-baseline --no-dispatcher --no-int8-extra > $O/r05_bench_one_lane.json 2> /dev/null; echo "bench one lane $?"
+python3 $R/bench.py $B --lanes 2 --no-cpu-baseline --no-dispatcher --no-int8-extra > $O/r05_bench_two_lanes.json 2> /dev/null; echo "bench two lanes $?"
 HDRTV_VARIANTS=le_rows=0 python3 $R/bench.py $B --layers --no-cpu-baseline --no-dispatcher --no-int8-extra > $O/r05_bench_le_rows_off.json 2> $O/r05_layers_le_rows_off.txt; echo "bench le_rows=0 $?"
 python3 $R/bench.py --int8 $B --layers --no-cpu-baseline --no-dispatcher > $O/r05_int8_bench.json 2> $O/r05_int8_layers.txt; echo "bench int8 full $?"
 python3 $R/bench.py --int8 --int8-recipe mixed $B --no-cpu-baseline --no-dispatcher > $O/r05_int8_mixed_bench.json 2> /dev/null; echo "bench int8 mixed $?"
@@ -22,11 +22,10 @@ python3 $R/tools/fp32_layers.py --size 2160x3840 --variant f32_mfma=1 --top 12 >
 exit 0
 fi
 cd /tmp && export TMPDIR=/tmp
-# per-kernel figures (stats that must agree with the roofline leg, every counter pass) are taken with ONE frame in flight: with two
-# lanes a kernel's begin-to-end time includes the share of the device the other lane's kernel holds.  The default command (two
-# lanes) is traced as well: r05_kernel_stats_2lanes.csv shows that stretch.
-Q2="--no-cpu-baseline --no-int8-extra --no-dispatcher --no-latency-tail"
-Q="$Q2 --lanes 1"
+# every pass with one frame in flight (the default) and without the `two_lanes` leg: with two lanes a kernel's begin-to-end time
+# includes the share of the device the other lane's kernel holds.  The two-lane mode is traced once: r05_kernel_stats_2lanes.csv.
+Q="--no-cpu-baseline --no-int8-extra --no-dispatcher --no-latency-tail --no-two-lanes"
+Q2="$Q --lanes 2"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r05f_kt -o p -- python3 $R/bench.py $B $Q > $O/r05f_kt.json 2> $O/r05f_kt.err; echo "kt $?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r05f_kt2 -o p -- python3 $R/bench.py $B $Q2 > $O/r05f_kt2.json 2> $O/r05f_kt2.err; echo "kt, two lanes $?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r05f_kt_i8 -o p -- python3 $R/bench.py --int8 $B $Q > $O/r05f_kt_i8.json 2> $O/r05f_kt_i8.err; echo "kt i8 $?"
@@ -39,7 +38,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d $O/r05f_sq2 -o p -- python3 $R/bench.py --steps 3 --warmup 1 $Q > $O/r05f_sq2.log 2>&1; echo "pmc sq2 $?"
 cd $R
 f() { find $O/$1 -name "*$2" | head -1; }
-python3 tools/pmc_to_json.py $(f r05f_pmc_FETCH_SIZE counter_collection.csv) $(f r05f_pmc_WRITE_SIZE counter_collection.csv) $O/pmc_traffic.json "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of \`bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-int8-extra --no-dispatcher --lanes 1\`, r05 final build" > /dev/null
+python3 tools/pmc_to_json.py $(f r05f_pmc_FETCH_SIZE counter_collection.csv) $(f r05f_pmc_WRITE_SIZE counter_collection.csv) $O/pmc_traffic.json "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of \`bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-int8-extra --no-dispatcher --no-two-lanes\`, r05 final build" > /dev/null
 python3 tools/pmc_to_json.py $(f r05f_pmc_i8_FETCH_SIZE counter_collection.csv) $(f r05f_pmc_i8_WRITE_SIZE counter_collection.csv) $O/pmc_traffic_int8.json "the same passes of \`bench.py --int8 ...\`, r05 final build" > /dev/null
 python3 tools/mfma_util.py $(f r05f_mfma counter_collection.csv) $(f r05f_mfma kernel_trace.csv) $O/r05_mfma_util.json > $O/r05_mfma_util.txt
 python3 tools/sq_breakdown.py $(f r05f_sq counter_collection.csv) $(f r05f_sq kernel_trace.csv) > $O/r05_sq_breakdown.txt
