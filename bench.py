@@ -506,11 +506,12 @@ def main():
 
     use_hg = not args.no_hg
     H, Wd = args.height, args.width
-    if args.int8 and not args.int8_predequantize and args.lanes > 1:
-        # W8A8 layers on int8 MFMA run one frame at a time (hdrtv_set_lanes refuses more: include/hdrtv_mi355x.h)
-        print("[bench] --int8 with predequantize off: one lane", file=sys.stderr)
+    if args.int8 and args.lanes > 1:
+        # W8A8 layers on int8 MFMA (the HG stand-in of every --int8 mode; the HR layers with predequantize off) run one frame at a
+        # time: hdrtv_set_lanes refuses more (include/hdrtv_mi355x.h)
+        print("[bench] --int8: one lane", file=sys.stderr)
         args.lanes = 1
-    fp16_graph = not (args.int8 and not args.int8_predequantize)
+    fp16_graph = not args.int8
     want_two = fp16_graph and not args.no_two_lanes and world == 1 and args.lanes == 1
     ctx_lanes = 2 if want_two else args.lanes           # the context holds the second workspace from the start; `value` uses args.lanes
     import contextlib
