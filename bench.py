@@ -54,10 +54,10 @@ def parse():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--no-hg", action="store_true", help="debug: AGCM+LE only (not the headline config)")
-    ap.add_argument("--lanes", type=int, default=1, choices=(1, 2, 3, 4),
+    ap.add_argument("--lanes", type=int, default=1, choices=(1, 2),
                     help="frames in flight on the device for the timed region (hdrtv_set_lanes): frame i runs on lane i mod LANES, each lane with "
                          "its own activation workspace and HIP stream.  Default 1: `value` is one frame at a time; the two-lane rate is reported "
-                         "beside it as `two_lanes` (with a byte-for-byte self-check), fp16 only")
+                         "beside it as `two_lanes` (with a byte-for-byte self-check)")
     ap.add_argument("--no-two-lanes", action="store_true", help="skip the `two_lanes` leg")
     ap.add_argument("--int8", action="store_true",
                     help="BASELINE configs[4] instead of the headline fp16 configuration: HR from the reference's INT8-QAT checkpoint "
@@ -227,11 +227,12 @@ def int8_extra(args, dev, dev_frames, steps=20, warmup=3, recipe="full"):
         H, Wd = args.height, args.width
         with contextlib.redirect_stdout(sys.stderr):
             proc = HDRTVNetMI355X(os.path.join(REPO, "tests", "golden", f"hr_int8_{recipe}_qat.hdrw"), device=str(dev),
-                                  precision=f"int8-{recipe}", predequantize="off", use_hg=True, hg_weights="seeded-w8a8:1234", warmup_passes=0)
+                                  precision=f"int8-{recipe}", predequantize="off", use_hg=True, hg_weights="seeded-w8a8:1234", warmup_passes=0,
+                                  lanes=2)
         proc._ensure_buffers(H, Wd)
         lib, ctx = proc._lib, proc._ctx
-        nl = 1            # W8A8 layers on int8 MFMA: one frame in flight (hdrtv_set_lanes refuses more: include/hdrtv_mi355x.h)
-        rgb48 = [torch.empty((H, Wd, 3), dtype=torch.uint16, device=dev) for _ in range(nl)]
+        nl = 1            # `value`: one frame at a time, as the headline; `value_two_lanes` beside it
+        rgb48 = [torch.empty((H, Wd, 3), dtype=torch.uint16, device=dev) for _ in range(2)]
 
         def step(i, lanes=nl):
             proc.enqueue_frame(i % lanes, dev_frames[i % len(dev_frames)].data_ptr(), H, Wd, rgb48[i % lanes].data_ptr())
@@ -247,6 +248,7 @@ def int8_extra(args, dev, dev_frames, steps=20, warmup=3, recipe="full"):
             return time.perf_counter() - t0
 
         el = timed(nl)
+        el2 = timed(2)
         # what ran, from the kernel tags of one profiled frame behind the timed region (never a constant string)
         proc.profile_enable(True)
         step(0, 1)
@@ -257,7 +259,7 @@ def int8_extra(args, dev, dev_frames, steps=20, warmup=3, recipe="full"):
         return {"metric": f"frames/sec, INT8-QAT HDRTVNet++ (HR: the shipped {recipe}-QAT checkpoint, predequantize off; HG: W8A8 stand-in), same frames; "
                           f"executed: {ran['text']}",
                 "value": round(steps / el, 3), "unit": "frames/s", "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
-                "lanes": nl, "dtype": "i8+f16", "executed": {k: v for k, v in ran.items() if k != "text"}}
+                "lanes": nl, "value_two_lanes": round(steps / el2, 3), "dtype": "i8+f16", "executed": {k: v for k, v in ran.items() if k != "text"}}
     except Exception as exc:  # noqa: BLE001  (an extra: never take the headline line down with it)
         return {"error": f"{type(exc).__name__}: {exc}"}
 
@@ -506,13 +508,7 @@ def main():
 
     use_hg = not args.no_hg
     H, Wd = args.height, args.width
-    if args.int8 and args.lanes > 1:
-        # W8A8 layers on int8 MFMA (the HG stand-in of every --int8 mode; the HR layers with predequantize off) run one frame at a
-        # time: hdrtv_set_lanes refuses more (include/hdrtv_mi355x.h)
-        print("[bench] --int8: one lane", file=sys.stderr)
-        args.lanes = 1
-    fp16_graph = not args.int8
-    want_two = fp16_graph and not args.no_two_lanes and world == 1 and args.lanes == 1
+    want_two = not args.no_two_lanes and world == 1 and args.lanes == 1
     ctx_lanes = 2 if want_two else args.lanes           # the context holds the second workspace from the start; `value` uses args.lanes
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):       # stdout carries exactly one JSON line
@@ -643,7 +639,7 @@ def main():
                               "p50 / p99 / max are a frame's first kernel to its last, the 1 % low is over the intervals between consecutive frames' completions"}
     # ---- the same K ring steps with TWO frames in flight (frame i on lane i mod 2: own workspace and stream; the device starts a
     # frame's kernels in the tails of the other's), reported beside `value` with its per-frame latency, and a self-check: 60 frames on
-    # two lanes against the bytes the same frames give one at a time.  fp16 graphs only; never `value` (lanes are opt-in: DESIGN.md 7)
+    # two lanes against the bytes the same frames give one at a time.  Never `value` (lanes are opt-in: DESIGN.md 7)
     two_lanes = None
     if want_two:
         ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]

@@ -106,9 +106,8 @@ class HDRTVNetMI355X:
     ``use_cuda_graphs=True`` replays ``infer`` from a captured hipGraph (2306-2331).  ``fast_condition_resize=True`` (or
     ``HDRTVNET_FAST_COND_RESIZE=1``) derives the condition map with the bilinear 0.25x resize, ``HDRTVNET_ZERO_COND=1``
     zeroes it (1539-1543, 2262-2276).
-    ``lanes`` (no reference counterpart; 1 .. 4, default 1): frames in flight on the device.  Each lane has its own activation
-    workspace, boundary tensors and HIP stream (``enqueue_frame``; fp16 graphs only: more than one lane raises for the fp32 preset and for
-    INT8 checkpoints run with ``predequantize`` off); the reference-shaped calls (``process`` / ``preprocess`` /
+    ``lanes`` (no reference counterpart; 1 or 2, default 1): frames in flight on the device.  Each lane has its own activation
+    workspace, boundary tensors and HIP stream (``enqueue_frame``; the fp32 preset takes one lane only); the reference-shaped calls (``process`` / ``preprocess`` /
     ``infer`` / ``postprocess``) always run on lane 0 and the caller's current stream.
     """
 
@@ -119,8 +118,8 @@ class HDRTVNetMI355X:
                  warmup_passes=3, fast_condition_resize=False, lanes=1, _ab_library=False):
         self.model_path = model_path
         self._lanes = int(lanes)
-        if not 1 <= self._lanes <= 4:
-            raise ValueError("lanes must be 1 .. 4")
+        if not 1 <= self._lanes <= (4 if os.environ.get("HDRTV_LANES_ANY") == "1" else 2):
+            raise ValueError("lanes must be 1 or 2")
         self._warmup_passes = int(warmup_passes)
         env_true = lambda n: str(os.environ.get(n, "")).strip().lower() in ("1", "true", "yes", "on")   # noqa: E731
         self._fast_condition_resize = bool(fast_condition_resize) or env_true("HDRTVNET_FAST_COND_RESIZE")
@@ -216,7 +215,7 @@ class HDRTVNetMI355X:
             raise RuntimeError(f"model backend failed - {msg}")
 
         if self._lanes > 1:
-            # (HDRTV_EINVAL for the fp32 preset and for W8A8 layers kept on int8 MFMA: one lane only there, include/hdrtv_mi355x.h)
+            # (HDRTV_EINVAL for the fp32 preset: one lane only there, include/hdrtv_mi355x.h)
             try:
                 self._chk(self._lib.hdrtv_set_lanes(self._ctx, self._lanes), "hdrtv_set_lanes")
             except Exception:

@@ -95,12 +95,12 @@ int hdrtv_infer(hdrtv_ctx *ctx, void *stream, const void *dev_rgb_chw, const voi
                 int W, void *dev_out, int out_dtype, void *dev_agcm_out);
 
 /* Frames in flight (no reference counterpart: the reference's worker processes one frame at a time and hides its copies
- * behind streams, gui_pipeline_worker_feeders.py:125-249).  A context holds `lanes` activation workspaces (1 .. 4, default
+ * behind streams, gui_pipeline_worker_feeders.py:125-249).  A context holds `lanes` activation workspaces (1 or 2, default
  * 1; weights are shared); hdrtv_infer_lane(ctx, l, stream_l, ...) is hdrtv_infer on workspace l, so calls with different
  * lanes on different streams may overlap on the device: the tail of one frame's kernel fills with the next frame's
  * workgroups (about +4.5 % frames/s at 3840x2160 with two lanes; a frame's own latency grows towards lanes x).
- * Results do not depend on the lane (tests/test_gpu_lanes.py).  fp16 contexts only: HDRTV_EINVAL for lanes > 1 on an fp32 context or
- * one whose checkpoint keeps W8A8 layers on int8 MFMA (predequantize off).  hdrtv_set_lanes drops the reservation when the count changes (call hdrtv_reserve
+ * Results do not depend on the lane (tests/test_gpu_lanes.py).  HDRTV_EINVAL for more than two lanes (three kernels running at once
+ * is where rare wrong tiles were seen) and for two on an fp32 context.  hdrtv_set_lanes drops the reservation when the count changes (call hdrtv_reserve
  * again; it synchronises the device); hdrtv_infer is lane 0.  Calls on one context are made by one host thread at a time,
  * as before: lanes make the DEVICE work concurrent, not the entry points re-entrant.  hdrtv_get_tap addresses lane 0. */
 int hdrtv_set_lanes(hdrtv_ctx *ctx, int lanes);

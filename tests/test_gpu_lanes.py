@@ -28,14 +28,14 @@ def _make(golden_dir, int8, lanes):
     return HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), use_hg=True, hg_weights="seeded:1234", warmup_passes=0, lanes=lanes)
 
 
-@pytest.mark.parametrize("int8,size", [(False, (2160, 3840)), (False, (540, 962))])
+@pytest.mark.parametrize("int8,size", [(False, (2160, 3840)), (False, (540, 962)), (True, (2160, 3840))])
 def test_overlapping_lanes_write_the_bytes_of_one_frame_at_a_time(torch_cuda, golden_dir, int8, size):
     from hdrtv_mi355x import weights as W
     torch = torch_cuda
     h, w = size
-    p = _make(golden_dir, int8, lanes=3)
+    p = _make(golden_dir, int8, lanes=2)
     try:
-        assert p.lanes == 3 and p._lib.hdrtv_get_lanes(p._ctx) == 3
+        assert p.lanes == 2 and p._lib.hdrtv_get_lanes(p._ctx) == 2
         dev = p.device
         frames = [torch.from_numpy(W.synthetic_frame(h, w, seed=70 + i, kind=("noise", "gradient", "noise")[i])).to(dev) for i in range(3)]
         # yardstick: lane 0 only, one frame at a time
@@ -46,16 +46,16 @@ def test_overlapping_lanes_write_the_bytes_of_one_frame_at_a_time(torch_cuda, go
             torch.cuda.synchronize(dev)
             want.append(o)
         assert not torch.equal(want[0], want[1]) and not torch.equal(want[0], want[2])
-        # 12 frames back to back, frame i on lane i mod 3, frame content rotating against the lanes: every lane sees every frame
-        # while the other two lanes are busy with different ones
+        # 12 frames back to back, frame i on lane i mod 2, frame content rotating against the lanes: every lane sees every frame
+        # while the other lane is busy with a different one
         outs = [torch.zeros((h, w, 3), dtype=torch.uint16, device=dev) for _ in range(12)]
-        which = [(i + i // 3) % 3 for i in range(12)]
+        which = [(i + i // 4) % 3 for i in range(12)]
         for i in range(12):
-            p.enqueue_frame(i % 3, frames[which[i]].data_ptr(), h, w, outs[i].data_ptr())
+            p.enqueue_frame(i % 2, frames[which[i]].data_ptr(), h, w, outs[i].data_ptr())
         torch.cuda.synchronize(dev)
-        assert {(i % 3, which[i]) for i in range(12)} == {(l, f) for l in range(3) for f in range(3)}
+        assert {(i % 2, which[i]) for i in range(12)} == {(l, f) for l in range(2) for f in range(3)}
         for i in range(12):
-            assert torch.equal(outs[i], want[which[i]]), (i, i % 3, which[i], int((outs[i] != want[which[i]]).sum()))
+            assert torch.equal(outs[i], want[which[i]]), (i, i % 2, which[i], int((outs[i] != want[which[i]]).sum()))
         # the reference-shaped calls still run on lane 0 and agree with it
         out, _ = p.infer(p.preprocess(frames[1].cpu().numpy()))
         o = torch.empty((h, w, 3), dtype=torch.uint16, device=dev)
@@ -112,45 +112,44 @@ def test_lane_count_is_part_of_the_reservation(torch_cuda, golden_dir):
         HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), use_hg=False, warmup_passes=0, lanes=5)
 
 
-def test_more_than_one_lane_is_refused_outside_the_fp16_graph(torch_cuda, golden_dir):
-    """W8A8 layers on int8 MFMA and the fp32 preset run one frame at a time: hdrtv_set_lanes(2) is HDRTV_EINVAL there (about one
-    frame in 500 came out with wrong hg.conv2 tiles when int8 frames overlapped -- tools/dbg/lane_stress2.py, not understood --
-    and the fp32 vector kernels keep the packed-f32 arithmetic that failed beside another stream's MFMA waves)."""
+def test_lane_limits(torch_cuda, golden_dir, monkeypatch):
+    """One or two lanes; the fp32 preset one.  Three kernels running at once is where wrong hg.conv2 tiles were seen with W8A8 layers
+    (about one frame in 500; none with two lanes or two hardware queues: tools/dbg/lane_stress2.py), and the fp32 vector kernels
+    keep the packed-f32 arithmetic that failed beside another stream's MFMA waves."""
     from hdrtv_mi355x.processor import HDRTVNetMI355X
-    with pytest.raises(RuntimeError, match="fp16 graph only"):
-        _make(golden_dir, True, lanes=2)
-    with pytest.raises(RuntimeError, match="fp16 graph only"):
+    monkeypatch.delenv("HDRTV_LANES_ANY", raising=False)
+    with pytest.raises(ValueError):
+        _make(golden_dir, False, lanes=3)
+    with pytest.raises(RuntimeError, match="one frame at a time"):
         HDRTVNetMI355X(os.path.join(golden_dir, "hr_weights.hdrw"), precision="fp32", use_hg=False, warmup_passes=0, lanes=2)
-    # an INT8 checkpoint run the reference's ROCm way (dequantised at load: fp16 compute) is an fp16 graph
-    p = HDRTVNetMI355X(os.path.join(golden_dir, "hr_int8_mixed_qat.hdrw"), precision="int8-mixed", use_hg=False, warmup_passes=0, lanes=2)
-    assert p.lanes == 2
-    p.close()
-    p = _make(golden_dir, True, lanes=1)
-    assert p.lanes == 1
-    p.close()
+    p = _make(golden_dir, True, lanes=2)
+    try:
+        assert p.lanes == 2 and p._lib.hdrtv_set_lanes(p._ctx, 3) < 0 and b"1 or 2" in p._lib.hdrtv_last_error(p._ctx)
+    finally:
+        p.close()
 
 
-@pytest.mark.parametrize("int8", [False])
+@pytest.mark.parametrize("int8", [False, True])
 def test_a_lane_is_not_disturbed_by_the_frames_in_flight_beside_it(torch_cuda, golden_dir, int8):
-    """Rounds of lane 0 = one fixed frame with OTHER frames enqueued on lanes 1 and 2 around it: lane 0's RGB48 bytes and its
+    """Rounds of lane 0 = one fixed frame with OTHER frames enqueued on lane 1 around it: lane 0's RGB48 bytes and its
     condition map are those of the quiet run every time.  (Round 5: packed-f32 arithmetic in pre_fused -- v_pk_mul / add / fma_f32
     from the SLP vectoriser -- read a stale operand when its waves shared a SIMD with conv1x1_i8's MFMA waves of another lane's
     frame: a handful of wrong condition-map values per disturbed call, 4 .. 14 of 40 such rounds; the library is built without
-    packed f32 since, tests/test_isa_contracts.py.  72 lane-frames here; tools/dbg/lane_stress2.py ran 7500 of them clean.)"""
+    packed f32 since, tests/test_isa_contracts.py.  72 lane-0 frames here; the stress tools ran 4000 int8 and 7500 + 9000 fp16 lane-frames clean.)"""
     from hdrtv_mi355x import weights as W
     torch = torch_cuda
     h, w = 2160, 3840
-    p = _make(golden_dir, int8, lanes=3)
+    p = _make(golden_dir, int8, lanes=2)
     try:
         dev = p.device
         frames = [torch.from_numpy(W.synthetic_frame(h, w, seed=70 + i, kind=("noise", "gradient", "noise", "gradient")[i])).to(dev) for i in range(4)]
-        outs = [torch.empty((h, w, 3), dtype=torch.uint16, device=dev) for _ in range(3)]
+        outs = [torch.empty((h, w, 3), dtype=torch.uint16, device=dev) for _ in range(2)]
         p.enqueue_frame(0, frames[2].data_ptr(), h, w, outs[0].data_ptr())
         torch.cuda.synchronize(dev)
         ref_out, ref_cond = outs[0].clone(), p._lane_bufs[0][1].clone()
         bad = []
-        for r in range(24):
-            order = (0, 1, 2) if r % 2 == 0 else (2, 1, 0)
+        for r in range(36):
+            order = (0, 1) if r % 2 == 0 else (1, 0)
             for rep in range(2):
                 for l in order:
                     p.enqueue_frame(l, frames[2 if l == 0 else (l + r + rep) % 4].data_ptr(), h, w, outs[l].data_ptr())
@@ -159,10 +158,8 @@ def test_a_lane_is_not_disturbed_by_the_frames_in_flight_beside_it(torch_cuda, g
             if nc or no:
                 bad.append((r, nc, no))
         print(f"  disturbed rounds (round, condition-map values, RGB48 values): {bad}")
-        # The packed-f32 failures were 4 .. 14 disturbed rounds of 40 with hundreds of thousands of values each.  What is left: ONE
-        # round of one run of this test showed 360 differing RGB48 values (condition map intact) -- 17 000 lane-frames of
-        # tools/dbg/lane_stress*.py on the same build showed none; not understood, which is why lanes stay opt-in.
-        # A second disturbed round, a disturbed condition map or a frame-wide difference fails.
-        assert len(bad) <= 1 and all(nc == 0 and no <= 25000 for _, nc, no in bad), bad
+        # (the packed-f32 failures were 4 .. 14 disturbed rounds of 40; with THREE lanes one round of one run of this test once showed
+        # 360 differing RGB48 values, and int8 frames about one in 500 a few wrong hg.conv2 tiles: hdrtv_set_lanes stops at two)
+        assert not bad, bad
     finally:
         p.close()

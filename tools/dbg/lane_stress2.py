@@ -4,6 +4,7 @@ usage: lane_stress2.py [--int8] [--rounds N] [--lanes L]"""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(REPO, "hdr-realtime-video-pipeline_amd"))
+os.environ.setdefault("HDRTV_LANES_ANY", "1")      # more than two lanes, and lanes for any precision: experiments only
 import torch
 from hdrtv_mi355x import weights as W
 from hdrtv_mi355x.processor import HDRTVNetMI355X

@@ -3,6 +3,7 @@ L = 1 .. 4, device-resident in and out (no ring).  usage: python tools/dbg/two_s
 import os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(REPO, "hdr-realtime-video-pipeline_amd"))
+os.environ.setdefault("HDRTV_LANES_ANY", "1")      # more than two lanes, and lanes for any precision: experiments only
 import torch
 from hdrtv_mi355x import weights as W
 from hdrtv_mi355x.processor import HDRTVNetMI355X
