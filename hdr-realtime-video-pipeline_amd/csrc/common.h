@@ -27,6 +27,18 @@ __device__ __forceinline__ float act_apply(float v, int act)
 // 0.1 (LeakyReLU 0.1).  A runtime `act` switch per element costs two scalar branches each.
 __host__ __device__ __forceinline__ float act_slope(int act) { return act == ACT_RELU ? 0.f : (act == ACT_LRELU01 ? 0.1f : 1.f); }
 __device__ __forceinline__ float act_fast(float v, float slope) { return fmaxf(v, slope * v); }
+// Four fp32 values -> f16x4 through the PACKED convert (v_cvt_pk_f16_f32: each value rounded fp32 -> f16, nearest even).  A scalar
+// (f16) cast of an FMA's result lets hipcc fuse the two into v_fma_mixlo_f16, which rounds the exact product-sum ONCE, to f16: a few
+// values per million then differ from the two-step form by one f16 step -- and a kernel and its twin must not differ (round 5: the
+// per-layer SFT convs against the fused row kernels, CondNet3.4's fused tail against conv_igemm, once the SLP vectoriser no longer
+// turned the scalar casts into packed converts by itself).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f16x4 cvt_h4(float a, float b, float c, float d)
+{
+    const f16x2_t lo = __builtin_convertvector(f32x2_t{a, b}, f16x2_t), hi = __builtin_convertvector(f32x2_t{c, d}, f16x2_t);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
 
 // Four activations -> four int8 codes of the reference's u8 activation quantiser (W8A8Conv2d.forward,
 // hdrtvnet_torch.py:353-356): q = clamp(rint((x - x_zero) / x_scale), 0, 255) evaluated as one FMA (inv = 1 / x_scale,

@@ -315,9 +315,8 @@ __global__ __launch_bounds__(64 * NW) void conv32p_kernel(Conv32Params p)
             for (int qd = 0; qd < 4; ++qd) {
                 f16x4 y = yv[gi][qd];
                 if constexpr (SFT) {
-                    f16x4 s1, s0;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { s1[k] = (f16)sc[gi][4 * qd + k]; s0[k] = (f16)sh[gi][4 * qd + k]; }
+                    const f16x4 s1 = cvt_h4(sc[gi][4 * qd], sc[gi][4 * qd + 1], sc[gi][4 * qd + 2], sc[gi][4 * qd + 3]);      // (packed converts: common.h)
+                    const f16x4 s0 = cvt_h4(sh[gi][4 * qd], sh[gi][4 * qd + 1], sh[gi][4 * qd + 2], sh[gi][4 * qd + 3]);
                     y = y * s1 + s0;
                 }
                 if constexpr (I8) {

@@ -309,8 +309,10 @@ __global__ __launch_bounds__(NT) void conv32s_kernel(Conv32Params p)
         auto pack_ss = [&](int gi) __attribute__((always_inline)) {
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { s1p[gi][qd][k] = (f16)sc[gi][4 * qd + k]; s0p[gi][qd][k] = (f16)sh[gi][4 * qd + k]; }
+                {       // (packed converts: common.h cvt_h4)
+                    s1p[gi][qd] = cvt_h4(sc[gi][4 * qd], sc[gi][4 * qd + 1], sc[gi][4 * qd + 2], sc[gi][4 * qd + 3]);
+                    s0p[gi][qd] = cvt_h4(sh[gi][4 * qd], sh[gi][4 * qd + 1], sh[gi][4 * qd + 2], sh[gi][4 * qd + 3]);
+                }
         };
 #pragma unroll
         for (int gi = 0; gi < N; ++gi) {

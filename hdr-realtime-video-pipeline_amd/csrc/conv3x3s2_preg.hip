@@ -178,8 +178,9 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3s2_preg_kernel(ConvParams p
                 f16x4 lo, hi;
                 const float4 s0 = *reinterpret_cast<const float4 *>(p.tail_s + 4 * lh), s1 = *reinterpret_cast<const float4 *>(p.tail_s + 8 + 4 * lh);
                 const float4 b0 = *reinterpret_cast<const float4 *>(p.tail_b + 4 * lh), b1 = *reinterpret_cast<const float4 *>(p.tail_b + 8 + 4 * lh);
-                lo[0] = (f16)(o[0] * s0.x + b0.x); lo[1] = (f16)(o[1] * s0.y + b0.y); lo[2] = (f16)(o[2] * s0.z + b0.z); lo[3] = (f16)(o[3] * s0.w + b0.w);
-                hi[0] = (f16)(o[4] * s1.x + b1.x); hi[1] = (f16)(o[5] * s1.y + b1.y); hi[2] = (f16)(o[6] * s1.z + b1.z); hi[3] = (f16)(o[7] * s1.w + b1.w);
+                // (packed converts, common.h cvt_h4: conv_igemm's epilogue rounds fp32 -> f16 as a step of its own)
+                lo = cvt_h4(o[0] * s0.x + b0.x, o[1] * s0.y + b0.y, o[2] * s0.z + b0.z, o[3] * s0.w + b0.w);
+                hi = cvt_h4(o[4] * s1.x + b1.x, o[5] * s1.y + b1.y, o[6] * s1.z + b1.z, o[7] * s1.w + b1.w);
                 f16 *d = p.tail_out + ((size_t)oy * p.Wo + ox) * 16;
                 *reinterpret_cast<f16x4 *>(d + 4 * lh) = lo;
                 *reinterpret_cast<f16x4 *>(d + 8 + 4 * lh) = hi;

@@ -110,11 +110,7 @@ constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 15) | (7 << 4) | ((lg
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // four fp32 -> f16 (round to nearest even) as two v_cvt_pk_f16_f32
-__device__ __forceinline__ f16x4 cvt4(float a, float b, float c, float d)
-{
-    const f16x2 lo = __builtin_convertvector(f32x2{a, b}, f16x2), hi = __builtin_convertvector(f32x2{c, d}, f16x2);
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
-}
+__device__ __forceinline__ f16x4 cvt4(float a, float b, float c, float d) { return cvt_h4(a, b, c, d); }      // common.h
 // accumulator quad qd (registers 4 qd .. 4 qd + 3) + bias -> f16
 __device__ __forceinline__ f16x4 bias_cvt4(const f32x16 &acc, int qd, const f32x4 &b)
 {

@@ -137,7 +137,7 @@ __device__ __forceinline__ void dequant_act(const i32x16 &iacc, const f32x4 (&sc
         const f32x4 sh = lds_rd<f32x4>(shift_tab + (unsigned)(bcls * CLSB + 32 * qd + 16 * lh));
         const float v0 = (float)iacc[4 * qd + 0] * scq[qd][0] + sh[0], v1 = (float)iacc[4 * qd + 1] * scq[qd][1] + sh[1],
                     v2 = (float)iacc[4 * qd + 2] * scq[qd][2] + sh[2], v3 = (float)iacc[4 * qd + 3] * scq[qd][3] + sh[3];
-        o[qd] = f16x4{(f16)act_fast(v0, slope), (f16)act_fast(v1, slope), (f16)act_fast(v2, slope), (f16)act_fast(v3, slope)};
+        o[qd] = cvt_h4(act_fast(v0, slope), act_fast(v1, slope), act_fast(v2, slope), act_fast(v3, slope));      // packed converts: common.h
     }
 }
 __device__ __forceinline__ void table_to_lds(char *dst, const RowsConvI8 &c, int tid, int coutp = 32)       // [scale coutp][shift 16 x coutp] floats
@@ -533,10 +533,11 @@ __global__ __launch_bounds__(512) void le_tail_rows_i8_kernel(RowsTailI8Params p
                                     act_fast((float)iacc[2] * scl[2] + sh[2], 1.f)};
                 const bool ok = cok && r >= y0 && r < yend;
                 f16 *d = p.dst_planar + (size_t)r * W + x0 + cx;
+                const f16x4 oh = cvt_h4(o[0], o[1], o[2], 0.f);          // packed converts (common.h): fp32 -> f16 as a step of its own
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
                     // the conv result is rounded to f16, the residual added in fp32 and the sum rounded again
-                    const float v = (float)(f16)o[ch] + (float)res[ch];
+                    const float v = (float)oh[ch] + (float)res[ch];
                     *(ok ? d + ch * plane : reinterpret_cast<f16 *>(trash)) = (f16)v;
                 }
             }
