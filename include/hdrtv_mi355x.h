@@ -98,10 +98,10 @@ int hdrtv_infer(hdrtv_ctx *ctx, void *stream, const void *dev_rgb_chw, const voi
  * behind streams, gui_pipeline_worker_feeders.py:125-249).  A context holds `lanes` activation workspaces (1 or 2, default
  * 1; weights are shared); hdrtv_infer_lane(ctx, l, stream_l, ...) is hdrtv_infer on workspace l, so calls with different
  * lanes on different streams may overlap on the device: the tail of one frame's kernel fills with the next frame's
- * workgroups (about +4.5 % frames/s at 3840x2160 with two lanes; a frame's own latency grows towards lanes x).
- * Results do not depend on the lane (tests/test_gpu_lanes.py).  HDRTV_EINVAL for more than two lanes (three kernels running at once
- * is where rare wrong tiles were seen) and for two on an fp32 context.  hdrtv_set_lanes drops the reservation when the count changes (call hdrtv_reserve
- * again; it synchronises the device); hdrtv_infer is lane 0.  Calls on one context are made by one host thread at a time,
+ * workgroups (+3 .. 4.5 % frames/s at 3840x2160 with two lanes, +11 % at 1920x1080; a frame's own latency doubles).
+ * Results do not depend on the lane (tests/test_gpu_lanes.py).  HDRTV_EINVAL for more than two lanes (three kernels running
+ * at once is where rare wrong tiles were seen) and for two on an fp32 context.  hdrtv_set_lanes drops the
+ * reservation when the count changes (call hdrtv_reserve again; it synchronises the device); hdrtv_infer is lane 0.  Calls on one context are made by one host thread at a time,
  * as before: lanes make the DEVICE work concurrent, not the entry points re-entrant.  hdrtv_get_tap addresses lane 0. */
 int hdrtv_set_lanes(hdrtv_ctx *ctx, int lanes);
 int hdrtv_get_lanes(const hdrtv_ctx *ctx);
